@@ -1,0 +1,187 @@
+/*
+ * flmr_hip.h -- C ABI of libflmr_hip.so: the MI355X (gfx950) late-interaction retrieval path.
+ *
+ * Drop-in boundary for the FLMR / ColBERTv2 search hot path of
+ * LinWeizheDragon/Retrieval-Augmented-Visual-Question-Answering.  "TPC/" below abbreviates
+ * third_party/ColBERT/colbert/ in the reference tree.  Each entry point names the reference
+ * interface it replaces.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no torch / C++ types; every function returns a flmr_status_t (0 = OK) and never throws;
+ *     flmr_last_error() returns a thread-local message for the last non-OK status.
+ *   - pointers are DEVICE pointers unless the parameter is documented as host; outputs are caller-
+ *     allocated; all work is enqueued on `stream` (a hipStream_t cast to void*; NULL = default stream)
+ *     and is asynchronous unless stated otherwise.
+ *   - layouts are the reference's CPU layouts: codes i32[N], residuals
+ *     u8[N, dim*nbits/8], doclens/offsets i64, row-major fp32 matrices.
+ *   - numerics follow the reference's CPU path (fp32 everywhere, zero-clamped packed MaxSim,
+ *     (score,pid)-lexicographic selection), not its fp16 CUDA path.
+ *   - this build supports dim == 128 and nbits in {1,2,4,8}; other shapes return FLMR_ERR_UNSUPPORTED.
+ */
+#ifndef FLMR_HIP_H
+#define FLMR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLMR_ABI_VERSION 1
+
+typedef enum flmr_status {
+    FLMR_OK = 0,
+    FLMR_ERR_INVALID = 1,     /* bad argument */
+    FLMR_ERR_UNSUPPORTED = 2, /* shape / option outside what this build implements */
+    FLMR_ERR_HIP = 3,         /* a HIP runtime call failed (message in flmr_last_error) */
+    FLMR_ERR_NOMEM = 4,
+    FLMR_ERR_CAPACITY = 5     /* a workspace bound given at flmr_searcher_create was exceeded */
+} flmr_status_t;
+
+typedef struct flmr_index flmr_index_t;       /* opaque: index resident in HBM */
+typedef struct flmr_searcher flmr_searcher_t; /* opaque: workspace + launch plan for batched search */
+typedef void* flmr_stream_t;                  /* hipStream_t */
+
+int flmr_abi_version(void);
+const char* flmr_last_error(void);
+/* number of visible HIP devices (0 and FLMR_ERR_HIP when the runtime reports none) */
+int flmr_device_count(int* count);
+
+/* ------------------------------------------------------------------------------------------------
+ * Index residency.  Replaces IndexLoader / ResidualCodec.load / ResidualEmbeddings.load_chunks /
+ * ResidualEmbeddingsStrided (TPC/search/index_loader.py:14-86, TPC/indexing/codecs/residual.py:134-150,
+ * residual_embeddings.py:27-52, residual_embeddings_strided.py:13-21): the host side parses the on-disk
+ * files, this call moves the arrays into HBM once.
+ * ---------------------------------------------------------------------------------------------- */
+#define FLMR_MEM_HOST 0   /* desc pointers are host memory: the library allocates HBM and copies (synchronous) */
+#define FLMR_MEM_DEVICE 1 /* desc pointers are device memory owned by the caller and must outlive the index */
+
+typedef struct flmr_index_desc {
+    int32_t dim;               /* 128 */
+    int32_t nbits;             /* 1, 2, 4 or 8 */
+    int32_t num_centroids;     /* K */
+    int32_t memory;            /* FLMR_MEM_HOST | FLMR_MEM_DEVICE */
+    int64_t num_embeddings;    /* N */
+    int64_t num_passages;      /* passages in this shard */
+    int64_t pid_base;          /* global pid of local passage 0 (sharded indexes); 0 otherwise */
+    const int32_t* codes;      /* [N] centroid id per token                   ({i}.codes.pt) */
+    const uint8_t* residuals;  /* [N, dim*nbits/8] packed bucket indices      ({i}.residuals.pt) */
+    const int64_t* doc_offsets;/* [num_passages+1] token offset per passage   (cumsum of doclens.{i}.json) */
+    const int32_t* ivf_pids;   /* [ivf_offsets[K]] sorted unique LOCAL pids per centroid (ivf.pid.pt) */
+    const int64_t* ivf_offsets;/* [K+1] */
+    const float* centroids;    /* [K, dim] fp32 (fp16 file values widened, residual.py:29) (centroids.pt) */
+    const float* bucket_weights; /* [2^nbits] (buckets.pt) -- ALWAYS a host pointer */
+} flmr_index_desc_t;
+
+int flmr_index_open(const flmr_index_desc_t* desc, flmr_index_t** out_index);
+int flmr_index_close(flmr_index_t* index);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched search.  Replaces the per-query loop Searcher._search_all_Q -> dense_search ->
+ * IndexScorer.rank (TPC/searcher.py:73-132, TPC/search/index_storage.py:67-182) for a whole batch
+ * of queries: S0 centroid scores + cell probe + IVF union, S1/S2 centroid-only pruning, S3 fused
+ * residual decompression + L2 normalisation + MaxSim, S4 top-k.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct flmr_search_params {
+    int32_t k;                        /* results per query; policy defaults are the host's job (searcher.py:92-118) */
+    int32_t ncells;                   /* 1..8 */
+    float centroid_score_threshold;   /* idx = max_j score >= thr (index_storage.py:116) */
+    int32_t ndocs;                    /* S1 keeps ndocs, S2 keeps ndocs/4 (filter_pids.cpp:126-164); 4..8192 */
+    int32_t nq_cand;                  /* config.query_maxlen: candidate generation uses Q[:, :nq_cand] (index_storage.py:77); <=128 */
+} flmr_search_params_t;
+
+/* max_queries / max_nq / max_params bound the workspace (allocated here, synchronous). */
+int flmr_searcher_create(const flmr_index_t* index, int32_t max_queries, int32_t max_nq,
+                         const flmr_search_params_t* max_params, flmr_searcher_t** out_searcher);
+int flmr_searcher_destroy(flmr_searcher_t* searcher);
+/* bytes of HBM held by the searcher's workspace */
+int flmr_searcher_workspace_bytes(const flmr_searcher_t* searcher, int64_t* bytes);
+
+/* Q [nqueries, nq, dim] fp32.  q_lens (nullable) i32[nqueries]: number of valid leading rows per query
+ * (rows removed by remove_zero_tensors, searcher.py:120-126, are compacted away by the host).
+ * out_pids i32[nqueries, k] (global pids, -1 padded), out_scores f32[nqueries, k] (0 padded),
+ * out_counts i32[nqueries] = number of valid results (<= k; fewer when fewer candidates survive:
+ * the build returns every surviving candidate once where the reference has UB). */
+int flmr_search_batch(flmr_searcher_t* searcher, const float* Q, const int32_t* q_lens, int32_t nqueries,
+                      int32_t nq, const flmr_search_params_t* params, int32_t* out_pids, float* out_scores,
+                      int32_t* out_counts, flmr_stream_t stream);
+
+/* Stage taps for parity tests: copy an internal per-query buffer of the LAST flmr_search_batch call to
+ * HOST memory (synchronises the stream).  `host_out` capacity in elements; *count receives the number
+ * of valid elements.  Element types: CENTROID_SCORES f32 [K, ncol] (ncol = nq_cand rounded up to 32),
+ * IDX_BITS u32 [ceil(K/32)], CELLS i32, CANDIDATES i32 (ascending local pids), STAGE1 i32 (unordered),
+ * STAGE2 i32 (descending (score,pid) order = filter_pids output), DOC_SCORES f32 (aligned with STAGE2). */
+typedef enum flmr_tap {
+    FLMR_TAP_CENTROID_SCORES = 0,
+    FLMR_TAP_IDX_BITS = 1,
+    FLMR_TAP_CELLS = 2,
+    FLMR_TAP_CANDIDATES = 3,
+    FLMR_TAP_STAGE1 = 4,
+    FLMR_TAP_STAGE2 = 5,
+    FLMR_TAP_DOC_SCORES = 6
+} flmr_tap_t;
+int flmr_searcher_tap(flmr_searcher_t* searcher, int32_t what, int32_t query, void* host_out, int64_t capacity,
+                      int64_t* count);
+
+/* Timing taps: per-stage HIP-event milliseconds of the LAST flmr_search_batch call when the searcher was
+ * put in profiling mode (flmr_searcher_set_profiling(s, 1)); ms[FLMR_NUM_STAGES] is HOST memory. */
+#define FLMR_NUM_STAGES 8
+int flmr_searcher_set_profiling(flmr_searcher_t* searcher, int32_t enable);
+int flmr_searcher_stage_ms(flmr_searcher_t* searcher, float* ms_host);
+const char* flmr_stage_name(int32_t stage);
+
+/* ------------------------------------------------------------------------------------------------
+ * Op-level entry points: 1:1 with the reference's four pybind functions + the scoring head.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* filter_pids_cpp (TPC/search/filter_pids.cpp:126-164).  centroid_scores f32[K, nq] row-major, idx u8[K]
+ * (bool), doclens/offsets i64 indexed by pid.  out_pids i32[ndocs/4] in descending (score,pid) order,
+ * *out_count (device i32) = number written.  npids < ndocs: keeps everything once (reference: UB). */
+int flmr_filter_pids(const int32_t* pids, int64_t npids, const float* centroid_scores, int32_t K, int32_t nq,
+                     const int32_t* codes, const int64_t* doclens, const int64_t* offsets, const uint8_t* idx,
+                     int32_t ndocs, int32_t* out_pids, int32_t* out_count, flmr_stream_t stream);
+
+/* decompress_residuals_cpp (TPC/search/decompress_residuals.cpp:80-155; CUDA twin
+ * TPC/indexing/codecs/decompress_residuals.cu:8-40).  out f32[sum doclens[pids], dim] packed in pid
+ * order; out_row_offsets i64[npids+1] (device, nullable) receives the exclusive prefix of the doc lengths.
+ * out_capacity_rows bounds `out`. */
+int flmr_decompress_residuals(const int32_t* pids, int32_t npids, const int64_t* doclens, const int64_t* offsets,
+                              const float* bucket_weights, const uint8_t* reversed_bit_map,
+                              const uint8_t* bucket_weight_combinations, const uint8_t* binary_residuals,
+                              const int32_t* codes, const float* centroids, int32_t dim, int32_t nbits,
+                              float* out, int64_t out_capacity_rows, int64_t* out_row_offsets, flmr_stream_t stream);
+
+/* segmented_lookup_cpp (TPC/search/segmented_lookup.cpp:127-144): ragged gather of rows of `row_bytes`
+ * bytes.  lengths/offsets i64[nseg] are per segment (already indexed by pid, as StridedTensor._prepare_lookup
+ * does, TPC/search/strided_tensor.py:59-75).  out_row_offsets i64[nseg+1] device scratch/output. */
+int flmr_segmented_lookup(const void* input, int64_t row_bytes, const int64_t* lengths, const int64_t* offsets,
+                          int32_t nseg, void* out, int64_t out_capacity_rows, int64_t* out_row_offsets,
+                          flmr_stream_t stream);
+
+/* segmented_maxsim_cpp (TPC/modeling/segmented_maxsim.cpp:49-93): scores f32[ntok, nq], lengths i64[ndocs]
+ * -> out f32[ndocs]; running max starts at 0 (zero clamp), then sum over nq. */
+int flmr_segmented_maxsim(const float* scores, const int64_t* lengths, int32_t ndocs, int32_t nq, float* out,
+                          flmr_stream_t stream);
+
+/* colbert_score_packed fused with decompression + F.normalize (TPC/search/index_storage.py:160-177,
+ * TPC/modeling/colbert.py:289-311): exact late-interaction score of Q [nq, dim] against `npids` local pids
+ * of `index`, without materialising D in HBM.  out f32[npids]. */
+int flmr_score_pids(const flmr_index_t* index, const float* Q, int32_t nq, const int32_t* pids, int32_t npids,
+                    float* out, flmr_stream_t stream);
+
+/* colbert_score / colbert_score_reduce, padded variant (TPC/modeling/colbert.py:235-286; callers
+ * src/models/retriever/FLMR.py score(), src/executors/FLMR_executor.py:799-847 exhaustive search).
+ * Q f32[q_batch, nq, dim] with q_batch in {1, B}; D f32[B, Ld, dim]; mask u8[B, Ld]; out f32[B].
+ * Padded tokens score -9999 (no zero clamp); forward only. */
+int flmr_colbert_score_padded(const float* Q, int32_t q_batch, int32_t nq, const float* D, const uint8_t* mask,
+                              int32_t B, int32_t Ld, int32_t dim, float* out, flmr_stream_t stream);
+
+/* Merge per-shard top-k lists after the RCCL all-gather: scores f32[nshards, nqueries, k],
+ * pids i32[nshards, nqueries, k] (-1 = empty) -> global top-k per query in descending (score,pid) order. */
+int flmr_merge_topk(const float* scores, const int32_t* pids, int32_t nshards, int32_t nqueries, int32_t k,
+                    float* out_scores, int32_t* out_pids, int32_t* out_counts, flmr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLMR_HIP_H */

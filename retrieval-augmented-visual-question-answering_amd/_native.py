@@ -1,0 +1,129 @@
+"""ctypes binding of libflmr_hip.so (the C ABI declared in include/flmr_hip.h).
+
+The HIP library is the product path.  There is NO CPU fallback here: if the shared object is missing or no
+MI355X is visible, loading fails loudly (FlmrNativeError).  PyTorch is used by callers only as plumbing for
+device memory and streams; every entry point takes raw device pointers.
+"""
+import ctypes as C
+import os
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "lib", "libflmr_hip.so")
+CSRC = os.path.join(PKG_DIR, "csrc")
+SOURCES = ["flmr_index.hip", "flmr_stage0.hip", "flmr_filter.hip", "flmr_maxsim.hip", "flmr_search.hip", "flmr_ops.hip"]
+HEADERS = ["flmr_common.h", "flmr_device.h"]
+
+FLMR_MEM_HOST, FLMR_MEM_DEVICE = 0, 1
+(TAP_CENTROID_SCORES, TAP_IDX_BITS, TAP_CELLS, TAP_CANDIDATES, TAP_STAGE1, TAP_STAGE2, TAP_DOC_SCORES) = range(7)
+NUM_STAGES = 8
+
+
+class FlmrNativeError(RuntimeError):
+    pass
+
+
+class IndexDesc(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("nbits", C.c_int32), ("num_centroids", C.c_int32), ("memory", C.c_int32),
+                ("num_embeddings", C.c_int64), ("num_passages", C.c_int64), ("pid_base", C.c_int64),
+                ("codes", C.c_void_p), ("residuals", C.c_void_p), ("doc_offsets", C.c_void_p),
+                ("ivf_pids", C.c_void_p), ("ivf_offsets", C.c_void_p), ("centroids", C.c_void_p),
+                ("bucket_weights", C.c_void_p)]
+
+
+class SearchParams(C.Structure):
+    _fields_ = [("k", C.c_int32), ("ncells", C.c_int32), ("centroid_score_threshold", C.c_float),
+                ("ndocs", C.c_int32), ("nq_cand", C.c_int32)]
+
+
+def hipcc_path():
+    for p in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if p and (os.path.isabs(p) and os.path.exists(p) or not os.path.isabs(p)):
+            return p
+    return "hipcc"
+
+
+def build_native(force=False, verbose=False):
+    """Compile csrc/*.hip for gfx950 into lib/libflmr_hip.so (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(REPO_ROOT, "include", "flmr_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I" + os.path.join(REPO_ROOT, "include"), "-I" + CSRC] + srcs + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+_SIGS = {
+    "flmr_abi_version": (C.c_int, []),
+    "flmr_last_error": (C.c_char_p, []),
+    "flmr_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "flmr_index_open": (C.c_int, [C.POINTER(IndexDesc), C.POINTER(C.c_void_p)]),
+    "flmr_index_close": (C.c_int, [C.c_void_p]),
+    "flmr_searcher_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SearchParams), C.POINTER(C.c_void_p)]),
+    "flmr_searcher_destroy": (C.c_int, [C.c_void_p]),
+    "flmr_searcher_workspace_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "flmr_search_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SearchParams),
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "flmr_searcher_tap": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "flmr_searcher_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
+    "flmr_searcher_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "flmr_stage_name": (C.c_char_p, [C.c_int32]),
+    "flmr_filter_pids": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "flmr_decompress_residuals": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                            C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "flmr_segmented_lookup": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                        C.c_int64, C.c_void_p, C.c_void_p]),
+    "flmr_segmented_maxsim": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "flmr_score_pids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "flmr_colbert_score_padded": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "flmr_merge_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
+}
+EXPORTED_SYMBOLS = sorted(_SIGS)
+
+
+def load(require_device=True):
+    """dlopen the library (never builds implicitly, never falls back).  With require_device the call also
+    fails when no HIP device is visible -- the product path is GPU-only."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FlmrNativeError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+                "There is no CPU fallback for the search path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)  # AttributeError => ABI mismatch, surfaced loudly
+            fn.restype, fn.argtypes = res, args
+        if lib.flmr_abi_version() != 1:
+            raise FlmrNativeError("libflmr_hip.so ABI version mismatch")
+        _lib = lib
+    if require_device:
+        n = C.c_int(0)
+        rc = _lib.flmr_device_count(C.byref(n))
+        if rc != 0 or n.value < 1:
+            raise FlmrNativeError("no MI355X / HIP device visible: " + _lib.flmr_last_error().decode())
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise FlmrNativeError(f"libflmr_hip status {rc}: {load(False).flmr_last_error().decode()}")
+
+
+def stream_ptr(torch_stream=None):
+    """Raw hipStream_t of the current (or given) torch stream."""
+    import torch
+    s = torch_stream if torch_stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)

@@ -1,0 +1,153 @@
+// Internal helpers shared by the HIP translation units of libflmr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "flmr_hip.h"
+
+#define FLMR_DIM 128            // embedding width this build is specialised for
+#define FLMR_WAVE 64            // CDNA wavefront
+#define FLMR_MAX_NCELLS 8
+#define FLMR_MAX_NQ_CAND 128    // candidate-generation width limit (4 column tiles of 32)
+#define FLMR_MAX_NDOCS 8192
+
+extern thread_local char flmr_err_buf[512];
+
+#define FLMR_FAIL(code, ...)                                     \
+    do {                                                         \
+        snprintf(flmr_err_buf, sizeof(flmr_err_buf), __VA_ARGS__); \
+        return (code);                                           \
+    } while (0)
+
+#define FLMR_HIP(expr)                                                                              \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess) {                                                                    \
+            snprintf(flmr_err_buf, sizeof(flmr_err_buf), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, \
+                     hipGetErrorString(e__));                                                       \
+            return FLMR_ERR_HIP;                                                                    \
+        }                                                                                           \
+    } while (0)
+
+#define FLMR_LAUNCH_CHECK() FLMR_HIP(hipGetLastError())
+
+static inline int64_t flmr_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t flmr_round_up(int64_t a, int64_t b) { return flmr_ceil_div(a, b) * b; }
+
+// ---- (score, pid) keys -----------------------------------------------------------------------
+// The reference selects with std::priority_queue<std::pair<float,int>> (filter_pids.cpp:24): descending
+// lexicographic (score, pid).  A 64-bit key whose unsigned order equals that order lets one integer
+// compare / radix pass do the same: high word = order-preserving map of the fp32 score, low word = pid.
+__host__ __device__ static inline uint32_t flmr_f2ord(float f) {
+    if (f == 0.0f) f = 0.0f;  // -0.0 == +0.0 for the reference's float compare
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ static inline float flmr_ord2f(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+__host__ __device__ static inline uint64_t flmr_make_key(float score, int32_t pid) {
+    return ((uint64_t)flmr_f2ord(score) << 32) | (uint32_t)pid;
+}
+__host__ __device__ static inline int32_t flmr_key_pid(uint64_t key) { return (int32_t)(uint32_t)key; }
+__host__ __device__ static inline float flmr_key_score(uint64_t key) { return flmr_ord2f((uint32_t)(key >> 32)); }
+
+// ---- index object ----------------------------------------------------------------------------
+struct flmr_index {
+    int32_t dim, nbits, K, device;
+    int64_t N, num_passages, pid_base;
+    int32_t packed_dim;  // dim*nbits/8 bytes per token
+    bool owns;           // arrays below were hipMalloc'ed by flmr_index_open
+    int32_t* codes;
+    uint8_t* residuals;
+    int64_t* doc_offsets;
+    int32_t* ivf_pids;
+    int64_t* ivf_offsets;
+    float* centroids;
+    float* wlut;  // [256][8/nbits] fused decode table: bucket_weights[lut[rev[byte]][l]]
+    float bucket_weights[256];
+    // host copy of the IVF list lengths sorted descending, prefix-summed: bound on #candidates for c cells
+    int64_t* ivf_len_prefix;  // [K+1] host
+    int64_t max_doclen;
+};
+
+// build the fused byte -> (8/nbits) fp32 decode table from the codec tables (host)
+void flmr_build_wlut(int nbits, const float* bucket_weights, const uint8_t* reversed_bit_map,
+                     const uint8_t* combos, float* wlut /* [256 * 8/nbits] */);
+void flmr_default_codec_tables(int nbits, uint8_t* reversed_bit_map /*256*/, uint8_t* combos /*256*8/nbits*/);
+
+// ---- kernels' host launchers (defined in the stage .hip files) ---------------------------------
+struct flmr_s0_args {
+    const float* centroids;  // [K,128]
+    const float* Q;          // [nqueries, nq, 128]
+    const int32_t* q_lens;   // nullable
+    int32_t K, nqueries, nq, nq_cand, ncol, ncells;
+    float thr;
+    float* cs;               // [nqueries, K, ncol]
+    uint32_t* idx_bits;      // [nqueries, idx_words]
+    int32_t idx_words;
+    float* part_val;         // [nqueries, nblk, ncol, ncells]
+    int32_t* part_idx;
+    int32_t nblk;            // number of 128-row blocks
+    int32_t* cells;          // [nqueries, max_cells]
+    int32_t* ncell;          // [nqueries]
+    int32_t max_cells;
+};
+int flmr_launch_centroid_scores(const flmr_s0_args& a, hipStream_t st);
+int flmr_launch_select_cells(const flmr_s0_args& a, hipStream_t st);
+
+int flmr_launch_ivf_mark(const int32_t* cells, const int32_t* ncell, int32_t max_cells, int32_t nqueries,
+                         const int32_t* ivf_pids, const int64_t* ivf_offsets, uint32_t* bitmap, int64_t bitmap_words,
+                         hipStream_t st);
+int flmr_launch_compact(const uint32_t* bitmap, int64_t bitmap_words, int64_t num_passages, int32_t nqueries,
+                        int32_t* cand, int64_t cand_cap, int32_t* cand_count, int32_t* overflow, hipStream_t st);
+
+struct flmr_filter_args {
+    const float* cs;           // [nqueries, K, ncol]  (per-query stride K*ncol)
+    int64_t cs_query_stride;
+    int32_t K, ncol, nq_cand, nqueries;
+    const int32_t* q_lens;     // nullable (effective columns = min(q_len, nq_cand))
+    const int32_t* codes;
+    const int64_t* doclens;    // nullable -> offsets[p+1]-offsets[p]
+    const int64_t* offsets;
+};
+// stage 1: candidates (cand[q*cand_stride + i], i < cand_count[q]) restricted to idx_bits -> keys
+int flmr_launch_filter_stage1(const flmr_filter_args& f, const uint32_t* idx_bits, int32_t idx_words,
+                              const int32_t* cand, int64_t cand_stride, const int32_t* cand_count, uint64_t* keys,
+                              hipStream_t st);
+// stage 2: all centroids, one wave per document
+int flmr_launch_filter_stage2(const flmr_filter_args& f, const int32_t* pids, int64_t pid_stride,
+                              const int32_t* counts, int32_t max_count, uint64_t* keys, int64_t key_stride,
+                              hipStream_t st);
+// top-n of count[q] keys, unordered output (radix select); n_out[q] = min(n, count[q])
+int flmr_launch_select_topn(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t nqueries,
+                            int32_t n, int32_t* out_pids, int64_t out_stride, int32_t* n_out, hipStream_t st);
+// sorted (descending key) top-n of count[q] <= FLMR_MAX_NDOCS keys; writes pids (+ optional scores), n_out.
+// pad_pid / pad_score fill positions [n_out, n) when fill != 0.
+int flmr_launch_sort_topn(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t max_count,
+                          int32_t nqueries, int32_t n, int32_t* out_pids, float* out_scores, int64_t out_stride,
+                          int32_t* n_out, int64_t pid_base, int fill, hipStream_t st);
+
+struct flmr_maxsim_args {
+    const flmr_index* ix;
+    const float* Q;           // [nqueries, nq, 128]
+    const int32_t* q_lens;    // nullable
+    int32_t nqueries, nq;
+    const int32_t* pids;      // [nqueries, pid_stride]
+    int64_t pid_stride;
+    const int32_t* counts;    // [nqueries]
+    int32_t max_count;
+    uint64_t* keys;           // out [nqueries, key_stride] (score,pid) keys   (nullable)
+    int64_t key_stride;
+    float* scores;            // out [nqueries, key_stride] fp32 scores        (nullable)
+};
+int flmr_launch_maxsim(const flmr_maxsim_args& a, hipStream_t st);
+
+int flmr_launch_exclusive_scan_lengths(const int32_t* pids, const int64_t* doclens, const int64_t* offsets, int32_t n,
+                                       int64_t* out_offsets /* [n+1] */, hipStream_t st);

@@ -1,0 +1,97 @@
+// Device-side helpers (wave64 reductions, block scans, small sorted lists) for the gfx950 kernels.
+#pragma once
+#include "flmr_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define FLMR_NEG_INF (-__builtin_huge_valf())
+
+// ---- top-NC list ordered by (value desc, index asc) --------------------------------------------
+// Used for the per-query-token probe of the `ncells` best centroids (candidate_generation.py:12-20).
+template <int NC>
+struct flmr_toplist {
+    float v[NC];
+    int id[NC];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int t = 0; t < NC; t++) { v[t] = FLMR_NEG_INF; id[t] = 0x7fffffff; }
+    }
+    __device__ __forceinline__ void insert(float x, int i) {
+#pragma unroll
+        for (int t = NC - 1; t >= 0; --t) {
+            const bool better = (x > v[t]) || (x == v[t] && i < id[t]);
+            if (better) {
+                if (t + 1 < NC) { v[t + 1] = v[t]; id[t + 1] = id[t]; }
+                v[t] = x; id[t] = i;
+            }
+        }
+    }
+    // merge with the list held by lane (lane ^ mask)
+    __device__ __forceinline__ void merge_xor(int mask) {
+        float ov[NC]; int oi[NC];
+#pragma unroll
+        for (int t = 0; t < NC; t++) { ov[t] = __shfl_xor(v[t], mask, 64); oi[t] = __shfl_xor(id[t], mask, 64); }
+#pragma unroll
+        for (int t = 0; t < NC; t++) insert(ov[t], oi[t]);
+    }
+};
+
+// ---- wave / block reductions ------------------------------------------------------------------
+__device__ __forceinline__ float flmr_half_wave_max(float x) {  // max over the 32 lanes sharing lane>>5
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) x = fmaxf(x, __shfl_xor(x, m, 64));
+    return x;
+}
+__device__ __forceinline__ int flmr_wave_inclusive_scan(int x, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+// exclusive scan over a block of up to 1024 threads; `lds` needs 17 ints; returns exclusive prefix, sets total
+__device__ __forceinline__ int flmr_block_exclusive_scan(int x, int* lds, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    int inc = flmr_wave_inclusive_scan(x, lane);
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        int w = (lane < nw) ? lds[lane] : 0;
+        int winc = flmr_wave_inclusive_scan(w, lane);
+        if (lane < nw) lds[lane] = winc - w;
+        if (lane == nw - 1) lds[16] = winc;
+    }
+    __syncthreads();
+    int res = inc - x + lds[wave];
+    *total = lds[16];
+    __syncthreads();
+    return res;
+}
+
+// ---- in-LDS bitonic sort, descending, n a power of two ------------------------------------------
+template <typename T>
+__device__ __forceinline__ void flmr_bitonic_sort_desc(T* s, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < n; t += blockDim.x) {
+                int p = t ^ j;
+                if (p > t) {
+                    T a = s[t], b = s[p];
+                    bool desc = ((t & k) == 0);
+                    if (desc ? (a < b) : (a > b)) { s[t] = b; s[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// sequential fp32 sum of per-column maxima, the reference's `score += per_doc_approx_scores[k]` order
+// (filter_pids.cpp:59-63): kept strictly k-ascending so pruning decisions are bit-identical to the CPU path.
+__device__ __forceinline__ float flmr_seq_sum(const float* v, int n) {
+    float s = 0.0f;
+    for (int k = 0; k < n; k++) s += v[k];
+    return s;
+}

@@ -1,0 +1,300 @@
+// Op-level entry points: 1:1 replacements of the reference's four pybind functions + the scoring head.
+//   filter_pids_cpp           TPC/search/filter_pids.cpp:126-164
+//   decompress_residuals_cpp  TPC/search/decompress_residuals.cpp:80-155 (CUDA twin: indexing/codecs/decompress_residuals.cu)
+//   segmented_lookup_cpp      TPC/search/segmented_lookup.cpp:127-144
+//   segmented_maxsim_cpp      TPC/modeling/segmented_maxsim.cpp:49-93
+//   colbert_score (padded)    TPC/modeling/colbert.py:235-286
+// These exist so each stage can be parity-tested in isolation and slotted behind the reference's class
+// attributes (IndexScorer.filter_pids, ...).  The batched search path (flmr_search.hip) does not use them.
+#include "flmr_device.h"
+
+// RAII-less scratch helper: ops allocate small temporaries and free them after a stream sync.
+struct scratch {
+    void* p[8];
+    int n = 0;
+    ~scratch() { for (int i = 0; i < n; i++) (void)hipFree(p[i]); }
+    template <typename T>
+    int alloc(T** out, size_t count) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, (count ? count : 1) * sizeof(T));
+        if (e != hipSuccess) { snprintf(flmr_err_buf, sizeof(flmr_err_buf), "hipMalloc: %s", hipGetErrorString(e)); return FLMR_ERR_HIP; }
+        p[n++] = q;
+        *out = static_cast<T*>(q);
+        return FLMR_OK;
+    }
+};
+#define RUN(x)             \
+    do {                   \
+        int rc__ = (x);    \
+        if (rc__) return rc__; \
+    } while (0)
+
+// ---- filter_pids -------------------------------------------------------------------------------
+__global__ void pack_idx_bits_kernel(const uint8_t* idx, int K, uint32_t* bits, int words) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= words) return;
+    uint32_t v = 0;
+    for (int b = 0; b < 32; b++) {
+        const int c = w * 32 + b;
+        if (c < K && idx[c]) v |= 1u << b;
+    }
+    bits[w] = v;
+}
+__global__ void set_i32_kernel(int32_t* p, int32_t v) { *p = v; }
+
+extern "C" int flmr_filter_pids(const int32_t* pids, int64_t npids, const float* cs, int32_t K, int32_t nq,
+                                const int32_t* codes, const int64_t* doclens, const int64_t* offsets, const uint8_t* idx,
+                                int32_t ndocs, int32_t* out_pids, int32_t* out_count, flmr_stream_t stream) {
+    if (!pids || !cs || !codes || !offsets || !idx || !out_pids || !out_count) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    if (ndocs < 4 || ndocs > FLMR_MAX_NDOCS) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "ndocs=%d (4..%d)", ndocs, FLMR_MAX_NDOCS);
+    if (nq < 1 || nq > FLMR_MAX_NQ_CAND) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nq=%d (1..%d)", nq, FLMR_MAX_NQ_CAND);
+    if (npids > 0x7fffffffLL) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "npids too large");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    scratch sc;
+    const int words = (int)flmr_ceil_div(K, 32);
+    uint32_t* bits; uint64_t *keys1, *keys2; int32_t *cnt, *s1, *n1;
+    RUN(sc.alloc(&bits, words));
+    RUN(sc.alloc(&keys1, (size_t)(npids > 0 ? npids : 1)));
+    RUN(sc.alloc(&keys2, ndocs));
+    RUN(sc.alloc(&cnt, 1));
+    RUN(sc.alloc(&s1, ndocs));
+    RUN(sc.alloc(&n1, 1));
+    hipLaunchKernelGGL(pack_idx_bits_kernel, dim3((unsigned)flmr_ceil_div(words, 256)), dim3(256), 0, st, idx, K, bits, words);
+    hipLaunchKernelGGL(set_i32_kernel, dim3(1), dim3(1), 0, st, cnt, (int32_t)npids);
+    flmr_filter_args f;
+    f.cs = cs; f.cs_query_stride = 0; f.K = K; f.ncol = nq; f.nq_cand = nq; f.nqueries = 1; f.q_lens = nullptr;
+    f.codes = codes; f.doclens = doclens; f.offsets = offsets;
+    const int64_t stride = npids > 0 ? npids : 1;
+    RUN(flmr_launch_filter_stage1(f, bits, words, pids, stride, cnt, keys1, st));
+    RUN(flmr_launch_select_topn(keys1, stride, cnt, 1, ndocs, s1, ndocs, n1, st));
+    RUN(flmr_launch_filter_stage2(f, s1, ndocs, n1, ndocs, keys2, ndocs, st));
+    RUN(flmr_launch_sort_topn(keys2, ndocs, n1, ndocs, 1, ndocs / 4, out_pids, nullptr, ndocs / 4, out_count, 0, 0, st));
+    FLMR_HIP(hipStreamSynchronize(st));
+    return FLMR_OK;
+}
+
+// ---- decompress_residuals ------------------------------------------------------------------------
+// one workgroup per document, one half-wave per token row, lane j owns dims 4j..4j+3
+__global__ __launch_bounds__(256) void decompress_rows_kernel(const int32_t* pids, const int64_t* doclens,
+                                                              const int64_t* offsets, const float* bucket_weights,
+                                                              const uint8_t* rev, const uint8_t* combos,
+                                                              const uint8_t* residuals, const int32_t* codes,
+                                                              const float* centroids, int dim, int nbits,
+                                                              const int64_t* out_row_offsets, float* out,
+                                                              int64_t out_capacity_rows) {
+    const int pid = pids[blockIdx.x];
+    const int64_t off = offsets[pid];
+    const int len = (int)(doclens ? doclens[pid] : (offsets[pid + 1] - offsets[pid]));
+    const int64_t orow = out_row_offsets[blockIdx.x];
+    const int vpb = 8 / nbits, packed = dim / vpb;
+    const int hw = threadIdx.x >> 5, j = threadIdx.x & 31;
+    for (int t = hw; t < len; t += 8) {
+        if (orow + t >= out_capacity_rows) return;
+        const int code = codes[off + t];
+        const uint8_t* rb = residuals + (size_t)(off + t) * packed;
+        for (int d0 = 4 * j; d0 < dim; d0 += 128) {
+            float4 v;
+            float* vp = reinterpret_cast<float*>(&v);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int d = d0 + e;
+                const int x = rev[rb[d / vpb]];
+                vp[e] = bucket_weights[combos[x * vpb + (d % vpb)]] + centroids[(size_t)code * dim + d];
+            }
+            *reinterpret_cast<float4*>(out + (size_t)(orow + t) * dim + d0) = v;
+        }
+    }
+}
+
+extern "C" int flmr_decompress_residuals(const int32_t* pids, int32_t npids, const int64_t* doclens, const int64_t* offsets,
+                                         const float* bucket_weights, const uint8_t* rev, const uint8_t* combos,
+                                         const uint8_t* residuals, const int32_t* codes, const float* centroids,
+                                         int32_t dim, int32_t nbits, float* out, int64_t out_capacity_rows,
+                                         int64_t* out_row_offsets, flmr_stream_t stream) {
+    if (!pids || !offsets || !bucket_weights || !rev || !combos || !residuals || !codes || !centroids || !out)
+        FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    if (dim % 128 != 0) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "dim=%d must be a multiple of 128", dim);
+    if (nbits != 1 && nbits != 2 && nbits != 4 && nbits != 8) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nbits=%d", nbits);
+    if (npids <= 0) return FLMR_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    scratch sc;
+    int64_t* ro = out_row_offsets;
+    if (!ro) RUN(sc.alloc(&ro, (size_t)npids + 1));
+    RUN(flmr_launch_exclusive_scan_lengths(pids, doclens, offsets, npids, ro, st));
+    hipLaunchKernelGGL(decompress_rows_kernel, dim3(npids), dim3(256), 0, st, pids, doclens, offsets, bucket_weights, rev,
+                       combos, residuals, codes, centroids, dim, nbits, ro, out, out_capacity_rows);
+    FLMR_LAUNCH_CHECK();
+    FLMR_HIP(hipStreamSynchronize(st));
+    return FLMR_OK;
+}
+
+// ---- segmented_lookup ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void segmented_copy_kernel(const uint8_t* in, int64_t row_bytes, const int64_t* lengths,
+                                                             const int64_t* offsets, const int64_t* out_row_offsets,
+                                                             uint8_t* out, int64_t out_capacity_rows) {
+    const int i = blockIdx.x;
+    const int64_t nbytes = lengths[i] * row_bytes;
+    if (out_row_offsets[i] + lengths[i] > out_capacity_rows) return;
+    const uint8_t* src = in + offsets[i] * row_bytes;
+    uint8_t* dst = out + out_row_offsets[i] * row_bytes;
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)nbytes) & 3) == 0) {
+        const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src);
+        uint32_t* d4 = reinterpret_cast<uint32_t*>(dst);
+        for (int64_t e = threadIdx.x; e < nbytes / 4; e += blockDim.x) d4[e] = s4[e];
+    } else {
+        for (int64_t e = threadIdx.x; e < nbytes; e += blockDim.x) dst[e] = src[e];
+    }
+}
+
+extern "C" int flmr_segmented_lookup(const void* input, int64_t row_bytes, const int64_t* lengths, const int64_t* offsets,
+                                     int32_t nseg, void* out, int64_t out_capacity_rows, int64_t* out_row_offsets,
+                                     flmr_stream_t stream) {
+    if (!input || !lengths || !offsets || !out) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    if (nseg <= 0) return FLMR_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    scratch sc;
+    int64_t* ro = out_row_offsets;
+    if (!ro) RUN(sc.alloc(&ro, (size_t)nseg + 1));
+    RUN(flmr_launch_exclusive_scan_lengths(nullptr, lengths, nullptr, nseg, ro, st));
+    hipLaunchKernelGGL(segmented_copy_kernel, dim3(nseg), dim3(256), 0, st, static_cast<const uint8_t*>(input), row_bytes,
+                       lengths, offsets, ro, static_cast<uint8_t*>(out), out_capacity_rows);
+    FLMR_LAUNCH_CHECK();
+    FLMR_HIP(hipStreamSynchronize(st));
+    return FLMR_OK;
+}
+
+// ---- segmented_maxsim ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void segmented_maxsim_kernel(const float* scores, const int64_t* row_offsets, int nq,
+                                                               float* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* colmax = reinterpret_cast<float*>(smem);
+    const int i = blockIdx.x;
+    const int64_t r0 = row_offsets[i], r1 = row_offsets[i + 1];
+    for (int k = threadIdx.x; k < nq; k += blockDim.x) {
+        float m = 0.0f;  // zero-initialised running max (segmented_maxsim.cpp:58-59)
+        for (int64_t r = r0; r < r1; r++) m = fmaxf(m, scores[(size_t)r * nq + k]);
+        colmax[k] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out[i] = flmr_seq_sum(colmax, nq);
+}
+
+extern "C" int flmr_segmented_maxsim(const float* scores, const int64_t* lengths, int32_t ndocs, int32_t nq, float* out,
+                                     flmr_stream_t stream) {
+    if (!scores || !lengths || !out) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    if (ndocs <= 0) return FLMR_OK;
+    if ((size_t)nq * 4 > 64 * 1024) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nq=%d too large", nq);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    scratch sc;
+    int64_t* ro;
+    RUN(sc.alloc(&ro, (size_t)ndocs + 1));
+    RUN(flmr_launch_exclusive_scan_lengths(nullptr, lengths, nullptr, ndocs, ro, st));
+    hipLaunchKernelGGL(segmented_maxsim_kernel, dim3(ndocs), dim3(256), (size_t)nq * 4, st, scores, ro, nq, out);
+    FLMR_LAUNCH_CHECK();
+    FLMR_HIP(hipStreamSynchronize(st));
+    return FLMR_OK;
+}
+
+// ---- fused decompress + normalise + MaxSim for an explicit pid list ----------------------------------
+extern "C" int flmr_score_pids(const flmr_index_t* ix, const float* Q, int32_t nq, const int32_t* pids, int32_t npids,
+                               float* out, flmr_stream_t stream) {
+    if (!ix || !Q || !pids || !out) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    if (npids <= 0) return FLMR_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    scratch sc;
+    int32_t* cnt;
+    RUN(sc.alloc(&cnt, 1));
+    hipLaunchKernelGGL(set_i32_kernel, dim3(1), dim3(1), 0, st, cnt, npids);
+    flmr_maxsim_args m;
+    m.ix = ix; m.Q = Q; m.q_lens = nullptr; m.nqueries = 1; m.nq = nq; m.pids = pids; m.pid_stride = npids;
+    m.counts = cnt; m.max_count = npids; m.keys = nullptr; m.key_stride = npids; m.scores = out;
+    RUN(flmr_launch_maxsim(m, st));
+    FLMR_HIP(hipStreamSynchronize(st));
+    return FLMR_OK;
+}
+
+// ---- colbert_score, padded variant (-9999 padding, no clamp) ------------------------------------------
+__global__ __launch_bounds__(256) void colbert_score_padded_kernel(const float* Q, int q_batch, int nq, const float* D,
+                                                                   const uint8_t* mask, int Ld, int dim, float* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned int* colmax = reinterpret_cast<unsigned int*>(smem);  // order-preserving uint image of the fp32 max
+    const int b = blockIdx.x;
+    const float* Qb = Q + (q_batch == 1 ? 0 : (size_t)b * nq * dim);
+    for (int k = threadIdx.x; k < nq; k += blockDim.x) colmax[k] = 0u;  // below every real value
+    __syncthreads();
+    for (int e = threadIdx.x; e < Ld * nq; e += blockDim.x) {
+        const int t = e / nq, j = e % nq;
+        float v = -9999.0f;
+        if (mask[(size_t)b * Ld + t]) {
+            const float* dr = D + ((size_t)b * Ld + t) * dim;
+            const float* qr = Qb + (size_t)j * dim;
+            v = 0.0f;
+            for (int k = 0; k < dim; k++) v = fmaf(dr[k], qr[k], v);
+        }
+        atomicMax(&colmax[j], flmr_f2ord(v));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.0f;
+        for (int k = 0; k < nq; k++) s += (Ld > 0) ? flmr_ord2f(colmax[k]) : FLMR_NEG_INF;
+        out[b] = s;
+    }
+}
+
+extern "C" int flmr_colbert_score_padded(const float* Q, int32_t q_batch, int32_t nq, const float* D, const uint8_t* mask,
+                                         int32_t B, int32_t Ld, int32_t dim, float* out, flmr_stream_t stream) {
+    if (!Q || !D || !mask || !out) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    if (q_batch != 1 && q_batch != B) FLMR_FAIL(FLMR_ERR_INVALID, "q_batch must be 1 or B");
+    if (B <= 0) return FLMR_OK;
+    if ((size_t)nq * 4 > 64 * 1024) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nq=%d too large", nq);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(colbert_score_padded_kernel, dim3(B), dim3(256), (size_t)nq * 4, st, Q, q_batch, nq, D, mask, Ld, dim,
+                       out);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
+// ---- merge of per-shard top-k lists (after the RCCL all-gather) -----------------------------------------
+__global__ __launch_bounds__(1024) void merge_topk_kernel(const float* scores, const int32_t* pids, int nshards,
+                                                          int nqueries, int k, int npow2, float* out_scores,
+                                                          int32_t* out_pids, int32_t* out_counts) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);
+    const int q = blockIdx.x;
+    for (int e = threadIdx.x; e < npow2; e += blockDim.x) {
+        unsigned long long key = 0ull;
+        if (e < nshards * k) {
+            const int sh = e / k, i = e % k;
+            const size_t src = ((size_t)sh * nqueries + q) * k + i;
+            if (pids[src] >= 0) key = flmr_make_key(scores[src], pids[src]);
+        }
+        s[e] = key;
+    }
+    __syncthreads();
+    flmr_bitonic_sort_desc<unsigned long long>(s, npow2);
+    int cnt = 0;
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        const unsigned long long key = s[i];
+        const bool ok = key != 0ull;
+        out_pids[(size_t)q * k + i] = ok ? flmr_key_pid(key) : -1;
+        out_scores[(size_t)q * k + i] = ok ? flmr_key_score(key) : 0.0f;
+    }
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < k; i++) cnt += (s[i] != 0ull);
+        out_counts[q] = cnt;
+    }
+}
+
+extern "C" int flmr_merge_topk(const float* scores, const int32_t* pids, int32_t nshards, int32_t nqueries, int32_t k,
+                               float* out_scores, int32_t* out_pids, int32_t* out_counts, flmr_stream_t stream) {
+    if (!scores || !pids || !out_scores || !out_pids || !out_counts) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    if (nshards < 1 || nqueries < 1 || k < 1) FLMR_FAIL(FLMR_ERR_INVALID, "bad sizes");
+    if ((int64_t)nshards * k > FLMR_MAX_NDOCS) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nshards*k=%d > %d", nshards * k, FLMR_MAX_NDOCS);
+    int npow2 = 2;
+    while (npow2 < nshards * k || npow2 < k) npow2 <<= 1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(nqueries), dim3(1024), (size_t)npow2 * 8, st, scores, pids, nshards, nqueries,
+                       k, npow2, out_scores, out_pids, out_counts);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}

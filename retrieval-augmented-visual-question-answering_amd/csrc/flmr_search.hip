@@ -1,0 +1,252 @@
+// Batched search orchestration: workspace planning + the S0..S4 launch sequence on one HIP stream.
+// Replaces Searcher._search_all_Q / dense_search / IndexScorer.rank (TPC/searcher.py:73-132,
+// TPC/search/index_storage.py:67-182) for a whole batch of queries at once.
+#include <new>
+
+#include "flmr_common.h"
+
+static const char* kStageNames[FLMR_NUM_STAGES] = {
+    "s0_centroid_scores", "s0_select_cells", "s0_candidates", "s1_filter", "s1_select", "s2_filter_sort",
+    "s3_maxsim", "s4_topk"};
+
+extern "C" const char* flmr_stage_name(int32_t s) { return (s >= 0 && s < FLMR_NUM_STAGES) ? kStageNames[s] : "?"; }
+
+struct flmr_searcher {
+    const flmr_index* ix;
+    int32_t max_queries, max_nq;
+    flmr_search_params_t maxp;
+    int32_t ncol_max, idx_words, nblk, max_cells, nc_bucket;
+    int64_t bitmap_words, cand_cap, bytes;
+    float* cs; uint32_t* idx_bits; float* part_val; int32_t* part_idx; int32_t* cells; int32_t* ncell;
+    uint32_t* bitmap; int32_t* cand; int32_t* cand_count; uint64_t* keys1; int32_t* s1_pids; int32_t* s1_count;
+    uint64_t* keys2; int32_t* s2_pids; int32_t* s2_count; uint64_t* keys3; float* doc_scores; int32_t* overflow;
+    // last call (for taps)
+    int32_t last_nqueries, last_ncol, last_ndocs;
+    hipStream_t last_stream;
+    bool profiling;
+    hipEvent_t ev[FLMR_NUM_STAGES + 1];
+    bool have_ms;
+};
+
+static int nc_bucket_of(int ncells) { return ncells <= 1 ? 1 : ncells <= 2 ? 2 : ncells <= 4 ? 4 : 8; }
+
+template <typename T>
+static int ws_alloc(flmr_searcher* s, T** p, size_t count) {
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    FLMR_HIP(hipMalloc(reinterpret_cast<void**>(p), bytes));
+    s->bytes += (int64_t)bytes;
+    return FLMR_OK;
+}
+
+static int check_params(const flmr_search_params_t* p) {
+    if (!p) FLMR_FAIL(FLMR_ERR_INVALID, "params is NULL");
+    if (p->ncells < 1 || p->ncells > FLMR_MAX_NCELLS) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "ncells=%d (1..%d)", p->ncells, FLMR_MAX_NCELLS);
+    if (p->ndocs < 4 || p->ndocs > FLMR_MAX_NDOCS) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "ndocs=%d (4..%d)", p->ndocs, FLMR_MAX_NDOCS);
+    if (p->nq_cand < 1 || p->nq_cand > FLMR_MAX_NQ_CAND) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nq_cand=%d (1..%d)", p->nq_cand, FLMR_MAX_NQ_CAND);
+    if (p->k < 1) FLMR_FAIL(FLMR_ERR_INVALID, "k=%d", p->k);
+    return FLMR_OK;
+}
+
+extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries, int32_t max_nq,
+                                    const flmr_search_params_t* maxp, flmr_searcher_t** out) {
+    if (!ix || !out) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    int rc = check_params(maxp);
+    if (rc) return rc;
+    if (max_queries < 1 || max_nq < 1) FLMR_FAIL(FLMR_ERR_INVALID, "max_queries/max_nq must be >= 1");
+    flmr_searcher* s = new (std::nothrow) flmr_searcher();
+    if (!s) FLMR_FAIL(FLMR_ERR_NOMEM, "host allocation failed");
+    memset(s, 0, sizeof(*s));
+    s->ix = ix; s->max_queries = max_queries; s->max_nq = max_nq; s->maxp = *maxp;
+    const int nqc = maxp->nq_cand < max_nq ? maxp->nq_cand : max_nq;
+    s->ncol_max = (int32_t)flmr_round_up(nqc, 32);
+    s->idx_words = (int32_t)flmr_ceil_div(ix->K, 32);
+    s->nblk = (int32_t)flmr_ceil_div(ix->K, 128);
+    s->max_cells = nqc * maxp->ncells;
+    s->nc_bucket = nc_bucket_of(maxp->ncells);
+    s->bitmap_words = flmr_ceil_div(ix->num_passages > 0 ? ix->num_passages : 1, 32);
+    const int mc = s->max_cells < ix->K ? s->max_cells : ix->K;
+    s->cand_cap = ix->ivf_len_prefix[mc] < ix->num_passages ? ix->ivf_len_prefix[mc] : ix->num_passages;
+    if (s->cand_cap < 1) s->cand_cap = 1;
+    const size_t B = (size_t)max_queries;
+    const int nd = maxp->ndocs, nd4 = maxp->ndocs / 4;
+#define WS(ptr, count)                          \
+    do {                                        \
+        rc = ws_alloc(s, &s->ptr, (count));     \
+        if (rc) { flmr_searcher_destroy(s); return rc; } \
+    } while (0)
+    WS(cs, B * (size_t)ix->K * s->ncol_max);
+    WS(idx_bits, B * (size_t)s->idx_words);
+    WS(part_val, B * (size_t)s->nblk * s->ncol_max * s->nc_bucket);
+    WS(part_idx, B * (size_t)s->nblk * s->ncol_max * s->nc_bucket);
+    WS(cells, B * (size_t)s->max_cells);
+    WS(ncell, B);
+    WS(bitmap, B * (size_t)s->bitmap_words);
+    WS(cand, B * (size_t)s->cand_cap);
+    WS(cand_count, B);
+    WS(keys1, B * (size_t)s->cand_cap);
+    WS(s1_pids, B * (size_t)nd);
+    WS(s1_count, B);
+    WS(keys2, B * (size_t)nd);
+    WS(s2_pids, B * (size_t)nd4);
+    WS(s2_count, B);
+    WS(keys3, B * (size_t)nd4);
+    WS(doc_scores, B * (size_t)nd4);
+    WS(overflow, 1);
+#undef WS
+    FLMR_HIP(hipMemset(s->overflow, 0, sizeof(int32_t)));
+    for (int i = 0; i <= FLMR_NUM_STAGES; i++) FLMR_HIP(hipEventCreate(&s->ev[i]));
+    *out = s;
+    return FLMR_OK;
+}
+
+extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
+    if (!s) return FLMR_OK;
+    void* ptrs[] = {s->cs, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
+                    s->keys1, s->s1_pids, s->s1_count, s->keys2, s->s2_pids, s->s2_count, s->keys3, s->doc_scores,
+                    s->overflow};
+    for (void* p : ptrs) (void)hipFree(p);
+    for (int i = 0; i <= FLMR_NUM_STAGES; i++)
+        if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
+    delete s;
+    return FLMR_OK;
+}
+
+extern "C" int flmr_searcher_workspace_bytes(const flmr_searcher_t* s, int64_t* bytes) {
+    if (!s || !bytes) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    *bytes = s->bytes;
+    return FLMR_OK;
+}
+
+extern "C" int flmr_searcher_set_profiling(flmr_searcher_t* s, int32_t enable) {
+    if (!s) FLMR_FAIL(FLMR_ERR_INVALID, "NULL searcher");
+    s->profiling = enable != 0;
+    s->have_ms = false;
+    return FLMR_OK;
+}
+
+extern "C" int flmr_searcher_stage_ms(flmr_searcher_t* s, float* ms) {
+    if (!s || !ms) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    if (!s->have_ms) FLMR_FAIL(FLMR_ERR_INVALID, "no profiled flmr_search_batch call yet");
+    FLMR_HIP(hipEventSynchronize(s->ev[FLMR_NUM_STAGES]));
+    for (int i = 0; i < FLMR_NUM_STAGES; i++) FLMR_HIP(hipEventElapsedTime(&ms[i], s->ev[i], s->ev[i + 1]));
+    return FLMR_OK;
+}
+
+extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32_t* q_lens, int32_t nqueries,
+                                 int32_t nq, const flmr_search_params_t* p, int32_t* out_pids, float* out_scores,
+                                 int32_t* out_counts, flmr_stream_t stream) {
+    if (!s || !Q || !out_pids || !out_scores || !out_counts) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (nqueries < 1 || nqueries > s->max_queries) FLMR_FAIL(FLMR_ERR_CAPACITY, "nqueries=%d > max_queries=%d", nqueries, s->max_queries);
+    if (nq < 1 || nq > s->max_nq) FLMR_FAIL(FLMR_ERR_CAPACITY, "nq=%d > max_nq=%d", nq, s->max_nq);
+    const int nqc = p->nq_cand < nq ? p->nq_cand : nq;
+    const int ncol = (int)flmr_round_up(nqc, 32);
+    if (ncol > s->ncol_max || nqc * p->ncells > s->max_cells || nc_bucket_of(p->ncells) > s->nc_bucket ||
+        p->ndocs > s->maxp.ndocs)
+        FLMR_FAIL(FLMR_ERR_CAPACITY, "params exceed the bounds given at flmr_searcher_create");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const flmr_index* ix = s->ix;
+    const bool prof = s->profiling;
+    int stage = 0;
+#define MARK()                                            \
+    do {                                                  \
+        if (prof) FLMR_HIP(hipEventRecord(s->ev[stage], st)); \
+        stage++;                                          \
+    } while (0)
+#define RUN(x)          \
+    do {                \
+        rc = (x);       \
+        if (rc) return rc; \
+    } while (0)
+
+    // ---- S0: centroid scores, idx bits, probed cells ----------------------------------------------
+    flmr_s0_args a0;
+    a0.centroids = ix->centroids; a0.Q = Q; a0.q_lens = q_lens;
+    a0.K = ix->K; a0.nqueries = nqueries; a0.nq = nq; a0.nq_cand = nqc; a0.ncol = ncol; a0.ncells = p->ncells;
+    a0.thr = p->centroid_score_threshold;
+    a0.cs = s->cs; a0.idx_bits = s->idx_bits; a0.idx_words = s->idx_words;
+    a0.part_val = s->part_val; a0.part_idx = s->part_idx; a0.nblk = s->nblk;
+    a0.cells = s->cells; a0.ncell = s->ncell; a0.max_cells = s->max_cells;
+    MARK();
+    RUN(flmr_launch_centroid_scores(a0, st));
+    MARK();
+    RUN(flmr_launch_select_cells(a0, st));
+    MARK();
+    // ---- S0c/d: IVF union -> ascending candidate pids ---------------------------------------------
+    RUN(flmr_launch_ivf_mark(s->cells, s->ncell, s->max_cells, nqueries, ix->ivf_pids, ix->ivf_offsets, s->bitmap,
+                             s->bitmap_words, st));
+    RUN(flmr_launch_compact(s->bitmap, s->bitmap_words, ix->num_passages, nqueries, s->cand, s->cand_cap,
+                            s->cand_count, s->overflow, st));
+    MARK();
+    // ---- S1: pruned centroid MaxSim over the candidates, keep ndocs ---------------------------------
+    flmr_filter_args f;
+    f.cs = s->cs; f.cs_query_stride = (int64_t)ix->K * ncol; f.K = ix->K; f.ncol = ncol; f.nq_cand = nqc;
+    f.nqueries = nqueries; f.q_lens = q_lens; f.codes = ix->codes; f.doclens = nullptr; f.offsets = ix->doc_offsets;
+    RUN(flmr_launch_filter_stage1(f, s->idx_bits, s->idx_words, s->cand, s->cand_cap, s->cand_count, s->keys1, st));
+    MARK();
+    RUN(flmr_launch_select_topn(s->keys1, s->cand_cap, s->cand_count, nqueries, p->ndocs, s->s1_pids, s->maxp.ndocs,
+                                s->s1_count, st));
+    MARK();
+    // ---- S2: full centroid MaxSim over the survivors, keep ndocs/4 in (score,pid) order ----------------
+    RUN(flmr_launch_filter_stage2(f, s->s1_pids, s->maxp.ndocs, s->s1_count, p->ndocs, s->keys2, s->maxp.ndocs, st));
+    RUN(flmr_launch_sort_topn(s->keys2, s->maxp.ndocs, s->s1_count, p->ndocs, nqueries, p->ndocs / 4, s->s2_pids,
+                              nullptr, s->maxp.ndocs / 4, s->s2_count, 0, 0, st));
+    MARK();
+    // ---- S3: decompress + normalise + MaxSim --------------------------------------------------------
+    flmr_maxsim_args m;
+    m.ix = ix; m.Q = Q; m.q_lens = q_lens; m.nqueries = nqueries; m.nq = nq;
+    m.pids = s->s2_pids; m.pid_stride = s->maxp.ndocs / 4; m.counts = s->s2_count; m.max_count = p->ndocs / 4;
+    m.keys = s->keys3; m.key_stride = s->maxp.ndocs / 4; m.scores = s->doc_scores;
+    RUN(flmr_launch_maxsim(m, st));
+    MARK();
+    // ---- S4: final ranking, global pids ---------------------------------------------------------------
+    RUN(flmr_launch_sort_topn(s->keys3, s->maxp.ndocs / 4, s->s2_count, p->ndocs / 4, nqueries, p->k, out_pids,
+                              out_scores, p->k, out_counts, ix->pid_base, 1, st));
+    MARK();
+#undef MARK
+#undef RUN
+    s->last_nqueries = nqueries; s->last_ncol = ncol; s->last_ndocs = p->ndocs; s->last_stream = st;
+    s->have_ms = prof;
+    return FLMR_OK;
+}
+
+extern "C" int flmr_searcher_tap(flmr_searcher_t* s, int32_t what, int32_t q, void* host_out, int64_t capacity,
+                                 int64_t* count) {
+    if (!s || !host_out || !count) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    if (q < 0 || q >= s->last_nqueries) FLMR_FAIL(FLMR_ERR_INVALID, "query %d outside the last batch (%d)", q, s->last_nqueries);
+    FLMR_HIP(hipStreamSynchronize(s->last_stream));
+    const flmr_index* ix = s->ix;
+    const void* src = nullptr;
+    int64_t n = 0;
+    size_t esz = 4;
+    int32_t c = 0;
+    const int nd4 = s->maxp.ndocs / 4;
+    switch (what) {
+        case FLMR_TAP_CENTROID_SCORES:
+            n = (int64_t)ix->K * s->last_ncol; src = s->cs + (size_t)q * n; break;
+        case FLMR_TAP_IDX_BITS:
+            n = s->idx_words; src = s->idx_bits + (size_t)q * n; break;
+        case FLMR_TAP_CELLS:
+            FLMR_HIP(hipMemcpy(&c, s->ncell + q, 4, hipMemcpyDeviceToHost));
+            n = c; src = s->cells + (size_t)q * s->max_cells; break;
+        case FLMR_TAP_CANDIDATES:
+            FLMR_HIP(hipMemcpy(&c, s->cand_count + q, 4, hipMemcpyDeviceToHost));
+            n = c; src = s->cand + (size_t)q * s->cand_cap; break;
+        case FLMR_TAP_STAGE1:
+            FLMR_HIP(hipMemcpy(&c, s->s1_count + q, 4, hipMemcpyDeviceToHost));
+            n = c; src = s->s1_pids + (size_t)q * s->maxp.ndocs; break;
+        case FLMR_TAP_STAGE2:
+            FLMR_HIP(hipMemcpy(&c, s->s2_count + q, 4, hipMemcpyDeviceToHost));
+            n = c; src = s->s2_pids + (size_t)q * nd4; break;
+        case FLMR_TAP_DOC_SCORES:
+            FLMR_HIP(hipMemcpy(&c, s->s2_count + q, 4, hipMemcpyDeviceToHost));
+            n = c; src = s->doc_scores + (size_t)q * nd4; break;
+        default: FLMR_FAIL(FLMR_ERR_INVALID, "unknown tap %d", what);
+    }
+    *count = n;
+    if (n > capacity) FLMR_FAIL(FLMR_ERR_CAPACITY, "tap needs %lld elements, capacity %lld", (long long)n, (long long)capacity);
+    if (n) FLMR_HIP(hipMemcpy(host_out, src, (size_t)n * esz, hipMemcpyDeviceToHost));
+    return FLMR_OK;
+}

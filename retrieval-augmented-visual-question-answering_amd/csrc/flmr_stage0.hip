@@ -1,0 +1,358 @@
+// Stage 0 of the search path: centroid scores, probed cells, IVF union -> candidate pids.
+//
+// Reference: TPC/search/candidate_generation.py:12-20 (get_cells: centroids @ Q.T, per-token top-ncells,
+// unique), :31-37 + TPC/search/segmented_lookup.cpp (IVF ragged gather), :45-64 (sort + unique_consecutive)
+// and TPC/search/index_storage.py:116 (idx = max_j score >= thr).
+//
+// MI355X design
+//   * centroid scores are the one dense contraction of the path: [K,128] x [128, nqueries*nq_cand].  It runs on
+//     the fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fmaf chain) with the centroid tile held in
+//     registers for the whole query loop, so the 4*128*K-byte centroid matrix is read once per row block, not once
+//     per query.  The epilogue fuses (a) the fp32 score-table store (the only HBM-sized output: 4*K*ncol bytes
+//     per query, read back sparsely by S1/S2), (b) the row-max >= thr test packed to one bit per centroid
+//     (a wave's 32 rows = one 32-bit word), (c) the per-column top-ncells of the block's 128 rows.
+//   * cells -> candidates: IVF lists are OR-ed into a per-query passage bitmap (idempotent, so duplicates
+//     across cells cost nothing) and compacted with popcount prefix sums into an ascending pid list: the
+//     reference's concatenate + sort + unique without a sort.
+#include "flmr_device.h"
+
+// ------------------------------------------------------------------------------------------------
+// cross-wave merge of the per-column top lists + store of the block partial
+// ------------------------------------------------------------------------------------------------
+template <int NC>
+__device__ __forceinline__ void s0_block_merge_store(flmr_toplist<NC>& tl, float* lds_v, int* lds_i, int wave, int lane,
+                                                     float* part_val, int32_t* part_idx, size_t part_base) {
+    // lds layout [4 waves][32 cols][NC]
+    if (lane < 32) {
+#pragma unroll
+        for (int t = 0; t < NC; t++) {
+            lds_v[(wave * 32 + lane) * NC + t] = tl.v[t];
+            lds_i[(wave * 32 + lane) * NC + t] = tl.id[t];
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 32) {
+        for (int w = 1; w < 4; w++) {
+#pragma unroll
+            for (int t = 0; t < NC; t++) tl.insert(lds_v[(w * 32 + lane) * NC + t], lds_i[(w * 32 + lane) * NC + t]);
+        }
+#pragma unroll
+        for (int t = 0; t < NC; t++) {
+            part_val[part_base + (size_t)lane * NC + t] = tl.v[t];
+            part_idx[part_base + (size_t)lane * NC + t] = tl.id[t];
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// S0a (MFMA): grid = (ceil(K/128), QSPLIT), block = 256 (4 waves x 32 centroid rows)
+// A operand (centroids) lane (i = lane&31, h = lane>>5) holds dims 64h..64h+63 of row i: the MFMA
+// contraction index is a permutation of the embedding dims (k-step s pairs dims s and 64+s), which is
+// just another valid fp32 summation order.
+// ------------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(256) void s0_centroid_scores_mfma(flmr_s0_args a) {
+    __shared__ float lds_v[4 * 32 * NC];
+    __shared__ int lds_i[4 * 32 * NC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * 128 + wave * 32;
+    const int T = a.ncol >> 5;
+
+    float av[64];
+    {
+        const int arow = row0 + i;
+        if (arow < a.K) {
+            const float4* p = reinterpret_cast<const float4*>(a.centroids + (size_t)arow * FLMR_DIM + 64 * h);
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                float4 v = p[t];
+                av[4 * t + 0] = v.x; av[4 * t + 1] = v.y; av[4 * t + 2] = v.z; av[4 * t + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 64; t++) av[t] = 0.0f;
+        }
+    }
+
+    for (int b = blockIdx.y; b < a.nqueries; b += gridDim.y) {
+        const int qlen = a.q_lens ? a.q_lens[b] : a.nq;
+        const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;
+        float rmax[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) rmax[r] = FLMR_NEG_INF;
+        float* cs_b = a.cs + (size_t)b * a.K * a.ncol;
+
+        for (int ct = 0; ct < T; ct++) {
+            const int col = ct * 32 + i;
+            const bool colok = col < nqc;
+            float bv[64];
+            if (colok) {
+                const float4* p = reinterpret_cast<const float4*>(a.Q + ((size_t)b * a.nq + col) * FLMR_DIM + 64 * h);
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    float4 v = p[t];
+                    bv[4 * t + 0] = v.x; bv[4 * t + 1] = v.y; bv[4 * t + 2] = v.z; bv[4 * t + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 64; t++) bv[t] = 0.0f;
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 64; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+
+            flmr_toplist<NC> tl;
+            tl.init();
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D layout of the 32x32 MFMA
+                const int grow = row0 + row;
+                const float v = acc[r];
+                if (grow < a.K) {
+                    cs_b[(size_t)grow * a.ncol + col] = v;
+                    if (colok) tl.insert(v, grow);
+                }
+                rmax[r] = fmaxf(rmax[r], flmr_half_wave_max(colok ? v : FLMR_NEG_INF));
+            }
+            tl.merge_xor(32);
+            const size_t part_base = (((size_t)b * a.nblk + blockIdx.x) * a.ncol + ct * 32) * NC;
+            s0_block_merge_store<NC>(tl, lds_v, lds_i, wave, lane, a.part_val, a.part_idx, part_base);
+        }
+        // idx bits: this wave's 32 rows are exactly one word
+        uint32_t w = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row0 + row < a.K && rmax[r] >= a.thr) w |= 1u << row;
+        }
+        w |= (uint32_t)__shfl_xor((int)w, 32, 64);
+        if (lane == 0 && row0 < a.K) a.idx_bits[(size_t)b * a.idx_words + (row0 >> 5)] = w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S0a (VALU cross-check path, FLMR_S0_IMPL=valu): plain k-ascending fp32 dot products, then a
+// post-processing kernel derives the idx bits and the block partials from the stored table.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void s0_centroid_scores_valu(flmr_s0_args a) {
+    const int b = blockIdx.y;
+    const int qlen = a.q_lens ? a.q_lens[b] : a.nq;
+    const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;
+    const size_t total = (size_t)a.K * a.ncol;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(e / a.ncol), col = (int)(e % a.ncol);
+        float acc = 0.0f;
+        if (col < nqc) {
+            const float* c = a.centroids + (size_t)row * FLMR_DIM;
+            const float* q = a.Q + ((size_t)b * a.nq + col) * FLMR_DIM;
+            for (int k = 0; k < FLMR_DIM; k++) acc = fmaf(c[k], q[k], acc);
+        }
+        a.cs[(size_t)b * total + e] = acc;
+    }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void s0_postprocess_table(flmr_s0_args a) {
+    __shared__ float lds_v[8 * 32 * NC];
+    __shared__ int lds_i[8 * 32 * NC];
+    __shared__ uint32_t lds_bits[4];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int qlen = a.q_lens ? a.q_lens[b] : a.nq;
+    const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;
+    const int row0 = blockIdx.x * 128;
+    const float* cs_b = a.cs + (size_t)b * a.K * a.ncol;
+    // idx bits: thread t < 128 owns row row0+t
+    if (tid < 128) {
+        const int row = row0 + tid;
+        float m = FLMR_NEG_INF;
+        if (row < a.K)
+            for (int c = 0; c < nqc; c++) m = fmaxf(m, cs_b[(size_t)row * a.ncol + c]);
+        const bool flag = (row < a.K) && (m >= a.thr);
+        unsigned long long bal = __ballot(flag);
+        if ((tid & 63) == 0) { lds_bits[(tid >> 6) * 2] = (uint32_t)bal; lds_bits[(tid >> 6) * 2 + 1] = (uint32_t)(bal >> 32); }
+    }
+    __syncthreads();
+    if (tid < 4 && row0 + tid * 32 < a.K) a.idx_bits[(size_t)b * a.idx_words + (row0 >> 5) + tid] = lds_bits[tid];
+    // partial top lists: thread (g = tid>>5, c = tid&31) scans rows g, g+8, ...
+    const int g = tid >> 5, c = tid & 31;
+    for (int ct = 0; ct < (a.ncol >> 5); ct++) {
+        const int col = ct * 32 + c;
+        flmr_toplist<NC> tl;
+        tl.init();
+        if (col < nqc)
+            for (int r = g; r < 128; r += 8) {
+                const int row = row0 + r;
+                if (row < a.K) tl.insert(cs_b[(size_t)row * a.ncol + col], row);
+            }
+#pragma unroll
+        for (int t = 0; t < NC; t++) { lds_v[(g * 32 + c) * NC + t] = tl.v[t]; lds_i[(g * 32 + c) * NC + t] = tl.id[t]; }
+        __syncthreads();
+        if (g == 0) {
+            for (int w = 1; w < 8; w++)
+#pragma unroll
+                for (int t = 0; t < NC; t++) tl.insert(lds_v[(w * 32 + c) * NC + t], lds_i[(w * 32 + c) * NC + t]);
+            const size_t base = (((size_t)b * a.nblk + blockIdx.x) * a.ncol + col) * NC;
+#pragma unroll
+            for (int t = 0; t < NC; t++) { a.part_val[base + t] = tl.v[t]; a.part_idx[base + t] = tl.id[t]; }
+        }
+        __syncthreads();
+    }
+}
+
+template <int NC>
+static int launch_s0_t(const flmr_s0_args& a, hipStream_t st, bool valu) {
+    const int qsplit = a.nqueries < 8 ? a.nqueries : 8;
+    if (!valu) {
+        hipLaunchKernelGGL(s0_centroid_scores_mfma<NC>, dim3(a.nblk, qsplit), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(s0_centroid_scores_valu, dim3(1024, a.nqueries), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(s0_postprocess_table<NC>, dim3(a.nblk, a.nqueries), dim3(256), 0, st, a);
+    }
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
+static int nc_bucket(int ncells) { return ncells <= 1 ? 1 : ncells <= 2 ? 2 : ncells <= 4 ? 4 : 8; }
+
+int flmr_launch_centroid_scores(const flmr_s0_args& a, hipStream_t st) {
+    const char* impl = getenv("FLMR_S0_IMPL");
+    const bool valu = impl && strcmp(impl, "valu") == 0;
+    switch (nc_bucket(a.ncells)) {
+        case 1: return launch_s0_t<1>(a, st, valu);
+        case 2: return launch_s0_t<2>(a, st, valu);
+        case 4: return launch_s0_t<4>(a, st, valu);
+        default: return launch_s0_t<8>(a, st, valu);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S0b: merge block partials -> per-token top-ncells -> unique cells.  grid = nqueries, block = 1024.
+// ------------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(1024) void s0_select_cells(flmr_s0_args a) {
+    __shared__ int raw[1024];
+    __shared__ int scan_lds[17];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qlen = a.q_lens ? a.q_lens[b] : a.nq;
+    const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;
+    raw[tid] = 0x7fffffff;
+    __syncthreads();
+    for (int col = wave; col < nqc; col += 16) {
+        flmr_toplist<NC> tl;
+        tl.init();
+        const int nent = a.nblk * NC;
+        for (int e = lane; e < nent; e += 64) {
+            const size_t off = (((size_t)b * a.nblk + (e / NC)) * a.ncol + col) * NC + (e % NC);
+            tl.insert(a.part_val[off], a.part_idx[off]);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) tl.merge_xor(m);
+        if (lane == 0) {
+#pragma unroll
+            for (int t = 0; t < NC; t++)
+                if (t < a.ncells && tl.id[t] < a.K) raw[col * a.ncells + t] = tl.id[t];
+        }
+    }
+    __syncthreads();
+    // ascending sort of <= 1024 ids (INT_MAX padded) + unique
+    for (int k = 2; k <= 1024; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            int p = tid ^ j;
+            if (p > tid) {
+                int x = raw[tid], y = raw[p];
+                bool asc = ((tid & k) == 0);
+                if (asc ? (x > y) : (x < y)) { raw[tid] = y; raw[p] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    const int v = raw[tid];
+    const int flag = (v != 0x7fffffff) && (tid == 0 || raw[tid - 1] != v);
+    int total;
+    const int pos = flmr_block_exclusive_scan(flag, scan_lds, &total);
+    if (flag) a.cells[(size_t)b * a.max_cells + pos] = v;
+    if (tid == 0) a.ncell[b] = total;
+}
+
+int flmr_launch_select_cells(const flmr_s0_args& a, hipStream_t st) {
+    if ((int64_t)a.nq_cand * a.ncells > 1024) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nq_cand*ncells > 1024");
+    switch (nc_bucket(a.ncells)) {
+        case 1: hipLaunchKernelGGL(s0_select_cells<1>, dim3(a.nqueries), dim3(1024), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(s0_select_cells<2>, dim3(a.nqueries), dim3(1024), 0, st, a); break;
+        case 4: hipLaunchKernelGGL(s0_select_cells<4>, dim3(a.nqueries), dim3(1024), 0, st, a); break;
+        default: hipLaunchKernelGGL(s0_select_cells<8>, dim3(a.nqueries), dim3(1024), 0, st, a); break;
+    }
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// S0c: OR the IVF lists of the probed cells into the per-query passage bitmap.
+// grid = (nqueries, max_cells): blockIdx.x = query keeps a query's blocks on one XCD (block id % 8).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void s0_ivf_mark(const int32_t* cells, const int32_t* ncell, int32_t max_cells,
+                                                   const int32_t* ivf_pids, const int64_t* ivf_offsets,
+                                                   uint32_t* bitmap, int64_t bitmap_words) {
+    const int b = blockIdx.x, ci = blockIdx.y;
+    if (ci >= ncell[b]) return;
+    const int c = cells[(size_t)b * max_cells + ci];
+    const int64_t beg = ivf_offsets[c], end = ivf_offsets[c + 1];
+    uint32_t* bm = bitmap + (size_t)b * bitmap_words;
+    for (int64_t e = beg + threadIdx.x; e < end; e += blockDim.x) {
+        const int pid = ivf_pids[e];
+        atomicOr(&bm[pid >> 5], 1u << (pid & 31));
+    }
+}
+
+int flmr_launch_ivf_mark(const int32_t* cells, const int32_t* ncell, int32_t max_cells, int32_t nqueries,
+                         const int32_t* ivf_pids, const int64_t* ivf_offsets, uint32_t* bitmap, int64_t bitmap_words,
+                         hipStream_t st) {
+    FLMR_HIP(hipMemsetAsync(bitmap, 0, (size_t)nqueries * bitmap_words * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(s0_ivf_mark, dim3(nqueries, max_cells), dim3(256), 0, st, cells, ncell, max_cells, ivf_pids,
+                       ivf_offsets, bitmap, bitmap_words);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// S0d: bitmap -> ascending candidate pid list (popcount + block scan per 1024-word tile).
+// grid = nqueries, block = 1024.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void s0_compact(const uint32_t* bitmap, int64_t bitmap_words, int64_t num_passages,
+                                                   int32_t* cand, int64_t cand_cap, int32_t* cand_count,
+                                                   int32_t* overflow) {
+    __shared__ int scan_lds[17];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t* bm = bitmap + (size_t)b * bitmap_words;
+    int32_t* out = cand + (size_t)b * cand_cap;
+    int64_t base = 0;
+    for (int64_t w0 = 0; w0 < bitmap_words; w0 += 1024) {
+        const int64_t w = w0 + tid;
+        uint32_t bits = (w < bitmap_words) ? bm[w] : 0u;
+        int total;
+        int pos = flmr_block_exclusive_scan(__popc(bits), scan_lds, &total);
+        while (bits) {
+            const int bit = __ffs(bits) - 1;
+            bits &= bits - 1;
+            const int64_t o = base + pos++;
+            if (o < cand_cap) out[o] = (int32_t)(w * 32 + bit);
+        }
+        base += total;
+    }
+    if (tid == 0) {
+        if (base > cand_cap) { atomicExch(overflow, 1); base = cand_cap; }
+        cand_count[b] = (int32_t)base;
+    }
+}
+
+int flmr_launch_compact(const uint32_t* bitmap, int64_t bitmap_words, int64_t num_passages, int32_t nqueries,
+                        int32_t* cand, int64_t cand_cap, int32_t* cand_count, int32_t* overflow, hipStream_t st) {
+    hipLaunchKernelGGL(s0_compact, dim3(nqueries), dim3(1024), 0, st, bitmap, bitmap_words, num_passages, cand,
+                       cand_cap, cand_count, overflow);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}

@@ -1,0 +1,105 @@
+"""torch-tensor front-ends of the op-level C-ABI entry points, with the reference's pybind signatures:
+
+    filter_pids(pids, centroid_scores, codes, doclens, offsets, idx, nfiltered_docs)      filter_pids.cpp:126-164
+    decompress_residuals(pids, lengths, offsets, bucket_weights, reversed_bit_map,
+                         bucket_weight_combinations, binary_residuals, codes, centroids, dim, nbits)
+                                                                                   decompress_residuals.cpp:80-155
+    segmented_lookup(input, pids, lengths, offsets)                                segmented_lookup.cpp:127-144
+    segmented_maxsim(scores, lengths)                                              segmented_maxsim.cpp:49-93
+
+Inputs may be CPU tensors (as the reference passes them): they are staged to HBM, the HIP kernel runs, and the
+result comes back as a CPU tensor like the reference's.  CUDA inputs are used in place.  There is no CPU
+implementation behind these functions.
+"""
+import ctypes as C
+
+import torch
+
+from . import _native
+
+
+def _d(t, dtype=None):
+    t = torch.as_tensor(t)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.to("cuda").contiguous()
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def filter_pids(pids, centroid_scores, codes, doclens, offsets, idx, nfiltered_docs, _codes_dev=None, _offsets_dev=None):
+    lib = _native.load()
+    pd, cs = _d(pids, torch.int32), _d(centroid_scores, torch.float32)
+    cd = _codes_dev if _codes_dev is not None else _d(codes, torch.int32)
+    od = _offsets_dev if _offsets_dev is not None else _d(offsets, torch.int64)
+    dl = _d(doclens, torch.int64)
+    ix = _d(idx, torch.bool).view(torch.uint8)
+    out = torch.empty(max(nfiltered_docs // 4, 1), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _native.check(lib.flmr_filter_pids(_p(pd), pd.numel(), _p(cs), cs.size(0), cs.size(1), _p(cd), _p(dl), _p(od), _p(ix),
+                                       int(nfiltered_docs), _p(out), _p(cnt), _native.stream_ptr()))
+    return out[: int(cnt.item())].cpu()
+
+
+def decompress_residuals(pids, lengths, offsets, bucket_weights, reversed_bit_map, bucket_weight_combinations,
+                         binary_residuals, codes, centroids, dim, nbits):
+    lib = _native.load()
+    pd = _d(pids, torch.int32)
+    ln, of = _d(lengths, torch.int64), _d(offsets, torch.int64)
+    nrows = int(torch.as_tensor(lengths).long()[torch.as_tensor(pids).long()].sum()) if pd.numel() else 0
+    out = torch.zeros((nrows, dim), dtype=torch.float32, device="cuda")
+    if pd.numel():
+        _native.check(lib.flmr_decompress_residuals(
+            _p(pd), pd.numel(), _p(ln), _p(of), _p(_d(bucket_weights, torch.float32)), _p(_d(reversed_bit_map, torch.uint8)),
+            _p(_d(bucket_weight_combinations, torch.uint8)), _p(_d(binary_residuals, torch.uint8)), _p(_d(codes, torch.int32)),
+            _p(_d(centroids, torch.float32)), int(dim), int(nbits), _p(out), nrows, None, _native.stream_ptr()))
+    return out.cpu()
+
+
+def segmented_lookup(input, pids, lengths, offsets):
+    lib = _native.load()
+    inp = torch.as_tensor(input)
+    ind = inp.to("cuda").contiguous()
+    ln, of = _d(lengths, torch.int64), _d(offsets, torch.int64)
+    nrows = int(torch.as_tensor(lengths).long().sum())
+    out = torch.zeros((nrows,) + tuple(inp.shape[1:]), dtype=inp.dtype, device="cuda")
+    row_bytes = inp.element_size() * (int(torch.tensor(inp.shape[1:]).prod()) if inp.dim() > 1 else 1)
+    if ln.numel():
+        _native.check(lib.flmr_segmented_lookup(_p(ind), row_bytes, _p(ln), _p(of), ln.numel(), _p(out), nrows, None,
+                                                _native.stream_ptr()))
+    return out.cpu() if not inp.is_cuda else out
+
+
+def segmented_maxsim(scores, lengths):
+    lib = _native.load()
+    sc, ln = _d(scores, torch.float32), _d(lengths, torch.int64)
+    out = torch.zeros(ln.numel(), dtype=torch.float32, device="cuda")
+    if ln.numel():
+        _native.check(lib.flmr_segmented_maxsim(_p(sc), _p(ln), ln.numel(), sc.size(1), _p(out), _native.stream_ptr()))
+    return out.cpu() if not torch.as_tensor(scores).is_cuda else out
+
+
+def colbert_score_padded(Q, D_padded, D_mask):
+    """Forward-only padded MaxSim (colbert.py:268-286): Q [1|B, Nq, d], D [B, Ld, d], mask [B, Ld(,1)] -> [B]."""
+    lib = _native.load()
+    Qd, Dd = _d(Q, torch.float32), _d(D_padded, torch.float32)
+    B, Ld, dim = Dd.shape
+    md = _d(torch.as_tensor(D_mask).reshape(B, Ld), torch.bool).view(torch.uint8)
+    out = torch.empty(B, dtype=torch.float32, device="cuda")
+    _native.check(lib.flmr_colbert_score_padded(_p(Qd), Qd.size(0), Qd.size(1), _p(Dd), _p(md), B, Ld, dim, _p(out),
+                                                _native.stream_ptr()))
+    return out
+
+
+def merge_topk(scores, pids):
+    """scores f32 / pids i32 [nshards, nqueries, k] (CUDA) -> merged (scores, pids, counts) [nqueries, k]."""
+    lib = _native.load()
+    sc, pd = _d(scores, torch.float32), _d(pids, torch.int32)
+    R, n, k = sc.shape
+    os_ = torch.empty((n, k), dtype=torch.float32, device="cuda")
+    op = torch.empty((n, k), dtype=torch.int32, device="cuda")
+    oc = torch.empty((n,), dtype=torch.int32, device="cuda")
+    _native.check(lib.flmr_merge_topk(_p(sc), _p(pd), R, n, k, _p(os_), _p(op), _p(oc), _native.stream_ptr()))
+    return os_, op, oc

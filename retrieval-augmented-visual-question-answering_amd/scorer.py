@@ -1,0 +1,212 @@
+"""`IndexScorer` -- host-side mirror of TPC/search/index_storage.py:21-182 (IndexLoader + CandidateGeneration +
+scoring) driving the HIP search path through the C ABI.
+
+Device policy: the reference reads `use_gpu=False` as "CPU extensions, fp32, zero-clamped
+MaxSim".  This build ALWAYS runs on the MI355X with exactly those CPU-path numerics, whatever `use_gpu`
+says; there is no host fallback (a missing library / device raises FlmrNativeError).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native
+from .index import DeviceIndex, IndexArrays, codec_tables, load_index_arrays
+
+
+class _Codec:
+    """The attributes of ResidualCodec that callers of IndexScorer read (residual.py:19-95)."""
+
+    def __init__(self, arrays: IndexArrays):
+        self.dim, self.nbits = arrays.dim, arrays.nbits
+        self.centroids = torch.from_numpy(arrays.centroids)
+        self.bucket_weights = torch.from_numpy(arrays.bucket_weights)
+        self.bucket_cutoffs = None if arrays.bucket_cutoffs is None else torch.from_numpy(np.asarray(arrays.bucket_cutoffs))
+        self.avg_residual = arrays.avg_residual
+        rev, lut = codec_tables(arrays.nbits)
+        self.reversed_bit_map = torch.from_numpy(rev)
+        self.decompression_lookup_table = torch.from_numpy(lut)
+        self.use_gpu = True
+
+
+class _Embeddings:
+    def __init__(self, arrays):
+        self.codes = torch.from_numpy(arrays.codes)
+        self.residuals = torch.from_numpy(arrays.residuals)
+
+
+class _Strided:
+    """Packed ragged container: `.tensor`, `.lengths`, `.offsets` (strided_tensor_core.py:17-31)."""
+
+    def __init__(self, tensor, lengths):
+        self.tensor = tensor
+        self.lengths = lengths.long()
+        self.offsets = torch.cat((torch.zeros(1, dtype=torch.long), torch.cumsum(self.lengths, dim=0)))
+
+
+class _EmbeddingsStrided:
+    def __init__(self, emb, doclens):
+        self.codes_strided = _Strided(emb.codes, doclens)
+        self.residuals_strided = _Strided(emb.residuals, doclens)
+
+
+def _op(name):
+    def call(*args, **kw):
+        from . import ops
+        return getattr(ops, name)(*args, **kw)
+    call.__name__ = name
+    return staticmethod(call)
+
+
+def _params(k, ncells, thr, ndocs, nq_cand):
+    return _native.SearchParams(int(k), int(ncells), float(thr), int(ndocs), int(nq_cand))
+
+
+class IndexScorer:
+    # class attributes the reference installs from its JIT-built extensions (index_storage.py:29-60)
+    filter_pids = _op("filter_pids")
+    decompress_residuals = _op("decompress_residuals")
+
+    def __init__(self, index_path=None, use_gpu=True, arrays: IndexArrays = None, device_index: DeviceIndex = None,
+                 max_batch=256):
+        if arrays is None and device_index is None:
+            arrays = load_index_arrays(index_path)
+        self.index_path = index_path
+        self.use_gpu = True  # see module docstring
+        self.arrays = arrays if arrays is not None else device_index.arrays
+        self.device_index = device_index or DeviceIndex(self.arrays)
+        self._lib = _native.load(require_device=True)
+        self.max_batch = int(max_batch)
+        self._searcher = None
+        self._searcher_key = None
+        if isinstance(self.arrays, IndexArrays):
+            self.codec = _Codec(self.arrays)
+            self.embeddings = _Embeddings(self.arrays)
+            self.doclens = torch.from_numpy(self.arrays.doclens)
+            self.ivf = _Strided(torch.from_numpy(self.arrays.ivf), torch.from_numpy(self.arrays.ivf_lengths))
+            self.embeddings_strided = _EmbeddingsStrided(self.embeddings, self.doclens)
+
+    # ---- native searcher (workspace) management ---------------------------------------------------------
+    def _get_searcher(self, nqueries, nq, p):
+        key = (max(nqueries, 1), nq, p.ncells, p.ndocs, p.nq_cand)
+        cur = self._searcher_key
+        if cur is None or key[0] > cur[0] or key[1] > cur[1] or key[2] > cur[2] or key[3] > cur[3] or key[4] > cur[4]:
+            grown = key if cur is None else tuple(max(a, b) for a, b in zip(key, cur))
+            self.close_searcher()
+            h = C.c_void_p()
+            mp = _params(1, grown[2], 0.0, grown[3], grown[4])
+            _native.check(self._lib.flmr_searcher_create(self.device_index.handle, grown[0], grown[1], C.byref(mp), C.byref(h)))
+            self._searcher, self._searcher_key = h, grown
+        return self._searcher
+
+    def close_searcher(self):
+        if self._searcher is not None:
+            self._lib.flmr_searcher_destroy(self._searcher)
+            self._searcher, self._searcher_key = None, None
+
+    def workspace_bytes(self):
+        b = C.c_int64(0)
+        _native.check(self._lib.flmr_searcher_workspace_bytes(self._searcher, C.byref(b)))
+        return b.value
+
+    def __del__(self):
+        try:
+            self.close_searcher()
+        except Exception:
+            pass
+
+    # ---- batched fast path ---------------------------------------------------------------------------------
+    def search_batch(self, Q, k, ncells, centroid_score_threshold, ndocs, nq_cand=32, q_lens=None, profile=False):
+        """Q: float32 [n, Nq, 128] (CPU or CUDA).  Returns CUDA tensors (pids i32 [n,k], scores f32 [n,k], counts i32 [n])."""
+        if Q.dim() != 3 or Q.size(-1) != self.arrays.dim:
+            raise ValueError(f"Q must be [n, Nq, {self.arrays.dim}], got {tuple(Q.shape)}")
+        Qd = Q.to(device="cuda", dtype=torch.float32).contiguous()
+        n, nq = Qd.size(0), Qd.size(1)
+        p = _params(k, ncells, centroid_score_threshold, ndocs, nq_cand)
+        s = self._get_searcher(min(n, self.max_batch), nq, p)
+        ql = None if q_lens is None else torch.as_tensor(q_lens).to(device="cuda", dtype=torch.int32).contiguous()
+        out_p = torch.empty((n, k), dtype=torch.int32, device="cuda")
+        out_s = torch.empty((n, k), dtype=torch.float32, device="cuda")
+        out_c = torch.empty((n,), dtype=torch.int32, device="cuda")
+        st = _native.stream_ptr()
+        self._lib.flmr_searcher_set_profiling(s, 1 if profile else 0)
+        B = self._searcher_key[0]
+        for b0 in range(0, n, B):
+            b1 = min(n, b0 + B)
+            _native.check(self._lib.flmr_search_batch(
+                s, C.c_void_p(Qd[b0:b1].data_ptr()), C.c_void_p(ql[b0:b1].data_ptr()) if ql is not None else None,
+                b1 - b0, nq, C.byref(p), C.c_void_p(out_p[b0:b1].data_ptr()), C.c_void_p(out_s[b0:b1].data_ptr()),
+                C.c_void_p(out_c[b0:b1].data_ptr()), st))
+        return out_p, out_s, out_c
+
+    def stage_ms(self):
+        ms = (C.c_float * _native.NUM_STAGES)()
+        _native.check(self._lib.flmr_searcher_stage_ms(self._searcher, ms))
+        return {self._lib.flmr_stage_name(i).decode(): float(ms[i]) for i in range(_native.NUM_STAGES)}
+
+    def tap(self, what, query=0):
+        """Stage output of the last search_batch chunk for `query` (index inside that chunk), as numpy."""
+        K = self.arrays.num_centroids
+        cap = {_native.TAP_CENTROID_SCORES: K * 128, _native.TAP_IDX_BITS: (K + 31) // 32,
+               _native.TAP_CELLS: 1024, _native.TAP_CANDIDATES: self.arrays.num_passages,
+               _native.TAP_STAGE1: 8192, _native.TAP_STAGE2: 2048, _native.TAP_DOC_SCORES: 2048}[what]
+        dt = {_native.TAP_CENTROID_SCORES: np.float32, _native.TAP_IDX_BITS: np.uint32,
+              _native.TAP_DOC_SCORES: np.float32}.get(what, np.int32)
+        buf = np.empty(max(cap, 1), dtype=dt)
+        cnt = C.c_int64(0)
+        _native.check(self._lib.flmr_searcher_tap(self._searcher, what, query, buf.ctypes.data, cap, C.byref(cnt)))
+        out = buf[:cnt.value].copy()
+        if what == _native.TAP_CENTROID_SCORES:
+            out = out.reshape(K, -1)
+        return out
+
+    # ---- reference-shaped API (index_storage.py:67-182) -----------------------------------------------------
+    def retrieve(self, config, Q):
+        """-> (candidate pids int32 ascending, centroid_scores f32 [K, nq_cand]) for ONE query (index_storage.py:67-80)."""
+        Q = Q if Q.dim() == 3 else Q.unsqueeze(0)
+        nqc = min(config.query_maxlen, Q.size(1))
+        self.search_batch(Q[:1], 1, config.ncells, config.centroid_score_threshold, max(config.ndocs, 4), config.query_maxlen)
+        pids = torch.from_numpy(self.tap(_native.TAP_CANDIDATES))
+        cs = torch.from_numpy(self.tap(_native.TAP_CENTROID_SCORES)[:, :nqc].copy())
+        return pids, cs
+
+    def rank(self, config, Q, filter_fn=None):
+        """-> (pids list, scores list), at most ndocs//4 entries, descending score (index_storage.py:86-98)."""
+        with torch.inference_mode():
+            Q = Q if Q.dim() == 3 else Q.unsqueeze(0)
+            if filter_fn is None:
+                kk = max(config.ndocs // 4, 1)
+                p, s, c = self.search_batch(Q[:1], kk, config.ncells, config.centroid_score_threshold, config.ndocs,
+                                            config.query_maxlen)
+                n = int(c[0])
+                return p[0, :n].tolist(), s[0, :n].tolist()
+            # per-query staging so the callable sees the same ascending int32 pid tensor (index_storage.py:90-91)
+            pids, centroid_scores = self.retrieve(config, Q)
+            pids = filter_fn(pids)
+            scores, pids = self.score_pids(config, Q, pids, centroid_scores)
+            order = torch.argsort(scores, descending=True, stable=True)
+            return pids[order].tolist(), scores[order].tolist()
+
+    def score_pids(self, config, Q, pids, centroid_scores):
+        """Pruning (S1+S2) + exact scoring of an explicit candidate list (index_storage.py:100-182)."""
+        from . import ops
+        pids = torch.as_tensor(pids).to(torch.int32)
+        idx = centroid_scores.max(-1).values >= config.centroid_score_threshold
+        offsets = self.embeddings_strided.codes_strided.offsets
+        fin = ops.filter_pids(pids, centroid_scores, self.embeddings.codes, self.doclens, offsets, idx, config.ndocs,
+                              _codes_dev=self._dev("codes"), _offsets_dev=self._dev("offsets"))
+        Qd = Q.to("cuda", torch.float32).reshape(-1, self.arrays.dim).contiguous()
+        fd = fin.to("cuda")
+        out = torch.empty(fd.numel(), dtype=torch.float32, device="cuda")
+        if fd.numel():
+            _native.check(self._lib.flmr_score_pids(self.device_index.handle, C.c_void_p(Qd.data_ptr()), Qd.size(0),
+                                                    C.c_void_p(fd.data_ptr()), fd.numel(), C.c_void_p(out.data_ptr()),
+                                                    _native.stream_ptr()))
+        return out.cpu(), fin
+
+    def _dev(self, name):
+        cache = self.__dict__.setdefault("_dev_cache", {})
+        if name not in cache:
+            src = {"codes": self.embeddings.codes, "offsets": self.embeddings_strided.codes_strided.offsets}[name]
+            cache[name] = src.to("cuda")
+        return cache[name]

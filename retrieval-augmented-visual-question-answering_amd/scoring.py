@@ -1,0 +1,63 @@
+"""The FLMR / ColBERT scoring head -- host-side mirror of `colbert_score`, `colbert_score_packed`,
+`colbert_score_reduce` and `ColBERT.segmented_maxsim` (TPC/modeling/colbert.py:235-311) and of the inherited
+`score(Q, D_padded, D_mask)` of the FLMR model classes (src/models/retriever/FLMR.py; TPC/modeling/colbert.py:217-224).
+
+Forward only.  When autograd needs the score (training, in-batch negatives) the caller must keep using its torch
+expression: these functions raise if an input requires grad instead of silently computing without a graph.
+"""
+import torch
+
+from . import ops
+
+
+def _no_grad_only(*tensors):
+    if torch.is_grad_enabled() and any(getattr(t, "requires_grad", False) for t in tensors):
+        raise RuntimeError("the HIP MaxSim scorer is forward-only; call it under torch.no_grad()/inference_mode()")
+
+
+def colbert_score_reduce(scores_padded, D_mask, config=None):
+    """[B, Ld, Nq] scores + mask -> [B] (colbert.py:235-263, 'colbert' interaction): tiny torch epilogue kept for
+    callers that already hold a padded score tensor on the device."""
+    interaction = getattr(config, "interaction", "colbert") if config is not None else "colbert"
+    if interaction != "colbert":
+        raise NotImplementedError("only the 'colbert' interaction is implemented (flipr asserts query_maxlen==64 upstream)")
+    pad = ~D_mask.view(scores_padded.size(0), scores_padded.size(1)).bool()
+    scores_padded = scores_padded.masked_fill(pad.unsqueeze(-1), -9999)
+    return scores_padded.max(1).values.sum(-1)
+
+
+def colbert_score(Q, D_padded, D_mask, config=None, use_gpu=False):
+    """Padded late-interaction score (colbert.py:268-286): Q [1|B, Nq, d] x D [B, Ld, d] -> [B] on the device."""
+    _no_grad_only(Q, D_padded)
+    assert Q.dim() == 3 and D_padded.dim() == 3 and Q.size(0) in (1, D_padded.size(0))
+    return ops.colbert_score_padded(Q, D_padded, D_mask)
+
+
+def colbert_score_packed(Q, D_packed, D_lengths, config=None):
+    """Single-query packed score (colbert.py:289-311) from an already materialised D_packed: GEMM by torch on the
+    device (plumbing), zero-clamped segmented MaxSim by the HIP op."""
+    _no_grad_only(Q, D_packed)
+    Qd = Q.squeeze(0).to("cuda", torch.float32)
+    scores = D_packed.to("cuda", torch.float32) @ Qd.T
+    return ops.segmented_maxsim(scores, torch.as_tensor(D_lengths).to("cuda"))
+
+
+class ColBERT:
+    """Only the class attribute the reference's packed scorer looks up (colbert.py:44-62, :311)."""
+    segmented_maxsim = staticmethod(ops.segmented_maxsim)
+
+    @classmethod
+    def try_load_torch_extensions(cls, use_gpu):
+        from . import _native
+        _native.load(require_device=True)
+        cls.loaded_extensions = True
+
+
+class FLMRScoringHead:
+    """`score(Q, D_padded, D_mask)` with the semantics the four FLMR model classes inherit from ColBERT.score
+    (colbert.py:217-224, similarity == 'cosine' path): exhaustive-search and RAG re-scoring callers
+    (src/executors/FLMR_executor.py:833, src/models/rag/rag_model_blip.py:435) can bind this in place of the
+    torch expression when gradients are off."""
+
+    def score(self, Q, D_padded, D_mask):
+        return colbert_score(Q, D_padded, D_mask)

@@ -1,0 +1,294 @@
+"""Parity of the HIP path (through the C ABI) against the reference's golden vectors and the CPU oracle.
+
+Bars (north_star): integer / index work bit-exact; fp32 scores within 1e-4; ranked ids identical except inside
+runs of reference scores closer than 1e-5 (a different valid fp32 summation order may swap those).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import INDEX_FIXTURES, load_golden, rank_records, tie_aware_equal
+
+pytestmark = pytest.mark.gpu
+
+GEMM_TOL = 2e-6
+SCORE_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    import ravqa_amd
+    from ravqa_amd import _native, ops
+    from ravqa_amd.scorer import IndexScorer
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    _native.load(require_device=True)  # fails loudly if libflmr_hip.so is missing: no fallback
+    return dict(torch=torch, pkg=ravqa_amd, native=_native, ops=ops, IndexScorer=IndexScorer)
+
+
+@pytest.fixture(scope="module")
+def scorers(hip):
+    out = {}
+    for name in INDEX_FIXTURES:
+        z = load_golden(name)
+        out[name] = (z, hip["IndexScorer"](arrays=hip["pkg"].IndexArrays.from_golden(z)))
+    return out
+
+
+def _search_one(hip, scorer, z, r):
+    torch = hip["torch"]
+    Q = torch.from_numpy(z[f"{r}.Q"]).unsqueeze(0)
+    ncells, thr, ndocs = int(z[f"{r}.ncells"]), float(z[f"{r}.thr"]), int(z[f"{r}.ndocs"])
+    p, s, c = scorer.search_batch(Q, max(ndocs // 4, 1), ncells, thr, ndocs, int(z[f"{r}.nq_cand"]))
+    n = int(c[0])
+    return p[0, :n].cpu().numpy(), s[0, :n].cpu().numpy()
+
+
+@pytest.mark.parametrize("name", INDEX_FIXTURES)
+def test_search_stages_vs_golden(hip, scorers, name):
+    """One query per call; every stage tap compared with the reference's tap."""
+    from oracle import oracle as orc
+    nat = hip["native"]
+    z, scorer = scorers[name]
+    oi = orc.OracleIndex.from_golden(z)
+    K = int(z["meta.K"])
+    for r in rank_records(z):
+        pids, scores = _search_one(hip, scorer, z, r)
+        nqc = min(int(z[f"{r}.nq_cand"]), z[f"{r}.Q"].shape[0])
+        cs = scorer.tap(nat.TAP_CENTROID_SCORES)[:, :nqc]
+        cs_ref = z[f"{r}.centroid_scores"]
+        assert np.max(np.abs(cs - cs_ref)) <= GEMM_TOL, r
+        # idx bits: identical except where the row max sits within GEMM_TOL of the threshold
+        bits = scorer.tap(nat.TAP_IDX_BITS)
+        idx = ((bits[np.arange(K) >> 5] >> (np.arange(K) & 31)) & 1).astype(bool)
+        near = np.abs(cs_ref.max(-1) - float(z[f"{r}.thr"])) <= GEMM_TOL
+        assert np.array_equal(idx[~near], z[f"{r}.idx"][~near]), r
+        assert np.array_equal(idx, cs.max(-1) >= np.float32(z[f"{r}.thr"])), r     # self-consistent with its own table
+        cells = scorer.tap(nat.TAP_CELLS)
+        assert np.array_equal(cells, orc.select_cells(cs, int(z[f"{r}.ncells"]))), r  # exact on its own table
+        assert np.array_equal(cells, z[f"{r}.cells"]), r
+        cand = scorer.tap(nat.TAP_CANDIDATES)
+        assert np.array_equal(cand, z[f"{r}.cand_pids"]), r
+        if f"{r}.undefined" in z:
+            assert len(set(pids.tolist())) == len(pids) == min(len(cand), int(z[f"{r}.ndocs"]) // 4), r
+            continue
+        s2 = scorer.tap(nat.TAP_STAGE2)
+        # pruning decisions are exact functions of the table bits: compare with the oracle run on THIS table
+        assert np.array_equal(s2, oi.filter_pids(cand, cs, idx, int(z[f"{r}.ndocs"]))), r
+        assert sorted(s2.tolist()) == sorted(z[f"{r}.filtered_pids"].tolist()), r
+        tie_aware_equal(z[f"{r}.final_pids"], z[f"{r}.final_scores"], pids, scores, tol=SCORE_TOL)
+
+
+@pytest.mark.parametrize("name", INDEX_FIXTURES)
+def test_filter_pids_op_bit_exact(hip, name):
+    """flmr_filter_pids fed with the reference's own centroid_scores: ids must be bit-exact, in order."""
+    torch, ops = hip["torch"], hip["ops"]
+    z = load_golden(name)
+    doclens = torch.from_numpy(z["index.doclens"])
+    offsets = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(doclens, 0)])
+    for r in rank_records(z):
+        out = ops.filter_pids(torch.from_numpy(z[f"{r}.cand_pids"]), torch.from_numpy(z[f"{r}.centroid_scores"]),
+                              torch.from_numpy(z["index.codes"]), doclens, offsets, torch.from_numpy(z[f"{r}.idx"]),
+                              int(z[f"{r}.ndocs"]))
+        if f"{r}.undefined" in z:
+            assert len(set(out.tolist())) == len(out) == min(len(z[f"{r}.cand_pids"]), int(z[f"{r}.ndocs"]) // 4)
+        else:
+            assert np.array_equal(out.numpy(), z[f"{r}.filtered_pids"]), r
+
+
+@pytest.mark.parametrize("name", INDEX_FIXTURES)
+def test_decompress_op_bit_exact(hip, name):
+    torch, ops = hip["torch"], hip["ops"]
+    z = load_golden(name)
+    doclens = torch.from_numpy(z["index.doclens"])
+    offsets = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(doclens, 0)])
+    D = ops.decompress_residuals(torch.from_numpy(z["op_decompress.pids"]), doclens, offsets,
+                                 torch.from_numpy(z["index.bucket_weights"]), torch.from_numpy(z["codec.reversed_bit_map"]),
+                                 torch.from_numpy(z["codec.decompression_lookup_table"]), torch.from_numpy(z["index.residuals"]),
+                                 torch.from_numpy(z["index.codes"]), torch.from_numpy(z["index.centroids_f16"].astype(np.float32)),
+                                 128, int(z["meta.nbits"]))
+    assert np.array_equal(D.numpy().view(np.uint32), z["op_decompress.D"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", INDEX_FIXTURES)
+def test_score_pids_fused_vs_oracle(hip, scorers, name):
+    """Fused decompress+normalise+MaxSim (flmr_score_pids) vs the oracle's unfused chain on the same pids."""
+    import ctypes as C
+    from oracle import oracle as orc
+    torch = hip["torch"]
+    z, scorer = scorers[name]
+    oi = orc.OracleIndex.from_golden(z)
+    pids = np.concatenate([z["op_decompress.pids"], np.arange(40, 140, dtype=np.int32)])
+    for r in rank_records(z)[:3]:
+        Q = z[f"{r}.Q"]
+        ref = orc.maxsim_packed(orc.normalize_rows(oi.decompress(pids)), Q, oi.doclens[pids])
+        Qd = torch.from_numpy(Q).cuda()
+        pd = torch.from_numpy(pids).cuda()
+        out = torch.empty(len(pids), dtype=torch.float32, device="cuda")
+        hip["native"].check(scorer._lib.flmr_score_pids(scorer.device_index.handle, C.c_void_p(Qd.data_ptr()), Q.shape[0],
+                                                         C.c_void_p(pd.data_ptr()), len(pids), C.c_void_p(out.data_ptr()),
+                                                         hip["native"].stream_ptr()))
+        assert np.max(np.abs(out.cpu().numpy() - ref)) <= SCORE_TOL, r
+
+
+def test_s0_mfma_equals_valu_kernel(hip, scorers):
+    """The fp32 MFMA centroid-score kernel (fused epilogue) vs the plain k-ascending VALU kernel + table post-pass."""
+    nat = hip["native"]
+    z, scorer = scorers["idx_nb2"]
+    taps = {}
+    for impl in ("mfma", "valu"):
+        os.environ["FLMR_S0_IMPL"] = impl
+        try:
+            _search_one(hip, scorer, z, "rank0")
+            taps[impl] = [scorer.tap(t) for t in (nat.TAP_CENTROID_SCORES, nat.TAP_IDX_BITS, nat.TAP_CELLS, nat.TAP_CANDIDATES)]
+        finally:
+            os.environ.pop("FLMR_S0_IMPL", None)
+    assert np.max(np.abs(taps["mfma"][0] - taps["valu"][0])) <= GEMM_TOL
+    for a, b in zip(taps["mfma"][1:], taps["valu"][1:]):
+        assert np.array_equal(a, b)
+
+
+def test_ops_vs_golden(hip):
+    torch, ops = hip["torch"], hip["ops"]
+    z = load_golden("ops")
+    pids = z["lookup.pids"]
+    for tag in ["u8", "i32", "i64", "f32", "f16"]:
+        out = ops.segmented_lookup(torch.from_numpy(z[f"lookup.{tag}.input"]), torch.from_numpy(pids),
+                                   torch.from_numpy(z["lookup.lengths"][pids]), torch.from_numpy(z["lookup.offsets"][pids]))
+        assert out.numpy().tobytes() == z[f"lookup.{tag}.output"].tobytes(), tag
+    out = ops.segmented_maxsim(torch.from_numpy(z["maxsim.scores"]), torch.from_numpy(z["maxsim.lengths"]))
+    assert out[0] == 0.0 and out[2] == 0.0
+    assert np.max(np.abs(out.numpy() - z["maxsim.output"])) <= 1e-5
+    out = ops.segmented_maxsim(torch.from_numpy(z["maxsim45.scores"]), torch.from_numpy(z["maxsim.lengths"]))
+    assert np.max(np.abs(out.numpy() - z["maxsim45.output"])) <= 1e-5
+    out = ops.colbert_score_padded(torch.from_numpy(z["padded.Q"]), torch.from_numpy(z["padded.D"]), torch.from_numpy(z["padded.mask"]))
+    assert np.max(np.abs(out.cpu().numpy() - z["padded.output"])) <= SCORE_TOL
+    assert float(out[3]) == -9999.0 * 32
+    out = ops.colbert_score_padded(torch.from_numpy(z["padded_aligned.Q"]), torch.from_numpy(z["padded.D"]), torch.from_numpy(z["padded.mask"]))
+    assert np.max(np.abs(out.cpu().numpy() - z["padded_aligned.output"])) <= SCORE_TOL
+
+
+def test_batched_equals_single_and_remove_zero(hip, scorers):
+    """Batch of different queries == the same queries one by one; q_lens path == host-side row removal."""
+    torch = hip["torch"]
+    z, scorer = scorers["idx_nb2"]
+    recs = ["rank0", "rank3"]  # both Nq=32, same config
+    Q = torch.stack([torch.from_numpy(z[f"{r}.Q"]) for r in recs])
+    p, s, c = scorer.search_batch(Q.repeat(5, 1, 1), 100, 2, 0.45, 1024, 32)
+    for i in range(10):
+        r = recs[i % 2]
+        n = int(c[i])
+        assert n == 100
+        tie_aware_equal(z[f"{r}.final_pids"][:100], z[f"{r}.final_scores"][:100], p[i].cpu().numpy(), s[i].cpu().numpy(),
+                        tol=SCORE_TOL)
+    # remove_zero_tensors: compact on the host, pass q_lens
+    from ravqa_amd.searcher import Searcher
+    Qraw = torch.from_numpy(z["rank_rz.Q_raw"]).unsqueeze(0)
+    Qc, lens = Searcher._compact_nonzero_rows(Qraw)
+    assert int(lens[0]) == z["rank_rz.Q"].shape[0]
+    assert torch.equal(Qc[0, : int(lens[0])], torch.from_numpy(z["rank_rz.Q"]))
+    nd = int(z["rank_rz.ndocs"])
+    p, s, c = scorer.search_batch(Qc, nd // 4, int(z["rank_rz.ncells"]), float(z["rank_rz.thr"]), nd, 32, q_lens=lens)
+    n = int(c[0])
+    tie_aware_equal(z["rank_rz.final_pids"], z["rank_rz.final_scores"], p[0, :n].cpu().numpy(), s[0, :n].cpu().numpy(), tol=SCORE_TOL)
+
+
+def test_searcher_dropin_api(hip, tmp_path):
+    """Searcher(index=..., config=...) under Run().context, _search_all_Q -> Ranking, dense_search, filter_fn path."""
+    torch, pkg = hip["torch"], hip["pkg"]
+    from ravqa_amd import ColBERTConfig, Queries, Run, RunConfig
+    from ravqa_amd.searcher import Searcher
+    z = load_golden("idx_nb2")
+    root = str(tmp_path)
+    pkg.IndexArrays.from_golden(z).save(os.path.join(root, "exp0", "indexes", "temp_index.nbits=2"))
+    with Run().context(RunConfig(nranks=1, rank=0, root=root, experiment="exp0")):
+        searcher = Searcher(index="temp_index.nbits=2", config=ColBERTConfig(total_visible_gpus=0))
+        recs = ["rank0", "rank3"]
+        Q = torch.stack([torch.from_numpy(z[f"{r}.Q"]) for r in recs])
+        ranking = searcher._search_all_Q(Queries(data={"qa": "what", "qb": "which"}), Q, k=100, progress=False)
+        d = ranking.todict()
+        assert list(d) == ["qa", "qb"] and searcher.config.ndocs == 1024 and searcher.config.ncells == 2
+        for qid, r in zip(d, recs):
+            pids, ranks, scores = zip(*d[qid])
+            assert list(ranks) == list(range(1, 101))
+            tie_aware_equal(z[f"{r}.final_pids"][:100], z[f"{r}.final_scores"][:100], pids, scores, tol=SCORE_TOL)
+        pids, ranks, scores = searcher.dense_search(Q[:1], k=10)
+        assert pids == list(d["qa"][i][0] for i in range(10)) and ranks == list(range(1, 11))
+        # filter_fn: keep even pids only -> every result even, and equals the oracle on the filtered candidate list
+        pids_f, _, scores_f = searcher.dense_search(Q[:1], k=10, filter_fn=lambda p: p[p % 2 == 0])
+        assert all(p % 2 == 0 for p in pids_f) and len(pids_f) == 10
+        from oracle import oracle as orc
+        oi = orc.OracleIndex.from_golden(z)
+        cand = z["rank0.cand_pids"]
+        cand = cand[cand % 2 == 0]
+        cs = z["rank0.centroid_scores"]
+        fin = oi.filter_pids(cand, cs, z["rank0.idx"], 1024)
+        ref = orc.maxsim_packed(orc.normalize_rows(oi.decompress(fin)), z["rank0.Q"], oi.doclens[fin])
+        order = np.argsort(-ref, kind="stable")[:10]
+        tie_aware_equal(fin[order], ref[order], pids_f, scores_f, tol=SCORE_TOL)
+
+
+@pytest.mark.parametrize("nbits,doclen,nq,nq_cand", [(2, (1, 200), 32, 32), (4, (100, 300), 96, 48), (1, (1, 40), 20, 32), (8, 64, 32, 32)])
+def test_random_corpus_vs_oracle(hip, nbits, doclen, nq, nq_cand):
+    """Seeded synthetic corpora at sizes the oracle finishes in seconds: ragged / long docs, Nq != 32, two column tiles."""
+    from oracle import oracle as orc
+    torch = hip["torch"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    corpus = synth.make_corpus(6000, doclen, 2048, nbits, seed=5 + nbits, device="cuda")
+    Q, _ = synth.make_queries(corpus, 12, nq, seed=9)
+    arrays = synth.corpus_to_arrays(corpus)
+    scorer = IndexScorer(arrays=arrays)
+    oi = orc.OracleIndex(arrays.dim, arrays.nbits, arrays.codes, arrays.residuals, arrays.doclens, arrays.ivf,
+                         arrays.ivf_lengths, arrays.centroids, arrays.bucket_weights)
+    ncells, thr, ndocs = 2, 0.45, 256
+    p, s, c = scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, nq_cand)
+    Qh = Q.cpu().numpy()
+    for i in range(Q.size(0)):
+        rp, rs, ncand = oi.rank(Qh[i], ncells, thr, ndocs, nq_cand)
+        n = int(c[i])
+        if ncand < ndocs:
+            assert n == min(ncand, ndocs // 4)
+            continue
+        tie_aware_equal(rp, rs, p[i, :n].cpu().numpy(), s[i, :n].cpu().numpy(), tol=SCORE_TOL)
+
+
+def test_full_size_properties(hip):
+    """Size-independent properties at a corpus the oracle cannot sweep: scores sorted, pids unique and in range,
+    planted passage retrieved, and the fused scorer is idempotent (re-scoring the returned pids reproduces the scores)."""
+    import ctypes as C
+    torch = hip["torch"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    corpus = synth.make_corpus(200_000, 128, 32768, 2, seed=0, device="cuda")
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=64)
+    Q, targets = synth.make_queries(corpus, 64, 32)
+    p, s, c = scorer.search_batch(Q, 100, 2, 0.45, 1024, 32)
+    torch.cuda.synchronize()
+    assert int(c.min()) == 100
+    assert bool((s[:, :-1] >= s[:, 1:]).all())
+    assert int(p.min()) >= 0 and int(p.max()) < 200_000
+    for i in range(64):
+        assert len(set(p[i].tolist())) == 100
+    assert float((p[:, :5] == targets.unsqueeze(1).to(torch.int32)).any(dim=1).float().mean()) >= 0.95
+    out = torch.empty(100, dtype=torch.float32, device="cuda")
+    for i in (0, 17, 63):
+        hip["native"].check(scorer._lib.flmr_score_pids(scorer.device_index.handle, C.c_void_p(Q[i].data_ptr()), 32,
+                                                         C.c_void_p(p[i].data_ptr()), 100, C.c_void_p(out.data_ptr()),
+                                                         hip["native"].stream_ptr()))
+        assert torch.equal(out, s[i])
+
+
+def test_merge_topk(hip):
+    torch, ops = hip["torch"], hip["ops"]
+    g = torch.Generator().manual_seed(0)
+    sc = torch.rand(4, 7, 10, generator=g).sort(dim=-1, descending=True).values
+    pd = torch.stack([torch.stack([torch.randperm(1000, generator=g)[:10] + 1000 * r for _ in range(7)]) for r in range(4)]).int()
+    pd[2, 3, 6:] = -1
+    ms, mp, mc = ops.merge_topk(sc.cuda(), pd.cuda())
+    for q in range(7):
+        keys = [(float(sc[r, q, i]), int(pd[r, q, i])) for r in range(4) for i in range(10) if pd[r, q, i] >= 0]
+        keys.sort(reverse=True)
+        assert mp[q].tolist() == [p for _, p in keys[:10]]
+        assert int(mc[q]) == 10
