@@ -50,11 +50,13 @@ def decompress_residuals(pids, lengths, offsets, bucket_weights, reversed_bit_ma
     ln, of = _d(lengths, torch.int64), _d(offsets, torch.int64)
     nrows = int(torch.as_tensor(lengths).long()[torch.as_tensor(pids).long()].sum()) if pd.numel() else 0
     out = torch.zeros((nrows, dim), dtype=torch.float32, device="cuda")
+    # keep every staged tensor referenced until the (synchronous) call returns
+    bw, rbm, lut = _d(bucket_weights, torch.float32), _d(reversed_bit_map, torch.uint8), _d(bucket_weight_combinations, torch.uint8)
+    res, cod, cen = _d(binary_residuals, torch.uint8), _d(codes, torch.int32), _d(centroids, torch.float32)
     if pd.numel():
         _native.check(lib.flmr_decompress_residuals(
-            _p(pd), pd.numel(), _p(ln), _p(of), _p(_d(bucket_weights, torch.float32)), _p(_d(reversed_bit_map, torch.uint8)),
-            _p(_d(bucket_weight_combinations, torch.uint8)), _p(_d(binary_residuals, torch.uint8)), _p(_d(codes, torch.int32)),
-            _p(_d(centroids, torch.float32)), int(dim), int(nbits), _p(out), nrows, None, _native.stream_ptr()))
+            _p(pd), pd.numel(), _p(ln), _p(of), _p(bw), _p(rbm), _p(lut), _p(res), _p(cod), _p(cen), int(dim), int(nbits),
+            _p(out), nrows, None, _native.stream_ptr()))
     return out.cpu()
 
 
