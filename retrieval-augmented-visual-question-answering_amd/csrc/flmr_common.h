@@ -75,6 +75,7 @@ struct flmr_index {
     // host copy of the IVF list lengths sorted descending, prefix-summed: bound on #candidates for c cells
     int64_t* ivf_len_prefix;  // [K+1] host
     int64_t max_doclen;
+    int32_t centroids_f16_exact;  // every centroid value is representable in fp16 (true for reference-format indexes)
 };
 
 // build the fused byte -> (8/nbits) fp32 decode table from the codec tables (host)
@@ -98,9 +99,13 @@ struct flmr_s0_args {
     int32_t* cells;          // [nqueries, max_cells]
     int32_t* ncell;          // [nqueries]
     int32_t max_cells;
+    _Float16* q_hi;          // [nqueries, ncol, 128] fp16 split of Q (fp16 MFMA path)
+    _Float16* q_lo;          //   Q ~= q_hi + q_lo * 2^-11
+    int32_t centroids_f16_exact;
 };
 int flmr_launch_centroid_scores(const flmr_s0_args& a, hipStream_t st);
 int flmr_launch_select_cells(const flmr_s0_args& a, hipStream_t st);
+int flmr_check_f16_exact(const float* dev, size_t n, int32_t* host_result);
 
 int flmr_launch_ivf_mark(const int32_t* cells, const int32_t* ncell, int32_t max_cells, int32_t nqueries,
                          const int32_t* ivf_pids, const int64_t* ivf_offsets, uint32_t* bitmap, int64_t bitmap_words,
@@ -120,7 +125,11 @@ struct flmr_filter_args {
 // stage 1: candidates (cand[q*cand_stride + i], i < cand_count[q]) restricted to idx_bits -> keys
 int flmr_launch_filter_stage1(const flmr_filter_args& f, const uint32_t* idx_bits, int32_t idx_words,
                               const int32_t* cand, int64_t cand_stride, const int32_t* cand_count, uint64_t* keys,
-                              hipStream_t st);
+                              const uint32_t* hit_bits, int64_t hit_words, const int32_t* hit_valid, hipStream_t st);
+// passage bitmap of the union of the surviving centroids' IVF lists (+ per-query validity flag)
+int flmr_launch_hit_bitmap(const uint32_t* idx_bits, int32_t idx_words, int32_t nqueries, const int32_t* ivf_pids,
+                           const int64_t* ivf_offsets, const int32_t* cand_count, uint32_t* hit_bits, int64_t hit_words,
+                           int32_t* hit_valid, hipStream_t st);
 // stage 2: all centroids, one wave per document
 int flmr_launch_filter_stage2(const flmr_filter_args& f, const int32_t* pids, int64_t pid_stride,
                               const int32_t* counts, int32_t max_count, uint64_t* keys, int64_t key_stride,

@@ -17,14 +17,24 @@ struct flmr_toplist {
 #pragma unroll
         for (int t = 0; t < NC; t++) { v[t] = FLMR_NEG_INF; id[t] = 0x7fffffff; }
     }
+    // general insert: (value desc, index asc); branch-free (selects only) so it schedules next to MFMAs
     __device__ __forceinline__ void insert(float x, int i) {
 #pragma unroll
         for (int t = NC - 1; t >= 0; --t) {
-            const bool better = (x > v[t]) || (x == v[t] && i < id[t]);
-            if (better) {
-                if (t + 1 < NC) { v[t + 1] = v[t]; id[t + 1] = id[t]; }
-                v[t] = x; id[t] = i;
-            }
+            const bool better = (x > v[t]) | ((x == v[t]) & (i < id[t]));
+            if (t + 1 < NC) { v[t + 1] = better ? v[t] : v[t + 1]; id[t + 1] = better ? id[t] : id[t + 1]; }
+            v[t] = better ? x : v[t];
+            id[t] = better ? i : id[t];
+        }
+    }
+    // insert for indices that arrive in ascending order: a strict '>' keeps the earlier (lower) index on ties
+    __device__ __forceinline__ void insert_ascending(float x, int i) {
+#pragma unroll
+        for (int t = NC - 1; t >= 0; --t) {
+            const bool better = x > v[t];
+            if (t + 1 < NC) { v[t + 1] = better ? v[t] : v[t + 1]; id[t + 1] = better ? id[t] : id[t + 1]; }
+            v[t] = better ? x : v[t];
+            id[t] = better ? i : id[t];
         }
     }
     // merge with the list held by lane (lane ^ mask)

@@ -22,7 +22,8 @@
 // column-tile loop with a compile-time trip count so the per-tile accumulators stay in registers
 #define FLMR_FOR_CT(ct, T) _Pragma("unroll") for (int ct = 0; ct < 4; ct++) if (ct < (T))
 
-#define S1_WAVES 4
+#define S1_WAVES 8  // stage-1 block = 512 threads
+#define S2_WAVES 4  // stage-2 block = 256 threads
 #define S1_GROUP 32  // docs transposed per wave before the sequential sums
 
 __device__ __forceinline__ int64_t doc_len_of(const int64_t* doclens, const int64_t* offsets, int pid) {
@@ -35,46 +36,82 @@ __device__ __forceinline__ int64_t shfl_i64(int64_t v, int src) {
     return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
-// lanes < nslots sum their doc's `nqc` column maxima k-ascending and emit the (score,pid) key
+// lanes < nslots emit the (score,pid) key of their doc: scanned docs sum their `nqc` column maxima k-ascending,
+// docs that provably contain no surviving centroid take the precomputed all-miss score (-9999 summed nqc times)
 __device__ __forceinline__ void emit_group(const float* tr /* [S1_GROUP][ncolp] */, int ncolp, int nqc, int nslots,
-                                           int lane, int my_pid, uint64_t* keys_out /* &keys[group base] */) {
+                                           int lane, int my_pid, bool scanned, float miss_score,
+                                           uint64_t* keys_out /* &keys[group base] */) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane < nslots) {
-        const float s = flmr_seq_sum(tr + lane * ncolp, nqc);
+        const float s = scanned ? flmr_seq_sum(tr + lane * ncolp, nqc) : miss_score;
         keys_out[lane] = flmr_make_key(s, my_pid);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
-// fold the hits of one 64-token chunk into the running column maxima (lane k <-> column k, two hits / step)
-__device__ __forceinline__ void s1_fold_hits(int code, const uint32_t* idxp, const float* cs, int ncol, int T, int nqc,
-                                             int k, int h, float* per) {
-    const bool hit = (code >= 0) && ((idxp[code >> 5] >> (code & 31)) & 1u);
-    unsigned long long m = __ballot(hit);
+// Per-block view of one query's surviving-centroid set: the K-bit mask, a per-word prefix popcount and the score
+// rows of the first S1_ROWCACHE surviving centroids, all in LDS.  A hit on a cached centroid costs two LDS reads
+// instead of a dependent trip to L2/HBM.
+struct s1_idx_view {
+    const uint32_t* bits;     // LDS (or global when the mask does not fit)
+    const uint16_t* prefix;   // LDS, saturating; nullptr when the mask is not LDS-resident
+    const float* rows;        // LDS [S1_ROWCACHE][ncol]
+    int nrows;                // number of cached rows
+};
+
+// Fold the surviving-centroid hits of one 128-token chunk of TWO documents (one per half-wave) into the running
+// column maxima.  Lane i of a half holds tokens i, 32+i, 64+i, 96+i of its document (cd[0..3], -1 = no token);
+// lane k of a half also owns score column k (+32 per column tile).  Each loop iteration retires one hit per half.
+__device__ __forceinline__ void s1_fold_pair(const int* cd, const s1_idx_view& iv, const float* cs, int ncol, int T,
+                                             int nqc, int lane, float* per) {
+    const int k = lane & 31, h = lane >> 5;
+    uint32_t wd[4];
+    uint32_t hm = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        wd[e] = cd[e] >= 0 ? iv.bits[cd[e] >> 5] : 0u;
+        hm |= (cd[e] >= 0 ? ((wd[e] >> (cd[e] & 31)) & 1u) : 0u) << e;
+    }
+    unsigned long long m = __ballot(hm != 0);
     while (m) {  // wave-uniform
-        const int sa = __builtin_ctzll(m);
-        m &= m - 1;
-        int sb = sa;
-        if (m) { sb = __builtin_ctzll(m); m &= m - 1; }
-        const int c = __shfl(code, h ? sb : sa, 64);
-        const float* row = cs + (size_t)c * ncol;
-        FLMR_FOR_CT(ct, T) if (ct * 32 + k < nqc) per[ct] = fmaxf(per[ct], row[ct * 32 + k]);
+        const uint32_t mh = h ? (uint32_t)(m >> 32) : (uint32_t)m;
+        const int src = mh ? (32 * h + __builtin_ctz(mh)) : -1;
+        // every lane prepares its first pending hit; only the two source lanes are read
+        const int fe = __builtin_ctz(hm | 16u);
+        const int code_f = fe == 0 ? cd[0] : fe == 1 ? cd[1] : fe == 2 ? cd[2] : cd[3];
+        const uint32_t word_f = fe == 0 ? wd[0] : fe == 1 ? wd[1] : fe == 2 ? wd[2] : wd[3];
+        int slot_f = 0x7fffffff;
+        if (hm && iv.prefix) slot_f = (int)iv.prefix[code_f >> 5] + __popc(word_f & ((1u << (code_f & 31)) - 1u));
+        const int c = __shfl(code_f, src < 0 ? lane : src, 64);
+        const int sl = __shfl(slot_f, src < 0 ? lane : src, 64);
+        if (src >= 0) {
+            const float* row = (sl < iv.nrows) ? (iv.rows + (size_t)sl * ncol) : (cs + (size_t)c * ncol);
+            FLMR_FOR_CT(ct, T) if (ct * 32 + k < nqc) per[ct] = fmaxf(per[ct], row[ct * 32 + k]);
+        }
+        if (lane == src) hm &= hm - 1;
+        m = __ballot(hm != 0);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stage 1.  grid = (nqueries, G), block = 256.  Dynamic LDS: transposes + idx words (if USE_LDS_IDX).
-// A wave takes 32 consecutive candidates at a time: lanes fetch the 32 (pid, offset, length) triples in
-// parallel, then the code runs of 4 docs are in flight together (2 x 64 tokens each) to cover HBM latency.
+// Stage 1.  grid = (nqueries, G), block = 512 (8 waves).  Dynamic LDS: transposes + mask + prefix + row cache.
+// A wave takes 32 consecutive candidates at a time: lanes fetch the 32 (pid, offset, length) triples in parallel
+// (the NEXT group's pids are prefetched while the current group is processed); documents are then processed two
+// at a time, one per half-wave (lane i holds tokens i, 32+i, 64+i, 96+i), four pairs = 16 code loads in flight.
 // ------------------------------------------------------------------------------------------------
+#define S1_ROWCACHE 128
+#define S1_PAIRS_IN_FLIGHT 4  // 8 documents = 16 code loads per wave in flight
+
 template <bool USE_LDS_IDX>
-__global__ __launch_bounds__(256) void filter_stage1_kernel(flmr_filter_args f, const uint32_t* idx_bits,
+__global__ __launch_bounds__(512) void filter_stage1_kernel(flmr_filter_args f, const uint32_t* idx_bits,
                                                             int32_t idx_words, const int32_t* cand,
                                                             int64_t cand_stride, const int32_t* cand_count,
-                                                            uint64_t* keys) {
+                                                            uint64_t* keys, const uint32_t* hit_bits,
+                                                            int64_t hit_words, const int32_t* hit_valid) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int scan_lds[17];
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int P = cand_count[b];
@@ -82,81 +119,201 @@ __global__ __launch_bounds__(256) void filter_stage1_kernel(flmr_filter_args f, 
     const int nqc = qlen < f.nq_cand ? qlen : f.nq_cand;
     const int T = (f.nq_cand + 31) >> 5;  // column tiles of 32; f.ncol is the row stride of the score table
     const int ncolp = T * 32 + 1;
+    // LDS carve: [tr: S1_WAVES*S1_GROUP*ncolp f32][rows: S1_ROWCACHE*ncol f32][rowcode: S1_ROWCACHE i32][bits][prefix u16]
     float* tr = reinterpret_cast<float*>(smem) + (size_t)wave * S1_GROUP * ncolp;
-    uint32_t* lidx = reinterpret_cast<uint32_t*>(smem + (size_t)S1_WAVES * S1_GROUP * ncolp * sizeof(float));
+    float* lrows = reinterpret_cast<float*>(smem) + (size_t)S1_WAVES * S1_GROUP * ncolp;
+    int* rowcode = reinterpret_cast<int*>(lrows + (size_t)S1_ROWCACHE * f.ncol);
+    uint32_t* lidx = reinterpret_cast<uint32_t*>(rowcode + S1_ROWCACHE);
+    uint16_t* lpre = reinterpret_cast<uint16_t*>(lidx + idx_words);
     const uint32_t* gidx = idx_bits + (size_t)b * idx_words;
-    if (USE_LDS_IDX) {
-        for (int w = threadIdx.x; w < idx_words; w += blockDim.x) lidx[w] = gidx[w];
-        __syncthreads();
-    }
-    const uint32_t* idxp = USE_LDS_IDX ? lidx : gidx;
     const float* cs = f.cs + (size_t)b * f.cs_query_stride;
+    s1_idx_view iv;
+    iv.bits = gidx; iv.prefix = nullptr; iv.rows = lrows; iv.nrows = 0;
+    if (USE_LDS_IDX) {
+        // mask + saturating exclusive popcount prefix per word; remember the codes of the first S1_ROWCACHE set bits
+        int base = 0;
+        for (int w0 = 0; w0 < idx_words; w0 += blockDim.x) {
+            const int w = w0 + threadIdx.x;
+            uint32_t bits = (w < idx_words) ? gidx[w] : 0u;
+            int total;
+            int pos = base + flmr_block_exclusive_scan(__popc(bits), scan_lds, &total);
+            if (w < idx_words) {
+                lidx[w] = bits;
+                lpre[w] = (uint16_t)(pos < 65535 ? pos : 65535);
+            }
+            while (bits && pos < S1_ROWCACHE) {
+                const int bit = __ffs(bits) - 1;
+                bits &= bits - 1;
+                rowcode[pos++] = w * 32 + bit;
+            }
+            base += total;
+        }
+        __syncthreads();
+        const int nrows = base < S1_ROWCACHE ? base : S1_ROWCACHE;
+        for (int e = threadIdx.x; e < nrows * f.ncol; e += blockDim.x)
+            lrows[e] = cs[(size_t)rowcode[e / f.ncol] * f.ncol + (e % f.ncol)];
+        __syncthreads();
+        iv.bits = lidx; iv.prefix = lpre; iv.nrows = nrows;
+    }
     const int32_t* cand_b = cand + (size_t)b * cand_stride;
     uint64_t* keys_b = keys + (size_t)b * cand_stride;
 
     const int waves_total = gridDim.y * S1_WAVES;
     const int wid = blockIdx.y * S1_WAVES + wave;
     const int k = lane & 31, h = lane >> 5;
+    const int gstride = waves_total * S1_GROUP;
 
-    for (int g0 = wid * S1_GROUP; g0 < P; g0 += waves_total * S1_GROUP) {
+    // hit_bits (optional): passage bitmap = union of the IVF lists of the surviving centroids.  A candidate outside
+    // it contains no surviving centroid, so its stage-1 score is the all-miss value and its codes are never read.
+    const uint32_t* hb = (hit_bits && hit_valid[b]) ? hit_bits + (size_t)b * hit_words : nullptr;
+    float miss_score = 0.0f;
+    for (int q = 0; q < nqc; q++) miss_score += -9999.0f;
+
+    int my_pid = 0;
+    bool my_scan = false;
+    int g0 = wid * S1_GROUP;
+    if (g0 + lane < P && lane < S1_GROUP) {
+        my_pid = cand_b[g0 + lane];
+        my_scan = hb ? ((hb[my_pid >> 5] >> (my_pid & 31)) & 1u) : true;
+    }
+    for (; g0 < P; g0 += gstride) {
         const int ndoc = (P - g0) < S1_GROUP ? (P - g0) : S1_GROUP;
-        int my_pid = 0, my_len = 0;
+        // prefetch the next group's pids + hit bits
+        int nx_pid = 0;
+        bool nx_scan = false;
+        if (g0 + gstride + lane < P && lane < S1_GROUP) {
+            nx_pid = cand_b[g0 + gstride + lane];
+            nx_scan = hb ? ((hb[nx_pid >> 5] >> (nx_pid & 31)) & 1u) : true;
+        }
+        int my_len = 0;
         int64_t my_off = 0;
-        if (lane < ndoc) {
-            my_pid = cand_b[g0 + lane];
+        if (my_scan) {
             my_off = f.offsets[my_pid];
             my_len = (int)doc_len_of(f.doclens, f.offsets, my_pid);
         }
-        for (int j0 = 0; j0 < ndoc; j0 += 4) {
-            int c0[4], c1[4], len[4];
-            int64_t off[4];
+        unsigned long long todo = __ballot(my_scan);
+        while (todo) {  // wave-uniform: S1_PAIRS_IN_FLIGHT pairs of documents per round, one document per half-wave
+            int jh[S1_PAIRS_IN_FLIGHT], len[S1_PAIRS_IN_FLIGHT];
+            int64_t off[S1_PAIRS_IN_FLIGHT];
+            int cd[S1_PAIRS_IN_FLIGHT][4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = (j0 + u < ndoc) ? (j0 + u) : j0;
+            for (int u = 0; u < S1_PAIRS_IN_FLIGHT; u++) {
+                const int ja = todo ? __builtin_ctzll(todo) : -1;
+                todo &= todo - 1;
+                const int jb = todo ? __builtin_ctzll(todo) : -1;
+                todo &= todo - 1;
+                jh[u] = h ? jb : ja;  // this half's document slot (-1: none)
+                const int j = jh[u] < 0 ? 0 : jh[u];
                 off[u] = shfl_i64(my_off, j);
-                len[u] = (j0 + u < ndoc) ? __shfl(my_len, j, 64) : 0;
-                c0[u] = (lane < len[u]) ? f.codes[off[u] + lane] : -1;
-                c1[u] = (lane + 64 < len[u]) ? f.codes[off[u] + 64 + lane] : -1;
+                len[u] = jh[u] < 0 ? 0 : __shfl(my_len, j, 64);
+#pragma unroll
+                for (int e = 0; e < 4; e++) cd[u][e] = (32 * e + k < len[u]) ? f.codes[off[u] + 32 * e + k] : -1;
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (j0 + u >= ndoc) break;  // wave-uniform
+            for (int u = 0; u < S1_PAIRS_IN_FLIGHT; u++) {
+                if (__ballot(jh[u] >= 0) == 0ull) break;  // wave-uniform
                 float per[4] = {-9999.0f, -9999.0f, -9999.0f, -9999.0f};
-                s1_fold_hits(c0[u], idxp, cs, f.ncol, T, nqc, k, h, per);
-                if (len[u] > 64) s1_fold_hits(c1[u], idxp, cs, f.ncol, T, nqc, k, h, per);
-                for (int t0 = 128; t0 < len[u]; t0 += 64) {  // long documents
-                    const int t = t0 + lane;
-                    const int code = (t < len[u]) ? f.codes[off[u] + t] : -1;
-                    s1_fold_hits(code, idxp, cs, f.ncol, T, nqc, k, h, per);
+                s1_fold_pair(cd[u], iv, cs, f.ncol, T, nqc, lane, per);
+                int t0 = 128;
+                while (__ballot(t0 < len[u])) {  // documents longer than 128 tokens
+                    int cx[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) cx[e] = (t0 + 32 * e + k < len[u]) ? f.codes[off[u] + t0 + 32 * e + k] : -1;
+                    s1_fold_pair(cx, iv, cs, f.ncol, T, nqc, lane, per);
+                    t0 += 128;
                 }
-                FLMR_FOR_CT(ct, T) {
-                    const float v = fmaxf(per[ct], __shfl_xor(per[ct], 32, 64));
-                    if (h == 0) tr[(j0 + u) * ncolp + ct * 32 + k] = v;
+                if (jh[u] >= 0) {
+                    FLMR_FOR_CT(ct, T) tr[jh[u] * ncolp + ct * 32 + k] = per[ct];
                 }
             }
         }
-        emit_group(tr, ncolp, nqc, ndoc, lane, my_pid, keys_b + g0);
+        emit_group(tr, ncolp, nqc, ndoc, lane, my_pid, my_scan, miss_score, keys_b + g0);
+        my_pid = nx_pid; my_scan = nx_scan;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hit bitmap: union of the IVF lists of the centroids that survive the threshold.  Built only when that union is
+// cheaper than scanning (sum of list lengths <= 2 x #candidates); otherwise hit_valid[q] = 0 and stage 1 scans all.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void s1_hit_budget_kernel(const uint32_t* idx_bits, int32_t idx_words,
+                                                            const int64_t* ivf_offsets, const int32_t* cand_count,
+                                                            int32_t* hit_valid) {
+    __shared__ unsigned long long total;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) total = 0ull;
+    __syncthreads();
+    unsigned long long mine = 0;
+    for (int w = threadIdx.x; w < idx_words; w += blockDim.x) {
+        uint32_t bits = idx_bits[(size_t)b * idx_words + w];
+        while (bits) {
+            const int c = w * 32 + __ffs(bits) - 1;
+            bits &= bits - 1;
+            mine += (unsigned long long)(ivf_offsets[c + 1] - ivf_offsets[c]);
+        }
+    }
+    atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) hit_valid[b] = total <= 2ull * (unsigned long long)cand_count[b];
+}
+
+__global__ __launch_bounds__(256) void s1_mark_hits_kernel(const uint32_t* idx_bits, int32_t idx_words,
+                                                           const int32_t* ivf_pids, const int64_t* ivf_offsets,
+                                                           const int32_t* hit_valid, uint32_t* hit_bits,
+                                                           int64_t hit_words) {
+    const int b = blockIdx.x;
+    if (!hit_valid[b]) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* hb = hit_bits + (size_t)b * hit_words;
+    const int w0 = (blockIdx.y * 4 + wave) * 16;
+    for (int w = w0; w < w0 + 16 && w < idx_words; w++) {
+        uint32_t bits = idx_bits[(size_t)b * idx_words + w];  // wave-uniform
+        while (bits) {
+            const int c = w * 32 + __ffs(bits) - 1;
+            bits &= bits - 1;
+            const int64_t beg = ivf_offsets[c], end = ivf_offsets[c + 1];
+            for (int64_t e = beg + lane; e < end; e += 64) {
+                const int pid = ivf_pids[e];
+                atomicOr(&hb[pid >> 5], 1u << (pid & 31));
+            }
+        }
+    }
+}
+
+int flmr_launch_hit_bitmap(const uint32_t* idx_bits, int32_t idx_words, int32_t nqueries, const int32_t* ivf_pids,
+                           const int64_t* ivf_offsets, const int32_t* cand_count, uint32_t* hit_bits, int64_t hit_words,
+                           int32_t* hit_valid, hipStream_t st) {
+    FLMR_HIP(hipMemsetAsync(hit_bits, 0, (size_t)nqueries * hit_words * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(s1_hit_budget_kernel, dim3(nqueries), dim3(256), 0, st, idx_bits, idx_words, ivf_offsets, cand_count,
+                       hit_valid);
+    hipLaunchKernelGGL(s1_mark_hits_kernel, dim3(nqueries, (unsigned)flmr_ceil_div(idx_words, 64)), dim3(256), 0, st,
+                       idx_bits, idx_words, ivf_pids, ivf_offsets, hit_valid, hit_bits, hit_words);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
 }
 
 int flmr_launch_filter_stage1(const flmr_filter_args& f, const uint32_t* idx_bits, int32_t idx_words,
                               const int32_t* cand, int64_t cand_stride, const int32_t* cand_count, uint64_t* keys,
-                              hipStream_t st) {
+                              const uint32_t* hit_bits, int64_t hit_words, const int32_t* hit_valid, hipStream_t st) {
     const int T = (f.nq_cand + 31) >> 5;
     const size_t tr_bytes = (size_t)S1_WAVES * S1_GROUP * (T * 32 + 1) * sizeof(float);
-    const size_t idx_bytes = (size_t)idx_words * 4;
-    const bool lds_idx = idx_bytes <= 40 * 1024;  // K <= 327680; larger K probes the mask through L1/L2
+    const size_t row_bytes = (size_t)S1_ROWCACHE * f.ncol * sizeof(float) + S1_ROWCACHE * sizeof(int);
+    const size_t idx_bytes = (size_t)idx_words * 4 + (size_t)idx_words * 2 + 16;
+    const bool lds_idx = tr_bytes + row_bytes + idx_bytes <= 100 * 1024;  // else probe the mask through L1/L2
+    if (lds_idx && tr_bytes + row_bytes + idx_bytes > 48 * 1024)
+        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_stage1_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(tr_bytes + row_bytes + idx_bytes)));
     // enough blocks per query to fill the chip even for one query; waves stride over the candidates
-    int G = (int)flmr_ceil_div(256 * 8, f.nqueries);
+    int G = (int)flmr_ceil_div(256 * 4, f.nqueries);
     if (G < 1) G = 1;
-    if (G > 256) G = 256;
-    dim3 grid(f.nqueries, G), block(256);
+    if (G > 128) G = 128;
+    dim3 grid(f.nqueries, G), block(S1_WAVES * 64);
     if (lds_idx)
-        hipLaunchKernelGGL(filter_stage1_kernel<true>, grid, block, tr_bytes + idx_bytes, st, f, idx_bits, idx_words,
-                           cand, cand_stride, cand_count, keys);
+        hipLaunchKernelGGL(filter_stage1_kernel<true>, grid, block, tr_bytes + row_bytes + idx_bytes, st, f, idx_bits,
+                           idx_words, cand, cand_stride, cand_count, keys, hit_bits, hit_words, hit_valid);
     else
-        hipLaunchKernelGGL(filter_stage1_kernel<false>, grid, block, tr_bytes, st, f, idx_bits, idx_words, cand,
-                           cand_stride, cand_count, keys);
+        hipLaunchKernelGGL(filter_stage1_kernel<false>, grid, block, tr_bytes + row_bytes, st, f, idx_bits, idx_words, cand,
+                           cand_stride, cand_count, keys, hit_bits, hit_words, hit_valid);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }
@@ -172,7 +329,7 @@ __global__ __launch_bounds__(256) void filter_stage2_kernel(flmr_filter_args f, 
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = counts[b];
-    const int d = blockIdx.y * S1_WAVES + wave;
+    const int d = blockIdx.y * S2_WAVES + wave;
     const int qlen = f.q_lens ? f.q_lens[b] : f.nq_cand;
     const int nqc = qlen < f.nq_cand ? qlen : f.nq_cand;
     const int T = (f.nq_cand + 31) >> 5;
@@ -222,8 +379,8 @@ int flmr_launch_filter_stage2(const flmr_filter_args& f, const int32_t* pids, in
                               const int32_t* counts, int32_t max_count, uint64_t* keys, int64_t key_stride,
                               hipStream_t st) {
     if (max_count <= 0) return FLMR_OK;
-    const size_t lds = (size_t)S1_WAVES * (((f.nq_cand + 31) >> 5) * 32 + 1) * sizeof(float);
-    dim3 grid(f.nqueries, (unsigned)flmr_ceil_div(max_count, S1_WAVES)), block(256);
+    const size_t lds = (size_t)S2_WAVES * (((f.nq_cand + 31) >> 5) * 32 + 1) * sizeof(float);
+    dim3 grid(f.nqueries, (unsigned)flmr_ceil_div(max_count, S2_WAVES)), block(S2_WAVES * 64);
     hipLaunchKernelGGL(filter_stage2_kernel, grid, block, lds, st, f, pids, pid_stride, counts, keys, key_stride);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;

@@ -122,6 +122,7 @@ extern "C" int flmr_index_open(const flmr_index_desc_t* d, flmr_index_t** out) {
     FLMR_TRY(to_device(d->ivf_pids, (size_t)ivf_total, d->memory, &ix->ivf_pids));
     FLMR_TRY(to_device(d->ivf_offsets, (size_t)K + 1, d->memory, &ix->ivf_offsets));
     FLMR_TRY(to_device(d->centroids, (size_t)K * FLMR_DIM, d->memory, &ix->centroids));
+    FLMR_TRY(flmr_check_f16_exact(ix->centroids, (size_t)K * FLMR_DIM, &ix->centroids_f16_exact));
     // fused decode table (always built on the host from the host bucket_weights)
     {
         const int vpb = 8 / ix->nbits;

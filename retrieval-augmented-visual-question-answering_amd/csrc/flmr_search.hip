@@ -20,6 +20,8 @@ struct flmr_searcher {
     float* cs; uint32_t* idx_bits; float* part_val; int32_t* part_idx; int32_t* cells; int32_t* ncell;
     uint32_t* bitmap; int32_t* cand; int32_t* cand_count; uint64_t* keys1; int32_t* s1_pids; int32_t* s1_count;
     uint64_t* keys2; int32_t* s2_pids; int32_t* s2_count; uint64_t* keys3; float* doc_scores; int32_t* overflow;
+    _Float16* q_hi; _Float16* q_lo;
+    uint32_t* hit_bits; int32_t* hit_valid;
     // last call (for taps)
     int32_t last_nqueries, last_ncol, last_ndocs;
     hipStream_t last_stream;
@@ -93,6 +95,10 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     WS(keys3, B * (size_t)nd4);
     WS(doc_scores, B * (size_t)nd4);
     WS(overflow, 1);
+    WS(q_hi, B * (size_t)s->ncol_max * FLMR_DIM);
+    WS(q_lo, B * (size_t)s->ncol_max * FLMR_DIM);
+    WS(hit_bits, B * (size_t)s->bitmap_words);
+    WS(hit_valid, B);
 #undef WS
     FLMR_HIP(hipMemset(s->overflow, 0, sizeof(int32_t)));
     for (int i = 0; i <= FLMR_NUM_STAGES; i++) FLMR_HIP(hipEventCreate(&s->ev[i]));
@@ -104,7 +110,7 @@ extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
     if (!s) return FLMR_OK;
     void* ptrs[] = {s->cs, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
                     s->keys1, s->s1_pids, s->s1_count, s->keys2, s->s2_pids, s->s2_count, s->keys3, s->doc_scores,
-                    s->overflow};
+                    s->overflow, s->q_hi, s->q_lo, s->hit_bits, s->hit_valid};
     for (void* p : ptrs) (void)hipFree(p);
     for (int i = 0; i <= FLMR_NUM_STAGES; i++)
         if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
@@ -169,6 +175,7 @@ extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32
     a0.cs = s->cs; a0.idx_bits = s->idx_bits; a0.idx_words = s->idx_words;
     a0.part_val = s->part_val; a0.part_idx = s->part_idx; a0.nblk = s->nblk;
     a0.cells = s->cells; a0.ncell = s->ncell; a0.max_cells = s->max_cells;
+    a0.q_hi = s->q_hi; a0.q_lo = s->q_lo; a0.centroids_f16_exact = ix->centroids_f16_exact;
     MARK();
     RUN(flmr_launch_centroid_scores(a0, st));
     MARK();
@@ -184,7 +191,12 @@ extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32
     flmr_filter_args f;
     f.cs = s->cs; f.cs_query_stride = (int64_t)ix->K * ncol; f.K = ix->K; f.ncol = ncol; f.nq_cand = nqc;
     f.nqueries = nqueries; f.q_lens = q_lens; f.codes = ix->codes; f.doclens = nullptr; f.offsets = ix->doc_offsets;
-    RUN(flmr_launch_filter_stage1(f, s->idx_bits, s->idx_words, s->cand, s->cand_cap, s->cand_count, s->keys1, st));
+    const bool use_hits = getenv("FLMR_S1_NO_HITMAP") == nullptr;
+    if (use_hits)
+        RUN(flmr_launch_hit_bitmap(s->idx_bits, s->idx_words, nqueries, ix->ivf_pids, ix->ivf_offsets, s->cand_count,
+                                   s->hit_bits, s->bitmap_words, s->hit_valid, st));
+    RUN(flmr_launch_filter_stage1(f, s->idx_bits, s->idx_words, s->cand, s->cand_cap, s->cand_count, s->keys1,
+                                  use_hits ? s->hit_bits : nullptr, s->bitmap_words, s->hit_valid, st));
     MARK();
     RUN(flmr_launch_select_topn(s->keys1, s->cand_cap, s->cand_count, nqueries, p->ndocs, s->s1_pids, s->maxp.ndocs,
                                 s->s1_count, st));

@@ -135,6 +135,173 @@ __global__ __launch_bounds__(256) void s0_centroid_scores_mfma(flmr_s0_args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// S0a (fp16-split MFMA, default): centroids of a reference-format index are fp16 values (centroids.pt is saved
+// as half, residual.py:161), so C is EXACT in fp16; Q is split as q_hi + q_lo*2^-11 with both halves fp16.  Every
+// fp16 x fp16 product is exact in fp32 and the MFMA accumulates in fp32, so
+//     C.q  ~=  mfma16(C, q_hi) + 2^-11 * mfma16(C, q_lo)
+// carries ~2^-22 relative error per term (fp32-roundoff class, far inside the 1e-4 score tolerance) at 1/8 of
+// the fp32-MFMA issue cost (2 x v_mfma_f32_32x32x16_f16 @ 32 cycles vs 8 x v_mfma_f32_32x32x2_f32 @ 64 per 16 dims).
+// The MFMA pairs element e of k-half h of A with element e of k-half h of B, so any (h,e)->dim map used for
+// BOTH operands is a valid contraction order: lane (i, h) holds dims 64h..64h+63 of its row, step s uses
+// dims 64h+8s..64h+8s+7.
+// A wave owns 128 centroid rows (4 row tiles, A image = 128 VGPRs) for the whole query loop and loads the query
+// tile once per 128 rows; the per-column top lists are carried across the 4 row tiles in registers, so the kernel
+// has no LDS and no block barrier.  grid = (ceil(K/512), QSPLIT), block = 256.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void s0_split_q(const float* Q, const int32_t* q_lens, int nq, int nq_cand, int ncol,
+                                                  _Float16* q_hi, _Float16* q_lo) {
+    const int b = blockIdx.y;
+    const int qlen = q_lens ? q_lens[b] : nq;
+    const int nqc = qlen < nq_cand ? qlen : nq_cand;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < ncol * FLMR_DIM; e += gridDim.x * blockDim.x) {
+        const int col = e / FLMR_DIM;
+        float v = 0.0f;
+        if (col < nqc) v = Q[((size_t)b * nq + col) * FLMR_DIM + (e % FLMR_DIM)];
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+        q_hi[(size_t)b * ncol * FLMR_DIM + e] = hi;
+        q_lo[(size_t)b * ncol * FLMR_DIM + e] = lo;
+    }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void s0_centroid_scores_f16(flmr_s0_args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int wtile = blockIdx.x * 4 + wave;  // 128-row tile index == partial-list block index
+    const int row0 = wtile * 128;
+    if (row0 >= a.K) return;  // no block-level barrier in this kernel
+    const int T = a.ncol >> 5;
+
+    f16x8 av[4][8];
+#pragma unroll
+    for (int rt = 0; rt < 4; rt++) {
+        const int arow = row0 + rt * 32 + i;
+        if (arow < a.K) {
+            const float4* p = reinterpret_cast<const float4*>(a.centroids + (size_t)arow * FLMR_DIM + 64 * h);
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const float4 x = p[2 * s], y = p[2 * s + 1];
+                av[rt][s][0] = (_Float16)x.x; av[rt][s][1] = (_Float16)x.y; av[rt][s][2] = (_Float16)x.z; av[rt][s][3] = (_Float16)x.w;
+                av[rt][s][4] = (_Float16)y.x; av[rt][s][5] = (_Float16)y.y; av[rt][s][6] = (_Float16)y.z; av[rt][s][7] = (_Float16)y.w;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; s++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) av[rt][s][e] = (_Float16)0.0f;
+        }
+    }
+
+    // flattened (query, column-tile) loop with the NEXT tile's B operand prefetched: one wave per SIMD runs this
+    // kernel (A image + two B images + accumulators ~ 300 registers), so the overlap has to be explicit.
+    const int nb = (a.nqueries - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int niter = nb * T;
+    f16x8 bh[8], bl[8], nh[8], nl[8];
+    auto load_b = [&](int it, f16x8* oh, f16x8* ol) {
+        const int b = blockIdx.y + (it / T) * gridDim.y, col = (it % T) * 32 + i;
+        const f16x8* ph = reinterpret_cast<const f16x8*>(a.q_hi + ((size_t)b * a.ncol + col) * FLMR_DIM + 64 * h);
+        const f16x8* pl = reinterpret_cast<const f16x8*>(a.q_lo + ((size_t)b * a.ncol + col) * FLMR_DIM + 64 * h);
+#pragma unroll
+        for (int s = 0; s < 8; s++) { oh[s] = ph[s]; ol[s] = pl[s]; }
+    };
+    const bool full_tile = row0 + 128 <= a.K;  // wave-uniform: no row guards needed
+    if (niter > 0) load_b(0, bh, bl);
+    uint32_t flags[4] = {0u, 0u, 0u, 0u};  // bit r of flags[rt]: some column of accumulator row r reached thr
+    for (int it = 0; it < niter; it++) {
+        const int b = blockIdx.y + (it / T) * gridDim.y, ct = it % T;
+        if (it + 1 < niter) load_b(it + 1, nh, nl);
+        const int qlen = a.q_lens ? a.q_lens[b] : a.nq;
+        const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;
+        float* cs_b = a.cs + (size_t)b * a.K * a.ncol;
+        const int col = ct * 32 + i;
+        const bool colok = col < nqc;
+        flmr_toplist<NC> tl;
+        tl.init();
+#pragma unroll
+        for (int rt = 0; rt < 4; rt++) {
+            f32x16 ah, al;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[rt][s], bh[s], ah, 0, 0, 0);
+                al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[rt][s], bl[s], al, 0, 0, 0);
+            }
+            // epilogue of one 32x32 tile: branch-free so the compiler can place it in the MFMA shadow of the next tile
+            float* crow = cs_b + (size_t)(row0 + rt * 32 + 4 * h) * a.ncol + col;
+            if (full_tile) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int lrow = (r & 3) + 8 * (r >> 2);
+                    const float v = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+                    crow[(size_t)lrow * a.ncol] = v;
+                    const float x = colok ? v : FLMR_NEG_INF;
+                    tl.insert_ascending(x, row0 + rt * 32 + 4 * h + lrow);
+                    flags[rt] |= (uint32_t)(x >= a.thr) << r;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int lrow = (r & 3) + 8 * (r >> 2);
+                    const int grow = row0 + rt * 32 + 4 * h + lrow;
+                    const float v = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+                    if (grow < a.K) crow[(size_t)lrow * a.ncol] = v;
+                    const float x = (colok && grow < a.K) ? v : FLMR_NEG_INF;
+                    tl.insert_ascending(x, grow < a.K ? grow : 0x7fffffff);
+                    flags[rt] |= (uint32_t)(x >= a.thr) << r;
+                }
+            }
+        }
+        tl.merge_xor(32);
+        if (lane < 32) {
+            const size_t base = ((((size_t)b * a.nblk + wtile) * a.ncol) + col) * NC;
+#pragma unroll
+            for (int t = 0; t < NC; t++) { a.part_val[base + t] = tl.v[t]; a.part_idx[base + t] = tl.id[t]; }
+        }
+        if (ct == T - 1) {
+            // idx bits: OR the 16-bit row flags over the 32 lanes (columns) of each half, then interleave the halves
+#pragma unroll
+            for (int rt = 0; rt < 4; rt++) {
+                uint32_t f = flags[rt];
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1) f |= (uint32_t)__shfl_xor((int)f, m, 64);
+                uint32_t w = 0;
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    if ((f >> r) & 1u) w |= 1u << ((r & 3) + 8 * (r >> 2) + 4 * h);
+                w |= (uint32_t)__shfl_xor((int)w, 32, 64);
+                if (lane == 0 && row0 + rt * 32 < a.K) a.idx_bits[(size_t)b * a.idx_words + ((row0 + rt * 32) >> 5)] = w;
+                flags[rt] = 0u;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; s++) { bh[s] = nh[s]; bl[s] = nl[s]; }
+    }
+}
+
+__global__ void check_f16_exact_kernel(const float* x, size_t n, int* flag) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[e];
+        if ((float)(_Float16)v != v) atomicAnd(flag, 0);
+    }
+}
+
+int flmr_check_f16_exact(const float* dev, size_t n, int32_t* host_result) {
+    int* flag = nullptr;
+    FLMR_HIP(hipMalloc(reinterpret_cast<void**>(&flag), sizeof(int)));
+    int one = 1;
+    FLMR_HIP(hipMemcpy(flag, &one, sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(check_f16_exact_kernel, dim3(1024), dim3(256), 0, 0, dev, n, flag);
+    FLMR_HIP(hipMemcpy(&one, flag, sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(flag);
+    *host_result = one;
+    return FLMR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // S0a (VALU cross-check path, FLMR_S0_IMPL=valu): plain k-ascending fp32 dot products, then a
 // post-processing kernel derives the idx bits and the block partials from the stored table.
 // ------------------------------------------------------------------------------------------------
@@ -203,10 +370,16 @@ __global__ __launch_bounds__(256) void s0_postprocess_table(flmr_s0_args a) {
     }
 }
 
+enum { S0_F16 = 0, S0_F32 = 1, S0_VALU = 2 };
+
 template <int NC>
-static int launch_s0_t(const flmr_s0_args& a, hipStream_t st, bool valu) {
+static int launch_s0_t(const flmr_s0_args& a, hipStream_t st, int impl) {
     const int qsplit = a.nqueries < 8 ? a.nqueries : 8;
-    if (!valu) {
+    if (impl == S0_F16) {
+        hipLaunchKernelGGL(s0_split_q, dim3((a.ncol * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens,
+                           a.nq, a.nq_cand, a.ncol, a.q_hi, a.q_lo);
+        hipLaunchKernelGGL(s0_centroid_scores_f16<NC>, dim3((a.nblk + 3) / 4, qsplit), dim3(256), 0, st, a);
+    } else if (impl == S0_F32) {
         hipLaunchKernelGGL(s0_centroid_scores_mfma<NC>, dim3(a.nblk, qsplit), dim3(256), 0, st, a);
     } else {
         hipLaunchKernelGGL(s0_centroid_scores_valu, dim3(1024, a.nqueries), dim3(256), 0, st, a);
@@ -218,14 +391,18 @@ static int launch_s0_t(const flmr_s0_args& a, hipStream_t st, bool valu) {
 
 static int nc_bucket(int ncells) { return ncells <= 1 ? 1 : ncells <= 2 ? 2 : ncells <= 4 ? 4 : 8; }
 
+// FLMR_S0_IMPL = f16 (default when every centroid is fp16-exact) | f32 (fp32 MFMA) | valu (plain FMA cross-check)
 int flmr_launch_centroid_scores(const flmr_s0_args& a, hipStream_t st) {
-    const char* impl = getenv("FLMR_S0_IMPL");
-    const bool valu = impl && strcmp(impl, "valu") == 0;
+    const char* env = getenv("FLMR_S0_IMPL");
+    int impl = a.centroids_f16_exact ? S0_F16 : S0_F32;
+    if (env && strcmp(env, "valu") == 0) impl = S0_VALU;
+    if (env && (strcmp(env, "f32") == 0 || strcmp(env, "mfma") == 0)) impl = S0_F32;
+    if (env && strcmp(env, "f16") == 0 && a.centroids_f16_exact) impl = S0_F16;
     switch (nc_bucket(a.ncells)) {
-        case 1: return launch_s0_t<1>(a, st, valu);
-        case 2: return launch_s0_t<2>(a, st, valu);
-        case 4: return launch_s0_t<4>(a, st, valu);
-        default: return launch_s0_t<8>(a, st, valu);
+        case 1: return launch_s0_t<1>(a, st, impl);
+        case 2: return launch_s0_t<2>(a, st, impl);
+        case 4: return launch_s0_t<4>(a, st, impl);
+        default: return launch_s0_t<8>(a, st, impl);
     }
 }
 

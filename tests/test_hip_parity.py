@@ -132,21 +132,24 @@ def test_score_pids_fused_vs_oracle(hip, scorers, name):
         assert np.max(np.abs(out.cpu().numpy() - ref)) <= SCORE_TOL, r
 
 
-def test_s0_mfma_equals_valu_kernel(hip, scorers):
-    """The fp32 MFMA centroid-score kernel (fused epilogue) vs the plain k-ascending VALU kernel + table post-pass."""
+def test_s0_kernel_variants_agree(hip, scorers):
+    """fp16-split MFMA (default), fp32 MFMA and the plain k-ascending VALU kernel + table post-pass: the score tables agree
+    to fp32-roundoff and every derived integer result (idx bits, cells, candidates) is identical."""
     nat = hip["native"]
-    z, scorer = scorers["idx_nb2"]
-    taps = {}
-    for impl in ("mfma", "valu"):
-        os.environ["FLMR_S0_IMPL"] = impl
-        try:
-            _search_one(hip, scorer, z, "rank0")
-            taps[impl] = [scorer.tap(t) for t in (nat.TAP_CENTROID_SCORES, nat.TAP_IDX_BITS, nat.TAP_CELLS, nat.TAP_CANDIDATES)]
-        finally:
-            os.environ.pop("FLMR_S0_IMPL", None)
-    assert np.max(np.abs(taps["mfma"][0] - taps["valu"][0])) <= GEMM_TOL
-    for a, b in zip(taps["mfma"][1:], taps["valu"][1:]):
-        assert np.array_equal(a, b)
+    for name, rec in (("idx_nb2", "rank0"), ("idx_nb2", "rank9"), ("idx_nb1", "rank_rz")):
+        z, scorer = scorers[name]
+        taps = {}
+        for impl in ("f16", "f32", "valu"):
+            os.environ["FLMR_S0_IMPL"] = impl
+            try:
+                _search_one(hip, scorer, z, rec)
+                taps[impl] = [scorer.tap(t) for t in (nat.TAP_CENTROID_SCORES, nat.TAP_IDX_BITS, nat.TAP_CELLS, nat.TAP_CANDIDATES)]
+            finally:
+                os.environ.pop("FLMR_S0_IMPL", None)
+        for impl in ("f16", "f32"):
+            assert np.max(np.abs(taps[impl][0] - taps["valu"][0])) <= 5e-7, (name, rec, impl)
+            for a, b in zip(taps[impl][1:], taps["valu"][1:]):
+                assert np.array_equal(a, b), (name, rec, impl)
 
 
 def test_ops_vs_golden(hip):
