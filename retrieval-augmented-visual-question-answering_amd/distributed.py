@@ -16,8 +16,12 @@ def all_gather_topk(scores, pids, group=None):
     world = dist.get_world_size(group)
     gs = torch.empty((world,) + tuple(scores.shape), dtype=scores.dtype, device=scores.device)
     gp = torch.empty((world,) + tuple(pids.shape), dtype=pids.dtype, device=pids.device)
-    dist.all_gather_into_tensor(gs, scores.contiguous(), group=group)
-    dist.all_gather_into_tensor(gp, pids.contiguous(), group=group)
+    try:
+        dist.all_gather_into_tensor(gs, scores.contiguous(), group=group)
+        dist.all_gather_into_tensor(gp, pids.contiguous(), group=group)
+    except (RuntimeError, NotImplementedError):  # backends without the fused form (older gloo)
+        dist.all_gather(list(gs.unbind(0)), scores.contiguous(), group=group)
+        dist.all_gather(list(gp.unbind(0)), pids.contiguous(), group=group)
     return gs, gp
 
 
