@@ -71,6 +71,7 @@ struct flmr_index {
     int64_t* ivf_offsets;
     float* centroids;
     float* wlut;  // [256][8/nbits] fused decode table: bucket_weights[lut[rev[byte]][l]]
+    _Float16* centroids_f16;  // [K,128] fp16 image of the centroids (only when centroids_f16_exact)
     float bucket_weights[256];
     // host copy of the IVF list lengths sorted descending, prefix-summed: bound on #candidates for c cells
     int64_t* ivf_len_prefix;  // [K+1] host
@@ -106,6 +107,7 @@ struct flmr_s0_args {
 int flmr_launch_centroid_scores(const flmr_s0_args& a, hipStream_t st);
 int flmr_launch_select_cells(const flmr_s0_args& a, hipStream_t st);
 int flmr_check_f16_exact(const float* dev, size_t n, int32_t* host_result);
+int flmr_convert_f16(const float* dev, size_t n, _Float16* out);
 
 int flmr_launch_ivf_mark(const int32_t* cells, const int32_t* ncell, int32_t max_cells, int32_t nqueries,
                          const int32_t* ivf_pids, const int64_t* ivf_offsets, uint32_t* bitmap, int64_t bitmap_words,
@@ -155,6 +157,8 @@ struct flmr_maxsim_args {
     uint64_t* keys;           // out [nqueries, key_stride] (score,pid) keys   (nullable)
     int64_t key_stride;
     float* scores;            // out [nqueries, key_stride] fp32 scores        (nullable)
+    _Float16* q_hi;           // scratch [nqueries, round_up(nq,32), 128]: fp16 split of Q (nullable -> fp32 MFMA kernel)
+    _Float16* q_lo;
 };
 int flmr_launch_maxsim(const flmr_maxsim_args& a, hipStream_t st);
 

@@ -123,6 +123,11 @@ extern "C" int flmr_index_open(const flmr_index_desc_t* d, flmr_index_t** out) {
     FLMR_TRY(to_device(d->ivf_offsets, (size_t)K + 1, d->memory, &ix->ivf_offsets));
     FLMR_TRY(to_device(d->centroids, (size_t)K * FLMR_DIM, d->memory, &ix->centroids));
     FLMR_TRY(flmr_check_f16_exact(ix->centroids, (size_t)K * FLMR_DIM, &ix->centroids_f16_exact));
+    if (ix->centroids_f16_exact) {
+        rc = hipMalloc(reinterpret_cast<void**>(&ix->centroids_f16), (size_t)K * FLMR_DIM * sizeof(_Float16)) == hipSuccess ? FLMR_OK : FLMR_ERR_NOMEM;
+        if (rc) { snprintf(flmr_err_buf, sizeof(flmr_err_buf), "hipMalloc centroids_f16"); flmr_index_close(ix); return rc; }
+        FLMR_TRY(flmr_convert_f16(ix->centroids, (size_t)K * FLMR_DIM, ix->centroids_f16));
+    }
     // fused decode table (always built on the host from the host bucket_weights)
     {
         const int vpb = 8 / ix->nbits;
@@ -148,6 +153,7 @@ extern "C" int flmr_index_close(flmr_index_t* ix) {
         (void)hipFree(ix->ivf_pids); (void)hipFree(ix->ivf_offsets); (void)hipFree(ix->centroids);
     }
     (void)hipFree(ix->wlut);
+    (void)hipFree(ix->centroids_f16);
     delete[] ix->ivf_len_prefix;
     delete ix;
     return FLMR_OK;

@@ -130,6 +130,233 @@ __global__ __launch_bounds__(256) void maxsim_kernel(flmr_maxsim_args m, const i
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// S3, fp16-split variant (default when the centroids are fp16-exact): one WAVE per finalist document.
+//   * a wave owns a strided list of documents of one query; lanes fetch all their (pid, offset, length) triples in
+//     parallel up front, the NEXT document's codes are loaded while the current one is scored, and the NEXT token
+//     tile's centroid half-rows (fp16 image, 128 B per lane) + residual bytes are issued right after the current tile
+//     has been decompressed -- so the dependent gather chain pid -> offset -> code -> row is off the critical path;
+//   * decompress -> fp32 row, L2 norm (fp32), scale by 1/max(||d||,eps), THEN split d = d_hi + 2^-11 d_lo in fp16;
+//     Q is split the same way once per batch (s3_split_q);  d.q ~= hi.hi + 2^-11 (hi.lo + lo.hi): three
+//     v_mfma_f32_32x32x16_f16 per 16 dims instead of eight v_mfma_f32_32x32x2_f32, ~2^-21 relative error per term;
+//   * the per-query-token running max (zero-initialised) lives in a per-wave LDS row; no block barrier, no atomics.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 hf8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void s3_split_q(const float* Q, const int32_t* q_lens, int nq, int nqp, _Float16* q_hi,
+                                                  _Float16* q_lo) {
+    const int b = blockIdx.y;
+    const int qlen = q_lens ? q_lens[b] : nq;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nqp * FLMR_DIM; e += gridDim.x * blockDim.x) {
+        const int row = e / FLMR_DIM;
+        float v = 0.0f;
+        if (row < qlen && row < nq) v = Q[((size_t)b * nq + row) * FLMR_DIM + (e % FLMR_DIM)];
+        const _Float16 hi = (_Float16)v;
+        q_hi[(size_t)b * nqp * FLMR_DIM + e] = hi;
+        q_lo[(size_t)b * nqp * FLMR_DIM + e] = (_Float16)((v - (float)hi) * 2048.0f);
+    }
+}
+
+template <int NBITS>
+struct s3_raw {          // one lane's share of one token: half a centroid row (fp16) + its residual bytes
+    hf8 c[8];
+    uint2 r[NBITS];
+    bool valid;
+};
+
+template <int NBITS>
+__device__ __forceinline__ void s3_issue_rows(s3_raw<NBITS>& raw, const int* cdreg, int t, int64_t off, int len, int i, int h,
+                                              const int32_t* __restrict__ codes, const uint8_t* __restrict__ residuals,
+                                              const _Float16* __restrict__ cen16) {
+    constexpr int PACKED = FLMR_DIM * NBITS / 8, NB = 8 * NBITS;
+    const int tok = t * 32 + i;
+    raw.valid = tok < len;
+    int code = 0;
+    if (t < 8) {  // tokens < 256 were preloaded: register t>>1 of lane (t&1)*32 + i (wave-uniform register choice)
+        const int sel = t >> 1;
+        const int reg = sel == 0 ? cdreg[0] : sel == 1 ? cdreg[1] : sel == 2 ? cdreg[2] : cdreg[3];
+        code = __shfl(reg, (t & 1) * 32 + i, 64);
+    } else if (raw.valid) {
+        code = codes[off + tok];
+    }
+    if (raw.valid) {
+        const hf8* pc = reinterpret_cast<const hf8*>(cen16 + (size_t)code * FLMR_DIM + 64 * h);
+#pragma unroll
+        for (int s = 0; s < 8; s++) raw.c[s] = pc[s];
+        const uint2* pr = reinterpret_cast<const uint2*>(residuals + (size_t)(off + tok) * PACKED + h * NB);
+#pragma unroll
+        for (int w = 0; w < NBITS; w++) raw.r[w] = pr[w];
+    }
+}
+
+template <int NBITS>
+__global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, const int32_t* __restrict__ codes,
+                                                            const uint8_t* __restrict__ residuals,
+                                                            const int64_t* __restrict__ doc_offsets,
+                                                            const _Float16* __restrict__ cen16,
+                                                            const float* __restrict__ wlut_g, int nqp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int VPB = 8 / NBITS;
+    float* wlut = reinterpret_cast<float*>(smem);  // [256 * VPB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    float* colmax = wlut + 256 * VPB + (size_t)wave * nqp;  // this wave's running maxima [nqp]
+    const int b = blockIdx.x;
+    const int cnt = m.counts[b];
+    const int qlen = m.q_lens ? m.q_lens[b] : m.nq;
+    for (int t = tid; t < 256 * VPB; t += 256) wlut[t] = wlut_g[t];
+    for (int t = lane; t < nqp; t += 64) colmax[t] = 0.0f;
+    __syncthreads();
+
+    const int W = gridDim.y * 4, w = blockIdx.y * 4 + wave;
+    const int ndw = cnt > w ? (cnt - w + W - 1) / W : 0;  // documents of this wave (<= 64, guaranteed by the launcher)
+    if (ndw == 0) return;
+    int my_pid = 0, my_len = 0;
+    int64_t my_off = 0;
+    if (lane < ndw) {
+        my_pid = m.pids[(size_t)b * m.pid_stride + w + lane * W];
+        my_off = doc_offsets[my_pid];
+        my_len = (int)(doc_offsets[my_pid + 1] - my_off);
+    }
+    const _Float16* qh_b = m.q_hi + (size_t)b * nqp * FLMR_DIM;
+    const _Float16* ql_b = m.q_lo + (size_t)b * nqp * FLMR_DIM;
+    hf8 bh[8], bl[8];
+    auto load_b = [&](int q0) {
+        const hf8* ph = reinterpret_cast<const hf8*>(qh_b + (size_t)(q0 + i) * FLMR_DIM + 64 * h);
+        const hf8* pl = reinterpret_cast<const hf8*>(ql_b + (size_t)(q0 + i) * FLMR_DIM + 64 * h);
+#pragma unroll
+        for (int s = 0; s < 8; s++) { bh[s] = ph[s]; bl[s] = pl[s]; }
+    };
+    const bool single_qt = nqp == 32;
+    if (single_qt) load_b(0);
+
+    auto load_codes = [&](int64_t off, int len, int* cd) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) cd[r] = (lane + 64 * r < len) ? codes[off + lane + 64 * r] : 0;
+    };
+    int cd[4], ncd[4];
+    {
+        const int64_t off0 = ((int64_t)__shfl((int)(uint32_t)((uint64_t)my_off >> 32), 0, 64) << 32) |
+                             (uint32_t)__shfl((int)(uint32_t)my_off, 0, 64);
+        load_codes(off0, __shfl(my_len, 0, 64), cd);
+    }
+    s3_raw<NBITS> raw;
+    bool have_raw = false;
+    for (int j = 0; j < ndw; j++) {
+        const int pid = __shfl(my_pid, j, 64);
+        const int len = __shfl(my_len, j, 64);
+        const int64_t off = ((int64_t)__shfl((int)(uint32_t)((uint64_t)my_off >> 32), j, 64) << 32) |
+                            (uint32_t)__shfl((int)(uint32_t)my_off, j, 64);
+        int nlen = 0;
+        int64_t noff = 0;
+        if (j + 1 < ndw) {
+            nlen = __shfl(my_len, j + 1, 64);
+            noff = ((int64_t)__shfl((int)(uint32_t)((uint64_t)my_off >> 32), j + 1, 64) << 32) |
+                   (uint32_t)__shfl((int)(uint32_t)my_off, j + 1, 64);
+            load_codes(noff, nlen, ncd);
+        }
+        const int ntiles = (len + 31) >> 5;
+        if (ntiles > 0 && !have_raw) s3_issue_rows<NBITS>(raw, cd, 0, off, len, i, h, codes, residuals, cen16);
+        have_raw = false;
+        for (int t = 0; t < ntiles; t++) {
+            // ---- decompress this lane's half row, normalise, split into fp16 hi/lo (the MFMA A operand) ----
+            hf8 ah[8], al[8];
+            {
+                float d[64];
+                float ss = 0.0f;
+#pragma unroll
+                for (int wq = 0; wq < NBITS; wq++) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const uint32_t word = e < 4 ? raw.r[wq].x : raw.r[wq].y;
+                        const uint32_t byte = (word >> (8 * (e & 3))) & 255u;
+                        const int kb = wq * 8 + e;
+#pragma unroll
+                        for (int l = 0; l < VPB; l++) {
+                            const int dd = kb * VPB + l;
+                            const float v = raw.valid ? (wlut[byte * VPB + l] + (float)raw.c[dd >> 3][dd & 7]) : 0.0f;
+                            d[dd] = v;
+                            ss = fmaf(v, v, ss);
+                        }
+                    }
+                }
+                ss += __shfl_xor(ss, 32, 64);
+                float nrm = sqrtf(ss);
+                nrm = nrm < 1e-12f ? 1e-12f : nrm;
+                const float inv = 1.0f / nrm;
+#pragma unroll
+                for (int dd = 0; dd < 64; dd++) {
+                    const float v = d[dd] * inv;
+                    const _Float16 hi = (_Float16)v;
+                    ah[dd >> 3][dd & 7] = hi;
+                    al[dd >> 3][dd & 7] = (_Float16)((v - (float)hi) * 2048.0f);
+                }
+            }
+            // ---- prefetch the next tile's rows (this document's next tile, or the next document's first tile) ----
+            if (t + 1 < ntiles) {
+                s3_issue_rows<NBITS>(raw, cd, t + 1, off, len, i, h, codes, residuals, cen16);
+            } else if (j + 1 < ndw && nlen > 0) {
+                s3_issue_rows<NBITS>(raw, ncd, 0, noff, nlen, i, h, codes, residuals, cen16);
+                have_raw = true;
+            }
+            // ---- 32 tokens x 32 query tokens per q-tile ----
+            for (int q0 = 0; q0 < qlen; q0 += 32) {
+                if (!single_qt) load_b(q0);
+                f32x16 acch, accl;
+#pragma unroll
+                for (int r = 0; r < 16; r++) { acch[r] = 0.0f; accl[r] = 0.0f; }
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[s], acch, 0, 0, 0);
+                    accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[s], accl, 0, 0, 0);
+                    accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s], accl, 0, 0, 0);
+                }
+                float mx = 0.0f;  // segmented_maxsim.cpp:58-59: the running max starts at zero
+#pragma unroll
+                for (int r = 0; r < 16; r++) mx = fmaxf(mx, fmaf(accl[r], 1.0f / 2048.0f, acch[r]));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const int col = q0 + i;
+                if (h == 0 && col < qlen) colmax[col] = fmaxf(colmax[col], mx);
+            }
+        }
+        // ---- document done: k-ascending sum of the column maxima, reset for the next document ----
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            float sc = 0.0f;
+            for (int k = 0; k < qlen; k++) sc += colmax[k];
+            const int dslot = w + j * W;
+            if (m.keys) m.keys[(size_t)b * m.key_stride + dslot] = flmr_make_key(sc, pid);
+            if (m.scores) m.scores[(size_t)b * m.key_stride + dslot] = sc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < nqp; t += 64) colmax[t] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) cd[r] = ncd[r];
+    }
+}
+
+template <int NBITS>
+static int launch_maxsim_f16_t(const flmr_maxsim_args& a, hipStream_t st) {
+    const flmr_index* ix = a.ix;
+    const int nqp = (int)flmr_round_up(a.nq, 32);
+    const size_t lds = (size_t)256 * (8 / NBITS) * sizeof(float) + (size_t)4 * nqp * sizeof(float);
+    if (lds > 64 * 1024) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nq=%d too large for the MaxSim kernel's LDS column maxima", a.nq);
+    hipLaunchKernelGGL(s3_split_q, dim3((nqp * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens, a.nq, nqp,
+                       a.q_hi, a.q_lo);
+    // waves per query: enough to fill the chip, at most 64 documents per wave, at least 1
+    int G = (int)flmr_ceil_div(4096, 4 * (int64_t)a.nqueries);
+    const int gmin = (int)flmr_ceil_div(a.max_count, 4 * 64);
+    if (G < gmin) G = gmin;
+    if (G > (int)flmr_ceil_div(a.max_count, 4)) G = (int)flmr_ceil_div(a.max_count, 4);
+    if (G < 1) G = 1;
+    hipLaunchKernelGGL(maxsim_f16_kernel<NBITS>, dim3(a.nqueries, G), dim3(256), lds, st, a, ix->codes, ix->residuals,
+                       ix->doc_offsets, ix->centroids_f16, ix->wlut, nqp);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
 template <int NBITS>
 static int launch_maxsim_t(const flmr_maxsim_args& a, hipStream_t st) {
     const flmr_index* ix = a.ix;
@@ -144,8 +371,19 @@ static int launch_maxsim_t(const flmr_maxsim_args& a, hipStream_t st) {
     return FLMR_OK;
 }
 
+// FLMR_S3_IMPL = f16 (default when the centroids are fp16-exact and split buffers are supplied) | f32
 int flmr_launch_maxsim(const flmr_maxsim_args& a, hipStream_t st) {
     if (a.max_count <= 0) return FLMR_OK;
+    const char* env = getenv("FLMR_S3_IMPL");
+    const bool f16 = a.ix->centroids_f16_exact && a.ix->centroids_f16 && a.q_hi && a.q_lo && !(env && strcmp(env, "f32") == 0);
+    if (f16) {
+        switch (a.ix->nbits) {
+            case 1: return launch_maxsim_f16_t<1>(a, st);
+            case 2: return launch_maxsim_f16_t<2>(a, st);
+            case 4: return launch_maxsim_f16_t<4>(a, st);
+            case 8: return launch_maxsim_f16_t<8>(a, st);
+        }
+    }
     switch (a.ix->nbits) {
         case 1: return launch_maxsim_t<1>(a, st);
         case 2: return launch_maxsim_t<2>(a, st);

@@ -208,6 +208,13 @@ extern "C" int flmr_score_pids(const flmr_index_t* ix, const float* Q, int32_t n
     flmr_maxsim_args m;
     m.ix = ix; m.Q = Q; m.q_lens = nullptr; m.nqueries = 1; m.nq = nq; m.pids = pids; m.pid_stride = npids;
     m.counts = cnt; m.max_count = npids; m.keys = nullptr; m.key_stride = npids; m.scores = out;
+    m.q_hi = nullptr; m.q_lo = nullptr;
+    _Float16 *qh = nullptr, *ql = nullptr;
+    if (ix->centroids_f16_exact) {
+        RUN(sc.alloc(&qh, (size_t)flmr_round_up(nq, 32) * FLMR_DIM));
+        RUN(sc.alloc(&ql, (size_t)flmr_round_up(nq, 32) * FLMR_DIM));
+        m.q_hi = qh; m.q_lo = ql;
+    }
     RUN(flmr_launch_maxsim(m, st));
     FLMR_HIP(hipStreamSynchronize(st));
     return FLMR_OK;

@@ -22,6 +22,7 @@ struct flmr_searcher {
     uint64_t* keys2; int32_t* s2_pids; int32_t* s2_count; uint64_t* keys3; float* doc_scores; int32_t* overflow;
     _Float16* q_hi; _Float16* q_lo;
     uint32_t* hit_bits; int32_t* hit_valid;
+    _Float16* q3_hi; _Float16* q3_lo;
     // last call (for taps)
     int32_t last_nqueries, last_ncol, last_ndocs;
     hipStream_t last_stream;
@@ -99,6 +100,8 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     WS(q_lo, B * (size_t)s->ncol_max * FLMR_DIM);
     WS(hit_bits, B * (size_t)s->bitmap_words);
     WS(hit_valid, B);
+    WS(q3_hi, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
+    WS(q3_lo, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
 #undef WS
     FLMR_HIP(hipMemset(s->overflow, 0, sizeof(int32_t)));
     for (int i = 0; i <= FLMR_NUM_STAGES; i++) FLMR_HIP(hipEventCreate(&s->ev[i]));
@@ -110,7 +113,7 @@ extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
     if (!s) return FLMR_OK;
     void* ptrs[] = {s->cs, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
                     s->keys1, s->s1_pids, s->s1_count, s->keys2, s->s2_pids, s->s2_count, s->keys3, s->doc_scores,
-                    s->overflow, s->q_hi, s->q_lo, s->hit_bits, s->hit_valid};
+                    s->overflow, s->q_hi, s->q_lo, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo};
     for (void* p : ptrs) (void)hipFree(p);
     for (int i = 0; i <= FLMR_NUM_STAGES; i++)
         if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
@@ -211,6 +214,7 @@ extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32
     m.ix = ix; m.Q = Q; m.q_lens = q_lens; m.nqueries = nqueries; m.nq = nq;
     m.pids = s->s2_pids; m.pid_stride = s->maxp.ndocs / 4; m.counts = s->s2_count; m.max_count = p->ndocs / 4;
     m.keys = s->keys3; m.key_stride = s->maxp.ndocs / 4; m.scores = s->doc_scores;
+    m.q_hi = s->q3_hi; m.q_lo = s->q3_lo;
     RUN(flmr_launch_maxsim(m, st));
     MARK();
     // ---- S4: final ranking, global pids ---------------------------------------------------------------

@@ -289,6 +289,16 @@ __global__ void check_f16_exact_kernel(const float* x, size_t n, int* flag) {
     }
 }
 
+__global__ void convert_f16_kernel(const float* x, size_t n, _Float16* out) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) out[e] = (_Float16)x[e];
+}
+
+int flmr_convert_f16(const float* dev, size_t n, _Float16* out) {
+    hipLaunchKernelGGL(convert_f16_kernel, dim3(1024), dim3(256), 0, 0, dev, n, out);
+    FLMR_HIP(hipDeviceSynchronize());
+    return FLMR_OK;
+}
+
 int flmr_check_f16_exact(const float* dev, size_t n, int32_t* host_result) {
     int* flag = nullptr;
     FLMR_HIP(hipMalloc(reinterpret_cast<void**>(&flag), sizeof(int)));
