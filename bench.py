@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--cpu-queries", type=int, default=12, help="queries of the batch timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-device-smoke", action="store_true",
+                    help="debug only: run all ranks on cuda:0 with a gloo group and a host-staged gather (exercises the "
+                         "sharding / merge code on a 1-GPU box; timings are meaningless)")
     return ap.parse_args()
 
 
@@ -51,11 +54,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, (world, args.gpus)
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(0 if args.single_device_smoke else local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.single_device_smoke:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     N_tok = args.passages * args.doclen
     K = args.centroids or 2 ** int(torch.log2(torch.tensor(16.0 * (N_tok ** 0.5))).floor())
@@ -92,8 +98,14 @@ def main():
         if world > 1:
             gs = torch.empty((world,) + tuple(s.shape), dtype=s.dtype, device="cuda")
             gp = torch.empty((world,) + tuple(p.shape), dtype=p.dtype, device="cuda")
-            dist.all_gather_into_tensor(gs, s)
-            dist.all_gather_into_tensor(gp, p)
+            if args.single_device_smoke:
+                hs, hp = [torch.empty_like(s, device="cpu") for _ in range(world)], [torch.empty_like(p, device="cpu") for _ in range(world)]
+                dist.all_gather(hs, s.cpu())
+                dist.all_gather(hp, p.cpu())
+                gs, gp = torch.stack(hs).cuda(), torch.stack(hp).cuda()
+            else:
+                dist.all_gather_into_tensor(gs, s)
+                dist.all_gather_into_tensor(gp, p)
             s, p, c = ops.merge_topk(gs, gp)
         return p, s, c
 
@@ -114,7 +126,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if args.single_device_smoke else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
@@ -143,11 +155,25 @@ def main():
         roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None}
     else:
-        nbytes = {"s1_filter": s1_bytes, "s3_maxsim": B * nfin_tok + 4 * d * min(K, nfin_tok) + 4 * nfin_tok}.get(dom, alg_bytes)
+        nbytes = {"s1_filter": s1_bytes, "s3_maxsim": B * nfin_tok + 4 * d * min(K, nfin_tok) + 4 * nfin_tok,
+                  "s2_filter_sort": 4 * ndocs * args.doclen + 4 * 32 * ndocs * args.doclen}.get(dom, alg_bytes)
         ach = nbytes / (dom_ms_per_query * 1e-3) / 1e9
         roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": None}
     roof["launch_ms"] = stage_ms[dom]
+    # HBM bytes per launch of the dominant kernel from the PMC passes (profiles/pmc_passes.sh: FETCH_SIZE doubled as the
+    # gfx950 guide prescribes, + WRITE_SIZE), when a summary for this round has been committed next to this file
+    try:
+        import csv
+        kname = {"s1_filter": "filter_stage1_kernel", "s0_centroid_scores": "s0_centroid_scores_f16", "s3_maxsim": "maxsim_f16_kernel",
+                 "s2_filter_sort": "filter_stage2_kernel"}.get(dom)
+        with open(os.path.join(ROOT, "profiles", "pmc_summary_latest.csv")) as f:
+            for row in csv.DictReader(f):
+                if kname and kname in row["kernel"] and args.passages == 1_000_000 and world == 1:
+                    roof["traffic"] = (2.0 * float(row["FETCH_SIZE"]) + float(row["WRITE_SIZE"])) * 1024.0
+                    roof["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/)"
+    except Exception:
+        pass
     roof["whole_path_algorithmic_GBs"] = alg_bytes * qps / 1e9
     roof["whole_path_frac_of_hbm_peak"] = alg_bytes * qps / 1e9 / HBM_PEAK_GBS
 

@@ -125,7 +125,7 @@ int flmr_searcher_tap(flmr_searcher_t* searcher, int32_t what, int32_t query, vo
 
 /* Timing taps: per-stage HIP-event milliseconds of the LAST flmr_search_batch call when the searcher was
  * put in profiling mode (flmr_searcher_set_profiling(s, 1)); ms[FLMR_NUM_STAGES] is HOST memory. */
-#define FLMR_NUM_STAGES 8
+#define FLMR_NUM_STAGES 9
 int flmr_searcher_set_profiling(flmr_searcher_t* searcher, int32_t enable);
 int flmr_searcher_stage_ms(flmr_searcher_t* searcher, float* ms_host);
 const char* flmr_stage_name(int32_t stage);

@@ -10,14 +10,14 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "lib", "libflmr_hip.so")
+LIB_PATH = os.environ.get("FLMR_HIP_LIB") or os.path.join(PKG_DIR, "lib", "libflmr_hip.so")  # override: A/B-ing kernel builds
 CSRC = os.path.join(PKG_DIR, "csrc")
 SOURCES = ["flmr_index.hip", "flmr_stage0.hip", "flmr_filter.hip", "flmr_maxsim.hip", "flmr_search.hip", "flmr_ops.hip"]
 HEADERS = ["flmr_common.h", "flmr_device.h"]
 
 FLMR_MEM_HOST, FLMR_MEM_DEVICE = 0, 1
 (TAP_CENTROID_SCORES, TAP_IDX_BITS, TAP_CELLS, TAP_CANDIDATES, TAP_STAGE1, TAP_STAGE2, TAP_DOC_SCORES) = range(7)
-NUM_STAGES = 8
+NUM_STAGES = 9
 
 
 class FlmrNativeError(RuntimeError):

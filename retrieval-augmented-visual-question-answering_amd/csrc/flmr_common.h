@@ -96,15 +96,17 @@ struct flmr_s0_args {
     int32_t idx_words;
     float* part_val;         // [nqueries, nblk, ncol, ncells]
     int32_t* part_idx;
-    int32_t nblk;            // number of 128-row blocks
+    int32_t nblk;            // number of partial-list row blocks (set by flmr_launch_centroid_scores for the kernel it picks)
     int32_t* cells;          // [nqueries, max_cells]
     int32_t* ncell;          // [nqueries]
     int32_t max_cells;
+    int32_t part_rows;       // 0: partials are per-block top-ncells lists; >0: partials are per-block column MAXIMA over
+                             // `part_rows` centroid rows and s0_select_cells rescans the winning blocks in the table
     _Float16* q_hi;          // [nqueries, ncol, 128] fp16 split of Q (fp16 MFMA path)
     _Float16* q_lo;          //   Q ~= q_hi + q_lo * 2^-11
     int32_t centroids_f16_exact;
 };
-int flmr_launch_centroid_scores(const flmr_s0_args& a, hipStream_t st);
+int flmr_launch_centroid_scores(flmr_s0_args& a, hipStream_t st);
 int flmr_launch_select_cells(const flmr_s0_args& a, hipStream_t st);
 int flmr_check_f16_exact(const float* dev, size_t n, int32_t* host_result);
 int flmr_convert_f16(const float* dev, size_t n, _Float16* out);

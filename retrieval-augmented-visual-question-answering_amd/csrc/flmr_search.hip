@@ -6,7 +6,7 @@
 #include "flmr_common.h"
 
 static const char* kStageNames[FLMR_NUM_STAGES] = {
-    "s0_centroid_scores", "s0_select_cells", "s0_candidates", "s1_filter", "s1_select", "s2_filter_sort",
+    "s0_centroid_scores", "s0_select_cells", "s0_candidates", "s1_hitmap", "s1_filter", "s1_select", "s2_filter_sort",
     "s3_maxsim", "s4_topk"};
 
 extern "C" const char* flmr_stage_name(int32_t s) { return (s >= 0 && s < FLMR_NUM_STAGES) ? kStageNames[s] : "?"; }
@@ -64,7 +64,7 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     const int nqc = maxp->nq_cand < max_nq ? maxp->nq_cand : max_nq;
     s->ncol_max = (int32_t)flmr_round_up(nqc, 32);
     s->idx_words = (int32_t)flmr_ceil_div(ix->K, 32);
-    s->nblk = (int32_t)flmr_ceil_div(ix->K, 128);
+    s->nblk = (int32_t)flmr_ceil_div(ix->K, 32);  // upper bound on partial-list blocks (>= 32 rows each, kernel-dependent)
     s->max_cells = nqc * maxp->ncells;
     s->nc_bucket = nc_bucket_of(maxp->ncells);
     s->bitmap_words = flmr_ceil_div(ix->num_passages > 0 ? ix->num_passages : 1, 32);
@@ -198,6 +198,7 @@ extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32
     if (use_hits)
         RUN(flmr_launch_hit_bitmap(s->idx_bits, s->idx_words, nqueries, ix->ivf_pids, ix->ivf_offsets, s->cand_count,
                                    s->hit_bits, s->bitmap_words, s->hit_valid, st));
+    MARK();
     RUN(flmr_launch_filter_stage1(f, s->idx_bits, s->idx_words, s->cand, s->cand_cap, s->cand_count, s->keys1,
                                   use_hits ? s->hit_bits : nullptr, s->bitmap_words, s->hit_valid, st));
     MARK();

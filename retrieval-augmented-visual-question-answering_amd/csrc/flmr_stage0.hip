@@ -166,119 +166,148 @@ __global__ __launch_bounds__(256) void s0_split_q(const float* Q, const int32_t*
     }
 }
 
-template <int NC>
-__global__ __launch_bounds__(256) void s0_centroid_scores_f16(flmr_s0_args a) {
+#ifndef S0_RT
+#define S0_RT 2                 // row tiles (of 32 centroids) per wave: A image = 64 VGPRs
+#endif
+#ifndef S0_CH
+#define S0_CH 6                 // (query, column-tile) items whose B operand is staged in LDS per block barrier
+#endif
+#ifndef S0_WAVES
+#define S0_WAVES 8               // waves per block (512 threads): two per SIMD, so one wave's MFMAs overlap the other's epilogue
+#endif
+#define S0_BROW 136             // halfs per staged B row (128 + 8 pad: conflict-free ds_read_b128 across rows)
+#define S0_LDS_STRIDE 36        // floats per staged row: 16-byte aligned rows for ds_read_b128
+
+__global__ __launch_bounds__(64 * S0_WAVES, 2) void s0_centroid_scores_f16(flmr_s0_args a) {
+    // dynamic LDS: [4 waves][32 rows][36 f32] staging tiles for the row-contiguous table stores, then the fp16 B
+    // operands (q_hi, q_lo) of S0_CH (query, column-tile) items, loaded once per block and shared by its 4 waves.
+    // Keeping B out of the global-load path matters: on CDNA4 vmcnt counts loads AND stores and retires in order, so
+    // a wave that waits for a B load issued after its table stores also waits for those stores to be acknowledged
+    // (~us each iteration); with B in LDS the only vmcnt waits left are the 63-deep rolling window of the stores.
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int wtile = blockIdx.x * 4 + wave;  // 128-row tile index == partial-list block index
-    const int row0 = wtile * 128;
-    if (row0 >= a.K) return;  // no block-level barrier in this kernel
+    float* stage = reinterpret_cast<float*>(smem) + wave * 32 * S0_LDS_STRIDE;
+    _Float16* bq = reinterpret_cast<_Float16*>(smem + S0_WAVES * 32 * S0_LDS_STRIDE * sizeof(float));
+    const int wtile = blockIdx.x * S0_WAVES + wave;  // (32*S0_RT)-row tile index == partial block index
+    const int row0 = wtile * 32 * S0_RT;
+    const bool active = row0 < a.K;  // the launcher guarantees K % (32*S0_RT) == 0; idle waves still join the barriers
     const int T = a.ncol >> 5;
 
-    f16x8 av[4][8];
+    f16x8 av[S0_RT][8];
 #pragma unroll
-    for (int rt = 0; rt < 4; rt++) {
-        const int arow = row0 + rt * 32 + i;
-        if (arow < a.K) {
-            const float4* p = reinterpret_cast<const float4*>(a.centroids + (size_t)arow * FLMR_DIM + 64 * h);
+    for (int rt = 0; rt < S0_RT; rt++) {
+        const float4* p = reinterpret_cast<const float4*>(a.centroids + (size_t)((active ? row0 : 0) + rt * 32 + i) * FLMR_DIM + 64 * h);
 #pragma unroll
-            for (int s = 0; s < 8; s++) {
-                const float4 x = p[2 * s], y = p[2 * s + 1];
-                av[rt][s][0] = (_Float16)x.x; av[rt][s][1] = (_Float16)x.y; av[rt][s][2] = (_Float16)x.z; av[rt][s][3] = (_Float16)x.w;
-                av[rt][s][4] = (_Float16)y.x; av[rt][s][5] = (_Float16)y.y; av[rt][s][6] = (_Float16)y.z; av[rt][s][7] = (_Float16)y.w;
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 8; s++)
-#pragma unroll
-                for (int e = 0; e < 8; e++) av[rt][s][e] = (_Float16)0.0f;
+        for (int s = 0; s < 8; s++) {
+            const float4 x = p[2 * s], y = p[2 * s + 1];
+            av[rt][s][0] = (_Float16)x.x; av[rt][s][1] = (_Float16)x.y; av[rt][s][2] = (_Float16)x.z; av[rt][s][3] = (_Float16)x.w;
+            av[rt][s][4] = (_Float16)y.x; av[rt][s][5] = (_Float16)y.y; av[rt][s][6] = (_Float16)y.z; av[rt][s][7] = (_Float16)y.w;
         }
     }
 
-    // flattened (query, column-tile) loop with the NEXT tile's B operand prefetched: one wave per SIMD runs this
-    // kernel (A image + two B images + accumulators ~ 300 registers), so the overlap has to be explicit.
+    // flattened (query, column-tile) item loop, S0_CH items per LDS chunk
     const int nb = (a.nqueries - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;
     const int niter = nb * T;
-    f16x8 bh[8], bl[8], nh[8], nl[8];
-    auto load_b = [&](int it, f16x8* oh, f16x8* ol) {
-        const int b = blockIdx.y + (it / T) * gridDim.y, col = (it % T) * 32 + i;
-        const f16x8* ph = reinterpret_cast<const f16x8*>(a.q_hi + ((size_t)b * a.ncol + col) * FLMR_DIM + 64 * h);
-        const f16x8* pl = reinterpret_cast<const f16x8*>(a.q_lo + ((size_t)b * a.ncol + col) * FLMR_DIM + 64 * h);
+    uint32_t idxw[S0_RT];  // the 32-bit idx word of each row tile, OR-ed over the column tiles of one query
 #pragma unroll
-        for (int s = 0; s < 8; s++) { oh[s] = ph[s]; ol[s] = pl[s]; }
-    };
-    const bool full_tile = row0 + 128 <= a.K;  // wave-uniform: no row guards needed
-    if (niter > 0) load_b(0, bh, bl);
-    uint32_t flags[4] = {0u, 0u, 0u, 0u};  // bit r of flags[rt]: some column of accumulator row r reached thr
-    for (int it = 0; it < niter; it++) {
+    for (int rt = 0; rt < S0_RT; rt++) idxw[rt] = 0u;
+    for (int c0 = 0; c0 < niter; c0 += S0_CH) {
+      const int nch = (niter - c0) < S0_CH ? (niter - c0) : S0_CH;
+      __syncthreads();  // every wave is done reading the previous chunk
+      for (int e = threadIdx.x; e < nch * 1024; e += 64 * S0_WAVES) {  // 16-byte pieces: [item][hi|lo][32 rows][16 pieces]
+          const int piece = e & 15, row = (e >> 4) & 31, hl = (e >> 9) & 1, item = e >> 10;
+          const int itx = c0 + item;
+          const int bb = blockIdx.y + (itx / T) * gridDim.y, colx = (itx % T) * 32 + row;
+          const _Float16* src = (hl ? a.q_lo : a.q_hi) + ((size_t)bb * a.ncol + colx) * FLMR_DIM + piece * 8;
+          *reinterpret_cast<f16x8*>(bq + ((item * 2 + hl) * 32 + row) * S0_BROW + piece * 8) = *reinterpret_cast<const f16x8*>(src);
+      }
+      __syncthreads();
+      if (active)
+      for (int j = 0; j < nch; j++) {
+        const int it = c0 + j;
         const int b = blockIdx.y + (it / T) * gridDim.y, ct = it % T;
-        if (it + 1 < niter) load_b(it + 1, nh, nl);
+        f16x8 bh[8], bl[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            bh[s] = *reinterpret_cast<const f16x8*>(bq + ((j * 2 + 0) * 32 + i) * S0_BROW + 64 * h + 8 * s);
+            bl[s] = *reinterpret_cast<const f16x8*>(bq + ((j * 2 + 1) * 32 + i) * S0_BROW + 64 * h + 8 * s);
+        }
         const int qlen = a.q_lens ? a.q_lens[b] : a.nq;
         const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;
         float* cs_b = a.cs + (size_t)b * a.K * a.ncol;
         const int col = ct * 32 + i;
-        const bool colok = col < nqc;
-        flmr_toplist<NC> tl;
-        tl.init();
+        const int c4 = (lane & 7) * 4;             // first of the 4 columns this lane stores
+        const int nvalid4 = nqc - (ct * 32 + c4);  // how many of them are real query tokens
+        const bool full_cols = nqc >= ct * 32 + 32;
+        float cmax = FLMR_NEG_INF;                 // running max of column `col` over this wave's rows
+        // software pipeline over the row tiles: the MFMAs of tile rt+1 are issued BEFORE the epilogue of tile rt, so the
+        // epilogue's VALU / LDS / store instructions fill the matrix pipe's shadow (one wave per SIMD cannot rely on
+        // another wave for that overlap)
+        f32x16 acc_h[2], acc_l[2];
+        auto tile_mfma = [&](int rt, f32x16& oh, f32x16& ol) {
 #pragma unroll
-        for (int rt = 0; rt < 4; rt++) {
-            f32x16 ah, al;
-#pragma unroll
-            for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
+            for (int r = 0; r < 16; r++) { oh[r] = 0.0f; ol[r] = 0.0f; }
 #pragma unroll
             for (int s = 0; s < 8; s++) {
-                ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[rt][s], bh[s], ah, 0, 0, 0);
-                al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[rt][s], bl[s], al, 0, 0, 0);
+                oh = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[rt][s], bh[s], oh, 0, 0, 0);
+                ol = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[rt][s], bl[s], ol, 0, 0, 0);
             }
-            // epilogue of one 32x32 tile: branch-free so the compiler can place it in the MFMA shadow of the next tile
-            float* crow = cs_b + (size_t)(row0 + rt * 32 + 4 * h) * a.ncol + col;
-            if (full_tile) {
+        };
+        tile_mfma(0, acc_h[0], acc_l[0]);
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int lrow = (r & 3) + 8 * (r >> 2);
-                    const float v = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
-                    crow[(size_t)lrow * a.ncol] = v;
-                    const float x = colok ? v : FLMR_NEG_INF;
-                    tl.insert_ascending(x, row0 + rt * 32 + 4 * h + lrow);
-                    flags[rt] |= (uint32_t)(x >= a.thr) << r;
-                }
-            } else {
+        for (int rt = 0; rt < S0_RT; rt++) {
+            if (rt + 1 < S0_RT) tile_mfma(rt + 1, acc_h[(rt + 1) & 1], acc_l[(rt + 1) & 1]);
+            const f32x16& ah = acc_h[rt & 1];
+            const f32x16& al = acc_l[rt & 1];
+            // epilogue, 3 VALU ops per score: combine hi/lo, column max, stage row-major in LDS
+            const int rbase = row0 + rt * 32;
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int lrow = (r & 3) + 8 * (r >> 2);
-                    const int grow = row0 + rt * 32 + 4 * h + lrow;
-                    const float v = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
-                    if (grow < a.K) crow[(size_t)lrow * a.ncol] = v;
-                    const float x = (colok && grow < a.K) ? v : FLMR_NEG_INF;
-                    tl.insert_ascending(x, grow < a.K ? grow : 0x7fffffff);
-                    flags[rt] |= (uint32_t)(x >= a.thr) << r;
-                }
+            for (int r = 0; r < 16; r++) {
+                const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+                cmax = fmaxf(cmax, v);
+                stage[lrow * S0_LDS_STRIDE + i] = v;
             }
-        }
-        tl.merge_xor(32);
-        if (lane < 32) {
-            const size_t base = ((((size_t)b * a.nblk + wtile) * a.ncol) + col) * NC;
+            __builtin_amdgcn_wave_barrier();  // DS ops of one wave execute in order: only the compiler must not reorder
+            // 4 x (8 rows x 128 B) fully coalesced stores: lane l -> row (l>>3)+8m, columns c4..c4+3; the same
+            // row-major view gives the ">= thr" test of 8 rows per ballot (index_storage.py:116)
 #pragma unroll
-            for (int t = 0; t < NC; t++) { a.part_val[base + t] = tl.v[t]; a.part_idx[base + t] = tl.id[t]; }
+            for (int mrow = 0; mrow < 4; mrow++) {
+                const int R = (lane >> 3) + 8 * mrow;
+                const float4 v4 = *reinterpret_cast<const float4*>(stage + R * S0_LDS_STRIDE + c4);
+#ifdef S0_DIAG_NO_STORE  // timing diagnostic only (results invalid): is the kernel bound by the table write?
+                if (v4.x == 12345.678f)
+#endif
+                *reinterpret_cast<float4*>(cs_b + (size_t)(rbase + R) * a.ncol + ct * 32 + c4) = v4;
+                float m4;
+                if (full_cols) {  // wave-uniform: every column of this tile is a real query token
+                    m4 = fmaxf(fmaxf(v4.x, v4.y), fmaxf(v4.z, v4.w));
+                } else {
+                    m4 = nvalid4 > 0 ? v4.x : FLMR_NEG_INF;
+                    m4 = fmaxf(m4, nvalid4 > 1 ? v4.y : FLMR_NEG_INF);
+                    m4 = fmaxf(m4, nvalid4 > 2 ? v4.z : FLMR_NEG_INF);
+                    m4 = fmaxf(m4, nvalid4 > 3 ? v4.w : FLMR_NEG_INF);
+                }
+                unsigned long long bal = __ballot(m4 >= a.thr);  // byte j of `bal` = the 8 lanes of row 8*mrow + j
+                bal |= bal >> 4; bal |= bal >> 2; bal |= bal >> 1;
+                bal &= 0x0101010101010101ull;
+                const uint32_t byte = (uint32_t)((bal * 0x0102040810204080ull) >> 56);  // bit j = row 8*mrow + j hit
+                idxw[rt] |= byte << (8 * mrow);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
+        // block maximum of each column (this wave's 32*S0_RT rows): the cell selection re-reads only the winners
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        if (lane < 32) a.part_val[((size_t)b * a.nblk + wtile) * a.ncol + col] = (col < nqc) ? cmax : FLMR_NEG_INF;
         if (ct == T - 1) {
-            // idx bits: OR the 16-bit row flags over the 32 lanes (columns) of each half, then interleave the halves
 #pragma unroll
-            for (int rt = 0; rt < 4; rt++) {
-                uint32_t f = flags[rt];
-#pragma unroll
-                for (int m = 16; m >= 1; m >>= 1) f |= (uint32_t)__shfl_xor((int)f, m, 64);
-                uint32_t w = 0;
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    if ((f >> r) & 1u) w |= 1u << ((r & 3) + 8 * (r >> 2) + 4 * h);
-                w |= (uint32_t)__shfl_xor((int)w, 32, 64);
-                if (lane == 0 && row0 + rt * 32 < a.K) a.idx_bits[(size_t)b * a.idx_words + ((row0 + rt * 32) >> 5)] = w;
-                flags[rt] = 0u;
+            for (int rt = 0; rt < S0_RT; rt++) {
+                if (lane == 0) a.idx_bits[(size_t)b * a.idx_words + ((row0 + rt * 32) >> 5)] = idxw[rt];
+                idxw[rt] = 0u;
             }
         }
-#pragma unroll
-        for (int s = 0; s < 8; s++) { bh[s] = nh[s]; bl[s] = nl[s]; }
+      }
     }
 }
 
@@ -383,12 +412,17 @@ __global__ __launch_bounds__(256) void s0_postprocess_table(flmr_s0_args a) {
 enum { S0_F16 = 0, S0_F32 = 1, S0_VALU = 2 };
 
 template <int NC>
-static int launch_s0_t(const flmr_s0_args& a, hipStream_t st, int impl) {
+static int launch_s0_t(flmr_s0_args& a, hipStream_t st, int impl) {
     const int qsplit = a.nqueries < 8 ? a.nqueries : 8;
+    a.nblk = (int)flmr_ceil_div(a.K, impl == S0_F16 ? 32 * S0_RT : 128);
+    a.part_rows = impl == S0_F16 ? 32 * S0_RT : 0;
     if (impl == S0_F16) {
         hipLaunchKernelGGL(s0_split_q, dim3((a.ncol * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens,
                            a.nq, a.nq_cand, a.ncol, a.q_hi, a.q_lo);
-        hipLaunchKernelGGL(s0_centroid_scores_f16<NC>, dim3((a.nblk + 3) / 4, qsplit), dim3(256), 0, st, a);
+        const size_t lds = (size_t)S0_WAVES * 32 * S0_LDS_STRIDE * sizeof(float) + (size_t)S0_CH * 2 * 32 * S0_BROW * sizeof(_Float16);
+        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_f16),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(s0_centroid_scores_f16, dim3((a.nblk + S0_WAVES - 1) / S0_WAVES, qsplit), dim3(64 * S0_WAVES), lds, st, a);
     } else if (impl == S0_F32) {
         hipLaunchKernelGGL(s0_centroid_scores_mfma<NC>, dim3(a.nblk, qsplit), dim3(256), 0, st, a);
     } else {
@@ -402,12 +436,13 @@ static int launch_s0_t(const flmr_s0_args& a, hipStream_t st, int impl) {
 static int nc_bucket(int ncells) { return ncells <= 1 ? 1 : ncells <= 2 ? 2 : ncells <= 4 ? 4 : 8; }
 
 // FLMR_S0_IMPL = f16 (default when every centroid is fp16-exact) | f32 (fp32 MFMA) | valu (plain FMA cross-check)
-int flmr_launch_centroid_scores(const flmr_s0_args& a, hipStream_t st) {
+int flmr_launch_centroid_scores(flmr_s0_args& a, hipStream_t st) {
     const char* env = getenv("FLMR_S0_IMPL");
-    int impl = a.centroids_f16_exact ? S0_F16 : S0_F32;
+    const bool f16_ok = a.centroids_f16_exact && (a.K % (32 * S0_RT) == 0);
+    int impl = f16_ok ? S0_F16 : S0_F32;
     if (env && strcmp(env, "valu") == 0) impl = S0_VALU;
     if (env && (strcmp(env, "f32") == 0 || strcmp(env, "mfma") == 0)) impl = S0_F32;
-    if (env && strcmp(env, "f16") == 0 && a.centroids_f16_exact) impl = S0_F16;
+    if (env && strcmp(env, "f16") == 0 && f16_ok) impl = S0_F16;
     switch (nc_bucket(a.ncells)) {
         case 1: return launch_s0_t<1>(a, st, impl);
         case 2: return launch_s0_t<2>(a, st, impl);
@@ -431,13 +466,35 @@ __global__ __launch_bounds__(1024) void s0_select_cells(flmr_s0_args a) {
     for (int col = wave; col < nqc; col += 16) {
         flmr_toplist<NC> tl;
         tl.init();
-        const int nent = a.nblk * NC;
-        for (int e = lane; e < nent; e += 64) {
-            const size_t off = (((size_t)b * a.nblk + (e / NC)) * a.ncol + col) * NC + (e % NC);
-            tl.insert(a.part_val[off], a.part_idx[off]);
-        }
+        if (a.part_rows == 0) {
+            // partials are per-block top lists: merge them
+            const int nent = a.nblk * NC;
+            for (int e = lane; e < nent; e += 64) {
+                const size_t off = (((size_t)b * a.nblk + (e / NC)) * a.ncol + col) * NC + (e % NC);
+                tl.insert(a.part_val[off], a.part_idx[off]);
+            }
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) tl.merge_xor(m);
+            for (int m = 32; m >= 1; m >>= 1) tl.merge_xor(m);
+        } else {
+            // partials are per-block column maxima: the global top-NC scores lie in the NC blocks with the largest
+            // maxima (a block holding a top-NC score can be beaten by at most NC-1 other blocks), so re-read just
+            // those blocks' rows of this column from the table and take the exact top-NC (value desc, index asc)
+            flmr_toplist<NC> bt;
+            bt.init();
+            for (int e = lane; e < a.nblk; e += 64) bt.insert(a.part_val[((size_t)b * a.nblk + e) * a.ncol + col], e);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) bt.merge_xor(m);
+            const float* cs_b = a.cs + (size_t)b * a.K * a.ncol;
+#pragma unroll
+            for (int t = 0; t < NC; t++) {
+                if (t >= a.ncells || bt.id[t] >= a.nblk) continue;  // wave-uniform (bt is identical in all lanes)
+                const int r0 = bt.id[t] * a.part_rows;
+                for (int r = lane; r < a.part_rows; r += 64)
+                    if (r0 + r < a.K) tl.insert(cs_b[(size_t)(r0 + r) * a.ncol + col], r0 + r);
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) tl.merge_xor(m);
+        }
         if (lane == 0) {
 #pragma unroll
             for (int t = 0; t < NC; t++)
