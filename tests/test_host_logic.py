@@ -137,3 +137,23 @@ def test_keys_order_like_priority_queue():
     pairs = [(-319968.0, 5), (-319968.0, 900), (0.0, 1), (-0.0, 2), (1.5, 0), (1.5, 7), (-2.25, 3), (30.0, 2 ** 31 - 1)]
     keys = sorted(pairs, key=lambda sp: (f2ord(sp[0]) << 32) | sp[1])
     assert keys == sorted(pairs, key=lambda sp: (sp[0], sp[1]))
+
+
+def test_evaluation_glue_matches_reference_semantics():
+    """Ranking -> top_ranking_passages -> Recall@K, with hand-computed expectations following
+    src/executors/FLMR_executor.py:852-895 and src/metrics/metrics_processors.py:481-601."""
+    from ravqa_amd.evaluation import ranking_to_batch_result, recall_pseudo_relevance, recall_with_pos_ids
+    contents = ["a red Bus on the road", "two cats", "the bus stop", "blue sky", "a DOG and a cat"]
+    idx2id = {i: f"p{i}" for i in range(5)}
+    ranking = {"q1": [(3, 1, 9.0), (0, 2, 8.0), (1, 3, 7.0)], "q2": [(1, 1, 5.0)]}   # q2 is short -> padded to max_K
+    extra = {"q1": {"answers": ["bus", "train"], "gold_answer": "bus", "pos_item_ids": ["p0"]},
+             "q2": {"answers": ["dog"], "gold_answer": "dog", "pos_item_ids": ["p4"]}}
+    res = ranking_to_batch_result(ranking, ["q1", "q2"], idx2id, contents, max_K=3, extra_fields=extra)
+    assert [p["passage_index"] for p in res[1]["top_ranking_passages"]] == [1, 1, 1]
+    assert res[0]["top_ranking_passages"][1] == {"passage_index": 0, "passage_id": "p0", "content": contents[0], "score": 8.0}
+    m = recall_pseudo_relevance(res, [1, 3])
+    assert m["recall_at_1"] == 0.0 and m["recall_at_3"] == 0.5            # q1 finds "bus" at rank 2; q2 never finds "dog"
+    assert m["precision_at_3"] == pytest.approx((1 / 3 + 0) / 2) and m["gold_recall_at_3"] == 0.5
+    g = recall_with_pos_ids(res, [1, 3])
+    assert g["pos_item_ids_recall_at_1"] == 0.0 and g["pos_item_ids_recall_at_3"] == 0.5
+    assert g["pos_item_ids_precision_at_3"] == pytest.approx((1 / 3) / 2)
