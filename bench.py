@@ -94,7 +94,7 @@ def main():
     t_build = time.time() - t0
 
     def step(profile=False):
-        p, s, c = scorer.search_batch(Q, k, ncells, thr, ndocs, args.nq, profile=profile)
+        p, s, c = scorer.search_batch(Q, k, ncells, thr, ndocs, 32, profile=profile)  # query_maxlen = 32 (index_storage.py:77)
         if world > 1:
             gs = torch.empty((world,) + tuple(s.shape), dtype=s.dtype, device="cuda")
             gp = torch.empty((world,) + tuple(p.shape), dtype=p.dtype, device="cuda")

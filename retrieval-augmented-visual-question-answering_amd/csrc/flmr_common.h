@@ -77,6 +77,8 @@ struct flmr_index {
     int64_t* ivf_len_prefix;  // [K+1] host
     int64_t max_doclen;
     int32_t centroids_f16_exact;  // every centroid value is representable in fp16 (true for reference-format indexes)
+    uint32_t* ivf_chunk_tab;      // [K][nchunks+1]: first entry of each IVF list with pid >= chunk*32768
+    int32_t nchunks;
 };
 
 // build the fused byte -> (8/nbits) fp32 decode table from the codec tables (host)
@@ -129,7 +131,21 @@ struct flmr_filter_args {
 // stage 1: candidates (cand[q*cand_stride + i], i < cand_count[q]) restricted to idx_bits -> keys
 int flmr_launch_filter_stage1(const flmr_filter_args& f, const uint32_t* idx_bits, int32_t idx_words,
                               const int32_t* cand, int64_t cand_stride, const int32_t* cand_count, uint64_t* keys,
-                              const uint32_t* hit_bits, int64_t hit_words, const int32_t* hit_valid, hipStream_t st);
+                              const uint32_t* hit_bits, int64_t hit_words, const int32_t* hit_valid,
+                              const uint8_t* hit_flags, hipStream_t st);
+// chunked candidate generation (flmr_candidates.hip): bitmaps in LDS per (query, 32768-passage chunk)
+struct flmr_cand_args {
+    int32_t nqueries, idx_words, max_cells, qmax, nchunks;
+    int64_t words, cand_cap;
+    const uint32_t* idx_bits; const int32_t* cells; const int32_t* ncell;
+    const int32_t* ivf_pids; const int64_t* ivf_offsets; const uint32_t* chunk_tab;
+    int32_t* qual; int32_t* nqual; int32_t* hit_valid;     // [nqueries, qmax], [nqueries], [nqueries]
+    uint32_t* cand_bits; uint32_t* hit_bits; int32_t* chunk_cnt;  // [nqueries, words] x2, [nqueries, nchunks]
+    int32_t* cand; uint8_t* cand_hit; int32_t* cand_count; int32_t* overflow;
+};
+int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st);
+int flmr_build_chunk_table(const int32_t* ivf_pids, const int64_t* ivf_offsets, int K, int64_t num_passages,
+                           uint32_t** out_tab, int32_t* out_nchunks);
 // passage bitmap of the union of the surviving centroids' IVF lists (+ per-query validity flag)
 int flmr_launch_hit_bitmap(const uint32_t* idx_bits, int32_t idx_words, int32_t nqueries, const int32_t* ivf_pids,
                            const int64_t* ivf_offsets, const int32_t* cand_count, uint32_t* hit_bits, int64_t hit_words,

@@ -109,7 +109,8 @@ __global__ __launch_bounds__(512) void filter_stage1_kernel(flmr_filter_args f, 
                                                             int32_t idx_words, const int32_t* cand,
                                                             int64_t cand_stride, const int32_t* cand_count,
                                                             uint64_t* keys, const uint32_t* hit_bits,
-                                                            int64_t hit_words, const int32_t* hit_valid) {
+                                                            int64_t hit_words, const int32_t* hit_valid,
+                                                            const uint8_t* hit_flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int scan_lds[17];
     const int b = blockIdx.x;
@@ -165,7 +166,9 @@ __global__ __launch_bounds__(512) void filter_stage1_kernel(flmr_filter_args f, 
 
     // hit_bits (optional): passage bitmap = union of the IVF lists of the surviving centroids.  A candidate outside
     // it contains no surviving centroid, so its stage-1 score is the all-miss value and its codes are never read.
-    const uint32_t* hb = (hit_bits && hit_valid[b]) ? hit_bits + (size_t)b * hit_words : nullptr;
+    const bool hits_on = hit_valid && hit_valid[b];
+    const uint32_t* hb = (hit_bits && hits_on && !hit_flags) ? hit_bits + (size_t)b * hit_words : nullptr;
+    const uint8_t* hf = (hit_flags && hits_on) ? hit_flags + (size_t)b * cand_stride : nullptr;  // aligned with cand
     float miss_score = 0.0f;
     for (int q = 0; q < nqc; q++) miss_score += -9999.0f;
 
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(512) void filter_stage1_kernel(flmr_filter_args f, 
     int g0 = wid * S1_GROUP;
     if (g0 + lane < P && lane < S1_GROUP) {
         my_pid = cand_b[g0 + lane];
-        my_scan = hb ? ((hb[my_pid >> 5] >> (my_pid & 31)) & 1u) : true;
+        my_scan = hf ? (hf[g0 + lane] != 0) : hb ? ((hb[my_pid >> 5] >> (my_pid & 31)) & 1u) : true;
     }
     for (; g0 < P; g0 += gstride) {
         const int ndoc = (P - g0) < S1_GROUP ? (P - g0) : S1_GROUP;
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(512) void filter_stage1_kernel(flmr_filter_args f, 
         bool nx_scan = false;
         if (g0 + gstride + lane < P && lane < S1_GROUP) {
             nx_pid = cand_b[g0 + gstride + lane];
-            nx_scan = hb ? ((hb[nx_pid >> 5] >> (nx_pid & 31)) & 1u) : true;
+            nx_scan = hf ? (hf[g0 + gstride + lane] != 0) : hb ? ((hb[nx_pid >> 5] >> (nx_pid & 31)) & 1u) : true;
         }
         int my_len = 0;
         int64_t my_off = 0;
@@ -294,7 +297,8 @@ int flmr_launch_hit_bitmap(const uint32_t* idx_bits, int32_t idx_words, int32_t 
 
 int flmr_launch_filter_stage1(const flmr_filter_args& f, const uint32_t* idx_bits, int32_t idx_words,
                               const int32_t* cand, int64_t cand_stride, const int32_t* cand_count, uint64_t* keys,
-                              const uint32_t* hit_bits, int64_t hit_words, const int32_t* hit_valid, hipStream_t st) {
+                              const uint32_t* hit_bits, int64_t hit_words, const int32_t* hit_valid,
+                              const uint8_t* hit_flags, hipStream_t st) {
     const int T = (f.nq_cand + 31) >> 5;
     const size_t tr_bytes = (size_t)S1_WAVES * S1_GROUP * (T * 32 + 1) * sizeof(float);
     const size_t row_bytes = (size_t)S1_ROWCACHE * f.ncol * sizeof(float) + S1_ROWCACHE * sizeof(int);
@@ -310,10 +314,10 @@ int flmr_launch_filter_stage1(const flmr_filter_args& f, const uint32_t* idx_bit
     dim3 grid(f.nqueries, G), block(S1_WAVES * 64);
     if (lds_idx)
         hipLaunchKernelGGL(filter_stage1_kernel<true>, grid, block, tr_bytes + row_bytes + idx_bytes, st, f, idx_bits,
-                           idx_words, cand, cand_stride, cand_count, keys, hit_bits, hit_words, hit_valid);
+                           idx_words, cand, cand_stride, cand_count, keys, hit_bits, hit_words, hit_valid, hit_flags);
     else
         hipLaunchKernelGGL(filter_stage1_kernel<false>, grid, block, tr_bytes + row_bytes, st, f, idx_bits, idx_words, cand,
-                           cand_stride, cand_count, keys, hit_bits, hit_words, hit_valid);
+                           cand_stride, cand_count, keys, hit_bits, hit_words, hit_valid, hit_flags);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }

@@ -65,7 +65,7 @@ extern "C" int flmr_filter_pids(const int32_t* pids, int64_t npids, const float*
     f.cs = cs; f.cs_query_stride = 0; f.K = K; f.ncol = nq; f.nq_cand = nq; f.nqueries = 1; f.q_lens = nullptr;
     f.codes = codes; f.doclens = doclens; f.offsets = offsets;
     const int64_t stride = npids > 0 ? npids : 1;
-    RUN(flmr_launch_filter_stage1(f, bits, words, pids, stride, cnt, keys1, nullptr, 0, nullptr, st));
+    RUN(flmr_launch_filter_stage1(f, bits, words, pids, stride, cnt, keys1, nullptr, 0, nullptr, nullptr, st));
     RUN(flmr_launch_select_topn(keys1, stride, cnt, 1, ndocs, s1, ndocs, n1, st));
     RUN(flmr_launch_filter_stage2(f, s1, ndocs, n1, ndocs, keys2, ndocs, st));
     RUN(flmr_launch_sort_topn(keys2, ndocs, n1, ndocs, 1, ndocs / 4, out_pids, nullptr, ndocs / 4, out_count, 0, 0, st));

@@ -23,6 +23,7 @@ struct flmr_searcher {
     _Float16* q_hi; _Float16* q_lo;
     uint32_t* hit_bits; int32_t* hit_valid;
     _Float16* q3_hi; _Float16* q3_lo;
+    int32_t* qual; int32_t* nqual; int32_t* chunk_cnt; uint8_t* cand_hit; int32_t qmax;
     // last call (for taps)
     int32_t last_nqueries, last_ncol, last_ndocs;
     hipStream_t last_stream;
@@ -100,6 +101,11 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     WS(q_lo, B * (size_t)s->ncol_max * FLMR_DIM);
     WS(hit_bits, B * (size_t)s->bitmap_words);
     WS(hit_valid, B);
+    s->qmax = 1024;
+    WS(qual, B * (size_t)s->qmax);
+    WS(nqual, B);
+    WS(chunk_cnt, B * (size_t)ix->nchunks);
+    WS(cand_hit, B * (size_t)s->cand_cap);
     WS(q3_hi, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
     WS(q3_lo, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
 #undef WS
@@ -113,7 +119,7 @@ extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
     if (!s) return FLMR_OK;
     void* ptrs[] = {s->cs, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
                     s->keys1, s->s1_pids, s->s1_count, s->keys2, s->s2_pids, s->s2_count, s->keys3, s->doc_scores,
-                    s->overflow, s->q_hi, s->q_lo, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo};
+                    s->overflow, s->q_hi, s->q_lo, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->cand_hit};
     for (void* p : ptrs) (void)hipFree(p);
     for (int i = 0; i <= FLMR_NUM_STAGES; i++)
         if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
@@ -185,22 +191,40 @@ extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32
     RUN(flmr_launch_select_cells(a0, st));
     MARK();
     // ---- S0c/d: IVF union -> ascending candidate pids ---------------------------------------------
-    RUN(flmr_launch_ivf_mark(s->cells, s->ncell, s->max_cells, nqueries, ix->ivf_pids, ix->ivf_offsets, s->bitmap,
-                             s->bitmap_words, st));
-    RUN(flmr_launch_compact(s->bitmap, s->bitmap_words, ix->num_passages, nqueries, s->cand, s->cand_cap,
-                            s->cand_count, s->overflow, st));
-    MARK();
+    // FLMR_CAND_IMPL=atomic keeps the first implementation (global atomicOr bitmap + separate hit bitmap) for A/B runs
+    const char* cimpl = getenv("FLMR_CAND_IMPL");
+    const bool chunked = !(cimpl && strcmp(cimpl, "atomic") == 0);
+    const bool use_hits = getenv("FLMR_S1_NO_HITMAP") == nullptr;
+    if (chunked) {
+        flmr_cand_args ca;
+        ca.nqueries = nqueries; ca.idx_words = s->idx_words; ca.max_cells = s->max_cells; ca.qmax = s->qmax;
+        ca.nchunks = ix->nchunks; ca.words = s->bitmap_words; ca.cand_cap = s->cand_cap;
+        ca.idx_bits = s->idx_bits; ca.cells = s->cells; ca.ncell = s->ncell;
+        ca.ivf_pids = ix->ivf_pids; ca.ivf_offsets = ix->ivf_offsets; ca.chunk_tab = ix->ivf_chunk_tab;
+        ca.qual = s->qual; ca.nqual = s->nqual; ca.hit_valid = s->hit_valid;
+        ca.cand_bits = s->bitmap; ca.hit_bits = s->hit_bits; ca.chunk_cnt = s->chunk_cnt;
+        ca.cand = s->cand; ca.cand_hit = s->cand_hit; ca.cand_count = s->cand_count; ca.overflow = s->overflow;
+        RUN(flmr_launch_candidates_chunked(ca, st));
+        MARK();
+        MARK();  // (the hit set is produced by the same pass: the s1_hitmap stage is empty in this mode)
+    } else {
+        RUN(flmr_launch_ivf_mark(s->cells, s->ncell, s->max_cells, nqueries, ix->ivf_pids, ix->ivf_offsets, s->bitmap,
+                                 s->bitmap_words, st));
+        RUN(flmr_launch_compact(s->bitmap, s->bitmap_words, ix->num_passages, nqueries, s->cand, s->cand_cap,
+                                s->cand_count, s->overflow, st));
+        MARK();
+        if (use_hits)
+            RUN(flmr_launch_hit_bitmap(s->idx_bits, s->idx_words, nqueries, ix->ivf_pids, ix->ivf_offsets, s->cand_count,
+                                       s->hit_bits, s->bitmap_words, s->hit_valid, st));
+        MARK();
+    }
     // ---- S1: pruned centroid MaxSim over the candidates, keep ndocs ---------------------------------
     flmr_filter_args f;
     f.cs = s->cs; f.cs_query_stride = (int64_t)ix->K * ncol; f.K = ix->K; f.ncol = ncol; f.nq_cand = nqc;
     f.nqueries = nqueries; f.q_lens = q_lens; f.codes = ix->codes; f.doclens = nullptr; f.offsets = ix->doc_offsets;
-    const bool use_hits = getenv("FLMR_S1_NO_HITMAP") == nullptr;
-    if (use_hits)
-        RUN(flmr_launch_hit_bitmap(s->idx_bits, s->idx_words, nqueries, ix->ivf_pids, ix->ivf_offsets, s->cand_count,
-                                   s->hit_bits, s->bitmap_words, s->hit_valid, st));
-    MARK();
     RUN(flmr_launch_filter_stage1(f, s->idx_bits, s->idx_words, s->cand, s->cand_cap, s->cand_count, s->keys1,
-                                  use_hits ? s->hit_bits : nullptr, s->bitmap_words, s->hit_valid, st));
+                                  (use_hits && !chunked) ? s->hit_bits : nullptr, s->bitmap_words, use_hits ? s->hit_valid : nullptr,
+                                  (use_hits && chunked) ? s->cand_hit : nullptr, st));
     MARK();
     RUN(flmr_launch_select_topn(s->keys1, s->cand_cap, s->cand_count, nqueries, p->ndocs, s->s1_pids, s->maxp.ndocs,
                                 s->s1_count, st));

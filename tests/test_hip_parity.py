@@ -300,3 +300,22 @@ def test_merge_topk(hip):
         keys.sort(reverse=True)
         assert mp[q].tolist() == [p for _, p in keys[:10]]
         assert int(mc[q]) == 10
+
+
+def test_candidate_generation_variants_agree(hip, scorers):
+    """Chunked LDS-bitmap candidate generation (default; hit flags fused) vs the first implementation (global atomicOr bitmap,
+    separate hit bitmap) vs no hit prefilter at all: identical candidates, stage-1 survivors sets and final results."""
+    nat = hip["native"]
+    z, scorer = scorers["idx_nb2"]
+    outs = {}
+    for tag, env in (("chunked", {}), ("atomic", {"FLMR_CAND_IMPL": "atomic"}), ("nohit", {"FLMR_S1_NO_HITMAP": "1"})):
+        os.environ.update(env)
+        try:
+            pids, scores = _search_one(hip, scorer, z, "rank3")
+            outs[tag] = (scorer.tap(nat.TAP_CANDIDATES), np.sort(scorer.tap(nat.TAP_STAGE1)), scorer.tap(nat.TAP_STAGE2), pids, scores)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    for tag in ("atomic", "nohit"):
+        for a, b in zip(outs["chunked"], outs[tag]):
+            assert np.array_equal(a, b), tag
