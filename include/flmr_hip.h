@@ -123,6 +123,11 @@ typedef enum flmr_tap {
 int flmr_searcher_tap(flmr_searcher_t* searcher, int32_t what, int32_t query, void* host_out, int64_t capacity,
                       int64_t* count);
 
+/* By default the per-query centroid-score table is kept SPARSE (only the rows of centroids that pass the threshold are
+ * stored; stage 2 and the cell probe recompute what they need).  Enable the full table before a batch whose
+ * FLMR_TAP_CENTROID_SCORES tap will be read (what IndexScorer.retrieve() returns, index_storage.py:67-80). */
+int flmr_searcher_set_full_table(flmr_searcher_t* searcher, int32_t enable);
+
 /* Timing taps: per-stage HIP-event milliseconds of the LAST flmr_search_batch call when the searcher was
  * put in profiling mode (flmr_searcher_set_profiling(s, 1)); ms[FLMR_NUM_STAGES] is HOST memory. */
 #define FLMR_NUM_STAGES 9

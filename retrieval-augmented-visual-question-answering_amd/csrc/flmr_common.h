@@ -102,6 +102,8 @@ struct flmr_s0_args {
     int32_t* cells;          // [nqueries, max_cells]
     int32_t* ncell;          // [nqueries]
     int32_t max_cells;
+    int32_t full_table;      // 1: store every row of the score table; 0: only rows of surviving centroids (fp16 S0, nq_cand<=32)
+    const _Float16* centroids_f16;  // [K,128] (nullable)
     int32_t part_rows;       // 0: partials are per-block top-ncells lists; >0: partials are per-block column MAXIMA over
                              // `part_rows` centroid rows and s0_select_cells rescans the winning blocks in the table
     _Float16* q_hi;          // [nqueries, ncol, 128] fp16 split of Q (fp16 MFMA path)
@@ -154,6 +156,10 @@ int flmr_launch_hit_bitmap(const uint32_t* idx_bits, int32_t idx_words, int32_t 
 int flmr_launch_filter_stage2(const flmr_filter_args& f, const int32_t* pids, int64_t pid_stride,
                               const int32_t* counts, int32_t max_count, uint64_t* keys, int64_t key_stride,
                               hipStream_t st);
+// stage 2 without the score table: recompute the survivors' centroid scores from the fp16 centroids (bitwise = S0)
+int flmr_launch_filter_stage2_mfma(const flmr_filter_args& f, const int32_t* pids, int64_t pid_stride, const int32_t* counts,
+                                   int32_t max_count, uint64_t* keys, int64_t key_stride, const _Float16* cen16,
+                                   const _Float16* q_hi, const _Float16* q_lo, hipStream_t st);
 // top-n of count[q] keys, unordered output (radix select); n_out[q] = min(n, count[q])
 int flmr_launch_select_topn(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t nqueries,
                             int32_t n, int32_t* out_pids, int64_t out_stride, int32_t* n_out, hipStream_t st);

@@ -379,6 +379,141 @@ __global__ __launch_bounds__(256) void filter_stage2_kernel(flmr_filter_args f, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stage 2, recompute variant (default on the fp16-centroid path): instead of gathering 128-byte rows of the per-query
+// score table (which then has to be written in full by S0: 4*K*32 bytes per query, the largest HBM stream of the path),
+// the centroid scores of a survivor's tokens are RECOMPUTED from the fp16 centroid rows with exactly the MFMA sequence
+// S0 uses (2 x v_mfma_f32_32x32x16_f16 per 16 dims against q_hi / q_lo, then fma(lo, 2^-11, hi)): an output element
+// depends only on its A row and B column, so the values are bitwise those S0 would have stored.  The 33 MB fp16
+// centroid matrix is shared by every query and lives in the Infinity Cache; the per-query tables never exist.
+// One wave per survivor; lanes fetch their documents' (pid, offset, length) up front, the next document's codes and the
+// next token tile's centroid half-rows are prefetched (same pipeline as the MaxSim kernel).
+// grid = (nqueries, G), block = 256, dynamic LDS = 4 * (ncol+1) floats.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 s2h8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256, 2) void filter_stage2_mfma_kernel(flmr_filter_args f, const int32_t* pids, int64_t pid_stride,
+                                                                    const int32_t* counts, uint64_t* keys, int64_t key_stride,
+                                                                    const _Float16* __restrict__ cen16,
+                                                                    const _Float16* __restrict__ q_hi,
+                                                                    const _Float16* __restrict__ q_lo) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int cnt = counts[b];
+    const int qlen = f.q_lens ? f.q_lens[b] : f.nq_cand;
+    const int nqc = qlen < f.nq_cand ? qlen : f.nq_cand;  // <= 32 on this path
+    float* tr = reinterpret_cast<float*>(smem) + (size_t)wave * 33;
+    const int W = gridDim.y * 4, w = blockIdx.y * 4 + wave;
+    const int ndw = cnt > w ? (cnt - w + W - 1) / W : 0;  // <= 64 documents per wave (launcher)
+    if (ndw == 0) return;
+    int my_pid = 0, my_len = 0;
+    int64_t my_off = 0;
+    if (lane < ndw) {
+        my_pid = pids[(size_t)b * pid_stride + w + lane * W];
+        my_off = f.offsets[my_pid];
+        my_len = (int)doc_len_of(f.doclens, f.offsets, my_pid);
+    }
+    s2h8 bh[8], bl[8];
+    {
+        const s2h8* ph = reinterpret_cast<const s2h8*>(q_hi + ((size_t)b * f.ncol + i) * FLMR_DIM + 64 * h);
+        const s2h8* pl = reinterpret_cast<const s2h8*>(q_lo + ((size_t)b * f.ncol + i) * FLMR_DIM + 64 * h);
+#pragma unroll
+        for (int s = 0; s < 8; s++) { bh[s] = ph[s]; bl[s] = pl[s]; }
+    }
+    auto load_codes = [&](int64_t off, int len, int* cd) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) cd[r] = (lane + 64 * r < len) ? f.codes[off + lane + 64 * r] : 0;
+    };
+    auto issue_rows = [&](s2h8* a, const int* cd, int t, int64_t off, int len) {
+        const int tok = t * 32 + i;
+        int code = 0;
+        if (t < 8) {
+            const int sel = t >> 1;
+            const int reg = sel == 0 ? cd[0] : sel == 1 ? cd[1] : sel == 2 ? cd[2] : cd[3];
+            code = __shfl(reg, (t & 1) * 32 + i, 64);
+        } else if (tok < len) {
+            code = f.codes[off + tok];
+        }
+        const s2h8* pc = reinterpret_cast<const s2h8*>(cen16 + (size_t)code * FLMR_DIM + 64 * h);  // row 0 for padding tokens
+#pragma unroll
+        for (int s = 0; s < 8; s++) a[s] = pc[s];
+    };
+    int cd[4], ncd[4];
+    load_codes(shfl_i64(my_off, 0), __shfl(my_len, 0, 64), cd);
+    s2h8 araw[8];
+    bool have_raw = false;
+    for (int j = 0; j < ndw; j++) {
+        const int pid = __shfl(my_pid, j, 64);
+        const int len = __shfl(my_len, j, 64);
+        const int64_t off = shfl_i64(my_off, j);
+        int nlen = 0;
+        int64_t noff = 0;
+        if (j + 1 < ndw) {
+            nlen = __shfl(my_len, j + 1, 64);
+            noff = shfl_i64(my_off, j + 1);
+            load_codes(noff, nlen, ncd);
+        }
+        const int ntiles = (len + 31) >> 5;
+        if (ntiles > 0 && !have_raw) issue_rows(araw, cd, 0, off, len);
+        have_raw = false;
+        float cmax = -9999.0f;  // filter_pids.cpp:30-33: per-token maxima start at -9999
+        for (int t = 0; t < ntiles; t++) {
+            s2h8 av[8];
+#pragma unroll
+            for (int s = 0; s < 8; s++) av[s] = araw[s];
+            if (t + 1 < ntiles) {
+                issue_rows(araw, cd, t + 1, off, len);
+            } else if (j + 1 < ndw && nlen > 0) {
+                issue_rows(araw, ncd, 0, noff, nlen);
+                have_raw = true;
+            }
+            f32x16 ah, al;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[s], ah, 0, 0, 0);
+                al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[s], al, 0, 0, 0);
+            }
+            const int nrow = len - t * 32;  // valid token rows in this tile
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+                cmax = fmaxf(cmax, row < nrow ? v : -9999.0f);
+            }
+        }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        if (h == 0) tr[i] = cmax;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            const float sc = flmr_seq_sum(tr, nqc);
+            keys[(size_t)b * key_stride + w + j * W] = flmr_make_key(sc, pid);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; r++) cd[r] = ncd[r];
+    }
+}
+
+int flmr_launch_filter_stage2_mfma(const flmr_filter_args& f, const int32_t* pids, int64_t pid_stride, const int32_t* counts,
+                                   int32_t max_count, uint64_t* keys, int64_t key_stride, const _Float16* cen16,
+                                   const _Float16* q_hi, const _Float16* q_lo, hipStream_t st) {
+    if (max_count <= 0) return FLMR_OK;
+    if (f.ncol != 32) FLMR_FAIL(FLMR_ERR_INVALID, "stage-2 recompute needs one column tile");
+    int G = (int)flmr_ceil_div(8192, 4 * (int64_t)f.nqueries);
+    const int gmin = (int)flmr_ceil_div(max_count, 4 * 64);
+    if (G < gmin) G = gmin;
+    if (G > (int)flmr_ceil_div(max_count, 4)) G = (int)flmr_ceil_div(max_count, 4);
+    if (G < 1) G = 1;
+    hipLaunchKernelGGL(filter_stage2_mfma_kernel, dim3(f.nqueries, G), dim3(256), 4 * 33 * sizeof(float), st, f, pids, pid_stride,
+                       counts, keys, key_stride, cen16, q_hi, q_lo);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
 int flmr_launch_filter_stage2(const flmr_filter_args& f, const int32_t* pids, int64_t pid_stride,
                               const int32_t* counts, int32_t max_count, uint64_t* keys, int64_t key_stride,
                               hipStream_t st) {

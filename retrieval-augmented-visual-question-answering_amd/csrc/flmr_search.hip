@@ -25,9 +25,10 @@ struct flmr_searcher {
     _Float16* q3_hi; _Float16* q3_lo;
     int32_t* qual; int32_t* nqual; int32_t* chunk_cnt; uint8_t* cand_hit; int32_t qmax;
     // last call (for taps)
-    int32_t last_nqueries, last_ncol, last_ndocs;
+    int32_t last_nqueries, last_ncol, last_ndocs, last_full_table;
     hipStream_t last_stream;
     bool profiling;
+    bool full_table;  // keep the whole centroid-score table (needed by the CENTROID_SCORES tap / retrieve())
     hipEvent_t ev[FLMR_NUM_STAGES + 1];
     bool have_ms;
 };
@@ -140,6 +141,12 @@ extern "C" int flmr_searcher_set_profiling(flmr_searcher_t* s, int32_t enable) {
     return FLMR_OK;
 }
 
+extern "C" int flmr_searcher_set_full_table(flmr_searcher_t* s, int32_t enable) {
+    if (!s) FLMR_FAIL(FLMR_ERR_INVALID, "NULL searcher");
+    s->full_table = enable != 0;
+    return FLMR_OK;
+}
+
 extern "C" int flmr_searcher_stage_ms(flmr_searcher_t* s, float* ms) {
     if (!s || !ms) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
     if (!s->have_ms) FLMR_FAIL(FLMR_ERR_INVALID, "no profiled flmr_search_batch call yet");
@@ -185,6 +192,12 @@ extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32
     a0.part_val = s->part_val; a0.part_idx = s->part_idx; a0.nblk = s->nblk;
     a0.cells = s->cells; a0.ncell = s->ncell; a0.max_cells = s->max_cells;
     a0.q_hi = s->q_hi; a0.q_lo = s->q_lo; a0.centroids_f16_exact = ix->centroids_f16_exact;
+    a0.centroids_f16 = ix->centroids_f16;
+    // sparse score table + recomputing stage 2: only on the fp16-split S0 path with a single column tile
+    const char* s0env = getenv("FLMR_S0_IMPL");
+    const bool f16_path = ix->centroids_f16_exact && ix->centroids_f16 && (ix->K % 64 == 0) && !(s0env && strcmp(s0env, "f16") != 0);
+    const bool sparse = f16_path && ncol == 32 && !s->full_table && getenv("FLMR_FULL_TABLE") == nullptr;
+    a0.full_table = sparse ? 0 : 1;
     MARK();
     RUN(flmr_launch_centroid_scores(a0, st));
     MARK();
@@ -230,7 +243,11 @@ extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32
                                 s->s1_count, st));
     MARK();
     // ---- S2: full centroid MaxSim over the survivors, keep ndocs/4 in (score,pid) order ----------------
-    RUN(flmr_launch_filter_stage2(f, s->s1_pids, s->maxp.ndocs, s->s1_count, p->ndocs, s->keys2, s->maxp.ndocs, st));
+    if (sparse)
+        RUN(flmr_launch_filter_stage2_mfma(f, s->s1_pids, s->maxp.ndocs, s->s1_count, p->ndocs, s->keys2, s->maxp.ndocs,
+                                           ix->centroids_f16, s->q_hi, s->q_lo, st));
+    else
+        RUN(flmr_launch_filter_stage2(f, s->s1_pids, s->maxp.ndocs, s->s1_count, p->ndocs, s->keys2, s->maxp.ndocs, st));
     RUN(flmr_launch_sort_topn(s->keys2, s->maxp.ndocs, s->s1_count, p->ndocs, nqueries, p->ndocs / 4, s->s2_pids,
                               nullptr, s->maxp.ndocs / 4, s->s2_count, 0, 0, st));
     MARK();
@@ -249,6 +266,7 @@ extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32
 #undef MARK
 #undef RUN
     s->last_nqueries = nqueries; s->last_ncol = ncol; s->last_ndocs = p->ndocs; s->last_stream = st;
+    s->last_full_table = a0.full_table;
     s->have_ms = prof;
     return FLMR_OK;
 }
@@ -266,6 +284,7 @@ extern "C" int flmr_searcher_tap(flmr_searcher_t* s, int32_t what, int32_t q, vo
     const int nd4 = s->maxp.ndocs / 4;
     switch (what) {
         case FLMR_TAP_CENTROID_SCORES:
+            if (!s->last_full_table) FLMR_FAIL(FLMR_ERR_INVALID, "the last batch ran with the sparse score table: call flmr_searcher_set_full_table(s, 1) first");
             n = (int64_t)ix->K * s->last_ncol; src = s->cs + (size_t)q * n; break;
         case FLMR_TAP_IDX_BITS:
             n = s->idx_words; src = s->idx_bits + (size_t)q * n; break;

@@ -240,6 +240,7 @@ __global__ __launch_bounds__(64 * S0_WAVES, 2) void s0_centroid_scores_f16(flmr_
         const int c4 = (lane & 7) * 4;             // first of the 4 columns this lane stores
         const int nvalid4 = nqc - (ct * 32 + c4);  // how many of them are real query tokens
         const bool full_cols = nqc >= ct * 32 + 32;
+        const bool sparse = !a.full_table && T == 1;
         float cmax = FLMR_NEG_INF;                 // running max of column `col` over this wave's rows
         // software pipeline over the row tiles: the MFMAs of tile rt+1 are issued BEFORE the epilogue of tile rt, so the
         // epilogue's VALU / LDS / store instructions fill the matrix pipe's shadow (one wave per SIMD cannot rely on
@@ -276,10 +277,6 @@ __global__ __launch_bounds__(64 * S0_WAVES, 2) void s0_centroid_scores_f16(flmr_
             for (int mrow = 0; mrow < 4; mrow++) {
                 const int R = (lane >> 3) + 8 * mrow;
                 const float4 v4 = *reinterpret_cast<const float4*>(stage + R * S0_LDS_STRIDE + c4);
-#ifdef S0_DIAG_NO_STORE  // timing diagnostic only (results invalid): is the kernel bound by the table write?
-                if (v4.x == 12345.678f)
-#endif
-                *reinterpret_cast<float4*>(cs_b + (size_t)(rbase + R) * a.ncol + ct * 32 + c4) = v4;
                 float m4;
                 if (full_cols) {  // wave-uniform: every column of this tile is a real query token
                     m4 = fmaxf(fmaxf(v4.x, v4.y), fmaxf(v4.z, v4.w));
@@ -294,6 +291,11 @@ __global__ __launch_bounds__(64 * S0_WAVES, 2) void s0_centroid_scores_f16(flmr_
                 bal &= 0x0101010101010101ull;
                 const uint32_t byte = (uint32_t)((bal * 0x0102040810204080ull) >> 56);  // bit j = row 8*mrow + j hit
                 idxw[rt] |= byte << (8 * mrow);
+                // table store.  Sparse mode keeps only the rows of surviving centroids (all stage 1 ever reads; stage 2
+                // and the cell selection recompute what they need from the fp16 centroids), which removes the
+                // 4*K*32-byte-per-query table write -- the largest HBM stream of the whole path.
+                if (!sparse || ((byte >> (lane >> 3)) & 1u))
+                    *reinterpret_cast<float4*>(cs_b + (size_t)(rbase + R) * a.ncol + ct * 32 + c4) = v4;
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -485,12 +487,49 @@ __global__ __launch_bounds__(1024) void s0_select_cells(flmr_s0_args a) {
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) bt.merge_xor(m);
             const float* cs_b = a.cs + (size_t)b * a.K * a.ncol;
+            const bool have_table = a.full_table || (a.ncol >> 5) != 1;
 #pragma unroll
             for (int t = 0; t < NC; t++) {
                 if (t >= a.ncells || bt.id[t] >= a.nblk) continue;  // wave-uniform (bt is identical in all lanes)
                 const int r0 = bt.id[t] * a.part_rows;
-                for (int r = lane; r < a.part_rows; r += 64)
-                    if (r0 + r < a.K) tl.insert(cs_b[(size_t)(r0 + r) * a.ncol + col], r0 + r);
+                if (have_table) {
+                    for (int r = lane; r < a.part_rows; r += 64)
+                        if (r0 + r < a.K) tl.insert(cs_b[(size_t)(r0 + r) * a.ncol + col], r0 + r);
+                } else {
+                    // sparse table: recompute the block's scores with the SAME MFMA sequence as s0_centroid_scores_f16
+                    // (bitwise identical values: an output element depends only on its A row and B column)
+                    const int i = lane & 31, h = lane >> 5;
+                    f16x8 bh[8], bl[8];
+                    {
+                        const int bcol = (col & ~31) + i;
+                        const f16x8* ph = reinterpret_cast<const f16x8*>(a.q_hi + ((size_t)b * a.ncol + bcol) * FLMR_DIM + 64 * h);
+                        const f16x8* pl = reinterpret_cast<const f16x8*>(a.q_lo + ((size_t)b * a.ncol + bcol) * FLMR_DIM + 64 * h);
+#pragma unroll
+                        for (int s = 0; s < 8; s++) { bh[s] = ph[s]; bl[s] = pl[s]; }
+                    }
+                    for (int rt = 0; rt * 32 < a.part_rows; rt++) {
+                        const float4* p = reinterpret_cast<const float4*>(a.centroids + (size_t)(r0 + rt * 32 + i) * FLMR_DIM + 64 * h);
+                        f32x16 ah, al;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
+#pragma unroll
+                        for (int s = 0; s < 8; s++) {
+                            const float4 x = p[2 * s], y = p[2 * s + 1];
+                            f16x8 av;
+                            av[0] = (_Float16)x.x; av[1] = (_Float16)x.y; av[2] = (_Float16)x.z; av[3] = (_Float16)x.w;
+                            av[4] = (_Float16)y.x; av[5] = (_Float16)y.y; av[6] = (_Float16)y.z; av[7] = (_Float16)y.w;
+                            ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bh[s], ah, 0, 0, 0);
+                            al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bl[s], al, 0, 0, 0);
+                        }
+                        const bool mine = i == (col & 31);
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const float v = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+                            const int row = r0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            tl.insert(mine ? v : FLMR_NEG_INF, mine ? row : 0x7fffffff);
+                        }
+                    }
+                }
             }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) tl.merge_xor(m);

@@ -116,7 +116,7 @@ class IndexScorer:
             pass
 
     # ---- batched fast path ---------------------------------------------------------------------------------
-    def search_batch(self, Q, k, ncells, centroid_score_threshold, ndocs, nq_cand=32, q_lens=None, profile=False):
+    def search_batch(self, Q, k, ncells, centroid_score_threshold, ndocs, nq_cand=32, q_lens=None, profile=False, full_table=False):
         """Q: float32 [n, Nq, 128] (CPU or CUDA).  Returns CUDA tensors (pids i32 [n,k], scores f32 [n,k], counts i32 [n])."""
         if Q.dim() != 3 or Q.size(-1) != self.arrays.dim:
             raise ValueError(f"Q must be [n, Nq, {self.arrays.dim}], got {tuple(Q.shape)}")
@@ -130,6 +130,7 @@ class IndexScorer:
         out_c = torch.empty((n,), dtype=torch.int32, device="cuda")
         st = _native.stream_ptr()
         self._lib.flmr_searcher_set_profiling(s, 1 if profile else 0)
+        self._lib.flmr_searcher_set_full_table(s, 1 if full_table else 0)  # needed for the CENTROID_SCORES tap
         B = self._searcher_key[0]
         for b0 in range(0, n, B):
             b1 = min(n, b0 + B)
@@ -165,7 +166,8 @@ class IndexScorer:
         """-> (candidate pids int32 ascending, centroid_scores f32 [K, nq_cand]) for ONE query (index_storage.py:67-80)."""
         Q = Q if Q.dim() == 3 else Q.unsqueeze(0)
         nqc = min(config.query_maxlen, Q.size(1))
-        self.search_batch(Q[:1], 1, config.ncells, config.centroid_score_threshold, max(config.ndocs, 4), config.query_maxlen)
+        self.search_batch(Q[:1], 1, config.ncells, config.centroid_score_threshold, max(config.ndocs, 4), config.query_maxlen,
+                          full_table=True)
         pids = torch.from_numpy(self.tap(_native.TAP_CANDIDATES))
         cs = torch.from_numpy(self.tap(_native.TAP_CENTROID_SCORES)[:, :nqc].copy())
         return pids, cs

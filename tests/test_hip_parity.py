@@ -36,11 +36,11 @@ def scorers(hip):
     return out
 
 
-def _search_one(hip, scorer, z, r):
+def _search_one(hip, scorer, z, r, full_table=False):
     torch = hip["torch"]
     Q = torch.from_numpy(z[f"{r}.Q"]).unsqueeze(0)
     ncells, thr, ndocs = int(z[f"{r}.ncells"]), float(z[f"{r}.thr"]), int(z[f"{r}.ndocs"])
-    p, s, c = scorer.search_batch(Q, max(ndocs // 4, 1), ncells, thr, ndocs, int(z[f"{r}.nq_cand"]))
+    p, s, c = scorer.search_batch(Q, max(ndocs // 4, 1), ncells, thr, ndocs, int(z[f"{r}.nq_cand"]), full_table=full_table)
     n = int(c[0])
     return p[0, :n].cpu().numpy(), s[0, :n].cpu().numpy()
 
@@ -54,7 +54,7 @@ def test_search_stages_vs_golden(hip, scorers, name):
     oi = orc.OracleIndex.from_golden(z)
     K = int(z["meta.K"])
     for r in rank_records(z):
-        pids, scores = _search_one(hip, scorer, z, r)
+        pids, scores = _search_one(hip, scorer, z, r, full_table=True)   # the centroid-score tap needs the whole table
         nqc = min(int(z[f"{r}.nq_cand"]), z[f"{r}.Q"].shape[0])
         cs = scorer.tap(nat.TAP_CENTROID_SCORES)[:, :nqc]
         cs_ref = z[f"{r}.centroid_scores"]
@@ -147,7 +147,7 @@ def test_s0_kernel_variants_agree(hip, scorers):
         for impl in ("f16", "f32", "valu"):
             os.environ["FLMR_S0_IMPL"] = impl
             try:
-                _search_one(hip, scorer, z, rec)
+                _search_one(hip, scorer, z, rec, full_table=True)
                 taps[impl] = [scorer.tap(t) for t in (nat.TAP_CENTROID_SCORES, nat.TAP_IDX_BITS, nat.TAP_CELLS, nat.TAP_CANDIDATES)]
             finally:
                 os.environ.pop("FLMR_S0_IMPL", None)
@@ -319,3 +319,19 @@ def test_candidate_generation_variants_agree(hip, scorers):
     for tag in ("atomic", "nohit"):
         for a, b in zip(outs["chunked"], outs[tag]):
             assert np.array_equal(a, b), tag
+
+
+@pytest.mark.parametrize("name", INDEX_FIXTURES)
+def test_sparse_table_path_equals_full_table_path(hip, scorers, name):
+    """Default path (score table kept only for surviving centroids; stage 2 and the cell probe recompute their scores with
+    the S0 MFMA sequence) vs the full-table path: every integer result and every score must be IDENTICAL, bit for bit."""
+    nat = hip["native"]
+    z, scorer = scorers[name]
+    for r in rank_records(z):
+        res = {}
+        for mode in (False, True):
+            pids, scores = _search_one(hip, scorer, z, r, full_table=mode)
+            res[mode] = [scorer.tap(t) for t in (nat.TAP_IDX_BITS, nat.TAP_CELLS, nat.TAP_CANDIDATES, nat.TAP_STAGE2)] + [pids, scores]
+            res[mode].insert(3, np.sort(scorer.tap(nat.TAP_STAGE1)))
+        for a, b in zip(res[False], res[True]):
+            assert np.array_equal(a, b), r
