@@ -335,3 +335,32 @@ def test_sparse_table_path_equals_full_table_path(hip, scorers, name):
             res[mode].insert(3, np.sort(scorer.tap(nat.TAP_STAGE1)))
         for a, b in zip(res[False], res[True]):
             assert np.array_equal(a, b), r
+
+
+def test_build_index_on_gpu_then_search(hip, tmp_path):
+    """End to end on the device without the reference or FAISS: embeddings -> indexing.build_index (k-means + compress + IVF,
+    torch/rocBLAS ops) -> reference on-disk format -> reload -> HIP search: planted passages come back in the top 5, and the
+    HIP result equals the CPU oracle on the same (re-loaded) index."""
+    from oracle import oracle as orc
+    torch, pkg = hip["torch"], hip["pkg"]
+    from ravqa_amd import indexing, synth
+    from ravqa_amd.scorer import IndexScorer
+    corpus = synth.make_corpus(4000, (8, 40), 512, 2, seed=17, device="cuda")  # used only as an embedding source
+    g = torch.Generator(device="cuda").manual_seed(3)
+    embs = torch.nn.functional.normalize(corpus.centroids[corpus.codes.long()] + 0.05 * torch.randn(corpus.codes.numel(), 128, generator=g, device="cuda"), dim=-1)
+    arrays = indexing.build_index(embs, corpus.doclens, nbits=4, kmeans_niters=4)
+    arrays.save(str(tmp_path / "built"))
+    re = pkg.load_index_arrays(str(tmp_path / "built"))
+    scorer = IndexScorer(arrays=re)
+    offs = corpus.doc_offsets
+    targets = torch.arange(0, 4000, 125, device="cuda")
+    Q = torch.stack([torch.nn.functional.normalize(embs[offs[t]:offs[t + 1]][torch.arange(32, device="cuda") % int(corpus.doclens[t])] +
+                                                   0.02 * torch.randn(32, 128, generator=g, device="cuda"), dim=-1) for t in targets])
+    p, s, c = scorer.search_batch(Q, 10, 2, 0.45, 256, 32)
+    assert float((p[:, :5] == targets.unsqueeze(1).to(torch.int32)).any(dim=1).float().mean()) >= 0.9
+    oi = orc.OracleIndex(re.dim, re.nbits, re.codes, re.residuals, re.doclens, re.ivf, re.ivf_lengths, re.centroids, re.bucket_weights)
+    Qh = Q.cpu().numpy()
+    for i in range(0, len(targets), 4):
+        rp, rs, ncand = oi.rank(Qh[i], 2, 0.45, 256)
+        if ncand >= 256:
+            tie_aware_equal(rp[:10], rs[:10], p[i, : int(c[i])].cpu().numpy(), s[i, : int(c[i])].cpu().numpy(), tol=SCORE_TOL)

@@ -157,3 +157,29 @@ def test_evaluation_glue_matches_reference_semantics():
     g = recall_with_pos_ids(res, [1, 3])
     assert g["pos_item_ids_recall_at_1"] == 0.0 and g["pos_item_ids_recall_at_3"] == 0.5
     assert g["pos_item_ids_precision_at_3"] == pytest.approx((1 / 3) / 2)
+
+
+def test_build_index_end_to_end_recall_with_oracle(tmp_path):
+    """Index build (k-means + compress + IVF) -> reference on-disk format -> reload -> search with the CPU oracle:
+    planted queries must retrieve their target passage (the k-means cannot be bit-compared with FAISS; Recall pins it)."""
+    from ravqa_amd import indexing
+    from oracle import oracle as orc
+    g = torch.Generator().manual_seed(0)
+    K_true, P = 64, 400
+    protos = torch.nn.functional.normalize(torch.randn(K_true, 128, generator=g), dim=-1)
+    doclens = torch.randint(4, 24, (P,), generator=g)
+    topics = torch.randint(0, K_true, (int(doclens.sum()),), generator=g)
+    embs = torch.nn.functional.normalize(protos[topics] + 0.05 * torch.randn(len(topics), 128, generator=g), dim=-1)
+    arrays = indexing.build_index(embs, doclens, nbits=2, num_partitions=64, kmeans_niters=6, sample_size=len(topics))
+    arrays.save(str(tmp_path / "idx"))
+    re = ravqa_amd.load_index_arrays(str(tmp_path / "idx"))
+    assert re.num_centroids == 64 and re.num_embeddings == len(topics) and re.config["kmeans_niters"] == 6
+    oi = orc.OracleIndex(re.dim, re.nbits, re.codes, re.residuals, re.doclens, re.ivf, re.ivf_lengths, re.centroids, re.bucket_weights)
+    offs = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(doclens, 0)])
+    hits = 0
+    for t in range(0, 100, 5):
+        toks = embs[offs[t]:offs[t + 1]]
+        Q = torch.nn.functional.normalize(toks[torch.arange(32) % len(toks)] + 0.02 * torch.randn(32, 128, generator=g), dim=-1)
+        pids, _, _ = oi.rank(Q.numpy(), 2, 0.45, 64)
+        hits += int(t in pids[:5].tolist())
+    assert hits >= 18, hits
