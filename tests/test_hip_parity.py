@@ -237,20 +237,29 @@ def test_searcher_dropin_api(hip, tmp_path):
         tie_aware_equal(fin[order], ref[order], pids_f, scores_f, tol=SCORE_TOL)
 
 
-@pytest.mark.parametrize("nbits,doclen,nq,nq_cand", [(2, (1, 200), 32, 32), (4, (100, 300), 96, 48), (1, (1, 40), 20, 32), (8, 64, 32, 32)])
-def test_random_corpus_vs_oracle(hip, nbits, doclen, nq, nq_cand):
-    """Seeded synthetic corpora at sizes the oracle finishes in seconds: ragged / long docs, Nq != 32, two column tiles."""
+@pytest.mark.parametrize("nbits,doclen,nq,nq_cand,K,policy", [
+    (2, (1, 200), 32, 32, 2048, (2, 0.45, 256)),
+    (4, (100, 300), 96, 48, 2048, (2, 0.45, 256)),      # two column tiles -> full table + table-gather stage 2
+    (1, (1, 40), 20, 32, 2048, (2, 0.45, 256)),         # fewer query tokens than the candidate-generation window
+    (8, 64, 32, 32, 2048, (2, 0.45, 256)),
+    (2, (200, 420), 32, 32, 1024, (1, 0.5, 64)),        # documents longer than 256 tokens (on-demand code loads), ncells=1
+    (2, (1, 60), 32, 32, 1000, (2, 0.45, 256)),         # K not a multiple of 64 -> fp32-MFMA S0 + table path
+    (2, 32, 64, 32, 4096, (4, 0.4, 4096)),              # the k > 100 policy of searcher.py:108-118
+])
+def test_random_corpus_vs_oracle(hip, nbits, doclen, nq, nq_cand, K, policy):
+    """Seeded synthetic corpora at sizes the oracle finishes in seconds: ragged / long docs, Nq != 32, two column tiles,
+    odd K, both k-policies."""
     from oracle import oracle as orc
     torch = hip["torch"]
     from ravqa_amd import synth
     from ravqa_amd.scorer import IndexScorer
-    corpus = synth.make_corpus(6000, doclen, 2048, nbits, seed=5 + nbits, device="cuda")
+    corpus = synth.make_corpus(12000 if policy[2] > 1024 else 6000, doclen, K, nbits, seed=5 + nbits, device="cuda")
     Q, _ = synth.make_queries(corpus, 12, nq, seed=9)
     arrays = synth.corpus_to_arrays(corpus)
     scorer = IndexScorer(arrays=arrays)
     oi = orc.OracleIndex(arrays.dim, arrays.nbits, arrays.codes, arrays.residuals, arrays.doclens, arrays.ivf,
                          arrays.ivf_lengths, arrays.centroids, arrays.bucket_weights)
-    ncells, thr, ndocs = 2, 0.45, 256
+    ncells, thr, ndocs = policy
     p, s, c = scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, nq_cand)
     Qh = Q.cpu().numpy()
     for i in range(Q.size(0)):
