@@ -337,6 +337,167 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// S3 for long queries (Nq > 32, e.g. FLMR's 512 text + 32..320 visual rows): same per-wave document pipeline, but the
+// query is walked in CHUNKS of S3_QC tiles of 32 rows that the 4 waves of a workgroup stage once in LDS (fp16 hi/lo,
+// rows padded to 272 B so ds_read_b128 across rows is conflict-free).  Loop order: chunk (outer, block barrier) ->
+// this wave's documents -> token tiles -> the chunk's q-tiles.  The A operand (decompress + normalise + split) is
+// recomputed once per chunk, which costs less than re-reading a 16 KB query tile from L2 per (token tile, q-tile) with
+// the latency exposed, as the short-query kernel would.  Column maxima live in a per-wave LDS row of the chunk's width;
+// at the end of a document within a chunk they are added, k-ascending, to the document's running sum, so the sum is
+// accumulated in exactly the global k order.
+// grid = (nqueries, G), block = 256; dynamic LDS = wlut + S3_QC * 17408 B + 4 waves * (32*S3_QC + 64) floats.
+// ------------------------------------------------------------------------------------------------
+#define S3_QC 4
+#define S3_BROW 136
+
+template <int NBITS>
+__global__ __launch_bounds__(256, 2) void maxsim_f16_multiq_kernel(flmr_maxsim_args m, const int32_t* __restrict__ codes,
+                                                                   const uint8_t* __restrict__ residuals,
+                                                                   const int64_t* __restrict__ doc_offsets,
+                                                                   const _Float16* __restrict__ cen16,
+                                                                   const float* __restrict__ wlut_g, int nqp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int VPB = 8 / NBITS;
+    float* wlut = reinterpret_cast<float*>(smem);                                  // [256 * VPB]
+    _Float16* bq = reinterpret_cast<_Float16*>(smem + 256 * VPB * sizeof(float));  // [S3_QC][hi|lo][32][S3_BROW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    float* colmax = reinterpret_cast<float*>(bq + S3_QC * 2 * 32 * S3_BROW) + (size_t)wave * (32 * S3_QC + 64);
+    float* docsum = colmax + 32 * S3_QC;                                          // [64] running sums of this wave's docs
+    const int b = blockIdx.x;
+    const int cnt = m.counts[b];
+    const int qlen = m.q_lens ? m.q_lens[b] : m.nq;
+    for (int t = tid; t < 256 * VPB; t += 256) wlut[t] = wlut_g[t];
+    const int W = gridDim.y * 4, w = blockIdx.y * 4 + wave;
+    const int ndw = cnt > w ? (cnt - w + W - 1) / W : 0;  // <= 64 (launcher); idle waves still join the barriers
+    int my_pid = 0, my_len = 0;
+    int64_t my_off = 0;
+    if (lane < ndw) {
+        my_pid = m.pids[(size_t)b * m.pid_stride + w + lane * W];
+        my_off = doc_offsets[my_pid];
+        my_len = (int)(doc_offsets[my_pid + 1] - my_off);
+    }
+    docsum[lane] = 0.0f;
+    const _Float16* qh_b = m.q_hi + (size_t)b * nqp * FLMR_DIM;
+    const _Float16* ql_b = m.q_lo + (size_t)b * nqp * FLMR_DIM;
+    auto load_codes = [&](int64_t off, int len, int* cd) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) cd[r] = (lane + 64 * r < len) ? codes[off + lane + 64 * r] : 0;
+    };
+    auto off_of = [&](int j) {
+        return ((int64_t)__shfl((int)(uint32_t)((uint64_t)my_off >> 32), j, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)my_off, j, 64);
+    };
+
+    for (int qc0 = 0; qc0 < qlen; qc0 += 32 * S3_QC) {
+        const int ntq = ((qlen - qc0 < 32 * S3_QC ? qlen - qc0 : 32 * S3_QC) + 31) >> 5;  // q-tiles in this chunk
+        __syncthreads();  // previous chunk fully consumed (also orders the wlut / docsum initialisation)
+        for (int e = tid; e < ntq * 1024; e += 256) {  // 16-byte pieces: [tile][hi|lo][32 rows][16 pieces]
+            const int piece = e & 15, row = (e >> 4) & 31, hl = (e >> 9) & 1, qt = e >> 10;
+            const _Float16* src = (hl ? ql_b : qh_b) + (size_t)(qc0 + qt * 32 + row) * FLMR_DIM + piece * 8;  // rows < nqp: zero padded
+            *reinterpret_cast<hf8*>(bq + ((qt * 2 + hl) * 32 + row) * S3_BROW + piece * 8) = *reinterpret_cast<const hf8*>(src);
+        }
+        __syncthreads();
+        if (ndw == 0) continue;
+        for (int t = lane; t < 32 * S3_QC; t += 64) colmax[t] = 0.0f;
+        int cd[4], ncd[4];
+        load_codes(off_of(0), __shfl(my_len, 0, 64), cd);
+        s3_raw<NBITS> raw;
+        bool have_raw = false;
+        for (int j = 0; j < ndw; j++) {
+            const int len = __shfl(my_len, j, 64);
+            const int64_t off = off_of(j);
+            int nlen = 0;
+            int64_t noff = 0;
+            if (j + 1 < ndw) {
+                nlen = __shfl(my_len, j + 1, 64);
+                noff = off_of(j + 1);
+                load_codes(noff, nlen, ncd);
+            }
+            const int ntiles = (len + 31) >> 5;
+            if (ntiles > 0 && !have_raw) s3_issue_rows<NBITS>(raw, cd, 0, off, len, i, h, codes, residuals, cen16);
+            have_raw = false;
+            for (int t = 0; t < ntiles; t++) {
+                hf8 ah[8], al[8];
+                {
+                    float d[64];
+                    float ss = 0.0f;
+#pragma unroll
+                    for (int wq = 0; wq < NBITS; wq++) {
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            const uint32_t word = e < 4 ? raw.r[wq].x : raw.r[wq].y;
+                            const uint32_t byte = (word >> (8 * (e & 3))) & 255u;
+                            const int kb = wq * 8 + e;
+#pragma unroll
+                            for (int l = 0; l < VPB; l++) {
+                                const int dd = kb * VPB + l;
+                                const float v = raw.valid ? (wlut[byte * VPB + l] + (float)raw.c[dd >> 3][dd & 7]) : 0.0f;
+                                d[dd] = v;
+                                ss = fmaf(v, v, ss);
+                            }
+                        }
+                    }
+                    ss += __shfl_xor(ss, 32, 64);
+                    float nrm = sqrtf(ss);
+                    nrm = nrm < 1e-12f ? 1e-12f : nrm;
+                    const float inv = 1.0f / nrm;
+#pragma unroll
+                    for (int dd = 0; dd < 64; dd++) {
+                        const float v = d[dd] * inv;
+                        const _Float16 hi = (_Float16)v;
+                        ah[dd >> 3][dd & 7] = hi;
+                        al[dd >> 3][dd & 7] = (_Float16)((v - (float)hi) * 2048.0f);
+                    }
+                }
+                if (t + 1 < ntiles) {
+                    s3_issue_rows<NBITS>(raw, cd, t + 1, off, len, i, h, codes, residuals, cen16);
+                } else if (j + 1 < ndw && nlen > 0) {
+                    s3_issue_rows<NBITS>(raw, ncd, 0, noff, nlen, i, h, codes, residuals, cen16);
+                    have_raw = true;
+                }
+                for (int qt = 0; qt < ntq; qt++) {
+                    f32x16 acch, accl, accm;  // three independent accumulation chains: hi.hi, hi.lo, lo.hi
+#pragma unroll
+                    for (int r = 0; r < 16; r++) { acch[r] = 0.0f; accl[r] = 0.0f; accm[r] = 0.0f; }
+#pragma unroll
+                    for (int s = 0; s < 8; s++) {
+                        const hf8 bh = *reinterpret_cast<const hf8*>(bq + ((qt * 2 + 0) * 32 + i) * S3_BROW + 64 * h + 8 * s);
+                        const hf8 bl = *reinterpret_cast<const hf8*>(bq + ((qt * 2 + 1) * 32 + i) * S3_BROW + 64 * h + 8 * s);
+                        acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acch, 0, 0, 0);
+                        accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, accl, 0, 0, 0);
+                        accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, accm, 0, 0, 0);
+                    }
+                    float mx = 0.0f;  // segmented_maxsim.cpp:58-59: the running max starts at zero
+#pragma unroll
+                    for (int r = 0; r < 16; r++) mx = fmaxf(mx, fmaf(accl[r] + accm[r], 1.0f / 2048.0f, acch[r]));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    if (h == 0) colmax[qt * 32 + i] = fmaxf(colmax[qt * 32 + i], mx);
+                }
+            }
+            // document done for this chunk: continue its k-ascending running sum with this chunk's columns
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                float sc = docsum[j];
+                const int ncols = (qlen - qc0) < 32 * S3_QC ? (qlen - qc0) : 32 * S3_QC;
+                for (int k = 0; k < ncols; k++) sc += colmax[k];
+                docsum[j] = sc;
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int t = lane; t < 32 * S3_QC; t += 64) colmax[t] = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) cd[r] = ncd[r];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < ndw) {
+        const int dslot = w + lane * W;
+        const float sc = docsum[lane];
+        if (m.keys) m.keys[(size_t)b * m.key_stride + dslot] = flmr_make_key(sc, my_pid);
+        if (m.scores) m.scores[(size_t)b * m.key_stride + dslot] = sc;
+    }
+}
+
 template <int NBITS>
 static int launch_maxsim_f16_t(const flmr_maxsim_args& a, hipStream_t st) {
     const flmr_index* ix = a.ix;
@@ -351,8 +512,17 @@ static int launch_maxsim_f16_t(const flmr_maxsim_args& a, hipStream_t st) {
     if (G < gmin) G = gmin;
     if (G > (int)flmr_ceil_div(a.max_count, 4)) G = (int)flmr_ceil_div(a.max_count, 4);
     if (G < 1) G = 1;
-    hipLaunchKernelGGL(maxsim_f16_kernel<NBITS>, dim3(a.nqueries, G), dim3(256), lds, st, a, ix->codes, ix->residuals,
-                       ix->doc_offsets, ix->centroids_f16, ix->wlut, nqp);
+    if (nqp > 32 && getenv("FLMR_S3_NO_MULTIQ") == nullptr) {
+        const size_t lds2 = (size_t)256 * (8 / NBITS) * sizeof(float) + (size_t)S3_QC * 2 * 32 * S3_BROW * sizeof(_Float16) +
+                            (size_t)4 * (32 * S3_QC + 64) * sizeof(float);
+        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_f16_multiq_kernel<NBITS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(maxsim_f16_multiq_kernel<NBITS>, dim3(a.nqueries, G), dim3(256), lds2, st, a, ix->codes,
+                           ix->residuals, ix->doc_offsets, ix->centroids_f16, ix->wlut, nqp);
+    } else {
+        hipLaunchKernelGGL(maxsim_f16_kernel<NBITS>, dim3(a.nqueries, G), dim3(256), lds, st, a, ix->codes, ix->residuals,
+                           ix->doc_offsets, ix->centroids_f16, ix->wlut, nqp);
+    }
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }
