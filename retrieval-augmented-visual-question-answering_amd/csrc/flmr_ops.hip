@@ -248,13 +248,130 @@ __global__ __launch_bounds__(256) void colbert_score_padded_kernel(const float* 
     }
 }
 
+// MFMA variant for dim == 128 (the FLMR / ColBERT head): one workgroup per document, the 4 waves walk the document's
+// 32-token tiles; both operands are split into fp16 hi/lo on the fly (D rows per tile, Q once per call by
+// score_split_q) and contracted with three v_mfma_f32_32x32x16_f16 per 16 dims (hi.hi + 2^-11 (hi.lo + lo.hi), fp32
+// accumulation, ~2^-21 relative error per term).  Query chunks of 128 rows are staged in LDS and shared by the waves.
+typedef _Float16 ph8 __attribute__((ext_vector_type(8)));
+#define PS_QC 4
+#define PS_BROW 136
+
+__global__ __launch_bounds__(256) void score_split_q(const float* Q, int rows, int nq, int nqp, _Float16* q_hi, _Float16* q_lo) {
+    // Q [q_batch, nq, 128] -> hi/lo [q_batch, nqp, 128], rows >= nq zero
+    const size_t total = (size_t)rows * nqp * FLMR_DIM;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t qb = e / ((size_t)nqp * FLMR_DIM);
+        const int r = (int)((e / FLMR_DIM) % nqp), d = (int)(e % FLMR_DIM);
+        const float v = r < nq ? Q[(qb * nq + r) * FLMR_DIM + d] : 0.0f;
+        const _Float16 hi = (_Float16)v;
+        q_hi[e] = hi;
+        q_lo[e] = (_Float16)((v - (float)hi) * 2048.0f);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void colbert_score_padded_mfma_kernel(const _Float16* __restrict__ q_hi,
+                                                                           const _Float16* __restrict__ q_lo, int q_batch,
+                                                                           int nq, int nqp, const float* __restrict__ D,
+                                                                           const uint8_t* __restrict__ mask, int Ld,
+                                                                           float* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* bq = reinterpret_cast<_Float16*>(smem);                                          // [PS_QC][hi|lo][32][PS_BROW]
+    unsigned int* colmax = reinterpret_cast<unsigned int*>(bq + PS_QC * 2 * 32 * PS_BROW);     // [nqp] order-preserving fp32 image
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const size_t qoff = (q_batch == 1 ? 0 : (size_t)b) * nqp * FLMR_DIM;
+    for (int k = tid; k < nqp; k += 256) colmax[k] = 0u;  // below every real value
+    const int ntiles = (Ld + 31) >> 5;
+    for (int qc0 = 0; qc0 < nq; qc0 += 32 * PS_QC) {
+        const int ntq = ((nq - qc0 < 32 * PS_QC ? nq - qc0 : 32 * PS_QC) + 31) >> 5;
+        __syncthreads();
+        for (int e = tid; e < ntq * 1024; e += 256) {
+            const int piece = e & 15, row = (e >> 4) & 31, hl = (e >> 9) & 1, qt = e >> 10;
+            const _Float16* src = (hl ? q_lo : q_hi) + qoff + (size_t)(qc0 + qt * 32 + row) * FLMR_DIM + piece * 8;
+            *reinterpret_cast<ph8*>(bq + ((qt * 2 + hl) * 32 + row) * PS_BROW + piece * 8) = *reinterpret_cast<const ph8*>(src);
+        }
+        __syncthreads();
+        for (int t = wave; t < ntiles; t += 4) {
+            const int tok = t * 32 + i;
+            const bool inb = tok < Ld;
+            ph8 ah[8], al[8];
+            {
+                const float4* p = reinterpret_cast<const float4*>(D + ((size_t)b * Ld + (inb ? tok : 0)) * FLMR_DIM + 64 * h);
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    const float4 x = p[2 * s], y = p[2 * s + 1];
+                    const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const _Float16 hi = (_Float16)v[e];
+                        ah[s][e] = hi;
+                        al[s][e] = (_Float16)((v[e] - (float)hi) * 2048.0f);
+                    }
+                }
+            }
+            // which of this lane's 16 accumulator rows are real, unmasked tokens (bit r)
+            uint32_t okbits = 0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < Ld && mask[(size_t)b * Ld + row]) okbits |= 1u << r;
+            }
+            for (int qt = 0; qt < ntq; qt++) {
+                f32x16 acch, accl, accm;
+#pragma unroll
+                for (int r = 0; r < 16; r++) { acch[r] = 0.0f; accl[r] = 0.0f; accm[r] = 0.0f; }
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    const ph8 bh = *reinterpret_cast<const ph8*>(bq + ((qt * 2 + 0) * 32 + i) * PS_BROW + 64 * h + 8 * s);
+                    const ph8 bl = *reinterpret_cast<const ph8*>(bq + ((qt * 2 + 1) * 32 + i) * PS_BROW + 64 * h + 8 * s);
+                    acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acch, 0, 0, 0);
+                    accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, accl, 0, 0, 0);
+                    accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, accm, 0, 0, 0);
+                }
+                float mx = FLMR_NEG_INF;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v = ((okbits >> r) & 1u) ? fmaf(accl[r] + accm[r], 1.0f / 2048.0f, acch[r]) : -9999.0f;  // colbert.py:240
+                    if (row < Ld) mx = fmaxf(mx, v);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const int col = qc0 + qt * 32 + i;
+                if (h == 0 && col < nq && mx > FLMR_NEG_INF) atomicMax(&colmax[col], flmr_f2ord(mx));
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float sc = 0.0f;
+        for (int k = 0; k < nq; k++) sc += (Ld > 0) ? flmr_ord2f(colmax[k]) : FLMR_NEG_INF;
+        out[b] = sc;
+    }
+}
+
 extern "C" int flmr_colbert_score_padded(const float* Q, int32_t q_batch, int32_t nq, const float* D, const uint8_t* mask,
                                          int32_t B, int32_t Ld, int32_t dim, float* out, flmr_stream_t stream) {
     if (!Q || !D || !mask || !out) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
     if (q_batch != 1 && q_batch != B) FLMR_FAIL(FLMR_ERR_INVALID, "q_batch must be 1 or B");
     if (B <= 0) return FLMR_OK;
-    if ((size_t)nq * 4 > 64 * 1024) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nq=%d too large", nq);
+    if ((size_t)nq * 4 > 48 * 1024) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nq=%d too large", nq);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const char* env = getenv("FLMR_SCORE_IMPL");
+    if (dim == FLMR_DIM && !(env && strcmp(env, "valu") == 0)) {
+        scratch sc;
+        const int nqp = (int)flmr_round_up(nq, 32);
+        _Float16 *qh, *ql;
+        RUN(sc.alloc(&qh, (size_t)q_batch * nqp * FLMR_DIM));
+        RUN(sc.alloc(&ql, (size_t)q_batch * nqp * FLMR_DIM));
+        hipLaunchKernelGGL(score_split_q, dim3(1024), dim3(256), 0, st, Q, q_batch, nq, nqp, qh, ql);
+        const size_t lds = (size_t)PS_QC * 2 * 32 * PS_BROW * sizeof(_Float16) + (size_t)nqp * sizeof(unsigned int);
+        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(colbert_score_padded_mfma_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(colbert_score_padded_mfma_kernel, dim3(B), dim3(256), lds, st, qh, ql, q_batch, nq, nqp, D, mask, Ld, out);
+        FLMR_LAUNCH_CHECK();
+        FLMR_HIP(hipStreamSynchronize(st));  // the split buffers are released on return
+        return FLMR_OK;
+    }
     hipLaunchKernelGGL(colbert_score_padded_kernel, dim3(B), dim3(256), (size_t)nq * 4, st, Q, q_batch, nq, D, mask, Ld, dim,
                        out);
     FLMR_LAUNCH_CHECK();

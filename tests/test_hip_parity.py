@@ -373,3 +373,28 @@ def test_build_index_on_gpu_then_search(hip, tmp_path):
         rp, rs, ncand = oi.rank(Qh[i], 2, 0.45, 256)
         if ncand >= 256:
             tie_aware_equal(rp[:10], rs[:10], p[i, : int(c[i])].cpu().numpy(), s[i, : int(c[i])].cpu().numpy(), tol=SCORE_TOL)
+
+
+def test_colbert_score_padded_mfma_vs_oracle(hip):
+    """Padded scoring head (colbert.py:235-286) on the fp16-split MFMA kernel vs the CPU oracle and vs the plain-FMA HIP
+    kernel: ragged masks, a fully masked document, Ld not a multiple of 32, Nq spanning two LDS chunks."""
+    from oracle import oracle as orc
+    torch, ops = hip["torch"], hip["ops"]
+    g = torch.Generator().manual_seed(5)
+    B, Ld, Nq = 37, 70, 200
+    D = torch.nn.functional.normalize(torch.randn(B, Ld, 128, generator=g), dim=-1)
+    lens = torch.randint(1, Ld + 1, (B,), generator=g)
+    lens[4] = 0
+    mask = torch.arange(Ld).unsqueeze(0) < lens.unsqueeze(1)
+    for Q in (torch.nn.functional.normalize(torch.randn(1, Nq, 128, generator=g), dim=-1),
+              torch.nn.functional.normalize(torch.randn(B, 45, 128, generator=g), dim=-1)):
+        ref = orc.colbert_score_padded(Q.numpy(), D.numpy(), mask.numpy())
+        got = ops.colbert_score_padded(Q, D, mask).cpu().numpy()
+        assert np.max(np.abs(got - ref) / (1.0 + np.abs(ref))) <= 2e-6
+        os.environ["FLMR_SCORE_IMPL"] = "valu"
+        try:
+            got2 = ops.colbert_score_padded(Q, D, mask).cpu().numpy()
+        finally:
+            os.environ.pop("FLMR_SCORE_IMPL", None)
+        assert np.max(np.abs(got2 - ref) / (1.0 + np.abs(ref))) <= 2e-6
+        assert got[4] == np.float32(-9999.0) * Q.shape[1] or abs(got[4] + 9999.0 * Q.shape[1]) < 1.0
