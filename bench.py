@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--cpu-queries", type=int, default=12, help="queries of the batch timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-mode", choices=["exact", "fast"], default="exact",
+                    help="N > 1: exact = three key exchanges, result bit-identical to the unsharded index (default); "
+                         "fast = one all-gather of per-shard top-k (superset semantics)")
     ap.add_argument("--single-device-smoke", action="store_true",
                     help="debug only: run all ranks on cuda:0 with a gloo group and a host-staged gather (exercises the "
                          "sharding / merge code on a 1-GPU box; timings are meaningless)")
@@ -93,7 +96,17 @@ def main():
     torch.cuda.synchronize()
     t_build = time.time() - t0
 
+    from ravqa_amd.distributed import ShardedSearcher
+    sharded = ShardedSearcher(scorer=scorer) if world > 1 else None
+
+    def host_gather(t):  # --single-device-smoke only: gloo cannot gather device tensors
+        parts = [torch.empty_like(t, device="cpu") for _ in range(world)]
+        dist.all_gather(parts, t.cpu())
+        return torch.stack(parts).cuda()
+
     def step(profile=False):
+        if world > 1 and args.shard_mode == "exact":
+            return sharded.search_batch_exact(Q, k, nq_cand=32, gather=host_gather if args.single_device_smoke else None)
         p, s, c = scorer.search_batch(Q, k, ncells, thr, ndocs, 32, profile=profile)  # query_maxlen = 32 (index_storage.py:77)
         if world > 1:
             gs = torch.empty((world,) + tuple(s.shape), dtype=s.dtype, device="cuda")
@@ -119,10 +132,12 @@ def main():
     stage_sum = {}
     barrier()
     t0 = time.perf_counter()
+    staged = world > 1 and args.shard_mode == "exact"   # the phased protocol has no per-stage event set
     for _ in range(args.steps):
         p, s, c = step(profile=True)
-        for name, ms in scorer.stage_ms().items():   # HIP events on the launch stream, recorded inside the timed region
-            stage_sum[name] = stage_sum.get(name, 0.0) + ms
+        if not staged:
+            for name, ms in scorer.stage_ms().items():   # HIP events on the launch stream, recorded inside the timed region
+                stage_sum[name] = stage_sum.get(name, 0.0) + ms
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -148,6 +163,8 @@ def main():
                  + 4 * d * min(K, nfin_tok) + 4 * d * args.nq + 8 * k + 4 * d * K / args.batch)
     s1_bytes = 16 * P_mean + 4 * P_mean * args.doclen
     s0_flops = 2.0 * K * d * min(args.nq, 32)
+    if not stage_ms:  # phased multi-GPU run: per-stage events are a single-GPU measurement (see the N=1 line)
+        stage_ms = {"whole_step": ms_per_step}
     dom = max(stage_ms, key=stage_ms.get)
     dom_ms_per_query = stage_ms[dom] / args.batch
     if dom == "s0_centroid_scores":
@@ -216,7 +233,7 @@ def main():
             "config": {"workload": f"FLMR late-interaction search, synthetic clustered corpus {args.passages} passages x "
                                    f"{args.doclen} tokens x 128-d, K={K}, nbits={args.nbits}, Nq={args.nq}, k={k} "
                                    f"(ncells={ncells}, thr={thr}, ndocs={ndocs}), {args.batch} queries/step",
-                       "parallelism": f"index sharded by passage over {world} GPU(s), all-gather of per-shard top-k" if world > 1 else "1 GPU",
+                       "parallelism": (f"index sharded by passage over {world} GPUs, " + ("3 all-gathers of (score,pid) keys, result identical to the unsharded index" if args.shard_mode == "exact" else "all-gather of per-shard top-k")) if world > 1 else "1 GPU",
                        "queries_per_step": args.batch},
             "recall_at_5": recall5,
             "roofline": roof,

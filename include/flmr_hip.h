@@ -106,6 +106,34 @@ int flmr_search_batch(flmr_searcher_t* searcher, const float* Q, const int32_t* 
                       int32_t nq, const flmr_search_params_t* params, int32_t* out_pids, float* out_scores,
                       int32_t* out_counts, flmr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Exact passage-sharded search (SURVEY 8e "exact-parity mode"; the reference has no multi-GPU search at all,
+ * src/executors/FLMR_executor.py:778-783).  Each rank owns a passage shard (pid_base) and runs three phases with
+ * one small all-gather of keys after each; a key is u64 = order-preserving(score) << 32 | GLOBAL pid, 0 = empty.
+ *   phase1: S0..S1 locally            -> out_keys [nqueries, ndocs]    (the shard's top-ndocs stage-1 keys)
+ *   gather + flmr_topn_keys(n = ndocs)      = the global stage-1 survivors, identical to the single-index ones
+ *   phase2: S2 of the shard's members -> out_keys [nqueries, ndocs]
+ *   gather + flmr_topn_keys(n = ndocs/4)    = the global stage-2 survivors
+ *   phase3: S3 of the shard's members -> out_keys [nqueries, ndocs/4]
+ *   gather + flmr_topn_keys(n = k) + flmr_unpack_keys = the final ranking, bit-identical to flmr_search_batch on the
+ *   unsharded index.  The same Q / q_lens / params must be passed to all three phases; params->ndocs must equal the
+ *   ndocs the searcher was created with.
+ * ---------------------------------------------------------------------------------------------- */
+int flmr_search_phase1(flmr_searcher_t* searcher, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
+                       const flmr_search_params_t* params, uint64_t* out_keys, flmr_stream_t stream);
+int flmr_search_phase2(flmr_searcher_t* searcher, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
+                       const flmr_search_params_t* params, const uint64_t* global_s1, int32_t n_in, uint64_t* out_keys,
+                       flmr_stream_t stream);
+int flmr_search_phase3(flmr_searcher_t* searcher, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
+                       const flmr_search_params_t* params, const uint64_t* global_s2, int32_t n_in, uint64_t* out_keys,
+                       flmr_stream_t stream);
+/* keys [nqueries, m] (m <= 8192) -> the n largest in descending order, 0 padded; out_counts (nullable) = #non-empty */
+int flmr_topn_keys(const uint64_t* keys, int32_t nqueries, int32_t m, int32_t n, uint64_t* out_keys, int32_t* out_counts,
+                   flmr_stream_t stream);
+/* descending keys [nqueries, n] -> out_pids i32 / out_scores f32 [nqueries, k] (-1 / 0 padded), out_counts i32[nqueries] */
+int flmr_unpack_keys(const uint64_t* keys, int32_t nqueries, int32_t n, int32_t k, int32_t* out_pids, float* out_scores,
+                     int32_t* out_counts, flmr_stream_t stream);
+
 /* Stage taps for parity tests: copy an internal per-query buffer of the LAST flmr_search_batch call to
  * HOST memory (synchronises the stream).  `host_out` capacity in elements; *count receives the number
  * of valid elements.  Element types: CENTROID_SCORES f32 [K, ncol] (ncol = nq_cand rounded up to 32),

@@ -72,6 +72,13 @@ _SIGS = {
     "flmr_searcher_workspace_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "flmr_search_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SearchParams),
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "flmr_search_phase1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SearchParams), C.c_void_p, C.c_void_p]),
+    "flmr_search_phase2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SearchParams), C.c_void_p,
+                                     C.c_int32, C.c_void_p, C.c_void_p]),
+    "flmr_search_phase3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SearchParams), C.c_void_p,
+                                     C.c_int32, C.c_void_p, C.c_void_p]),
+    "flmr_topn_keys": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "flmr_unpack_keys": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "flmr_searcher_tap": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "flmr_searcher_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "flmr_searcher_set_full_table": (C.c_int, [C.c_void_p, C.c_int32]),

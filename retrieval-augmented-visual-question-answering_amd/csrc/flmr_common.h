@@ -162,7 +162,18 @@ int flmr_launch_filter_stage2_mfma(const flmr_filter_args& f, const int32_t* pid
                                    const _Float16* q_hi, const _Float16* q_lo, hipStream_t st);
 // top-n of count[q] keys, unordered output (radix select); n_out[q] = min(n, count[q])
 int flmr_launch_select_topn(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t nqueries,
-                            int32_t n, int32_t* out_pids, int64_t out_stride, int32_t* n_out, hipStream_t st);
+                            int32_t n, int32_t* out_pids, int64_t out_stride, int32_t* n_out, hipStream_t st,
+                            uint64_t* out_keys = nullptr, uint64_t key_add = 0);
+// exact sharded protocol helpers (keys carry GLOBAL pids between ranks; 0 = empty)
+int flmr_launch_sort_keys_topn(const uint64_t* keys, int32_t nqueries, int32_t m, int32_t n, uint64_t* out,
+                               int32_t* out_counts, hipStream_t st);
+int flmr_launch_filter_local_keys(const uint64_t* keys, int32_t nqueries, int32_t n_in, int64_t pid_base,
+                                  int64_t num_passages, int32_t* out_pids, int64_t out_stride, int32_t* out_count,
+                                  hipStream_t st);
+int flmr_launch_export_keys(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t nqueries, uint64_t key_add,
+                            int32_t n, uint64_t* out, hipStream_t st);
+int flmr_launch_unpack_keys(const uint64_t* keys, int32_t nqueries, int32_t n, int32_t k, int32_t* out_pids, float* out_scores,
+                            int32_t* out_counts, hipStream_t st);
 // sorted (descending key) top-n of count[q] <= FLMR_MAX_NDOCS keys; writes pids (+ optional scores), n_out.
 // pad_pid / pad_score fill positions [n_out, n) when fill != 0.
 int flmr_launch_sort_topn(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t max_count,

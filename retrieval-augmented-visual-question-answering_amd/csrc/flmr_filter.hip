@@ -532,7 +532,8 @@ int flmr_launch_filter_stage2(const flmr_filter_args& f, const int32_t* pids, in
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys, int64_t key_stride,
                                                            const int32_t* counts, int32_t n, int32_t* out_pids,
-                                                           int64_t out_stride, int32_t* n_out) {
+                                                           int64_t out_stride, int32_t* n_out, uint64_t* out_keys,
+                                                           uint64_t key_add) {
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long s_prefix;
     __shared__ int s_remaining;
@@ -541,8 +542,12 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys,
     const int P = counts[b];
     const uint64_t* kb = keys + (size_t)b * key_stride;
     int32_t* ob = out_pids + (size_t)b * out_stride;
+    uint64_t* okb = out_keys ? out_keys + (size_t)b * out_stride : nullptr;  // optional: the selected keys (+ pid base), 0 padded
     if (P <= n) {
-        for (int i = tid; i < P; i += blockDim.x) ob[i] = flmr_key_pid(kb[i]);
+        for (int i = tid; i < n; i += blockDim.x) {
+            if (i < P) ob[i] = flmr_key_pid(kb[i]);
+            if (okb) okb[i] = i < P ? kb[i] + key_add : 0ull;
+        }
         if (tid == 0) n_out[b] = P;
         return;
     }
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys,
             const uint64_t key = kb[i];
             if (key >= thr) {
                 const int pos = atomicAdd(&s_out, 1);
-                if (pos < n) ob[pos] = flmr_key_pid(key);
+                if (pos < n) { ob[pos] = flmr_key_pid(key); if (okb) okb[pos] = key + key_add; }
             }
         }
     }
@@ -601,9 +606,10 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys,
 }
 
 int flmr_launch_select_topn(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t nqueries,
-                            int32_t n, int32_t* out_pids, int64_t out_stride, int32_t* n_out, hipStream_t st) {
+                            int32_t n, int32_t* out_pids, int64_t out_stride, int32_t* n_out, hipStream_t st,
+                            uint64_t* out_keys, uint64_t key_add) {
     hipLaunchKernelGGL(select_topn_kernel, dim3(nqueries), dim3(1024), 0, st, keys, key_stride, counts, n, out_pids,
-                       out_stride, n_out);
+                       out_stride, n_out, out_keys, key_add);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }
@@ -644,6 +650,108 @@ int flmr_launch_sort_topn(const uint64_t* keys, int64_t key_stride, const int32_
     while (npow2 < max_count) npow2 <<= 1;
     hipLaunchKernelGGL(sort_topn_kernel, dim3(nqueries), dim3(1024), (size_t)npow2 * 8, st, keys, key_stride, counts,
                        npow2, n, out_pids, out_scores, out_stride, n_out, pid_base, fill);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Helpers of the exact sharded protocol (SURVEY 8e "exact-parity mode"): keys travel between ranks as
+// u64 = order-preserving(score) << 32 | GLOBAL pid, 0 = empty slot.
+// ------------------------------------------------------------------------------------------------
+// keys [nqueries, m] -> the n largest, descending, 0 padded (m <= FLMR_MAX_NDOCS: in-LDS bitonic sort)
+__global__ __launch_bounds__(1024) void sort_keys_topn_kernel(const uint64_t* keys, int m, int npow2, int n, uint64_t* out,
+                                                              int32_t* out_counts) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* sk = reinterpret_cast<unsigned long long*>(smem);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < npow2; i += blockDim.x) sk[i] = i < m ? keys[(size_t)b * m + i] : 0ull;
+    __syncthreads();
+    flmr_bitonic_sort_desc<unsigned long long>(sk, npow2);
+    for (int i = tid; i < n; i += blockDim.x) out[(size_t)b * n + i] = i < npow2 ? sk[i] : 0ull;
+    if (out_counts && tid == 0) {
+        int c = 0;
+        for (int i = 0; i < n && i < npow2; i++) c += sk[i] != 0ull;
+        out_counts[b] = c;
+    }
+}
+
+int flmr_launch_sort_keys_topn(const uint64_t* keys, int32_t nqueries, int32_t m, int32_t n, uint64_t* out,
+                               int32_t* out_counts, hipStream_t st) {
+    if (m > FLMR_MAX_NDOCS) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "topn_keys: %d keys per query > %d", m, FLMR_MAX_NDOCS);
+    int npow2 = 2;
+    while (npow2 < m) npow2 <<= 1;
+    hipLaunchKernelGGL(sort_keys_topn_kernel, dim3(nqueries), dim3(1024), (size_t)npow2 * 8, st, keys, m, npow2, n, out,
+                       out_counts);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
+// global keys [nqueries, n_in] -> LOCAL pids of this shard (pid in [pid_base, pid_base + num_passages)), any order
+__global__ __launch_bounds__(256) void filter_local_keys_kernel(const uint64_t* keys, int n_in, int64_t pid_base,
+                                                                int64_t num_passages, int32_t* out_pids, int64_t out_stride,
+                                                                int32_t* out_count) {
+    __shared__ int cnt;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_in; i += blockDim.x) {
+        const uint64_t key = keys[(size_t)b * n_in + i];
+        const int64_t pid = (int64_t)(uint32_t)key - pid_base;
+        if (key != 0ull && pid >= 0 && pid < num_passages) {
+            const int pos = atomicAdd(&cnt, 1);
+            if (pos < out_stride) out_pids[(size_t)b * out_stride + pos] = (int32_t)pid;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out_count[b] = cnt < out_stride ? cnt : (int)out_stride;
+}
+
+int flmr_launch_filter_local_keys(const uint64_t* keys, int32_t nqueries, int32_t n_in, int64_t pid_base,
+                                  int64_t num_passages, int32_t* out_pids, int64_t out_stride, int32_t* out_count,
+                                  hipStream_t st) {
+    hipLaunchKernelGGL(filter_local_keys_kernel, dim3(nqueries), dim3(256), 0, st, keys, n_in, pid_base, num_passages, out_pids,
+                       out_stride, out_count);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
+// internal keys [nqueries, key_stride] (count[q] valid, local pids) -> out [nqueries, n] with global pids, 0 padded
+__global__ __launch_bounds__(256) void export_keys_kernel(const uint64_t* keys, int64_t key_stride, const int32_t* counts,
+                                                          uint64_t key_add, int n, uint64_t* out) {
+    const int b = blockIdx.x;
+    const int c = counts[b];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) out[(size_t)b * n + i] = i < c ? keys[(size_t)b * key_stride + i] + key_add : 0ull;
+}
+
+int flmr_launch_export_keys(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t nqueries, uint64_t key_add,
+                            int32_t n, uint64_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(export_keys_kernel, dim3(nqueries), dim3(256), 0, st, keys, key_stride, counts, key_add, n, out);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
+// sorted keys [nqueries, n] -> (pids, scores, counts) of the first k
+__global__ __launch_bounds__(256) void unpack_keys_kernel(const uint64_t* keys, int n, int k, int32_t* out_pids, float* out_scores,
+                                                          int32_t* out_counts) {
+    __shared__ int cnt;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        const uint64_t key = i < n ? keys[(size_t)b * n + i] : 0ull;
+        out_pids[(size_t)b * k + i] = key ? flmr_key_pid(key) : -1;
+        out_scores[(size_t)b * k + i] = key ? flmr_key_score(key) : 0.0f;
+        mine += key != 0ull;
+    }
+    atomicAdd(&cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) out_counts[b] = cnt;
+}
+
+int flmr_launch_unpack_keys(const uint64_t* keys, int32_t nqueries, int32_t n, int32_t k, int32_t* out_pids, float* out_scores,
+                            int32_t* out_counts, hipStream_t st) {
+    hipLaunchKernelGGL(unpack_keys_kernel, dim3(nqueries), dim3(256), 0, st, keys, n, k, out_pids, out_scores, out_counts);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }

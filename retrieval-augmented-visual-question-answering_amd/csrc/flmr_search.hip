@@ -155,36 +155,47 @@ extern "C" int flmr_searcher_stage_ms(flmr_searcher_t* s, float* ms) {
     return FLMR_OK;
 }
 
-extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32_t* q_lens, int32_t nqueries,
-                                 int32_t nq, const flmr_search_params_t* p, int32_t* out_pids, float* out_scores,
-                                 int32_t* out_counts, flmr_stream_t stream) {
-    if (!s || !Q || !out_pids || !out_scores || !out_counts) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
-    int rc = check_params(p);
-    if (rc) return rc;
+// ---- one batch = a context (validated parameters + kernel argument blocks) run through stage helpers -----------------
+struct run_ctx {
+    flmr_searcher* s;
+    const float* Q;
+    const int32_t* q_lens;
+    int32_t nqueries, nq, nqc, ncol;
+    flmr_search_params_t p;
+    bool sparse;
+    hipStream_t st;
+    flmr_s0_args a0;
+    flmr_filter_args f;
+    int stage;  // profiling event cursor
+};
+
+#define RUN(x)          \
+    do {                \
+        int rc__ = (x); \
+        if (rc__) return rc__; \
+    } while (0)
+
+static int mark(run_ctx& c) {
+    if (c.s->profiling && c.stage <= FLMR_NUM_STAGES) FLMR_HIP(hipEventRecord(c.s->ev[c.stage], c.st));
+    c.stage++;
+    return FLMR_OK;
+}
+
+static int prepare_ctx(run_ctx& c, flmr_searcher* s, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
+                       const flmr_search_params_t* p, flmr_stream_t stream) {
+    if (!s || !Q) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    RUN(check_params(p));
     if (nqueries < 1 || nqueries > s->max_queries) FLMR_FAIL(FLMR_ERR_CAPACITY, "nqueries=%d > max_queries=%d", nqueries, s->max_queries);
     if (nq < 1 || nq > s->max_nq) FLMR_FAIL(FLMR_ERR_CAPACITY, "nq=%d > max_nq=%d", nq, s->max_nq);
     const int nqc = p->nq_cand < nq ? p->nq_cand : nq;
     const int ncol = (int)flmr_round_up(nqc, 32);
-    if (ncol > s->ncol_max || nqc * p->ncells > s->max_cells || nc_bucket_of(p->ncells) > s->nc_bucket ||
-        p->ndocs > s->maxp.ndocs)
+    if (ncol > s->ncol_max || nqc * p->ncells > s->max_cells || nc_bucket_of(p->ncells) > s->nc_bucket || p->ndocs > s->maxp.ndocs)
         FLMR_FAIL(FLMR_ERR_CAPACITY, "params exceed the bounds given at flmr_searcher_create");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const flmr_index* ix = s->ix;
-    const bool prof = s->profiling;
-    int stage = 0;
-#define MARK()                                            \
-    do {                                                  \
-        if (prof) FLMR_HIP(hipEventRecord(s->ev[stage], st)); \
-        stage++;                                          \
-    } while (0)
-#define RUN(x)          \
-    do {                \
-        rc = (x);       \
-        if (rc) return rc; \
-    } while (0)
-
-    // ---- S0: centroid scores, idx bits, probed cells ----------------------------------------------
-    flmr_s0_args a0;
+    c.s = s; c.Q = Q; c.q_lens = q_lens; c.nqueries = nqueries; c.nq = nq; c.nqc = nqc; c.ncol = ncol; c.p = *p;
+    c.st = reinterpret_cast<hipStream_t>(stream);
+    c.stage = 0;
+    flmr_s0_args& a0 = c.a0;
     a0.centroids = ix->centroids; a0.Q = Q; a0.q_lens = q_lens;
     a0.K = ix->K; a0.nqueries = nqueries; a0.nq = nq; a0.nq_cand = nqc; a0.ncol = ncol; a0.ncells = p->ncells;
     a0.thr = p->centroid_score_threshold;
@@ -193,24 +204,37 @@ extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32
     a0.cells = s->cells; a0.ncell = s->ncell; a0.max_cells = s->max_cells;
     a0.q_hi = s->q_hi; a0.q_lo = s->q_lo; a0.centroids_f16_exact = ix->centroids_f16_exact;
     a0.centroids_f16 = ix->centroids_f16;
+    a0.part_rows = 0;
     // sparse score table + recomputing stage 2: only on the fp16-split S0 path with a single column tile
     const char* s0env = getenv("FLMR_S0_IMPL");
     const bool f16_path = ix->centroids_f16_exact && ix->centroids_f16 && (ix->K % 64 == 0) && !(s0env && strcmp(s0env, "f16") != 0);
-    const bool sparse = f16_path && ncol == 32 && !s->full_table && getenv("FLMR_FULL_TABLE") == nullptr;
-    a0.full_table = sparse ? 0 : 1;
-    MARK();
-    RUN(flmr_launch_centroid_scores(a0, st));
-    MARK();
-    RUN(flmr_launch_select_cells(a0, st));
-    MARK();
-    // ---- S0c/d: IVF union -> ascending candidate pids ---------------------------------------------
+    c.sparse = f16_path && ncol == 32 && !s->full_table && getenv("FLMR_FULL_TABLE") == nullptr;
+    a0.full_table = c.sparse ? 0 : 1;
+    flmr_filter_args& f = c.f;
+    f.cs = s->cs; f.cs_query_stride = (int64_t)ix->K * ncol; f.K = ix->K; f.ncol = ncol; f.nq_cand = nqc;
+    f.nqueries = nqueries; f.q_lens = q_lens; f.codes = ix->codes; f.doclens = nullptr; f.offsets = ix->doc_offsets;
+    s->last_nqueries = nqueries; s->last_ncol = ncol; s->last_ndocs = p->ndocs; s->last_stream = c.st;
+    s->last_full_table = a0.full_table;
+    return FLMR_OK;
+}
+
+// S0 (scores, cells), candidates (+ hit flags), S1, top-ndocs selection -> s->s1_pids / s1_count (+ optional global keys)
+static int stage_s0_s1(run_ctx& c, uint64_t* out_keys) {
+    flmr_searcher* s = c.s;
+    const flmr_index* ix = s->ix;
+    hipStream_t st = c.st;
+    RUN(mark(c));
+    RUN(flmr_launch_centroid_scores(c.a0, st));
+    RUN(mark(c));
+    RUN(flmr_launch_select_cells(c.a0, st));
+    RUN(mark(c));
     // FLMR_CAND_IMPL=atomic keeps the first implementation (global atomicOr bitmap + separate hit bitmap) for A/B runs
     const char* cimpl = getenv("FLMR_CAND_IMPL");
     const bool chunked = !(cimpl && strcmp(cimpl, "atomic") == 0);
     const bool use_hits = getenv("FLMR_S1_NO_HITMAP") == nullptr;
     if (chunked) {
         flmr_cand_args ca;
-        ca.nqueries = nqueries; ca.idx_words = s->idx_words; ca.max_cells = s->max_cells; ca.qmax = s->qmax;
+        ca.nqueries = c.nqueries; ca.idx_words = s->idx_words; ca.max_cells = s->max_cells; ca.qmax = s->qmax;
         ca.nchunks = ix->nchunks; ca.words = s->bitmap_words; ca.cand_cap = s->cand_cap;
         ca.idx_bits = s->idx_bits; ca.cells = s->cells; ca.ncell = s->ncell;
         ca.ivf_pids = ix->ivf_pids; ca.ivf_offsets = ix->ivf_offsets; ca.chunk_tab = ix->ivf_chunk_tab;
@@ -218,58 +242,130 @@ extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32
         ca.cand_bits = s->bitmap; ca.hit_bits = s->hit_bits; ca.chunk_cnt = s->chunk_cnt;
         ca.cand = s->cand; ca.cand_hit = s->cand_hit; ca.cand_count = s->cand_count; ca.overflow = s->overflow;
         RUN(flmr_launch_candidates_chunked(ca, st));
-        MARK();
-        MARK();  // (the hit set is produced by the same pass: the s1_hitmap stage is empty in this mode)
+        RUN(mark(c));
+        RUN(mark(c));  // (the hit set is produced by the same pass: the s1_hitmap stage is empty in this mode)
     } else {
-        RUN(flmr_launch_ivf_mark(s->cells, s->ncell, s->max_cells, nqueries, ix->ivf_pids, ix->ivf_offsets, s->bitmap,
+        RUN(flmr_launch_ivf_mark(s->cells, s->ncell, s->max_cells, c.nqueries, ix->ivf_pids, ix->ivf_offsets, s->bitmap,
                                  s->bitmap_words, st));
-        RUN(flmr_launch_compact(s->bitmap, s->bitmap_words, ix->num_passages, nqueries, s->cand, s->cand_cap,
+        RUN(flmr_launch_compact(s->bitmap, s->bitmap_words, ix->num_passages, c.nqueries, s->cand, s->cand_cap,
                                 s->cand_count, s->overflow, st));
-        MARK();
+        RUN(mark(c));
         if (use_hits)
-            RUN(flmr_launch_hit_bitmap(s->idx_bits, s->idx_words, nqueries, ix->ivf_pids, ix->ivf_offsets, s->cand_count,
+            RUN(flmr_launch_hit_bitmap(s->idx_bits, s->idx_words, c.nqueries, ix->ivf_pids, ix->ivf_offsets, s->cand_count,
                                        s->hit_bits, s->bitmap_words, s->hit_valid, st));
-        MARK();
+        RUN(mark(c));
     }
-    // ---- S1: pruned centroid MaxSim over the candidates, keep ndocs ---------------------------------
-    flmr_filter_args f;
-    f.cs = s->cs; f.cs_query_stride = (int64_t)ix->K * ncol; f.K = ix->K; f.ncol = ncol; f.nq_cand = nqc;
-    f.nqueries = nqueries; f.q_lens = q_lens; f.codes = ix->codes; f.doclens = nullptr; f.offsets = ix->doc_offsets;
-    RUN(flmr_launch_filter_stage1(f, s->idx_bits, s->idx_words, s->cand, s->cand_cap, s->cand_count, s->keys1,
+    RUN(flmr_launch_filter_stage1(c.f, s->idx_bits, s->idx_words, s->cand, s->cand_cap, s->cand_count, s->keys1,
                                   (use_hits && !chunked) ? s->hit_bits : nullptr, s->bitmap_words, use_hits ? s->hit_valid : nullptr,
                                   (use_hits && chunked) ? s->cand_hit : nullptr, st));
-    MARK();
-    RUN(flmr_launch_select_topn(s->keys1, s->cand_cap, s->cand_count, nqueries, p->ndocs, s->s1_pids, s->maxp.ndocs,
-                                s->s1_count, st));
-    MARK();
-    // ---- S2: full centroid MaxSim over the survivors, keep ndocs/4 in (score,pid) order ----------------
-    if (sparse)
-        RUN(flmr_launch_filter_stage2_mfma(f, s->s1_pids, s->maxp.ndocs, s->s1_count, p->ndocs, s->keys2, s->maxp.ndocs,
-                                           ix->centroids_f16, s->q_hi, s->q_lo, st));
-    else
-        RUN(flmr_launch_filter_stage2(f, s->s1_pids, s->maxp.ndocs, s->s1_count, p->ndocs, s->keys2, s->maxp.ndocs, st));
-    RUN(flmr_launch_sort_topn(s->keys2, s->maxp.ndocs, s->s1_count, p->ndocs, nqueries, p->ndocs / 4, s->s2_pids,
-                              nullptr, s->maxp.ndocs / 4, s->s2_count, 0, 0, st));
-    MARK();
-    // ---- S3: decompress + normalise + MaxSim --------------------------------------------------------
-    flmr_maxsim_args m;
-    m.ix = ix; m.Q = Q; m.q_lens = q_lens; m.nqueries = nqueries; m.nq = nq;
-    m.pids = s->s2_pids; m.pid_stride = s->maxp.ndocs / 4; m.counts = s->s2_count; m.max_count = p->ndocs / 4;
-    m.keys = s->keys3; m.key_stride = s->maxp.ndocs / 4; m.scores = s->doc_scores;
-    m.q_hi = s->q3_hi; m.q_lo = s->q3_lo;
-    RUN(flmr_launch_maxsim(m, st));
-    MARK();
-    // ---- S4: final ranking, global pids ---------------------------------------------------------------
-    RUN(flmr_launch_sort_topn(s->keys3, s->maxp.ndocs / 4, s->s2_count, p->ndocs / 4, nqueries, p->k, out_pids,
-                              out_scores, p->k, out_counts, ix->pid_base, 1, st));
-    MARK();
-#undef MARK
-#undef RUN
-    s->last_nqueries = nqueries; s->last_ncol = ncol; s->last_ndocs = p->ndocs; s->last_stream = st;
-    s->last_full_table = a0.full_table;
-    s->have_ms = prof;
+    RUN(mark(c));
+    RUN(flmr_launch_select_topn(s->keys1, s->cand_cap, s->cand_count, c.nqueries, c.p.ndocs, s->s1_pids, s->maxp.ndocs,
+                                s->s1_count, st, out_keys, (uint64_t)ix->pid_base));
+    RUN(mark(c));
     return FLMR_OK;
 }
+
+// S2 over s->s1_pids / s1_count -> s->keys2 (slot-aligned with s1_pids)
+static int stage_s2(run_ctx& c) {
+    flmr_searcher* s = c.s;
+    const flmr_index* ix = s->ix;
+    if (c.sparse)
+        RUN(flmr_launch_filter_stage2_mfma(c.f, s->s1_pids, s->maxp.ndocs, s->s1_count, c.p.ndocs, s->keys2, s->maxp.ndocs,
+                                           ix->centroids_f16, s->q_hi, s->q_lo, c.st));
+    else
+        RUN(flmr_launch_filter_stage2(c.f, s->s1_pids, s->maxp.ndocs, s->s1_count, c.p.ndocs, s->keys2, s->maxp.ndocs, c.st));
+    return FLMR_OK;
+}
+
+// S3 over s->s2_pids / s2_count -> s->keys3 / doc_scores (slot-aligned with s2_pids)
+static int stage_s3(run_ctx& c) {
+    flmr_searcher* s = c.s;
+    flmr_maxsim_args m;
+    m.ix = s->ix; m.Q = c.Q; m.q_lens = c.q_lens; m.nqueries = c.nqueries; m.nq = c.nq;
+    m.pids = s->s2_pids; m.pid_stride = s->maxp.ndocs / 4; m.counts = s->s2_count; m.max_count = c.p.ndocs / 4;
+    m.keys = s->keys3; m.key_stride = s->maxp.ndocs / 4; m.scores = s->doc_scores;
+    m.q_hi = s->q3_hi; m.q_lo = s->q3_lo;
+    return flmr_launch_maxsim(m, c.st);
+}
+
+extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32_t* q_lens, int32_t nqueries,
+                                 int32_t nq, const flmr_search_params_t* p, int32_t* out_pids, float* out_scores,
+                                 int32_t* out_counts, flmr_stream_t stream) {
+    if (!out_pids || !out_scores || !out_counts) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    run_ctx c;
+    RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
+    RUN(stage_s0_s1(c, nullptr));
+    // ---- S2: full centroid MaxSim over the survivors, keep ndocs/4 in (score,pid) order ----------------
+    RUN(stage_s2(c));
+    RUN(flmr_launch_sort_topn(s->keys2, s->maxp.ndocs, s->s1_count, p->ndocs, nqueries, p->ndocs / 4, s->s2_pids,
+                              nullptr, s->maxp.ndocs / 4, s->s2_count, 0, 0, c.st));
+    RUN(mark(c));
+    // ---- S3: decompress + normalise + MaxSim --------------------------------------------------------
+    RUN(stage_s3(c));
+    RUN(mark(c));
+    // ---- S4: final ranking, global pids ---------------------------------------------------------------
+    RUN(flmr_launch_sort_topn(s->keys3, s->maxp.ndocs / 4, s->s2_count, p->ndocs / 4, nqueries, p->k, out_pids,
+                              out_scores, p->k, out_counts, s->ix->pid_base, 1, c.st));
+    RUN(mark(c));
+    s->have_ms = s->profiling;
+    return FLMR_OK;
+}
+
+// ---- exact sharded protocol ("exact-parity mode"): three phases with a key exchange after each --------------
+// phase 1: S0..S1 on this shard -> its top-ndocs stage-1 keys (global pids), 0 padded, unordered.
+extern "C" int flmr_search_phase1(flmr_searcher_t* s, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
+                                  const flmr_search_params_t* p, uint64_t* out_keys, flmr_stream_t stream) {
+    if (!out_keys) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    run_ctx c;
+    RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
+    if (s->maxp.ndocs != p->ndocs) FLMR_FAIL(FLMR_ERR_INVALID, "the phased protocol needs ndocs == the searcher's max ndocs (key rows are ndocs wide)");
+    s->have_ms = false;
+    return stage_s0_s1(c, out_keys);
+}
+
+// phase 2: global_s1 [nqueries, n_in] = the GLOBAL top-ndocs stage-1 keys; this shard scores its own members in stage 2
+// -> out_keys [nqueries, ndocs] (global pids, 0 padded).  Q / q_lens / params must be those of phase 1.
+extern "C" int flmr_search_phase2(flmr_searcher_t* s, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
+                                  const flmr_search_params_t* p, const uint64_t* global_s1, int32_t n_in, uint64_t* out_keys,
+                                  flmr_stream_t stream) {
+    if (!global_s1 || !out_keys) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    run_ctx c;
+    RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
+    RUN(flmr_launch_filter_local_keys(global_s1, nqueries, n_in, s->ix->pid_base, s->ix->num_passages, s->s1_pids, s->maxp.ndocs,
+                                      s->s1_count, c.st));
+    RUN(stage_s2(c));
+    return flmr_launch_export_keys(s->keys2, s->maxp.ndocs, s->s1_count, nqueries, (uint64_t)s->ix->pid_base, p->ndocs, out_keys, c.st);
+}
+
+// phase 3: global_s2 [nqueries, n_in] = the GLOBAL top-(ndocs/4) stage-2 keys; this shard computes the exact MaxSim of its
+// own members -> out_keys [nqueries, ndocs/4] (global pids, 0 padded).
+extern "C" int flmr_search_phase3(flmr_searcher_t* s, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
+                                  const flmr_search_params_t* p, const uint64_t* global_s2, int32_t n_in, uint64_t* out_keys,
+                                  flmr_stream_t stream) {
+    if (!global_s2 || !out_keys) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    run_ctx c;
+    RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
+    RUN(flmr_launch_filter_local_keys(global_s2, nqueries, n_in, s->ix->pid_base, s->ix->num_passages, s->s2_pids,
+                                      s->maxp.ndocs / 4, s->s2_count, c.st));
+    RUN(stage_s3(c));
+    return flmr_launch_export_keys(s->keys3, s->maxp.ndocs / 4, s->s2_count, nqueries, (uint64_t)s->ix->pid_base, p->ndocs / 4,
+                                   out_keys, c.st);
+}
+
+// keys [nqueries, m] -> the n largest, descending, 0 padded (+ optional counts); m <= 8192
+extern "C" int flmr_topn_keys(const uint64_t* keys, int32_t nqueries, int32_t m, int32_t n, uint64_t* out_keys,
+                              int32_t* out_counts, flmr_stream_t stream) {
+    if (!keys || !out_keys) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    return flmr_launch_sort_keys_topn(keys, nqueries, m, n, out_keys, out_counts, reinterpret_cast<hipStream_t>(stream));
+}
+
+// descending keys [nqueries, n] -> pids / scores / counts of the first k
+extern "C" int flmr_unpack_keys(const uint64_t* keys, int32_t nqueries, int32_t n, int32_t k, int32_t* out_pids,
+                                float* out_scores, int32_t* out_counts, flmr_stream_t stream) {
+    if (!keys || !out_pids || !out_scores || !out_counts) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    return flmr_launch_unpack_keys(keys, nqueries, n, k, out_pids, out_scores, out_counts, reinterpret_cast<hipStream_t>(stream));
+}
+#undef RUN
 
 extern "C" int flmr_searcher_tap(flmr_searcher_t* s, int32_t what, int32_t q, void* host_out, int64_t capacity,
                                  int64_t* count) {

@@ -54,6 +54,32 @@ class ShardedSearcher:
         ncells, thr, ndocs = self.k_policy(k)
         return self.scorer.search_batch(Q, k, ncells, thr, ndocs, nq_cand, q_lens=q_lens)
 
+    def search_batch_exact(self, Q, k, nq_cand=32, q_lens=None, gather=None):
+        """Exact-parity mode: three phases with one all-gather of u64 keys after each; the result is
+        bit-identical to searching the unsharded index.  `gather(t)` must return the [world, ...] stack of `t` over the
+        ranks (default: torch.distributed.all_gather_into_tensor on the device)."""
+        from . import ops
+        ncells, thr, ndocs = self.k_policy(k)
+
+        def default_gather(t):
+            if self.world == 1:
+                return t.unsqueeze(0)
+            g = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(g, t.contiguous(), group=self.group)
+            return g
+
+        gather = gather or default_gather
+
+        def exchange(keys, n):  # [B, m] per rank -> global top-n per query
+            g = gather(keys)                                              # [W, B, m]
+            return ops.topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n)
+
+        k1 = self.scorer.phase1(Q, k, ncells, thr, ndocs, nq_cand, q_lens=q_lens)
+        s1 = exchange(k1, ndocs)
+        s2 = exchange(self.scorer.phase2(s1), ndocs // 4)
+        fin = exchange(self.scorer.phase3(s2), min(k, max(ndocs // 4, 1)))
+        return ops.unpack_keys(fin, k)
+
     def search_batch(self, Q, k, **kw):
         pids, scores, counts = self._local(Q, k, **kw)
         if self.world == 1:

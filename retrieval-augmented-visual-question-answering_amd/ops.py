@@ -105,3 +105,24 @@ def merge_topk(scores, pids):
     oc = torch.empty((n,), dtype=torch.int32, device="cuda")
     _native.check(lib.flmr_merge_topk(_p(sc), _p(pd), R, n, k, _p(os_), _p(op), _p(oc), _native.stream_ptr()))
     return os_, op, oc
+
+
+def topn_keys(keys, n):
+    """keys int64 [nq, m] (u64 bit patterns: score bits << 32 | pid, 0 = empty) -> the n largest per row, descending."""
+    lib = _native.load()
+    kd = keys.to("cuda").contiguous()
+    out = torch.empty((kd.size(0), n), dtype=torch.int64, device="cuda")
+    _native.check(lib.flmr_topn_keys(_p(kd), kd.size(0), kd.size(1), int(n), _p(out), None, _native.stream_ptr()))
+    return out
+
+
+def unpack_keys(keys, k):
+    """descending keys int64 [nq, n] -> (pids i32 [nq,k], scores f32 [nq,k], counts i32 [nq])."""
+    lib = _native.load()
+    kd = keys.to("cuda").contiguous()
+    nq = kd.size(0)
+    op = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    os_ = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    oc = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    _native.check(lib.flmr_unpack_keys(_p(kd), nq, kd.size(1), int(k), _p(op), _p(os_), _p(oc), _native.stream_ptr()))
+    return op, os_, oc

@@ -140,6 +140,44 @@ class IndexScorer:
                 C.c_void_p(out_c[b0:b1].data_ptr()), st))
         return out_p, out_s, out_c
 
+    # ---- exact sharded protocol (include/flmr_hip.h: flmr_search_phase1..3) -------------------------------------------
+    def _phase_args(self, Q, k, ncells, thr, ndocs, nq_cand, q_lens):
+        Qd = Q.to(device="cuda", dtype=torch.float32).contiguous()
+        n, nq = Qd.size(0), Qd.size(1)
+        p = _params(k, ncells, thr, ndocs, nq_cand)
+        if self._searcher_key is not None and self._searcher_key[3] != ndocs:
+            self.close_searcher()  # key rows are exactly ndocs wide: the workspace must be created for this ndocs
+        s = self._get_searcher(n, nq, p)
+        ql = None if q_lens is None else torch.as_tensor(q_lens).to(device="cuda", dtype=torch.int32).contiguous()
+        return Qd, ql, n, nq, p, s
+
+    def phase1(self, Q, k, ncells, thr, ndocs, nq_cand=32, q_lens=None):
+        """-> int64 tensor [n, ndocs]: this shard's top-ndocs stage-1 keys (score bits << 32 | global pid, 0 = empty)."""
+        Qd, ql, n, nq, p, s = self._phase_args(Q, k, ncells, thr, ndocs, nq_cand, q_lens)
+        self._phase_state = (Qd, ql, n, nq, p)
+        out = torch.empty((n, ndocs), dtype=torch.int64, device="cuda")
+        _native.check(self._lib.flmr_search_phase1(s, C.c_void_p(Qd.data_ptr()), C.c_void_p(ql.data_ptr()) if ql is not None else None,
+                                                   n, nq, C.byref(p), C.c_void_p(out.data_ptr()), _native.stream_ptr()))
+        return out
+
+    def phase2(self, global_s1):
+        Qd, ql, n, nq, p = self._phase_state
+        g = global_s1.contiguous()
+        out = torch.empty((n, p.ndocs), dtype=torch.int64, device="cuda")
+        _native.check(self._lib.flmr_search_phase2(self._searcher, C.c_void_p(Qd.data_ptr()), C.c_void_p(ql.data_ptr()) if ql is not None else None,
+                                                   n, nq, C.byref(p), C.c_void_p(g.data_ptr()), g.size(1), C.c_void_p(out.data_ptr()),
+                                                   _native.stream_ptr()))
+        return out
+
+    def phase3(self, global_s2):
+        Qd, ql, n, nq, p = self._phase_state
+        g = global_s2.contiguous()
+        out = torch.empty((n, p.ndocs // 4), dtype=torch.int64, device="cuda")
+        _native.check(self._lib.flmr_search_phase3(self._searcher, C.c_void_p(Qd.data_ptr()), C.c_void_p(ql.data_ptr()) if ql is not None else None,
+                                                   n, nq, C.byref(p), C.c_void_p(g.data_ptr()), g.size(1), C.c_void_p(out.data_ptr()),
+                                                   _native.stream_ptr()))
+        return out
+
     def stage_ms(self):
         ms = (C.c_float * _native.NUM_STAGES)()
         _native.check(self._lib.flmr_searcher_stage_ms(self._searcher, ms))

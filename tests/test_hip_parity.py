@@ -398,3 +398,29 @@ def test_colbert_score_padded_mfma_vs_oracle(hip):
             os.environ.pop("FLMR_SCORE_IMPL", None)
         assert np.max(np.abs(got2 - ref) / (1.0 + np.abs(ref))) <= 2e-6
         assert got[4] == np.float32(-9999.0) * Q.shape[1] or abs(got[4] + 9999.0 * Q.shape[1]) < 1.0
+
+
+@pytest.mark.parametrize("nshards", [2, 3])
+def test_exact_sharded_protocol_equals_unsharded(hip, nshards):
+    """SURVEY 8e exact-parity mode: passage shards + three key exchanges reproduce the single-index result bit for bit.
+    The ranks are emulated in one process (one IndexScorer per shard on the same GPU, the all-gather is a torch.stack)."""
+    torch, pkg, ops = hip["torch"], hip["pkg"], hip["ops"]
+    from ravqa_amd.scorer import IndexScorer
+    z = load_golden("idx_nb2")
+    full = pkg.IndexArrays.from_golden(z)
+    single = IndexScorer(arrays=full)
+    shards = [IndexScorer(arrays=full.shard(r, nshards)) for r in range(nshards)]
+    recs = ["rank0", "rank3"]
+    Q = torch.stack([torch.from_numpy(z[f"{r}.Q"]) for r in recs]).repeat(3, 1, 1)
+    for (k, ncells, thr, ndocs) in [(100, 2, 0.45, 1024), (10, 1, 0.5, 64)]:
+        p_ref, s_ref, c_ref = single.search_batch(Q, k, ncells, thr, ndocs, 32)
+
+        def exchange(keys_per_rank, n):
+            g = torch.stack(keys_per_rank)                              # [W, B, m]
+            return ops.topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n)
+
+        s1 = exchange([sh.phase1(Q, k, ncells, thr, ndocs, 32) for sh in shards], ndocs)
+        s2 = exchange([sh.phase2(s1) for sh in shards], ndocs // 4)
+        fin = exchange([sh.phase3(s2) for sh in shards], min(k, ndocs // 4))
+        p, s, c = ops.unpack_keys(fin, k)
+        assert torch.equal(c, c_ref) and torch.equal(p, p_ref) and torch.equal(s, s_ref), (nshards, k)
