@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--cpu-queries", type=int, default=12, help="queries of the batch timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replicate-stage0", action="store_true",
+                    help="exact shard mode: every rank runs stage 0 for the whole batch instead of 1/N of the queries + an exchange")
     ap.add_argument("--shard-mode", choices=["exact", "fast"], default="exact",
                     help="N > 1: exact = three key exchanges, result bit-identical to the unsharded index (default); "
                          "fast = one all-gather of per-shard top-k (superset semantics)")
@@ -106,7 +108,8 @@ def main():
 
     def step(profile=False):
         if world > 1 and args.shard_mode == "exact":
-            return sharded.search_batch_exact(Q, k, nq_cand=32, gather=host_gather if args.single_device_smoke else None)
+            return sharded.search_batch_exact(Q, k, nq_cand=32, gather=host_gather if args.single_device_smoke else None,
+                                              split_stage0=not args.replicate_stage0)
         p, s, c = scorer.search_batch(Q, k, ncells, thr, ndocs, 32, profile=profile)  # query_maxlen = 32 (index_storage.py:77)
         if world > 1:
             gs = torch.empty((world,) + tuple(s.shape), dtype=s.dtype, device="cuda")
@@ -233,7 +236,7 @@ def main():
             "config": {"workload": f"FLMR late-interaction search, synthetic clustered corpus {args.passages} passages x "
                                    f"{args.doclen} tokens x 128-d, K={K}, nbits={args.nbits}, Nq={args.nq}, k={k} "
                                    f"(ncells={ncells}, thr={thr}, ndocs={ndocs}), {args.batch} queries/step",
-                       "parallelism": (f"index sharded by passage over {world} GPUs, " + ("3 all-gathers of (score,pid) keys, result identical to the unsharded index" if args.shard_mode == "exact" else "all-gather of per-shard top-k")) if world > 1 else "1 GPU",
+                       "parallelism": (f"index sharded by passage over {world} GPUs, " + (("stage 0 replicated, " if args.replicate_stage0 else "stage 0 split by query + exchange of idx bitsets/cells, ") + "3 all-gathers of (score,pid) keys, result identical to the unsharded index" if args.shard_mode == "exact" else "all-gather of per-shard top-k")) if world > 1 else "1 GPU",
                        "queries_per_step": args.batch},
             "recall_at_5": recall5,
             "roofline": roof,

@@ -121,6 +121,21 @@ int flmr_search_batch(flmr_searcher_t* searcher, const float* Q, const int32_t* 
  * ---------------------------------------------------------------------------------------------- */
 int flmr_search_phase1(flmr_searcher_t* searcher, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
                        const flmr_search_params_t* params, uint64_t* out_keys, flmr_stream_t stream);
+/* Query-split stage 0 (optional phase 0).  Stage 0 (centroids x Q', cells, idx -- colbert/search/candidate_generation.py:10-37,
+ * index_storage.py:114-118) does not depend on the passage shard, so instead of every rank repeating it for the whole
+ * batch, rank r runs flmr_search_probe on the query slice [q_begin, q_begin + q_count), the ranks all-gather the three
+ * small outputs, and flmr_search_phase1_probed (instead of flmr_search_phase1) continues from them; it rebuilds the
+ * score-table rows of the qualifying centroids with the identical MFMA sequence, so results stay bit-identical.
+ *   out_idx_bits [q_count, idx_words] u32, out_cells [q_count, max_cells] i32, out_ncell [q_count] i32 (device);
+ *   idx_words / max_cells from flmr_searcher_probe_dims.  FLMR_ERR_UNSUPPORTED when the searcher is not on the
+ *   sparse-table path (centroids not fp16-exact, K % 64 != 0, or nq_cand > 32): use flmr_search_phase1 then. */
+int flmr_searcher_probe_dims(const flmr_searcher_t* searcher, int32_t* idx_words, int32_t* max_cells);
+int flmr_search_probe(flmr_searcher_t* searcher, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
+                      const flmr_search_params_t* params, int32_t q_begin, int32_t q_count, uint32_t* out_idx_bits,
+                      int32_t* out_cells, int32_t* out_ncell, flmr_stream_t stream);
+int flmr_search_phase1_probed(flmr_searcher_t* searcher, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
+                              const flmr_search_params_t* params, const uint32_t* idx_bits, const int32_t* cells,
+                              const int32_t* ncell, uint64_t* out_keys, flmr_stream_t stream);
 int flmr_search_phase2(flmr_searcher_t* searcher, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
                        const flmr_search_params_t* params, const uint64_t* global_s1, int32_t n_in, uint64_t* out_keys,
                        flmr_stream_t stream);
@@ -213,6 +228,21 @@ int flmr_colbert_score_padded(const float* Q, int32_t q_batch, int32_t nq, const
  * pids i32[nshards, nqueries, k] (-1 = empty) -> global top-k per query in descending (score,pid) order. */
 int flmr_merge_topk(const float* scores, const int32_t* pids, int32_t nshards, int32_t nqueries, int32_t k,
                     float* out_scores, int32_t* out_pids, int32_t* out_counts, flmr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Index build ops: ResidualCodec.compress (colbert/indexing/codecs/residual.py:169-222).  All pointers are
+ * DEVICE pointers, dim == 128.
+ *   flmr_nearest_centroids  out_codes[t] = argmax_c centroids[c] . emb[t] (lowest c on ties), residual.py:206-216.
+ *                           centroids f32 [K,128] must be fp16-representable (the index stores them as half,
+ *                           residual.py:161) -> FLMR_ERR_UNSUPPORTED otherwise.  Synchronises `stream` before returning.
+ *   flmr_compress_residuals out_residuals u8 [n, 16*nbits]: bucketize(emb - centroids[codes], bucket_cutoffs[2^nbits - 1])
+ *                           then the reference's bit order (each nbits group LSB-first, bytes packed MSB-first),
+ *                           residual.py:186-204 (binarize) -- the layout flmr_index_open / decompress_residuals.cpp read.
+ * ---------------------------------------------------------------------------------------------- */
+int flmr_nearest_centroids(const float* centroids, int64_t K, const float* emb, int64_t n, int32_t* out_codes,
+                           flmr_stream_t stream);
+int flmr_compress_residuals(const float* centroids, int64_t K, const float* emb, const int32_t* codes, int64_t n,
+                            const float* bucket_cutoffs, int32_t nbits, uint8_t* out_residuals, flmr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.environ.get("FLMR_HIP_LIB") or os.path.join(PKG_DIR, "lib", "libflmr_hip.so")  # override: A/B-ing kernel builds
 CSRC = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["flmr_index.hip", "flmr_stage0.hip", "flmr_candidates.hip", "flmr_filter.hip", "flmr_maxsim.hip", "flmr_search.hip", "flmr_ops.hip"]
+SOURCES = ["flmr_index.hip", "flmr_stage0.hip", "flmr_candidates.hip", "flmr_filter.hip", "flmr_maxsim.hip", "flmr_search.hip", "flmr_ops.hip", "flmr_build.hip"]
 HEADERS = ["flmr_common.h", "flmr_device.h"]
 
 FLMR_MEM_HOST, FLMR_MEM_DEVICE = 0, 1
@@ -73,12 +73,20 @@ _SIGS = {
     "flmr_search_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SearchParams),
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "flmr_search_phase1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SearchParams), C.c_void_p, C.c_void_p]),
+    "flmr_searcher_probe_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "flmr_search_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SearchParams), C.c_int32,
+                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "flmr_search_phase1_probed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SearchParams),
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "flmr_search_phase2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SearchParams), C.c_void_p,
                                      C.c_int32, C.c_void_p, C.c_void_p]),
     "flmr_search_phase3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SearchParams), C.c_void_p,
                                      C.c_int32, C.c_void_p, C.c_void_p]),
     "flmr_topn_keys": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "flmr_unpack_keys": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "flmr_nearest_centroids": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "flmr_compress_residuals": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
+                                          C.c_void_p, C.c_void_p]),
     "flmr_searcher_tap": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "flmr_searcher_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "flmr_searcher_set_full_table": (C.c_int, [C.c_void_p, C.c_int32]),

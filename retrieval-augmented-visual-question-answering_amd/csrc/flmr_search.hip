@@ -219,15 +219,23 @@ static int prepare_ctx(run_ctx& c, flmr_searcher* s, const float* Q, const int32
 }
 
 // S0 (scores, cells), candidates (+ hit flags), S1, top-ndocs selection -> s->s1_pids / s1_count (+ optional global keys)
+static int stage_cand_s1(run_ctx& c, uint64_t* out_keys);
+
 static int stage_s0_s1(run_ctx& c, uint64_t* out_keys) {
-    flmr_searcher* s = c.s;
-    const flmr_index* ix = s->ix;
     hipStream_t st = c.st;
     RUN(mark(c));
     RUN(flmr_launch_centroid_scores(c.a0, st));
     RUN(mark(c));
     RUN(flmr_launch_select_cells(c.a0, st));
     RUN(mark(c));
+    return stage_cand_s1(c, out_keys);
+}
+
+// candidates (+ hit flags), S1, top-ndocs selection, given idx_bits / cells / ncell (and the table rows of idx) in place
+static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
+    flmr_searcher* s = c.s;
+    const flmr_index* ix = s->ix;
+    hipStream_t st = c.st;
     // FLMR_CAND_IMPL=atomic keeps the first implementation (global atomicOr bitmap + separate hit bitmap) for A/B runs
     const char* cimpl = getenv("FLMR_CAND_IMPL");
     const bool chunked = !(cimpl && strcmp(cimpl, "atomic") == 0);
@@ -321,6 +329,58 @@ extern "C" int flmr_search_phase1(flmr_searcher_t* s, const float* Q, const int3
     if (s->maxp.ndocs != p->ndocs) FLMR_FAIL(FLMR_ERR_INVALID, "the phased protocol needs ndocs == the searcher's max ndocs (key rows are ndocs wide)");
     s->have_ms = false;
     return stage_s0_s1(c, out_keys);
+}
+
+// ---- query-split stage 0 (optional phase 0 of the sharded protocol) ----------------------------------------------------
+// Stage 0 does not depend on the passage shard, so W ranks would repeat the same K x 128 x 32 product per query.  Instead
+// rank r runs flmr_search_probe for its slice of the batch, the ranks all-gather (idx bitset, cells, ncell) -- K/8 bytes
+// + a few cells per query -- and flmr_search_phase1_probed rebuilds the sparse score-table rows from the bitset.
+extern "C" int flmr_searcher_probe_dims(const flmr_searcher_t* s, int32_t* idx_words, int32_t* max_cells) {
+    if (!s || !idx_words || !max_cells) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    *idx_words = s->idx_words;
+    *max_cells = s->max_cells;
+    return FLMR_OK;
+}
+
+extern "C" int flmr_search_probe(flmr_searcher_t* s, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
+                                 const flmr_search_params_t* p, int32_t q_begin, int32_t q_count, uint32_t* out_idx_bits,
+                                 int32_t* out_cells, int32_t* out_ncell, flmr_stream_t stream) {
+    if (!out_idx_bits || !out_cells || !out_ncell) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    run_ctx c;
+    RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
+    if (!c.sparse) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "query-split stage 0 needs the sparse-table path (fp16-exact centroids, K %% 64 == 0, nq_cand <= 32)");
+    if (q_begin < 0 || q_count < 0 || q_begin + q_count > nqueries) FLMR_FAIL(FLMR_ERR_INVALID, "query slice [%d, %d) outside the batch of %d", q_begin, q_begin + q_count, nqueries);
+    s->have_ms = false;
+    if (q_count == 0) return FLMR_OK;
+    flmr_s0_args a0 = c.a0;  // the slice uses workspace slots 0..q_count; its results go straight to the caller's buffers
+    a0.Q = Q + (size_t)q_begin * nq * FLMR_DIM;
+    a0.q_lens = q_lens ? q_lens + q_begin : nullptr;
+    a0.nqueries = q_count;
+    a0.idx_bits = out_idx_bits; a0.cells = out_cells; a0.ncell = out_ncell;
+    RUN(flmr_launch_centroid_scores(a0, c.st));
+    return flmr_launch_select_cells(a0, c.st);
+}
+
+extern "C" int flmr_search_phase1_probed(flmr_searcher_t* s, const float* Q, const int32_t* q_lens, int32_t nqueries,
+                                         int32_t nq, const flmr_search_params_t* p, const uint32_t* idx_bits,
+                                         const int32_t* cells, const int32_t* ncell, uint64_t* out_keys,
+                                         flmr_stream_t stream) {
+    if (!idx_bits || !cells || !ncell || !out_keys) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    run_ctx c;
+    RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
+    if (!c.sparse) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "query-split stage 0 needs the sparse-table path (fp16-exact centroids, K %% 64 == 0, nq_cand <= 32)");
+    if (s->maxp.ndocs != p->ndocs) FLMR_FAIL(FLMR_ERR_INVALID, "the phased protocol needs ndocs == the searcher's max ndocs (key rows are ndocs wide)");
+    s->have_ms = false;
+    FLMR_HIP(hipMemcpyAsync(s->idx_bits, idx_bits, (size_t)nqueries * s->idx_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, c.st));
+    FLMR_HIP(hipMemcpyAsync(s->cells, cells, (size_t)nqueries * s->max_cells * sizeof(int32_t), hipMemcpyDeviceToDevice, c.st));
+    FLMR_HIP(hipMemcpyAsync(s->ncell, ncell, (size_t)nqueries * sizeof(int32_t), hipMemcpyDeviceToDevice, c.st));
+    RUN(mark(c));
+    RUN(flmr_launch_split_q(c.a0, c.st));
+    RUN(flmr_launch_qual_rows(s->idx_bits, s->idx_words, nqueries, s->cs, c.f.cs_query_stride, c.ncol, s->ix->centroids_f16,
+                              s->q_hi, s->q_lo, c.st));
+    RUN(mark(c));
+    RUN(mark(c));
+    return stage_cand_s1(c, out_keys);
 }
 
 // phase 2: global_s1 [nqueries, n_in] = the GLOBAL top-ndocs stage-1 keys; this shard scores its own members in stage 2

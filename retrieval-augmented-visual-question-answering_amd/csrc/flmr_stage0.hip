@@ -178,6 +178,9 @@ __global__ __launch_bounds__(256) void s0_split_q(const float* Q, const int32_t*
 #define S0_BROW 136             // halfs per staged B row (128 + 8 pad: conflict-free ds_read_b128 across rows)
 #define S0_LDS_STRIDE 36        // floats per staged row: 16-byte aligned rows for ds_read_b128
 
+// ARGMAX = true (index build, flmr_nearest_centroids): additionally tracks the row index of every block maximum in
+// part_idx (first row on ties); the search path instantiates ARGMAX = false and pays nothing for it.
+template <bool ARGMAX>
 __global__ __launch_bounds__(64 * S0_WAVES, 2) void s0_centroid_scores_f16(flmr_s0_args a) {
     // dynamic LDS: [4 waves][32 rows][36 f32] staging tiles for the row-contiguous table stores, then the fp16 B
     // operands (q_hi, q_lo) of S0_CH (query, column-tile) items, loaded once per block and shared by its 4 waves.
@@ -242,6 +245,7 @@ __global__ __launch_bounds__(64 * S0_WAVES, 2) void s0_centroid_scores_f16(flmr_
         const bool full_cols = nqc >= ct * 32 + 32;
         const bool sparse = !a.full_table && T == 1;
         float cmax = FLMR_NEG_INF;                 // running max of column `col` over this wave's rows
+        int carg = 0x7fffffff;                     // (ARGMAX) its row
         // software pipeline over the row tiles: the MFMAs of tile rt+1 are issued BEFORE the epilogue of tile rt, so the
         // epilogue's VALU / LDS / store instructions fill the matrix pipe's shadow (one wave per SIMD cannot rely on
         // another wave for that overlap)
@@ -267,7 +271,11 @@ __global__ __launch_bounds__(64 * S0_WAVES, 2) void s0_centroid_scores_f16(flmr_
             for (int r = 0; r < 16; r++) {
                 const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float v = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
-                cmax = fmaxf(cmax, v);
+                if constexpr (ARGMAX) {
+                    if (v > cmax) { cmax = v; carg = rbase + lrow; }  // rows are visited in ascending order: first maximum
+                } else {
+                    cmax = fmaxf(cmax, v);
+                }
                 stage[lrow * S0_LDS_STRIDE + i] = v;
             }
             __builtin_amdgcn_wave_barrier();  // DS ops of one wave execute in order: only the compiler must not reorder
@@ -300,7 +308,14 @@ __global__ __launch_bounds__(64 * S0_WAVES, 2) void s0_centroid_scores_f16(flmr_
             __builtin_amdgcn_wave_barrier();
         }
         // block maximum of each column (this wave's 32*S0_RT rows): the cell selection re-reads only the winners
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        if constexpr (ARGMAX) {
+            const float ov = __shfl_xor(cmax, 32, 64);
+            const int oa = __shfl_xor(carg, 32, 64);
+            if (ov > cmax || (ov == cmax && oa < carg)) { cmax = ov; carg = oa; }
+            if (lane < 32) a.part_idx[((size_t)b * a.nblk + wtile) * a.ncol + col] = carg;
+        } else {
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        }
         if (lane < 32) a.part_val[((size_t)b * a.nblk + wtile) * a.ncol + col] = (col < nqc) ? cmax : FLMR_NEG_INF;
         if (ct == T - 1) {
 #pragma unroll
@@ -422,15 +437,71 @@ static int launch_s0_t(flmr_s0_args& a, hipStream_t st, int impl) {
         hipLaunchKernelGGL(s0_split_q, dim3((a.ncol * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens,
                            a.nq, a.nq_cand, a.ncol, a.q_hi, a.q_lo);
         const size_t lds = (size_t)S0_WAVES * 32 * S0_LDS_STRIDE * sizeof(float) + (size_t)S0_CH * 2 * 32 * S0_BROW * sizeof(_Float16);
-        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_f16),
+        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_f16<false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(s0_centroid_scores_f16, dim3((a.nblk + S0_WAVES - 1) / S0_WAVES, qsplit), dim3(64 * S0_WAVES), lds, st, a);
+        hipLaunchKernelGGL(s0_centroid_scores_f16<false>, dim3((a.nblk + S0_WAVES - 1) / S0_WAVES, qsplit), dim3(64 * S0_WAVES), lds, st, a);
     } else if (impl == S0_F32) {
         hipLaunchKernelGGL(s0_centroid_scores_mfma<NC>, dim3(a.nblk, qsplit), dim3(256), 0, st, a);
     } else {
         hipLaunchKernelGGL(s0_centroid_scores_valu, dim3(1024, a.nqueries), dim3(256), 0, st, a);
         hipLaunchKernelGGL(s0_postprocess_table<NC>, dim3(a.nblk, a.nqueries), dim3(256), 0, st, a);
     }
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
+// ---- index build: nearest centroid of every column (token) = argmax over ALL K rows ----------------------------------
+// block partials (value, first row) -> the column's global (max value, lowest row).  grid = nqueries, block = 256:
+// thread (col = tid & 31, seg = tid >> 5) walks blocks seg, seg+8, ... (128-byte coalesced rows), LDS merge of the 8 segs.
+__global__ __launch_bounds__(256) void s0_argmax_reduce(flmr_s0_args a, int32_t* out_codes) {
+    __shared__ float sv[8][32];
+    __shared__ int si[8][32];
+    const int b = blockIdx.x, col = threadIdx.x & 31, seg = threadIdx.x >> 5;
+    const int qlen = a.q_lens ? a.q_lens[b] : a.nq;
+    const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;
+    float bv = FLMR_NEG_INF;
+    int bi = 0x7fffffff;
+    for (int e = seg; e < a.nblk; e += 8) {
+        const size_t off = ((size_t)b * a.nblk + e) * a.ncol + col;
+        const float v = a.part_val[off];
+        const int id = a.part_idx[off];
+        if (v > bv || (v == bv && id < bi)) { bv = v; bi = id; }
+    }
+    sv[seg][col] = bv; si[seg][col] = bi;
+    __syncthreads();
+    if (seg == 0 && col < nqc) {
+        for (int s = 1; s < 8; s++) {
+            const float v = sv[s][col];
+            const int id = si[s][col];
+            if (v > bv || (v == bv && id < bi)) { bv = v; bi = id; }
+        }
+        out_codes[(size_t)b * a.nq + col] = bi;
+    }
+}
+
+// a: centroids (fp16-exact, K % 64 == 0), Q = the embeddings viewed as [nqueries, 32, 128], q_lens (last query may be short),
+// q_hi/q_lo, part_val/part_idx [nqueries, K/64, 32], idx_bits [nqueries, K/32] (scratch).  out_codes [nqueries * 32].
+int flmr_launch_centroid_argmax(flmr_s0_args& a, int32_t* out_codes, hipStream_t st) {
+    if (a.K % (32 * S0_RT) != 0 || a.ncol != 32 || a.nq != 32) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "centroid argmax needs K %% 64 == 0 and 32-column tiles");
+    a.nblk = a.K / (32 * S0_RT);
+    a.part_rows = 32 * S0_RT;
+    a.full_table = 0;
+    a.thr = __builtin_inff();  // nothing qualifies: no table rows are stored
+    const int qsplit = a.nqueries < 8 ? a.nqueries : 8;
+    hipLaunchKernelGGL(s0_split_q, dim3((a.ncol * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens, a.nq,
+                       a.nq_cand, a.ncol, a.q_hi, a.q_lo);
+    const size_t lds = (size_t)S0_WAVES * 32 * S0_LDS_STRIDE * sizeof(float) + (size_t)S0_CH * 2 * 32 * S0_BROW * sizeof(_Float16);
+    FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_f16<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(s0_centroid_scores_f16<true>, dim3((a.nblk + S0_WAVES - 1) / S0_WAVES, qsplit), dim3(64 * S0_WAVES), lds, st, a);
+    hipLaunchKernelGGL(s0_argmax_reduce, dim3(a.nqueries), dim3(256), 0, st, a, out_codes);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
+int flmr_launch_split_q(const flmr_s0_args& a, hipStream_t st) {
+    hipLaunchKernelGGL(s0_split_q, dim3((a.ncol * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens, a.nq,
+                       a.nq_cand, a.ncol, a.q_hi, a.q_lo);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }

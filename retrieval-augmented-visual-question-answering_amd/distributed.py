@@ -40,6 +40,7 @@ class ShardedSearcher:
             from . import ops
             merge = ops.merge_topk
         self._merge = merge
+        self._split_ok = None  # query-split stage 0 supported by the native searcher? (decided on first use)
 
     @classmethod
     def from_arrays(cls, arrays, group=None, max_batch=256):
@@ -54,7 +55,7 @@ class ShardedSearcher:
         ncells, thr, ndocs = self.k_policy(k)
         return self.scorer.search_batch(Q, k, ncells, thr, ndocs, nq_cand, q_lens=q_lens)
 
-    def search_batch_exact(self, Q, k, nq_cand=32, q_lens=None, gather=None):
+    def search_batch_exact(self, Q, k, nq_cand=32, q_lens=None, gather=None, split_stage0=True):
         """Exact-parity mode: three phases with one all-gather of u64 keys after each; the result is
         bit-identical to searching the unsharded index.  `gather(t)` must return the [world, ...] stack of `t` over the
         ranks (default: torch.distributed.all_gather_into_tensor on the device)."""
@@ -74,7 +75,30 @@ class ShardedSearcher:
             g = gather(keys)                                              # [W, B, m]
             return ops.topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n)
 
-        k1 = self.scorer.phase1(Q, k, ncells, thr, ndocs, nq_cand, q_lens=q_lens)
+        k1 = None
+        if self.world > 1 and split_stage0 and self._split_ok is not False:
+            # stage 0 does not depend on the passage shard: each rank probes 1/W of the queries, the ranks exchange the
+            # idx bitsets + cells (K/8 bytes + a few ints per query) and rebuild the table rows they need locally
+            B = Q.size(0)
+            per = -(-B // self.world)
+            lo = min(B, self.rank * per)
+            cnt = min(B, lo + per) - lo
+            try:
+                iw, mc = self.scorer.probe_dims(Q, k, ncells, thr, ndocs, nq_cand)
+                bufs = (torch.zeros((per, iw), dtype=torch.int32, device="cuda"),
+                        torch.zeros((per, mc), dtype=torch.int32, device="cuda"),
+                        torch.zeros((per,), dtype=torch.int32, device="cuda"))
+                self.scorer.probe(Q, k, ncells, thr, ndocs, lo, cnt, nq_cand, q_lens=q_lens, out=bufs)
+                self._split_ok = True
+            except RuntimeError:
+                if self._split_ok:  # it worked before: a real failure, not an unsupported shape
+                    raise
+                self._split_ok = False  # same decision on every rank: it depends only on the replicated centroids / shape
+            if self._split_ok:
+                bits, cells, ncell = (gather(t).reshape((-1,) + tuple(t.shape[1:])) for t in bufs)
+                k1 = self.scorer.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, nq_cand, q_lens=q_lens)
+        if k1 is None:
+            k1 = self.scorer.phase1(Q, k, ncells, thr, ndocs, nq_cand, q_lens=q_lens)
         s1 = exchange(k1, ndocs)
         s2 = exchange(self.scorer.phase2(s1), ndocs // 4)
         fin = exchange(self.scorer.phase3(s2), min(k, max(ndocs // 4, 1)))

@@ -12,7 +12,8 @@ encoder -- the caller supplies the (already L2-normalised) token embeddings and 
   index    nearest centroid by dot product, residual, bucketize, bit-pack            (synth.compress = residual.py:169-204)
   finalize IVF = sorted unique pids per centroid                                    (synth.build_ivf = indexing/utils.py:8-53)
 
-All tensor work runs on the device the embeddings live on (rocBLAS GEMMs through torch for the assignment steps).
+With the embeddings on the GPU the `index` step runs on the HIP kernels of csrc/flmr_build.hip (ops.compress); k-means and
+the quantiles use torch on the same device.
 """
 import math
 
@@ -83,8 +84,13 @@ def build_index(embeddings, doclens, nbits=2, num_partitions=None, kmeans_niters
     # ---- compress every embedding (residual.py:169-204) ----
     codes = torch.empty(N, dtype=torch.int32, device=dev)
     residuals = torch.empty((N, dim * nbits // 8), dtype=torch.uint8, device=dev)
+    if dev.type == "cuda":
+        from . import ops  # HIP kernels: fp16-split MFMA argmax + fused residual/bucketize/bit-pack (csrc/flmr_build.hip)
+        compress = lambda e: ops.compress(e, centroids, cutoffs, nbits)
+    else:  # host tensors (tests, tiny corpora): the torch restatement of the same steps
+        compress = lambda e: synth.compress(e, centroids, cutoffs, nbits)
     for i in range(0, N, chunk):
-        c, r = synth.compress(embeddings[i:i + chunk].float(), centroids, cutoffs, nbits)
+        c, r = compress(embeddings[i:i + chunk].float())
         codes[i:i + chunk], residuals[i:i + chunk] = c, r
     ivf, ivf_lengths = synth.build_ivf(codes, doclens, K)
     cpu = lambda t: t.detach().cpu().numpy()

@@ -126,3 +126,32 @@ def unpack_keys(keys, k):
     oc = torch.empty((nq,), dtype=torch.int32, device="cuda")
     _native.check(lib.flmr_unpack_keys(_p(kd), nq, kd.size(1), int(k), _p(op), _p(os_), _p(oc), _native.stream_ptr()))
     return op, os_, oc
+
+
+# ---- index build (include/flmr_hip.h "Index build ops"; residual.py:169-222) -------------------------------------------
+def nearest_centroids(embs, centroids):
+    """codes int32 [N] = argmax_c centroids[c] . embs[t] (residual.py:206-216); centroids must be fp16-representable."""
+    lib = _native.load()
+    e, c = _d(embs, torch.float32), _d(centroids, torch.float32)
+    assert e.dim() == 2 and e.size(1) == 128 and c.size(1) == 128
+    out = torch.empty(e.size(0), dtype=torch.int32, device="cuda")
+    _native.check(lib.flmr_nearest_centroids(_p(c), c.size(0), _p(e), e.size(0), _p(out), _native.stream_ptr()))
+    return out
+
+
+def compress_residuals(embs, centroids, codes, bucket_cutoffs, nbits):
+    """packed residual bytes uint8 [N, 16*nbits] for the given codes (residual.py:186-204)."""
+    lib = _native.load()
+    e, c = _d(embs, torch.float32), _d(centroids, torch.float32)
+    cd, cut = _d(codes, torch.int32), _d(bucket_cutoffs, torch.float32)
+    assert cut.numel() == 2 ** nbits - 1, "bucket_cutoffs must hold 2^nbits - 1 values"
+    out = torch.empty((e.size(0), 16 * nbits), dtype=torch.uint8, device="cuda")
+    _native.check(lib.flmr_compress_residuals(_p(c), c.size(0), _p(e), _p(cd), e.size(0), _p(cut), int(nbits), _p(out),
+                                              _native.stream_ptr()))
+    return out
+
+
+def compress(embs, centroids, bucket_cutoffs, nbits):
+    """ResidualCodec.compress on the GPU -> (codes int32 [N], residuals uint8 [N, 16*nbits])."""
+    codes = nearest_centroids(embs, centroids)
+    return codes, compress_residuals(embs, centroids, codes, bucket_cutoffs, nbits)

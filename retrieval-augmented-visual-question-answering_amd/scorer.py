@@ -160,6 +160,41 @@ class IndexScorer:
                                                    n, nq, C.byref(p), C.c_void_p(out.data_ptr()), _native.stream_ptr()))
         return out
 
+    def probe_dims(self, Q, k, ncells, thr, ndocs, nq_cand=32):
+        """(idx_words, max_cells) of the probe buffers for this batch shape (creates the searcher)."""
+        _, _, _, _, _, s = self._phase_args(Q, k, ncells, thr, ndocs, nq_cand, None)
+        iw, mc = C.c_int32(0), C.c_int32(0)
+        _native.check(self._lib.flmr_searcher_probe_dims(s, C.byref(iw), C.byref(mc)))
+        return iw.value, mc.value
+
+    def probe(self, Q, k, ncells, thr, ndocs, q_begin, q_count, nq_cand=32, q_lens=None, out=None):
+        """Stage 0 for the query slice [q_begin, q_begin+q_count) of the batch -> (idx_bits i32 [q_count, idx_words],
+        cells i32 [q_count, max_cells], ncell i32 [q_count]) on the device (include/flmr_hip.h: flmr_search_probe)."""
+        Qd, ql, n, nq, p, s = self._phase_args(Q, k, ncells, thr, ndocs, nq_cand, q_lens)
+        iw, mc = C.c_int32(0), C.c_int32(0)
+        _native.check(self._lib.flmr_searcher_probe_dims(s, C.byref(iw), C.byref(mc)))
+        if out is None:
+            out = (torch.empty((q_count, iw.value), dtype=torch.int32, device="cuda"),
+                   torch.empty((q_count, mc.value), dtype=torch.int32, device="cuda"),
+                   torch.empty((q_count,), dtype=torch.int32, device="cuda"))
+        bits, cells, ncell = out
+        _native.check(self._lib.flmr_search_probe(s, C.c_void_p(Qd.data_ptr()), C.c_void_p(ql.data_ptr()) if ql is not None else None,
+                                                  n, nq, C.byref(p), q_begin, q_count, C.c_void_p(bits.data_ptr()),
+                                                  C.c_void_p(cells.data_ptr()), C.c_void_p(ncell.data_ptr()), _native.stream_ptr()))
+        return bits, cells, ncell
+
+    def phase1_probed(self, Q, k, ncells, thr, ndocs, idx_bits, cells, ncell, nq_cand=32, q_lens=None):
+        """phase1 continuing from the gathered probe state of ALL queries (flmr_search_phase1_probed)."""
+        Qd, ql, n, nq, p, s = self._phase_args(Q, k, ncells, thr, ndocs, nq_cand, q_lens)
+        self._phase_state = (Qd, ql, n, nq, p)
+        bits, cells, ncell = idx_bits.contiguous(), cells.contiguous(), ncell.contiguous()
+        assert bits.size(0) >= n and cells.size(0) >= n and ncell.numel() >= n
+        out = torch.empty((n, ndocs), dtype=torch.int64, device="cuda")
+        _native.check(self._lib.flmr_search_phase1_probed(s, C.c_void_p(Qd.data_ptr()), C.c_void_p(ql.data_ptr()) if ql is not None else None,
+                                                          n, nq, C.byref(p), C.c_void_p(bits.data_ptr()), C.c_void_p(cells.data_ptr()),
+                                                          C.c_void_p(ncell.data_ptr()), C.c_void_p(out.data_ptr()), _native.stream_ptr()))
+        return out
+
     def phase2(self, global_s1):
         Qd, ql, n, nq, p = self._phase_state
         g = global_s1.contiguous()

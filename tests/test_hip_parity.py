@@ -424,3 +424,100 @@ def test_exact_sharded_protocol_equals_unsharded(hip, nshards):
         fin = exchange([sh.phase3(s2) for sh in shards], min(k, ndocs // 4))
         p, s, c = ops.unpack_keys(fin, k)
         assert torch.equal(c, c_ref) and torch.equal(p, p_ref) and torch.equal(s, s_ref), (nshards, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nshards", [2, 3])
+def test_query_split_stage0_equals_unsharded(hip, nshards):
+    """Phase 0 of the sharded protocol: each rank runs stage 0 for a slice of the queries only (flmr_search_probe), the
+    (idx bitset, cells, ncell) triples are gathered and flmr_search_phase1_probed rebuilds the table rows -- the final
+    ranking must still be bit-identical to the unsharded search."""
+    torch, pkg, ops = hip["torch"], hip["pkg"], hip["ops"]
+    from ravqa_amd.scorer import IndexScorer
+    z = load_golden("idx_nb2")
+    full = pkg.IndexArrays.from_golden(z)
+    single = IndexScorer(arrays=full)
+    shards = [IndexScorer(arrays=full.shard(r, nshards)) for r in range(nshards)]
+    recs = ["rank0", "rank3"]
+    Q = torch.stack([torch.from_numpy(z[f"{r}.Q"]) for r in recs]).repeat(4, 1, 1)[:7]   # 7 queries: ragged slices
+    B = Q.size(0)
+    per = -(-B // nshards)
+    for (k, ncells, thr, ndocs) in [(100, 2, 0.45, 1024), (10, 1, 0.5, 64), (10, 2, -1.0, 64)]:   # thr=-1: every centroid qualifies
+        p_ref, s_ref, c_ref = single.search_batch(Q, k, ncells, thr, ndocs, 32)
+
+        def exchange(keys_per_rank, n):
+            g = torch.stack(keys_per_rank)
+            return ops.topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n)
+
+        parts = []
+        for r, sh in enumerate(shards):
+            lo = min(B, r * per)
+            parts.append(sh.probe(Q, k, ncells, thr, ndocs, lo, min(B, lo + per) - lo, 32))
+        bits, cells, ncell = (torch.cat([p_[j] for p_ in parts]) for j in range(3))
+        # the probe state must equal what the unsharded search computed
+        for q in range(B):
+            single.search_batch(Q[q:q + 1], k, ncells, thr, ndocs, 32)
+            ref_bits = single.tap(pkg._native.TAP_IDX_BITS, 0).view(np.int32)
+            assert np.array_equal(bits[q].cpu().numpy(), ref_bits), q
+            ref_cells = single.tap(pkg._native.TAP_CELLS, 0)
+            assert np.array_equal(cells[q, :int(ncell[q])].cpu().numpy(), ref_cells), q
+        s1 = exchange([sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32) for sh in shards], ndocs)
+        s2 = exchange([sh.phase2(s1) for sh in shards], ndocs // 4)
+        fin = exchange([sh.phase3(s2) for sh in shards], min(k, ndocs // 4))
+        p, s, c = ops.unpack_keys(fin, k)
+        assert torch.equal(c, c_ref) and torch.equal(p, p_ref) and torch.equal(s, s_ref), (nshards, k, thr)
+
+
+@pytest.mark.parametrize("name", ["idx_nb1", "idx_nb2", "idx_nb4", "idx_nb8"])
+def test_compress_ops_match_reference_vectors(hip, name):
+    """Index build ops (flmr_nearest_centroids + flmr_compress_residuals) vs the reference's ResidualCodec.compress output
+    (tests/golden: compress.embs -> compress.codes / compress.residuals), residual.py:169-222.  Codes may differ only where
+    the two best centroids are within fp32 rounding of each other; the packed bytes must be bit-exact for equal codes."""
+    torch, ops = hip["torch"], hip["ops"]
+    z = load_golden(name)
+    nbits = int(z["meta.nbits"])
+    cen = torch.from_numpy(z["index.centroids_f16"].astype(np.float32))
+    embs = torch.from_numpy(z["compress.embs"])
+    codes = ops.nearest_centroids(embs, cen).cpu().numpy()
+    ref_codes = z["compress.codes"]
+    diff = np.nonzero(codes != ref_codes)[0]
+    if diff.size:
+        sc = embs.numpy()[diff].astype(np.float64) @ cen.numpy().astype(np.float64).T
+        gap = np.abs(sc[np.arange(diff.size), codes[diff]] - sc[np.arange(diff.size), ref_codes[diff]])
+        assert gap.max() <= 1e-6, gap.max()
+    res = ops.compress_residuals(embs, cen, torch.from_numpy(ref_codes), torch.from_numpy(z["index.bucket_cutoffs"]), nbits)
+    assert np.array_equal(res.cpu().numpy(), z["compress.residuals"])
+
+
+def test_nearest_centroids_large_and_odd_sizes(hip):
+    """fp16-split MFMA argmax vs an fp64 argmax: K not a multiple of 64 (padded inside), n not a multiple of 32, several
+    workspace chunks, exact ties (duplicate centroids -> the lower index wins)."""
+    torch, ops = hip["torch"], hip["ops"]
+    from ravqa_amd import synth
+    g = torch.Generator().manual_seed(5)
+    for (K, n) in [(1000, 4133), (4096, 150_001)]:
+        cen = torch.nn.functional.normalize(torch.randn(K, 128, generator=g), dim=-1).half().float()
+        cen[K // 2] = cen[3]                                         # exact duplicate: index 3 must win
+        codes_true = torch.randint(0, K, (n,), generator=g)
+        embs = torch.nn.functional.normalize(cen[codes_true] + 0.05 * torch.randn(n, 128, generator=g), dim=-1)
+        got = ops.nearest_centroids(embs, cen).cpu()
+        sc = (embs.cuda().double() @ cen.cuda().double().T)
+        ref = sc.argmax(dim=1).cpu()
+        bad = torch.nonzero(got.long() != ref).flatten()
+        if bad.numel():
+            gap = (sc[bad.cuda(), ref[bad].cuda()] - sc[bad.cuda(), got[bad].long().cuda()]).abs().max().item()
+            assert gap <= 1e-6, gap
+        assert not bool((got == K // 2).any())
+        # fused residual / bucketize / bit-pack == the torch restatement (bit-exact), every nbits
+        for nbits in (1, 2, 4, 8):
+            cut, _ = synth.bucket_tables((embs - cen[got.long()])[:20000], nbits)
+            want = synth.compress(embs, cen, cut, nbits, codes=got.long())[1]
+            have = ops.compress_residuals(embs, cen, got, cut, nbits).cpu()
+            assert torch.equal(have, want), (K, n, nbits)
+
+
+def test_nearest_centroids_rejects_non_fp16_centroids(hip):
+    torch, ops, pkg = hip["torch"], hip["ops"], hip["pkg"]
+    cen = torch.nn.functional.normalize(torch.randn(128, 128), dim=-1)  # not rounded to half
+    with pytest.raises(pkg.FlmrNativeError):
+        ops.nearest_centroids(torch.randn(64, 128), cen)
