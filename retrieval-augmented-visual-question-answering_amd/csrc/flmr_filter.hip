@@ -598,9 +598,13 @@ int flmr_launch_filter_stage2(const flmr_filter_args& f, const int32_t* pids, in
 
 // ------------------------------------------------------------------------------------------------
 // Radix select: the n largest of count[q] 64-bit keys, unordered.  grid = nqueries, block = 1024.
-// 8 passes of 8 bits from the top; the histogram lives in LDS; the leader digit of each wave is
+// Up to 8 passes of 8 bits from the top; the histogram lives in LDS; the leader digit of each wave is
 // aggregated with a ballot so the heavily repeated high bytes do not serialise on one LDS address.
+// The first KPT * 1024 keys of a query are loaded ONCE into registers -- one block per query means one block per CU, so
+// a pass that re-reads global memory is pure exposed latency (30 dependent iterations x 9 passes before); only the tail
+// of longer lists streams from global memory in every pass.  The passes stop once the selected bucket is taken whole.
 // ------------------------------------------------------------------------------------------------
+template <int KPT>
 __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys, int64_t key_stride,
                                                            const int32_t* counts, int32_t n, int32_t* out_pids,
                                                            int64_t out_stride, int32_t* n_out, uint64_t* out_keys,
@@ -609,6 +613,7 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys,
     __shared__ unsigned long long s_prefix;
     __shared__ int s_remaining;
     __shared__ int s_out;
+    __shared__ int s_done;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int P = counts[b];
     const uint64_t* kb = keys + (size_t)b * key_stride;
@@ -622,22 +627,50 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys,
         if (tid == 0) n_out[b] = P;
         return;
     }
-    if (tid == 0) { s_prefix = 0ull; s_remaining = n; s_out = 0; }
+    uint64_t kreg[KPT];  // keys [0, KPT*1024) of the list; anything beyond streams from global memory in every pass
+#pragma unroll
+    for (int j = 0; j < KPT; j++) kreg[j] = (j * 1024 + tid < P) ? kb[j * 1024 + tid] : 0ull;
+    // once the bucket that still has to be split holds <= SEL_LCAP keys they are copied to LDS and the remaining passes
+    // touch nothing else
+    constexpr int SEL_LCAP = 4096;
+    __shared__ unsigned long long s_list[SEL_LCAP];
+    __shared__ int s_nlist, s_compact;
+    if (tid == 0) { s_prefix = 0ull; s_remaining = n; s_out = 0; s_done = 0; s_nlist = 0; s_compact = 0; }
     for (int pass = 0; pass < 8; pass++) {
         const int shift = 56 - 8 * pass;
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
+        if (s_done) break;  // block-uniform (written before the previous barrier pair)
         const unsigned long long prefix = s_prefix;
-        for (int i0 = 0; i0 < P; i0 += blockDim.x) {
-            const int i = i0 + tid;
-            bool act = false;
-            unsigned int dg = 0;
-            if (i < P) {
-                const uint64_t key = kb[i];
-                act = (pass == 0) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
-                dg = (unsigned int)(key >> shift) & 255u;
+        if (s_compact) {  // block-uniform
+            const int nl = s_nlist;
+            for (int i0 = 0; i0 < nl; i0 += 1024) {
+                const int i = i0 + tid;
+                const bool valid = i < nl;
+                const uint64_t key = valid ? s_list[i] : 0ull;
+                const bool act = valid && ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+                if (act) atomicAdd(&hist[(unsigned int)(key >> shift) & 255u], 1u);
             }
-            unsigned long long am = __ballot(act);
+            __syncthreads();
+            if (tid == 0) {
+                int rem = s_remaining;
+                int dsel = 0, csel = 0;
+                for (int dgt = 255; dgt >= 0; --dgt) {
+                    const int c = (int)hist[dgt];
+                    if (c >= rem) { dsel = dgt; csel = c; break; }
+                    rem -= c;
+                }
+                s_remaining = rem;
+                s_prefix = prefix | ((unsigned long long)dsel << shift);
+                if (csel == rem) s_done = 1;
+            }
+            __syncthreads();
+            continue;
+        }
+        auto count = [&](bool valid, uint64_t key) {
+            const bool act = valid && ((pass == 0) || ((key >> (shift + 8)) == (prefix >> (shift + 8))));
+            const unsigned int dg = (unsigned int)(key >> shift) & 255u;
+            const unsigned long long am = __ballot(act);
             if (am) {
                 const int leader = __builtin_ctzll(am);
                 const unsigned int ld = (unsigned int)__shfl((int)dg, leader, 64);
@@ -645,32 +678,64 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys,
                 if (lane == leader) atomicAdd(&hist[ld], (unsigned int)__popcll(same));
                 if (act && dg != ld) atomicAdd(&hist[dg], 1u);
             }
+        };
+#pragma unroll
+        for (int j = 0; j < KPT; j++) count(j * 1024 + tid < P, kreg[j]);
+        for (int i0 = KPT * 1024; i0 < P; i0 += 4 * 1024) {  // 4 loads in flight per thread: the tail is latency-bound too
+            uint64_t kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) kk[u] = (i0 + u * 1024 + tid < P) ? kb[i0 + u * 1024 + tid] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; u++) count(i0 + u * 1024 + tid < P, kk[u]);
         }
         __syncthreads();
         if (tid == 0) {
             int rem = s_remaining;
-            int dsel = 0;
+            int dsel = 0, csel = 0;
             for (int dgt = 255; dgt >= 0; --dgt) {
                 const int c = (int)hist[dgt];
-                if (c >= rem) { dsel = dgt; break; }
+                if (c >= rem) { dsel = dgt; csel = c; break; }
                 rem -= c;
             }
             s_remaining = rem;  // how many keys with the selected digit (and prefix) are still needed
             s_prefix = prefix | ((unsigned long long)dsel << shift);
+            if (csel == rem) s_done = 1;  // the whole bucket is taken: every key >= the prefix (low bits 0) is selected
+            else if (csel <= SEL_LCAP && pass < 7) s_compact = 1;
         }
         __syncthreads();
-    }
-    // s_prefix is now the n-th largest key: keep everything >= it (keys are unique per pid)
-    const unsigned long long thr = s_prefix;
-    for (int i0 = 0; i0 < P; i0 += blockDim.x) {
-        const int i = i0 + tid;
-        if (i < P) {
-            const uint64_t key = kb[i];
-            if (key >= thr) {
-                const int pos = atomicAdd(&s_out, 1);
-                if (pos < n) { ob[pos] = flmr_key_pid(key); if (okb) okb[pos] = key + key_add; }
+        if (s_compact && !s_done) {  // copy the bucket (keys whose top 8*(pass+1) bits equal the new prefix) to LDS
+            const unsigned long long np = s_prefix;
+            auto take = [&](bool valid, uint64_t key) {
+                if (valid && ((key >> shift) == (np >> shift))) s_list[atomicAdd(&s_nlist, 1)] = key;
+            };
+#pragma unroll
+            for (int j = 0; j < KPT; j++) take(j * 1024 + tid < P, kreg[j]);
+            for (int i0 = KPT * 1024; i0 < P; i0 += 4 * 1024) {
+                uint64_t kk[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) kk[u] = (i0 + u * 1024 + tid < P) ? kb[i0 + u * 1024 + tid] : 0ull;
+#pragma unroll
+                for (int u = 0; u < 4; u++) take(i0 + u * 1024 + tid < P, kk[u]);
             }
+            // (the barrier at the top of the next pass orders these writes before the list is read)
         }
+    }
+    // s_prefix is now the n-th largest key (or the floor of the last bucket, taken whole): keep everything >= it
+    const unsigned long long thr = s_prefix;
+    auto emit = [&](bool valid, uint64_t key) {
+        if (valid && key >= thr) {
+            const int pos = atomicAdd(&s_out, 1);
+            if (pos < n) { ob[pos] = flmr_key_pid(key); if (okb) okb[pos] = key + key_add; }
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < KPT; j++) emit(j * 1024 + tid < P, kreg[j]);
+    for (int i0 = KPT * 1024; i0 < P; i0 += 4 * 1024) {
+        uint64_t kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) kk[u] = (i0 + u * 1024 + tid < P) ? kb[i0 + u * 1024 + tid] : 0ull;
+#pragma unroll
+        for (int u = 0; u < 4; u++) emit(i0 + u * 1024 + tid < P, kk[u]);
     }
     __syncthreads();
     if (tid == 0) n_out[b] = s_out < n ? s_out : n;
@@ -679,8 +744,13 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys,
 int flmr_launch_select_topn(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t nqueries,
                             int32_t n, int32_t* out_pids, int64_t out_stride, int32_t* n_out, hipStream_t st,
                             uint64_t* out_keys, uint64_t key_add) {
-    hipLaunchKernelGGL(select_topn_kernel, dim3(nqueries), dim3(1024), 0, st, keys, key_stride, counts, n, out_pids,
-                       out_stride, n_out, out_keys, key_add);
+    // keys per thread held in registers: sized from the candidate capacity (the tail of longer lists streams)
+    if (key_stride <= 16 * 1024)
+        hipLaunchKernelGGL(select_topn_kernel<16>, dim3(nqueries), dim3(1024), 0, st, keys, key_stride, counts, n, out_pids,
+                           out_stride, n_out, out_keys, key_add);
+    else
+        hipLaunchKernelGGL(select_topn_kernel<24>, dim3(nqueries), dim3(1024), 0, st, keys, key_stride, counts, n, out_pids,
+                           out_stride, n_out, out_keys, key_add);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }

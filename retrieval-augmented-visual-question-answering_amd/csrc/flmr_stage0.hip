@@ -535,6 +535,23 @@ __global__ __launch_bounds__(1024) void s0_select_cells(flmr_s0_args a) {
     const int qlen = a.q_lens ? a.q_lens[b] : a.nq;
     const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;
     raw[tid] = 0x7fffffff;
+    // block-maxima partials with a single column tile: every wave scans a slice of the rows for ALL 32 columns with
+    // 128-byte coalesced reads (lane = (row parity, column)) and leaves its per-column top-NC blocks in LDS; the per-column
+    // loop below then merges 16 short lists instead of walking 2048 rows with a 128-byte stride per column.
+    __shared__ float pre_v[16][32][NC];
+    __shared__ int pre_i[16][32][NC];
+    const bool pre = a.part_rows != 0 && a.ncol == 32;
+    if (pre) {
+        flmr_toplist<NC> bt;
+        bt.init();
+        for (int e = wave * 2 + (lane >> 5); e < a.nblk; e += 32)
+            bt.insert(a.part_val[((size_t)b * a.nblk + e) * 32 + (lane & 31)], e);
+        bt.merge_xor(32);
+        if (lane < 32) {
+#pragma unroll
+            for (int t = 0; t < NC; t++) { pre_v[wave][lane][t] = bt.v[t]; pre_i[wave][lane][t] = bt.id[t]; }
+        }
+    }
     __syncthreads();
     for (int col = wave; col < nqc; col += 16) {
         flmr_toplist<NC> tl;
@@ -554,7 +571,11 @@ __global__ __launch_bounds__(1024) void s0_select_cells(flmr_s0_args a) {
             // those blocks' rows of this column from the table and take the exact top-NC (value desc, index asc)
             flmr_toplist<NC> bt;
             bt.init();
-            for (int e = lane; e < a.nblk; e += 64) bt.insert(a.part_val[((size_t)b * a.nblk + e) * a.ncol + col], e);
+            if (pre) {
+                for (int e = lane; e < 16 * NC; e += 64) bt.insert(pre_v[e / NC][col][e % NC], pre_i[e / NC][col][e % NC]);
+            } else {
+                for (int e = lane; e < a.nblk; e += 64) bt.insert(a.part_val[((size_t)b * a.nblk + e) * a.ncol + col], e);
+            }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) bt.merge_xor(m);
             const float* cs_b = a.cs + (size_t)b * a.K * a.ncol;

@@ -61,3 +61,37 @@ class FLMRScoringHead:
 
     def score(self, Q, D_padded, D_mask):
         return colbert_score(Q, D_padded, D_mask)
+
+
+def exhaustive_search(query_embeddings, item_embeddings, item_embedding_mask, k, item_chunk=None):
+    """Brute-force late-interaction search: every query against every item, top-k by score -- the `else` branch of
+    `FLMRExecutor.evaluate_outputs` (src/executors/FLMR_executor.py:799-847), which fills `rate_batch[nq, n_items]` four
+    items at a time through `model.score` and then sorts each row descending.
+
+    query_embeddings [nq, Nq, d]; item_embeddings [n_items, Ld, d]; item_embedding_mask [n_items, Ld(,1)] (1 = real token).
+    Returns (indices int64 [nq, k'], scores f32 [nq, k'], rate_batch f32 [nq, n_items]) on the device, k' = min(k, n_items).
+    The items are uploaded once and stay resident; each query is one launch of the padded MaxSim kernel over all items
+    (q_batch == 1 broadcast), `item_chunk` bounds the items per launch for corpora larger than HBM headroom."""
+    _no_grad_only(query_embeddings, item_embeddings)
+    Q = torch.as_tensor(query_embeddings).to("cuda", torch.float32)
+    D = torch.as_tensor(item_embeddings)
+    M = torch.as_tensor(item_embedding_mask)
+    n_items = D.size(0)
+    M = M.reshape(n_items, -1)
+    item_chunk = item_chunk or n_items
+    rate = torch.empty((Q.size(0), n_items), dtype=torch.float32, device="cuda")
+    for i0 in range(0, n_items, item_chunk):
+        Dc = D[i0:i0 + item_chunk].to("cuda", torch.float32).contiguous()
+        Mc = M[i0:i0 + item_chunk].to("cuda")
+        for q in range(Q.size(0)):
+            rate[q, i0:i0 + Dc.size(0)] = ops.colbert_score_padded(Q[q:q + 1], Dc, Mc)
+    scores, indices = torch.sort(rate, dim=-1, descending=True)
+    kk = min(int(k), n_items)
+    return indices[:, :kk], scores[:, :kk], rate
+
+
+def exhaustive_ranking_dict(indices, scores):
+    """(indices, scores) -> {query_index: [(item index, rank from 0, int(score))]} exactly as FLMR_executor.py:838-845
+    builds it (the reference truncates the score to an int there; kept so downstream records match)."""
+    idx, sc = indices.cpu(), scores.cpu()
+    return {q: [(int(idx[q, i]), i, int(sc[q, i])) for i in range(idx.size(1))] for q in range(idx.size(0))}

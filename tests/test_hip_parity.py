@@ -521,3 +521,28 @@ def test_nearest_centroids_rejects_non_fp16_centroids(hip):
     cen = torch.nn.functional.normalize(torch.randn(128, 128), dim=-1)  # not rounded to half
     with pytest.raises(pkg.FlmrNativeError):
         ops.nearest_centroids(torch.randn(64, 128), cen)
+
+
+def test_exhaustive_search_matches_torch_expression(hip):
+    """FLMR_executor.py:799-847 exhaustive branch: rate_batch from the padded HIP scorer == the torch expression of
+    colbert_score (colbert.py:235-286: D @ Q^T, mask-fill -9999, max over Ld, sum over Nq), top-k order identical."""
+    torch = hip["torch"]
+    from ravqa_amd import scoring
+    g = torch.Generator().manual_seed(11)
+    nq, Nq, n_items, Ld = 5, 32, 203, 41
+    Q = torch.nn.functional.normalize(torch.randn(nq, Nq, 128, generator=g), dim=-1)
+    D = torch.nn.functional.normalize(torch.randn(n_items, Ld, 128, generator=g), dim=-1)
+    lens = torch.randint(1, Ld + 1, (n_items,), generator=g)
+    mask = (torch.arange(Ld).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(-1)
+    idx, sc, rate = scoring.exhaustive_search(Q, D, mask, 10, item_chunk=64)
+    ref = torch.empty(nq, n_items, dtype=torch.float64)
+    for q in range(nq):
+        s = (D.double() @ Q[q].double().T)                          # [n_items, Ld, Nq]
+        s = s.masked_fill(~mask.expand(-1, -1, Nq), -9999.0)
+        ref[q] = s.max(1).values.sum(-1)
+    assert float((rate.cpu().double() - ref).abs().max()) <= 1e-4
+    ref_sorted, ref_idx = torch.sort(ref, dim=-1, descending=True)
+    for q in range(nq):
+        tie_aware_equal(ref_idx[q, :10].numpy(), ref_sorted[q, :10].float().numpy(), idx[q].cpu().numpy(), sc[q].cpu().numpy(), tol=SCORE_TOL)
+    rd = scoring.exhaustive_ranking_dict(idx, sc)
+    assert rd[0][0] == (int(idx[0, 0]), 0, int(sc[0, 0])) and len(rd) == nq and len(rd[0]) == 10
