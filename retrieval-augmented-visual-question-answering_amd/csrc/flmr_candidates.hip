@@ -52,7 +52,8 @@ int flmr_build_chunk_table(const int32_t* ivf_pids, const int64_t* ivf_offsets, 
 __global__ __launch_bounds__(1024) void qualifying_kernel(const uint32_t* idx_bits, int idx_words,
                                                           const int64_t* ivf_offsets, const int32_t* cells,
                                                           const int32_t* ncell, int max_cells, int32_t* qual,
-                                                          int32_t* nqual, int qmax, int32_t* hit_valid) {
+                                                          int32_t* nqual, int qmax, int32_t* hit_valid,
+                                                          int32_t* key_count) {
     __shared__ int scan_lds[17];
     __shared__ unsigned long long tot_q, tot_c;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(1024) void qualifying_kernel(const uint32_t* idx_bi
     if (tid == 0) {
         nqual[b] = base < qmax ? base : qmax;
         hit_valid[b] = (base <= qmax) && (tot_q <= 2ull * tot_c);
+        if (key_count) key_count[b] = 0;
     }
 }
 
@@ -130,6 +132,211 @@ __global__ __launch_bounds__(256) void cand_mark_chunks_kernel(const int32_t* ce
     if (tid == 0) chunk_cnt[(size_t)b * nchunks + ch] = cnt_lds;
 }
 
+// ---- kernel A': mark + STAGE 1 BY SCATTER ---------------------------------------------------------------------------------
+// The stage-1 score of a passage (filter_pids.cpp:27-69 with the idx mask of index_storage.py:116) depends only on the SET
+// of surviving centroids that occur in it: sum_k max_{c in set} centroid_scores[c][k] (per-k maxima start at -9999, summed
+// in ascending k).  "Centroid c occurs in passage p" is exactly "p is in ivf[c]" (the IVF is built from the codes,
+// indexing/utils.py:8-53), so the per-passage sets can be read off the surviving centroids' IVF lists and the passages'
+// codes never have to be scanned: this replaces the 4*sum(doclen) bytes/candidate code scan -- the largest term of the
+// whole path's compulsory traffic in the reference formulation -- by the (c, pid) pairs of the surviving lists.
+// Per (query, chunk) workgroup, after the bitmaps are marked: every candidate that is also in the hit set gets a slot
+// (popcount rank inside the chunk) with 32 fp32 accumulators in LDS; the surviving lists' slices are walked a second time
+// and each (c, pid) pair does a 32-wide ds_max of c's score row into pid's slot (scores are order-encoded as ints so the
+// integer LDS atomic max is exact); then one thread per candidate sums its columns in ascending k and writes the key.
+// Keys go to keys[b][base + rank] with base from a per-query atomic counter: the top-ndocs selection is order-free.
+// More hits in a chunk than S1S_SLOTS are handled in windows of slots.
+#define S1S_SLOTS 1120   // accumulator slots per window: with the bitmaps this fills the CU's 160 KB of LDS
+#define S1S_STRIDE 33
+#define S1S_WAVES 16     // one 1024-thread workgroup per CU
+
+__device__ __forceinline__ int s1s_enc(float x) { const int i = __float_as_int(x); return i ^ ((i >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float s1s_dec(int e) { return __int_as_float(e ^ ((e >> 31) & 0x7fffffff)); }
+
+// IVF list slices of this (query, chunk) owned by one wave: list ids wave, wave+16, ... (at most 64 of them: the
+// launcher guarantees n <= 1024), one per lane, so that the dependent chain  id -> (offset, chunk table) -> pids
+// costs its first two global round trips once per wave instead of once per list.
+struct s1s_slices {
+    int c;            // centroid id of this lane's list
+    int64_t beg;      // ivf_offsets[c]
+    uint32_t s, e;    // slice [s, e) of the list inside this chunk
+    int n;            // number of lists of this wave (wave-uniform)
+};
+__device__ __forceinline__ s1s_slices s1s_load_slices(const int32_t* ids, int n_total, int wave, int lane,
+                                                      const int64_t* ivf_offsets, const uint32_t* tab, int nchunks, int ch) {
+    s1s_slices m;
+    m.n = wave < n_total ? (n_total - wave + S1S_WAVES - 1) / S1S_WAVES : 0;
+    m.c = 0; m.beg = 0; m.s = 0; m.e = 0;
+    if (lane < m.n) {
+        m.c = ids[wave + S1S_WAVES * lane];
+        m.beg = ivf_offsets[m.c];
+        m.s = tab[(size_t)m.c * (nchunks + 1) + ch];
+        m.e = tab[(size_t)m.c * (nchunks + 1) + ch + 1];
+    }
+    return m;
+}
+__device__ __forceinline__ int64_t s1s_bcast64(int64_t v, int j) {
+    const int lo = __builtin_amdgcn_readlane((int)(uint32_t)v, j), hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), j);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
+__global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_cand_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* cb = reinterpret_cast<uint32_t*>(smem);                   // candidate bitmap of the chunk
+    uint32_t* hb = cb + CAND_CHUNK_WORDS;                               // hit-set bitmap
+    uint16_t* cbase = reinterpret_cast<uint16_t*>(hb + CAND_CHUNK_WORDS);  // exclusive candidate count before word w
+    uint16_t* hbase = cbase + CAND_CHUNK_WORDS;                         // exclusive (candidate & hit) count before word w
+    int* acc = reinterpret_cast<int*>(hbase + CAND_CHUNK_WORDS);        // [S1S_SLOTS][S1S_STRIDE]
+    __shared__ int scan_lds[17];
+    __shared__ int s_base;
+    const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = lane & 31, h = lane >> 5;
+    cb[tid] = 0u; hb[tid] = 0u;  // CAND_CHUNK_WORDS == blockDim.x
+    const int nl = a.ncell[b];
+    const bool scatter = a.hit_valid[b] != 0;
+    const int nq = scatter ? a.nqual[b] : 0;
+    const int pid0 = ch * CAND_CHUNK_PIDS;
+    const s1s_slices mc = s1s_load_slices(a.cells + (size_t)b * a.max_cells, nl, wave, lane, a.ivf_offsets, a.chunk_tab, a.nchunks, ch);
+    const s1s_slices mq = s1s_load_slices(a.qual + (size_t)b * a.qmax, nq, wave, lane, a.ivf_offsets, a.chunk_tab, a.nchunks, ch);
+    __syncthreads();
+    // lists are taken four at a time: the first 64 entries of each are requested before any is consumed
+    auto mark = [&](const s1s_slices& m, uint32_t* dst) {
+        for (int j0 = 0; j0 < m.n; j0 += 4) {
+            int pidv[4];
+            int64_t begv[4];
+            uint32_t sv[4], ev[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = (j0 + u < m.n) ? j0 + u : j0;
+                begv[u] = s1s_bcast64(m.beg, j);
+                sv[u] = (uint32_t)__builtin_amdgcn_readlane((int)m.s, j);
+                ev[u] = (j0 + u < m.n) ? (uint32_t)__builtin_amdgcn_readlane((int)m.e, j) : sv[u];
+                pidv[u] = (sv[u] + lane < ev[u]) ? a.ivf_pids[begv[u] + sv[u] + lane] - pid0 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (pidv[u] >= 0) atomicOr(&dst[pidv[u] >> 5], 1u << (pidv[u] & 31));
+                for (uint32_t x = sv[u] + 64 + lane; x < ev[u]; x += 64) {
+                    const int pid = a.ivf_pids[begv[u] + x] - pid0;
+                    atomicOr(&dst[pid >> 5], 1u << (pid & 31));
+                }
+            }
+        }
+    };
+    mark(mc, cb);
+    mark(mq, hb);
+    __syncthreads();
+    // bitmaps out (the ascending candidate list is still produced by cand_emit_kernel) + the two popcount prefixes
+    const int64_t gw = (int64_t)ch * CAND_CHUNK_WORDS + tid;
+    uint32_t cw = cb[tid];
+    const uint32_t hw = hb[tid];
+    if (gw < a.words) {
+        a.cand_bits[(size_t)b * a.words + gw] = cw;
+        a.hit_bits[(size_t)b * a.words + gw] = hw;
+    } else {
+        cw = 0u;
+    }
+    const uint32_t hcw = cw & hw;
+    int cnt, nh;
+    const int cpos = flmr_block_exclusive_scan(__popc(cw), scan_lds, &cnt);
+    __syncthreads();
+    const int hpos = flmr_block_exclusive_scan(__popc(hcw), scan_lds, &nh);
+    cbase[tid] = (uint16_t)cpos;
+    hbase[tid] = (uint16_t)hpos;
+    if (tid == 0) {
+        a.chunk_cnt[(size_t)b * a.nchunks + ch] = cnt;
+        s_base = (scatter && cnt) ? atomicAdd(&a.key_count[b], cnt) : 0;
+    }
+    if (!scatter) return;  // this query's stage 1 is done by the scanning kernel (block-uniform)
+    __syncthreads();
+    if (cnt == 0) return;
+    const int qlen = a.q_lens ? a.q_lens[b] : a.nq_cand;
+    const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;  // <= 32 on this path
+    float miss_score = 0.0f;
+    for (int q = 0; q < nqc; q++) miss_score += -9999.0f;
+    const float* cs_b = a.cs + (size_t)b * a.cs_query_stride;
+    uint64_t* keys_b = a.keys + (size_t)b * a.cand_cap;
+    const int64_t kbase = s_base;
+    const int init = s1s_enc(-9999.0f);
+    for (int win0 = 0; win0 == 0 || win0 < nh; win0 += S1S_SLOTS) {
+        const int nslot = (nh - win0) < S1S_SLOTS ? (nh - win0) : S1S_SLOTS;
+        for (int e = tid; e < nslot * S1S_STRIDE; e += 64 * S1S_WAVES) acc[e] = init;
+        __syncthreads();
+        // the surviving lists again: (centroid, passage) pairs -> 32-wide max into the passage's slot; four lists at a
+        // time (their score rows and first 64 entries are requested up front)
+        auto scatter_pids = [&](int pid, int rowk) {
+            int slot = -1;
+            if (pid >= 0) {
+                const int w = pid >> 5, bit = pid & 31;
+                const uint32_t cwd = cb[w];
+                if ((cwd >> bit) & 1u) slot = (int)hbase[w] + __popc(cwd & hb[w] & ((1u << bit) - 1u)) - win0;
+            }
+            unsigned long long m = __ballot(slot >= 0 && slot < nslot);
+            while (m) {  // wave-uniform: two (centroid, passage) pairs per iteration, one per half-wave
+                const int ja = __builtin_ctzll(m);
+                m &= m - 1;
+                const int jb = m ? __builtin_ctzll(m) : -1;
+                if (m) m &= m - 1;
+                const int jj = h ? jb : ja;
+                const int sl = __shfl(slot, jj < 0 ? 0 : jj, 64);
+                if (jj >= 0) atomicMax(&acc[sl * S1S_STRIDE + k], rowk);
+            }
+        };
+        for (int j0 = 0; j0 < mq.n; j0 += 4) {
+            int pidv[4], rowv[4];
+            int64_t begv[4];
+            uint32_t sv[4], ev[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = (j0 + u < mq.n) ? j0 + u : j0;
+                begv[u] = s1s_bcast64(mq.beg, j);
+                sv[u] = (uint32_t)__builtin_amdgcn_readlane((int)mq.s, j);
+                ev[u] = (j0 + u < mq.n) ? (uint32_t)__builtin_amdgcn_readlane((int)mq.e, j) : sv[u];
+                rowv[u] = s1s_enc(cs_b[(size_t)__builtin_amdgcn_readlane(mq.c, j) * 32 + k]);
+                pidv[u] = (sv[u] + lane < ev[u]) ? a.ivf_pids[begv[u] + sv[u] + lane] - pid0 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (sv[u] >= ev[u]) continue;  // wave-uniform
+                scatter_pids(pidv[u], rowv[u]);
+                for (uint32_t x0 = sv[u] + 64; x0 < ev[u]; x0 += 64)
+                    scatter_pids(x0 + lane < ev[u] ? a.ivf_pids[begv[u] + x0 + lane] - pid0 : -1, rowv[u]);
+            }
+        }
+        __syncthreads();
+        // per-slot score = ascending-k sum of the column maxima (filter_pids.cpp:59-63), one thread per slot, kept in the
+        // row's padding word
+        for (int sl = tid; sl < nslot; sl += 64 * S1S_WAVES) {
+            float v[32];
+#pragma unroll
+            for (int q = 0; q < 32; q++) v[q] = s1s_dec(acc[sl * S1S_STRIDE + q]);
+            float sc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 32; q++) sc += q < nqc ? v[q] : 0.0f;
+            acc[sl * S1S_STRIDE + 32] = __float_as_int(sc);
+        }
+        __syncthreads();
+        // one thread per bitmap word: keys of its candidates (hits of this window; the misses with window 0)
+        {
+            uint32_t bits = cw;
+            while (bits) {
+                const int bit = __ffs(bits) - 1;
+                bits &= bits - 1;
+                const uint32_t below = (1u << bit) - 1u;
+                const int64_t pos = kbase + cpos + __popc(cw & below);
+                const int pid = pid0 + tid * 32 + bit;
+                if ((hcw >> bit) & 1u) {
+                    const int slot = hpos + __popc(hcw & below) - win0;
+                    if (slot >= 0 && slot < nslot && pos < a.cand_cap)
+                        keys_b[pos] = flmr_make_key(__int_as_float(acc[slot * S1S_STRIDE + 32]), pid);
+                } else if (win0 == 0 && pos < a.cand_cap) {
+                    keys_b[pos] = flmr_make_key(miss_score, pid);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- kernel B: bitmap chunk -> ascending pids at the chunk's global rank, one hit flag per candidate --------------------------
 __global__ __launch_bounds__(1024) void cand_emit_kernel(const uint32_t* cand_bits, const uint32_t* hit_bits, int64_t words,
                                                          const int32_t* chunk_cnt, int nchunks, int32_t* cand, int64_t cand_cap,
@@ -165,10 +372,18 @@ __global__ __launch_bounds__(1024) void cand_emit_kernel(const uint32_t* cand_bi
 
 int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
     hipLaunchKernelGGL(qualifying_kernel, dim3(a.nqueries), dim3(1024), 0, st, a.idx_bits, a.idx_words, a.ivf_offsets, a.cells,
-                       a.ncell, a.max_cells, a.qual, a.nqual, a.qmax, a.hit_valid);
-    hipLaunchKernelGGL(cand_mark_chunks_kernel, dim3(a.nqueries, a.nchunks), dim3(256), 0, st, a.cells, a.ncell, a.max_cells,
-                       a.qual, a.nqual, a.qmax, a.hit_valid, a.ivf_pids, a.ivf_offsets, a.chunk_tab, a.nchunks, a.cand_bits,
-                       a.hit_bits, a.words, a.chunk_cnt);
+                       a.ncell, a.max_cells, a.qual, a.nqual, a.qmax, a.hit_valid, a.scatter ? a.key_count : nullptr);
+    if (a.scatter) {
+        const size_t lds = (size_t)CAND_CHUNK_WORDS * (2 * sizeof(uint32_t) + 2 * sizeof(uint16_t)) +
+                           (size_t)S1S_SLOTS * S1S_STRIDE * sizeof(int);
+        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cand_mark_score_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(cand_mark_score_kernel, dim3(a.nqueries, a.nchunks), dim3(64 * S1S_WAVES), lds, st, a);
+    } else {
+        hipLaunchKernelGGL(cand_mark_chunks_kernel, dim3(a.nqueries, a.nchunks), dim3(256), 0, st, a.cells, a.ncell, a.max_cells,
+                           a.qual, a.nqual, a.qmax, a.hit_valid, a.ivf_pids, a.ivf_offsets, a.chunk_tab, a.nchunks, a.cand_bits,
+                           a.hit_bits, a.words, a.chunk_cnt);
+    }
     hipLaunchKernelGGL(cand_emit_kernel, dim3(a.nqueries, a.nchunks), dim3(1024), 0, st, a.cand_bits, a.hit_bits, a.words,
                        a.chunk_cnt, a.nchunks, a.cand, a.cand_cap, a.cand_hit, a.cand_count, a.overflow);
     FLMR_LAUNCH_CHECK();

@@ -138,7 +138,7 @@ struct flmr_filter_args {
 int flmr_launch_filter_stage1(const flmr_filter_args& f, const uint32_t* idx_bits, int32_t idx_words,
                               const int32_t* cand, int64_t cand_stride, const int32_t* cand_count, uint64_t* keys,
                               const uint32_t* hit_bits, int64_t hit_words, const int32_t* hit_valid,
-                              const uint8_t* hit_flags, hipStream_t st);
+                              const uint8_t* hit_flags, hipStream_t st, const int32_t* skip = nullptr);
 // chunked candidate generation (flmr_candidates.hip): bitmaps in LDS per (query, 32768-passage chunk)
 struct flmr_cand_args {
     int32_t nqueries, idx_words, max_cells, qmax, nchunks;
@@ -148,6 +148,10 @@ struct flmr_cand_args {
     int32_t* qual; int32_t* nqual; int32_t* hit_valid;     // [nqueries, qmax], [nqueries], [nqueries]
     uint32_t* cand_bits; uint32_t* hit_bits; int32_t* chunk_cnt;  // [nqueries, words] x2, [nqueries, nchunks]
     int32_t* cand; uint8_t* cand_hit; int32_t* cand_count; int32_t* overflow;
+    // stage 1 by scatter over the surviving centroids' IVF lists (cand_mark_score_kernel), for queries with hit_valid
+    int32_t scatter;                 // 0: bitmaps only (stage 1 = filter_stage1_kernel for every query)
+    const float* cs; int64_t cs_query_stride; int32_t nq_cand; const int32_t* q_lens;
+    uint64_t* keys; int32_t* key_count;   // [nqueries, cand_cap] unordered stage-1 keys, [nqueries] running count
 };
 int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st);
 int flmr_build_chunk_table(const int32_t* ivf_pids, const int64_t* ivf_offsets, int K, int64_t num_passages,

@@ -110,10 +110,11 @@ __global__ __launch_bounds__(512) void filter_stage1_kernel(flmr_filter_args f, 
                                                             int64_t cand_stride, const int32_t* cand_count,
                                                             uint64_t* keys, const uint32_t* hit_bits,
                                                             int64_t hit_words, const int32_t* hit_valid,
-                                                            const uint8_t* hit_flags) {
+                                                            const uint8_t* hit_flags, const int32_t* skip) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int scan_lds[17];
     const int b = blockIdx.x;
+    if (skip && skip[b]) return;  // this query's stage-1 keys were produced by cand_mark_score_kernel
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int P = cand_count[b];
     const int qlen = f.q_lens ? f.q_lens[b] : f.nq_cand;
@@ -298,7 +299,7 @@ int flmr_launch_hit_bitmap(const uint32_t* idx_bits, int32_t idx_words, int32_t 
 int flmr_launch_filter_stage1(const flmr_filter_args& f, const uint32_t* idx_bits, int32_t idx_words,
                               const int32_t* cand, int64_t cand_stride, const int32_t* cand_count, uint64_t* keys,
                               const uint32_t* hit_bits, int64_t hit_words, const int32_t* hit_valid,
-                              const uint8_t* hit_flags, hipStream_t st) {
+                              const uint8_t* hit_flags, hipStream_t st, const int32_t* skip) {
     const int T = (f.nq_cand + 31) >> 5;
     const size_t tr_bytes = (size_t)S1_WAVES * S1_GROUP * (T * 32 + 1) * sizeof(float);
     const size_t row_bytes = (size_t)S1_ROWCACHE * f.ncol * sizeof(float) + S1_ROWCACHE * sizeof(int);
@@ -314,10 +315,10 @@ int flmr_launch_filter_stage1(const flmr_filter_args& f, const uint32_t* idx_bit
     dim3 grid(f.nqueries, G), block(S1_WAVES * 64);
     if (lds_idx)
         hipLaunchKernelGGL(filter_stage1_kernel<true>, grid, block, tr_bytes + row_bytes + idx_bytes, st, f, idx_bits,
-                           idx_words, cand, cand_stride, cand_count, keys, hit_bits, hit_words, hit_valid, hit_flags);
+                           idx_words, cand, cand_stride, cand_count, keys, hit_bits, hit_words, hit_valid, hit_flags, skip);
     else
         hipLaunchKernelGGL(filter_stage1_kernel<false>, grid, block, tr_bytes + row_bytes, st, f, idx_bits, idx_words, cand,
-                           cand_stride, cand_count, keys, hit_bits, hit_words, hit_valid, hit_flags);
+                           cand_stride, cand_count, keys, hit_bits, hit_words, hit_valid, hit_flags, skip);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }

@@ -21,7 +21,7 @@ struct flmr_searcher {
     uint32_t* bitmap; int32_t* cand; int32_t* cand_count; uint64_t* keys1; int32_t* s1_pids; int32_t* s1_count;
     uint64_t* keys2; int32_t* s2_pids; int32_t* s2_count; uint64_t* keys3; float* doc_scores; int32_t* overflow;
     _Float16* q_hi; _Float16* q_lo;
-    uint32_t* hit_bits; int32_t* hit_valid;
+    uint32_t* hit_bits; int32_t* hit_valid; int32_t* key_count;
     _Float16* q3_hi; _Float16* q3_lo;
     int32_t* qual; int32_t* nqual; int32_t* chunk_cnt; uint8_t* cand_hit; int32_t qmax;
     // last call (for taps)
@@ -102,6 +102,7 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     WS(q_lo, B * (size_t)s->ncol_max * FLMR_DIM);
     WS(hit_bits, B * (size_t)s->bitmap_words);
     WS(hit_valid, B);
+    WS(key_count, B);
     s->qmax = 1024;
     WS(qual, B * (size_t)s->qmax);
     WS(nqual, B);
@@ -120,7 +121,7 @@ extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
     if (!s) return FLMR_OK;
     void* ptrs[] = {s->cs, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
                     s->keys1, s->s1_pids, s->s1_count, s->keys2, s->s2_pids, s->s2_count, s->keys3, s->doc_scores,
-                    s->overflow, s->q_hi, s->q_lo, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->cand_hit};
+                    s->overflow, s->q_hi, s->q_lo, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->cand_hit, s->key_count};
     for (void* p : ptrs) (void)hipFree(p);
     for (int i = 0; i <= FLMR_NUM_STAGES; i++)
         if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
@@ -240,6 +241,7 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
     const char* cimpl = getenv("FLMR_CAND_IMPL");
     const bool chunked = !(cimpl && strcmp(cimpl, "atomic") == 0);
     const bool use_hits = getenv("FLMR_S1_NO_HITMAP") == nullptr;
+    bool scatter = false;
     if (chunked) {
         flmr_cand_args ca;
         ca.nqueries = c.nqueries; ca.idx_words = s->idx_words; ca.max_cells = s->max_cells; ca.qmax = s->qmax;
@@ -249,6 +251,13 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
         ca.qual = s->qual; ca.nqual = s->nqual; ca.hit_valid = s->hit_valid;
         ca.cand_bits = s->bitmap; ca.hit_bits = s->hit_bits; ca.chunk_cnt = s->chunk_cnt;
         ca.cand = s->cand; ca.cand_hit = s->cand_hit; ca.cand_count = s->cand_count; ca.overflow = s->overflow;
+        // stage 1 by scatter over the surviving centroids' IVF lists (single column tile, sparse or full table alike);
+        // FLMR_S1_IMPL=scan keeps the code-scanning kernel for every query (A/B runs, cross-check tests)
+        const char* s1impl = getenv("FLMR_S1_IMPL");
+        scatter = use_hits && c.ncol == 32 && !(s1impl && strcmp(s1impl, "scan") == 0);
+        ca.scatter = scatter ? 1 : 0;
+        ca.cs = s->cs; ca.cs_query_stride = c.f.cs_query_stride; ca.nq_cand = c.nqc; ca.q_lens = c.q_lens;
+        ca.keys = s->keys1; ca.key_count = s->key_count;
         RUN(flmr_launch_candidates_chunked(ca, st));
         RUN(mark(c));
         RUN(mark(c));  // (the hit set is produced by the same pass: the s1_hitmap stage is empty in this mode)
@@ -265,7 +274,7 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
     }
     RUN(flmr_launch_filter_stage1(c.f, s->idx_bits, s->idx_words, s->cand, s->cand_cap, s->cand_count, s->keys1,
                                   (use_hits && !chunked) ? s->hit_bits : nullptr, s->bitmap_words, use_hits ? s->hit_valid : nullptr,
-                                  (use_hits && chunked) ? s->cand_hit : nullptr, st));
+                                  (use_hits && chunked) ? s->cand_hit : nullptr, st, scatter ? s->hit_valid : nullptr));
     RUN(mark(c));
     RUN(flmr_launch_select_topn(s->keys1, s->cand_cap, s->cand_count, c.nqueries, c.p.ndocs, s->s1_pids, s->maxp.ndocs,
                                 s->s1_count, st, out_keys, (uint64_t)ix->pid_base));

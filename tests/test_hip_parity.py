@@ -546,3 +546,38 @@ def test_exhaustive_search_matches_torch_expression(hip):
         tie_aware_equal(ref_idx[q, :10].numpy(), ref_sorted[q, :10].float().numpy(), idx[q].cpu().numpy(), sc[q].cpu().numpy(), tol=SCORE_TOL)
     rd = scoring.exhaustive_ranking_dict(idx, sc)
     assert rd[0][0] == (int(idx[0, 0]), 0, int(sc[0, 0])) and len(rd) == nq and len(rd[0]) == 10
+
+
+@pytest.mark.parametrize("nbits,doclen,K,npass,policy", [
+    (2, (1, 200), 2048, 6000, (2, 0.45, 256)),
+    (2, 64, 512, 70_000, (2, 0.3, 1024)),      # small K on a 3-chunk corpus: > 480 hit candidates per chunk -> several slot windows
+    (4, (10, 90), 1024, 40_000, (4, 0.4, 4096)),
+])
+def test_stage1_scatter_equals_code_scan(hip, nbits, doclen, K, npass, policy):
+    """Stage 1 computed from the surviving centroids' IVF lists (cand_mark_score_kernel, default) must give exactly the keys
+    of the code-scanning kernel (filter_stage1_kernel, FLMR_S1_IMPL=scan): same stage-1 survivor sets, same stage-2
+    finalists, bitwise the same final result.  The scan kernel is itself pinned to the reference by the golden-vector tests."""
+    nat, torch = hip["native"], hip["torch"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    corpus = synth.make_corpus(npass, doclen, K, nbits, seed=31, device="cuda")
+    Q, _ = synth.make_queries(corpus, 9, 32, seed=4)
+    q_lens = torch.tensor([32, 32, 20, 32, 1, 32, 32, 7, 32], dtype=torch.int32)
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=16)
+    ncells, thr, ndocs = policy
+    outs = {}
+    for tag, env in (("scatter", {}), ("scan", {"FLMR_S1_IMPL": "scan"})):
+        os.environ.update(env)
+        try:
+            p, s, c = scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=q_lens)
+            torch.cuda.synchronize()
+            taps = [(np.sort(scorer.tap(nat.TAP_STAGE1, q)), scorer.tap(nat.TAP_STAGE2, q)) for q in range(Q.size(0))]
+            outs[tag] = (p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), taps)
+        finally:
+            for k_ in env:
+                os.environ.pop(k_, None)
+    a, b = outs["scatter"], outs["scan"]
+    for q in range(Q.size(0)):
+        assert np.array_equal(a[3][q][0], b[3][q][0]), ("stage-1 survivors", q)
+        assert np.array_equal(a[3][q][1], b[3][q][1]), ("stage-2 finalists", q)
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
