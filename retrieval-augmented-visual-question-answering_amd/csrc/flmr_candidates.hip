@@ -197,33 +197,42 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     const int pid0 = ch * CAND_CHUNK_PIDS;
     const s1s_slices mc = s1s_load_slices(a.cells + (size_t)b * a.max_cells, nl, wave, lane, a.ivf_offsets, a.chunk_tab, a.nchunks, ch);
     const s1s_slices mq = s1s_load_slices(a.qual + (size_t)b * a.qmax, nq, wave, lane, a.ivf_offsets, a.chunk_tab, a.nchunks, ch);
+    const int init = s1s_enc(-9999.0f);
+    if (scatter)  // first window's accumulators, written while the metadata loads are in flight
+        for (int e = tid; e < S1S_SLOTS * S1S_STRIDE; e += 64 * S1S_WAVES) acc[e] = init;
     __syncthreads();
-    // lists are taken four at a time: the first 64 entries of each are requested before any is consumed
-    auto mark = [&](const s1s_slices& m, uint32_t* dst) {
-        for (int j0 = 0; j0 < m.n; j0 += 4) {
-            int pidv[4];
-            int64_t begv[4];
-            uint32_t sv[4], ev[4];
+    // lists are taken four at a time: the first 64 entries of each are requested before any is consumed, and the first
+    // group of the surviving lists is requested together with the first group of the probed cells' lists
+    struct grp { int pidv[4]; int64_t begv[4]; uint32_t sv[4], ev[4]; };
+    auto issue = [&](const s1s_slices& m, int j0, grp& g) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = (j0 + u < m.n) ? j0 + u : j0;
-                begv[u] = s1s_bcast64(m.beg, j);
-                sv[u] = (uint32_t)__builtin_amdgcn_readlane((int)m.s, j);
-                ev[u] = (j0 + u < m.n) ? (uint32_t)__builtin_amdgcn_readlane((int)m.e, j) : sv[u];
-                pidv[u] = (sv[u] + lane < ev[u]) ? a.ivf_pids[begv[u] + sv[u] + lane] - pid0 : -1;
-            }
+        for (int u = 0; u < 4; u++) {
+            const int j = (j0 + u < m.n) ? j0 + u : (j0 < m.n ? j0 : 0);
+            g.begv[u] = s1s_bcast64(m.beg, j);
+            g.sv[u] = (uint32_t)__builtin_amdgcn_readlane((int)m.s, j);
+            g.ev[u] = (j0 + u < m.n) ? (uint32_t)__builtin_amdgcn_readlane((int)m.e, j) : g.sv[u];
+            g.pidv[u] = (g.sv[u] + lane < g.ev[u]) ? a.ivf_pids[g.begv[u] + g.sv[u] + lane] - pid0 : -1;
+        }
+    };
+    auto consume = [&](const grp& g, uint32_t* dst) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (pidv[u] >= 0) atomicOr(&dst[pidv[u] >> 5], 1u << (pidv[u] & 31));
-                for (uint32_t x = sv[u] + 64 + lane; x < ev[u]; x += 64) {
-                    const int pid = a.ivf_pids[begv[u] + x] - pid0;
-                    atomicOr(&dst[pid >> 5], 1u << (pid & 31));
-                }
+        for (int u = 0; u < 4; u++) {
+            if (g.pidv[u] >= 0) atomicOr(&dst[g.pidv[u] >> 5], 1u << (g.pidv[u] & 31));
+            for (uint32_t x = g.sv[u] + 64 + lane; x < g.ev[u]; x += 64) {
+                const int pid = a.ivf_pids[g.begv[u] + x] - pid0;
+                atomicOr(&dst[pid >> 5], 1u << (pid & 31));
             }
         }
     };
-    mark(mc, cb);
-    mark(mq, hb);
+    {
+        grp gc, gq;
+        issue(mc, 0, gc);
+        issue(mq, 0, gq);
+        consume(gc, cb);
+        for (int j0 = 4; j0 < mc.n; j0 += 4) { issue(mc, j0, gc); consume(gc, cb); }
+        consume(gq, hb);
+        for (int j0 = 4; j0 < mq.n; j0 += 4) { issue(mq, j0, gq); consume(gq, hb); }
+    }
     __syncthreads();
     // bitmaps out (the ascending candidate list is still produced by cand_emit_kernel) + the two popcount prefixes
     const int64_t gw = (int64_t)ch * CAND_CHUNK_WORDS + tid;
@@ -256,13 +265,16 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     const float* cs_b = a.cs + (size_t)b * a.cs_query_stride;
     uint64_t* keys_b = a.keys + (size_t)b * a.cand_cap;
     const int64_t kbase = s_base;
-    const int init = s1s_enc(-9999.0f);
     for (int win0 = 0; win0 == 0 || win0 < nh; win0 += S1S_SLOTS) {
         const int nslot = (nh - win0) < S1S_SLOTS ? (nh - win0) : S1S_SLOTS;
-        for (int e = tid; e < nslot * S1S_STRIDE; e += 64 * S1S_WAVES) acc[e] = init;
-        __syncthreads();
+        if (win0 > 0) {
+            for (int e = tid; e < nslot * S1S_STRIDE; e += 64 * S1S_WAVES) acc[e] = init;
+            __syncthreads();
+        }
         // the surviving lists again: (centroid, passage) pairs -> 32-wide max into the passage's slot; four lists at a
         // time (their score rows and first 64 entries are requested up front)
+        // every lane owns one (centroid, passage) pair and walks the 32 columns itself: 32 ds_max per 64 pairs, no
+        // cross-lane dependency chain; the row value of column q is broadcast from lane q of rowk
         auto scatter_pids = [&](int pid, int rowk) {
             int slot = -1;
             if (pid >= 0) {
@@ -270,17 +282,15 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
                 const uint32_t cwd = cb[w];
                 if ((cwd >> bit) & 1u) slot = (int)hbase[w] + __popc(cwd & hb[w] & ((1u << bit) - 1u)) - win0;
             }
-            unsigned long long m = __ballot(slot >= 0 && slot < nslot);
-            while (m) {  // wave-uniform: two (centroid, passage) pairs per iteration, one per half-wave
-                const int ja = __builtin_ctzll(m);
-                m &= m - 1;
-                const int jb = m ? __builtin_ctzll(m) : -1;
-                if (m) m &= m - 1;
-                const int jj = h ? jb : ja;
-                const int sl = __shfl(slot, jj < 0 ? 0 : jj, 64);
-                if (jj >= 0) atomicMax(&acc[sl * S1S_STRIDE + k], rowk);
+            const bool on = slot >= 0 && slot < nslot;
+            int* dst = acc + (on ? slot : 0) * S1S_STRIDE;
+#pragma unroll
+            for (int q = 0; q < 32; q++) {
+                const int v = __builtin_amdgcn_readlane(rowk, q);
+                if (on) atomicMax(dst + q, v);
             }
         };
+#ifndef S1S_DIAG_NOSCATTER
         for (int j0 = 0; j0 < mq.n; j0 += 4) {
             int pidv[4], rowv[4];
             int64_t begv[4];
@@ -302,9 +312,11 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
                     scatter_pids(x0 + lane < ev[u] ? a.ivf_pids[begv[u] + x0 + lane] - pid0 : -1, rowv[u]);
             }
         }
+#endif
         __syncthreads();
         // per-slot score = ascending-k sum of the column maxima (filter_pids.cpp:59-63), one thread per slot, kept in the
         // row's padding word
+#ifndef S1S_DIAG_NOSUM
         for (int sl = tid; sl < nslot; sl += 64 * S1S_WAVES) {
             float v[32];
 #pragma unroll
@@ -314,6 +326,7 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
             for (int q = 0; q < 32; q++) sc += q < nqc ? v[q] : 0.0f;
             acc[sl * S1S_STRIDE + 32] = __float_as_int(sc);
         }
+#endif
         __syncthreads();
         // one thread per bitmap word: keys of its candidates (hits of this window; the misses with window 0)
         {
@@ -340,10 +353,15 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
 // ---- kernel B: bitmap chunk -> ascending pids at the chunk's global rank, one hit flag per candidate --------------------------
 __global__ __launch_bounds__(1024) void cand_emit_kernel(const uint32_t* cand_bits, const uint32_t* hit_bits, int64_t words,
                                                          const int32_t* chunk_cnt, int nchunks, int32_t* cand, int64_t cand_cap,
-                                                         uint8_t* cand_hit, int32_t* cand_count, int32_t* overflow) {
+                                                         uint8_t* cand_hit, int32_t* cand_count, int32_t* overflow,
+                                                         const int32_t* skip, const int32_t* key_count) {
     __shared__ int scan_lds[17];
     __shared__ int base_lds;
     const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+    if (skip && skip[b]) {  // stage 1 of this query was done by scatter: nobody reads the ascending list (taps rebuild it)
+        if (ch == 0 && tid == 0) cand_count[b] = (int32_t)(key_count[b] < cand_cap ? key_count[b] : cand_cap);
+        return;
+    }
     if (tid == 0) base_lds = 0;
     __syncthreads();
     int part = 0;
@@ -385,7 +403,16 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
                            a.hit_bits, a.words, a.chunk_cnt);
     }
     hipLaunchKernelGGL(cand_emit_kernel, dim3(a.nqueries, a.nchunks), dim3(1024), 0, st, a.cand_bits, a.hit_bits, a.words,
-                       a.chunk_cnt, a.nchunks, a.cand, a.cand_cap, a.cand_hit, a.cand_count, a.overflow);
+                       a.chunk_cnt, a.nchunks, a.cand, a.cand_cap, a.cand_hit, a.cand_count, a.overflow,
+                       a.scatter ? a.hit_valid : nullptr, a.key_count);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
+// the ascending candidate lists of every query of the last batch (FLMR_TAP_CANDIDATES after a scatter-mode search)
+int flmr_launch_cand_emit_all(const flmr_cand_args& a, hipStream_t st) {
+    hipLaunchKernelGGL(cand_emit_kernel, dim3(a.nqueries, a.nchunks), dim3(1024), 0, st, a.cand_bits, a.hit_bits, a.words,
+                       a.chunk_cnt, a.nchunks, a.cand, a.cand_cap, a.cand_hit, a.cand_count, a.overflow, nullptr, nullptr);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }

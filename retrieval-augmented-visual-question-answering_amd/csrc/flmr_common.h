@@ -154,6 +154,7 @@ struct flmr_cand_args {
     uint64_t* keys; int32_t* key_count;   // [nqueries, cand_cap] unordered stage-1 keys, [nqueries] running count
 };
 int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st);
+int flmr_launch_cand_emit_all(const flmr_cand_args& a, hipStream_t st);
 int flmr_build_chunk_table(const int32_t* ivf_pids, const int64_t* ivf_offsets, int K, int64_t num_passages,
                            uint32_t** out_tab, int32_t* out_nchunks);
 // passage bitmap of the union of the surviving centroids' IVF lists (+ per-query validity flag)

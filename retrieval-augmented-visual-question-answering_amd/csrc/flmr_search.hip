@@ -26,6 +26,8 @@ struct flmr_searcher {
     int32_t* qual; int32_t* nqual; int32_t* chunk_cnt; uint8_t* cand_hit; int32_t qmax;
     // last call (for taps)
     int32_t last_nqueries, last_ncol, last_ndocs, last_full_table;
+    flmr_cand_args last_ca{};   // candidate-stage arguments of the last batch (lazy FLMR_TAP_CANDIDATES in scatter mode)
+    bool last_scatter = false;
     hipStream_t last_stream;
     bool profiling;
     bool full_table;  // keep the whole centroid-score table (needed by the CENTROID_SCORES tap / retrieve())
@@ -242,6 +244,7 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
     const bool chunked = !(cimpl && strcmp(cimpl, "atomic") == 0);
     const bool use_hits = getenv("FLMR_S1_NO_HITMAP") == nullptr;
     bool scatter = false;
+    s->last_scatter = false;
     if (chunked) {
         flmr_cand_args ca;
         ca.nqueries = c.nqueries; ca.idx_words = s->idx_words; ca.max_cells = s->max_cells; ca.qmax = s->qmax;
@@ -259,6 +262,7 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
         ca.cs = s->cs; ca.cs_query_stride = c.f.cs_query_stride; ca.nq_cand = c.nqc; ca.q_lens = c.q_lens;
         ca.keys = s->keys1; ca.key_count = s->key_count;
         RUN(flmr_launch_candidates_chunked(ca, st));
+        s->last_ca = ca; s->last_scatter = scatter;
         RUN(mark(c));
         RUN(mark(c));  // (the hit set is produced by the same pass: the s1_hitmap stage is empty in this mode)
     } else {
@@ -457,6 +461,12 @@ extern "C" int flmr_searcher_tap(flmr_searcher_t* s, int32_t what, int32_t q, vo
             FLMR_HIP(hipMemcpy(&c, s->ncell + q, 4, hipMemcpyDeviceToHost));
             n = c; src = s->cells + (size_t)q * s->max_cells; break;
         case FLMR_TAP_CANDIDATES:
+            if (s->last_scatter) {  // the hot path skipped the ascending lists: build them now from the bitmaps
+                int rc = flmr_launch_cand_emit_all(s->last_ca, s->last_stream);
+                if (rc) return rc;
+                FLMR_HIP(hipStreamSynchronize(s->last_stream));
+                s->last_scatter = false;
+            }
             FLMR_HIP(hipMemcpy(&c, s->cand_count + q, 4, hipMemcpyDeviceToHost));
             n = c; src = s->cand + (size_t)q * s->cand_cap; break;
         case FLMR_TAP_STAGE1:
