@@ -180,7 +180,12 @@ __global__ __launch_bounds__(256) void s0_split_q(const float* Q, const int32_t*
 
 // ARGMAX = true (index build, flmr_nearest_centroids): additionally tracks the row index of every block maximum in
 // part_idx (first row on ties); the search path instantiates ARGMAX = false and pays nothing for it.
-template <bool ARGMAX>
+// SPARSE = true (single column tile, only the rows of surviving centroids are stored): the ">= thr" test is a v_cmp per
+// accumulator register whose 64-bit lane mask splits into the two rows the register holds (lanes 0-31 / 32-63), so the idx
+// tile-level "anything survives?" test is scalar; only a tile that does hold a surviving row (rare) goes through the LDS
+// staging + row stores of the dense epilogue.  That halves the kernel's LDS traffic, which at 16 KB of B fragments +
+// 8 KB of staging per (wave, query) was as long as its MFMA time.
+template <bool ARGMAX, bool SPARSE>
 __global__ __launch_bounds__(64 * S0_WAVES, 2) void s0_centroid_scores_f16(flmr_s0_args a) {
     // dynamic LDS: [4 waves][32 rows][36 f32] staging tiles for the row-contiguous table stores, then the fp16 B
     // operands (q_hi, q_lo) of S0_CH (query, column-tile) items, loaded once per block and shared by its 4 waves.
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(64 * S0_WAVES, 2) void s0_centroid_scores_f16(flmr_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
-    float* stage = reinterpret_cast<float*>(smem) + wave * 32 * S0_LDS_STRIDE;
+    float* stage = reinterpret_cast<float*>(smem) + wave * 32 * S0_LDS_STRIDE;  // (!SPARSE only)
     _Float16* bq = reinterpret_cast<_Float16*>(smem + S0_WAVES * 32 * S0_LDS_STRIDE * sizeof(float));
     const int wtile = blockIdx.x * S0_WAVES + wave;  // (32*S0_RT)-row tile index == partial block index
     const int row0 = wtile * 32 * S0_RT;
@@ -267,6 +272,26 @@ __global__ __launch_bounds__(64 * S0_WAVES, 2) void s0_centroid_scores_f16(flmr_
             const f32x16& al = acc_l[rt & 1];
             // epilogue, 3 VALU ops per score: combine hi/lo, column max, stage row-major in LDS
             const int rbase = row0 + rt * 32;
+            bool staged = true;
+            if constexpr (SPARSE) {
+                unsigned long long any = 0ull;
+                // lanes whose column is a real query token (both halves): rows only count those (index_storage.py:116)
+                const unsigned long long colmask = full_cols ? ~0ull : (((1ull << nqc) - 1ull) * 0x100000001ull);
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float v = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+                    if constexpr (ARGMAX) {
+                        if (v > cmax) { cmax = v; carg = rbase + (r & 3) + 8 * (r >> 2) + 4 * h; }
+                    } else {
+                        cmax = fmaxf(cmax, v);
+                    }
+                    any |= __ballot(v >= a.thr);
+                }
+                // wave-uniform and rare: some row of this tile survives -> the staged epilogue below stores it and sets
+                // its idx bit (its column max / argmax updates are idempotent)
+                staged = (any & colmask) != 0ull;
+            }
+            if (staged) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -306,6 +331,7 @@ __global__ __launch_bounds__(64 * S0_WAVES, 2) void s0_centroid_scores_f16(flmr_
                     *reinterpret_cast<float4*>(cs_b + (size_t)(rbase + R) * a.ncol + ct * 32 + c4) = v4;
             }
             __builtin_amdgcn_wave_barrier();
+            }  // staged
         }
         // block maximum of each column (this wave's 32*S0_RT rows): the cell selection re-reads only the winners
         if constexpr (ARGMAX) {
@@ -437,9 +463,17 @@ static int launch_s0_t(flmr_s0_args& a, hipStream_t st, int impl) {
         hipLaunchKernelGGL(s0_split_q, dim3((a.ncol * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens,
                            a.nq, a.nq_cand, a.ncol, a.q_hi, a.q_lo);
         const size_t lds = (size_t)S0_WAVES * 32 * S0_LDS_STRIDE * sizeof(float) + (size_t)S0_CH * 2 * 32 * S0_BROW * sizeof(_Float16);
-        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_f16<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(s0_centroid_scores_f16<false>, dim3((a.nblk + S0_WAVES - 1) / S0_WAVES, qsplit), dim3(64 * S0_WAVES), lds, st, a);
+        const bool sparse = !a.full_table && a.ncol == 32 && getenv("FLMR_S0_STAGED") == nullptr;
+        const dim3 grid((a.nblk + S0_WAVES - 1) / S0_WAVES, qsplit), block(64 * S0_WAVES);
+        if (sparse) {
+            FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_f16<false, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((s0_centroid_scores_f16<false, true>), grid, block, lds, st, a);
+        } else {
+            FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_f16<false, false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((s0_centroid_scores_f16<false, false>), grid, block, lds, st, a);
+        }
     } else if (impl == S0_F32) {
         hipLaunchKernelGGL(s0_centroid_scores_mfma<NC>, dim3(a.nblk, qsplit), dim3(256), 0, st, a);
     } else {
@@ -491,9 +525,9 @@ int flmr_launch_centroid_argmax(flmr_s0_args& a, int32_t* out_codes, hipStream_t
     hipLaunchKernelGGL(s0_split_q, dim3((a.ncol * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens, a.nq,
                        a.nq_cand, a.ncol, a.q_hi, a.q_lo);
     const size_t lds = (size_t)S0_WAVES * 32 * S0_LDS_STRIDE * sizeof(float) + (size_t)S0_CH * 2 * 32 * S0_BROW * sizeof(_Float16);
-    FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_f16<true>),
+    FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_f16<true, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(s0_centroid_scores_f16<true>, dim3((a.nblk + S0_WAVES - 1) / S0_WAVES, qsplit), dim3(64 * S0_WAVES), lds, st, a);
+    hipLaunchKernelGGL((s0_centroid_scores_f16<true, true>), dim3((a.nblk + S0_WAVES - 1) / S0_WAVES, qsplit), dim3(64 * S0_WAVES), lds, st, a);
     hipLaunchKernelGGL(s0_argmax_reduce, dim3(a.nqueries), dim3(256), 0, st, a, out_codes);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
