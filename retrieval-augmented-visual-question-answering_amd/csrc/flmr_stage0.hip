@@ -561,25 +561,35 @@ int flmr_launch_centroid_scores(flmr_s0_args& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // S0b: merge block partials -> per-token top-ncells -> unique cells.  grid = nqueries, block = 1024.
 // ------------------------------------------------------------------------------------------------
+#define SC_WAVES 8  // 512 threads: the MFMA recompute needs ~190 VGPRs (B 64 + A 64 + accumulators 32 + lists)
 template <int NC>
-__global__ __launch_bounds__(1024) void s0_select_cells(flmr_s0_args a) {
+__global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a) {
     __shared__ int raw[1024];
     __shared__ int scan_lds[17];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qlen = a.q_lens ? a.q_lens[b] : a.nq;
     const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;
-    raw[tid] = 0x7fffffff;
+    raw[tid] = 0x7fffffff; raw[tid + 64 * SC_WAVES] = 0x7fffffff;
     // block-maxima partials with a single column tile: every wave scans a slice of the rows for ALL 32 columns with
     // 128-byte coalesced reads (lane = (row parity, column)) and leaves its per-column top-NC blocks in LDS; the per-column
     // loop below then merges 16 short lists instead of walking 2048 rows with a 128-byte stride per column.
-    __shared__ float pre_v[16][32][NC];
-    __shared__ int pre_i[16][32][NC];
+    __shared__ float pre_v[SC_WAVES][32][NC];
+    __shared__ int pre_i[SC_WAVES][32][NC];
     const bool pre = a.part_rows != 0 && a.ncol == 32;
     if (pre) {
         flmr_toplist<NC> bt;
         bt.init();
-        for (int e = wave * 2 + (lane >> 5); e < a.nblk; e += 32)
-            bt.insert(a.part_val[((size_t)b * a.nblk + e) * 32 + (lane & 31)], e);
+        // 8 loads in flight per lane: one workgroup per query means one per CU, so a load -> insert chain per row would
+        // expose the full memory latency 64 times per wave
+        constexpr int RS = 2 * SC_WAVES;  // rows per sweep of the workgroup
+        for (int e0 = wave * 2 + (lane >> 5); e0 < a.nblk; e0 += RS * 8) {
+            float pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                pv[u] = (e0 + RS * u < a.nblk) ? a.part_val[((size_t)b * a.nblk + e0 + RS * u) * 32 + (lane & 31)] : FLMR_NEG_INF;
+#pragma unroll
+            for (int u = 0; u < 8; u++) bt.insert(pv[u], (e0 + RS * u < a.nblk) ? e0 + RS * u : 0x7fffffff);
+        }
         bt.merge_xor(32);
         if (lane < 32) {
 #pragma unroll
@@ -587,7 +597,7 @@ __global__ __launch_bounds__(1024) void s0_select_cells(flmr_s0_args a) {
         }
     }
     __syncthreads();
-    for (int col = wave; col < nqc; col += 16) {
+    for (int col = wave; col < nqc; col += SC_WAVES) {
         flmr_toplist<NC> tl;
         tl.init();
         if (a.part_rows == 0) {
@@ -606,7 +616,7 @@ __global__ __launch_bounds__(1024) void s0_select_cells(flmr_s0_args a) {
             flmr_toplist<NC> bt;
             bt.init();
             if (pre) {
-                for (int e = lane; e < 16 * NC; e += 64) bt.insert(pre_v[e / NC][col][e % NC], pre_i[e / NC][col][e % NC]);
+                for (int e = lane; e < SC_WAVES * NC; e += 64) bt.insert(pre_v[e / NC][col][e % NC], pre_i[e / NC][col][e % NC]);
             } else {
                 for (int e = lane; e < a.nblk; e += 64) bt.insert(a.part_val[((size_t)b * a.nblk + e) * a.ncol + col], e);
             }
@@ -633,19 +643,34 @@ __global__ __launch_bounds__(1024) void s0_select_cells(flmr_s0_args a) {
 #pragma unroll
                         for (int s = 0; s < 8; s++) { bh[s] = ph[s]; bl[s] = pl[s]; }
                     }
-                    for (int rt = 0; rt * 32 < a.part_rows; rt++) {
-                        const float4* p = reinterpret_cast<const float4*>(a.centroids + (size_t)(r0 + rt * 32 + i) * FLMR_DIM + 64 * h);
+                    // the A fragments of both row tiles are requested before the first MFMA (fp16 copy of the centroids when
+                    // the index holds one: half the bytes, no conversion)
+                    f16x8 av[S0_RT][8];
+#pragma unroll
+                    for (int rt = 0; rt < S0_RT; rt++) {
+                        if (a.centroids_f16) {
+                            const f16x8* p16 = reinterpret_cast<const f16x8*>(a.centroids_f16 + (size_t)(r0 + rt * 32 + i) * FLMR_DIM + 64 * h);
+#pragma unroll
+                            for (int s = 0; s < 8; s++) av[rt][s] = p16[s];
+                        } else {
+                            const float4* p = reinterpret_cast<const float4*>(a.centroids + (size_t)(r0 + rt * 32 + i) * FLMR_DIM + 64 * h);
+#pragma unroll
+                            for (int s = 0; s < 8; s++) {
+                                const float4 x = p[2 * s], y = p[2 * s + 1];
+                                av[rt][s][0] = (_Float16)x.x; av[rt][s][1] = (_Float16)x.y; av[rt][s][2] = (_Float16)x.z; av[rt][s][3] = (_Float16)x.w;
+                                av[rt][s][4] = (_Float16)y.x; av[rt][s][5] = (_Float16)y.y; av[rt][s][6] = (_Float16)y.z; av[rt][s][7] = (_Float16)y.w;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < S0_RT; rt++) {
                         f32x16 ah, al;
 #pragma unroll
                         for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
 #pragma unroll
                         for (int s = 0; s < 8; s++) {
-                            const float4 x = p[2 * s], y = p[2 * s + 1];
-                            f16x8 av;
-                            av[0] = (_Float16)x.x; av[1] = (_Float16)x.y; av[2] = (_Float16)x.z; av[3] = (_Float16)x.w;
-                            av[4] = (_Float16)y.x; av[5] = (_Float16)y.y; av[6] = (_Float16)y.z; av[7] = (_Float16)y.w;
-                            ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bh[s], ah, 0, 0, 0);
-                            al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bl[s], al, 0, 0, 0);
+                            ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[rt][s], bh[s], ah, 0, 0, 0);
+                            al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[rt][s], bl[s], al, 0, 0, 0);
                         }
                         const bool mine = i == (col & 31);
 #pragma unroll
@@ -667,33 +692,46 @@ __global__ __launch_bounds__(1024) void s0_select_cells(flmr_s0_args a) {
         }
     }
     __syncthreads();
-    // ascending sort of <= 1024 ids (INT_MAX padded) + unique
+    // ascending sort of <= 1024 ids (INT_MAX padded) + unique; two elements per thread
+    constexpr int NT = 64 * SC_WAVES;
     for (int k = 2; k <= 1024; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            int p = tid ^ j;
-            if (p > tid) {
-                int x = raw[tid], y = raw[p];
-                bool asc = ((tid & k) == 0);
-                if (asc ? (x > y) : (x < y)) { raw[tid] = y; raw[p] = x; }
+#pragma unroll
+            for (int u = 0; u < 1024 / NT; u++) {
+                const int t = tid + u * NT;
+                const int p = t ^ j;
+                if (p > t) {
+                    const int x = raw[t], y = raw[p];
+                    const bool asc = ((t & k) == 0);
+                    if (asc ? (x > y) : (x < y)) { raw[t] = y; raw[p] = x; }
+                }
             }
             __syncthreads();
         }
     }
-    const int v = raw[tid];
-    const int flag = (v != 0x7fffffff) && (tid == 0 || raw[tid - 1] != v);
+    int vv[1024 / NT], flag[1024 / NT], cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 1024 / NT; u++) {  // thread t owns the consecutive elements t*2, t*2+1 so that ranks stay ordered
+        const int t = tid * (1024 / NT) + u;
+        vv[u] = raw[t];
+        flag[u] = (vv[u] != 0x7fffffff) && (t == 0 || raw[t - 1] != vv[u]);
+        cnt += flag[u];
+    }
     int total;
-    const int pos = flmr_block_exclusive_scan(flag, scan_lds, &total);
-    if (flag) a.cells[(size_t)b * a.max_cells + pos] = v;
+    int pos = flmr_block_exclusive_scan(cnt, scan_lds, &total);
+#pragma unroll
+    for (int u = 0; u < 1024 / NT; u++)
+        if (flag[u]) a.cells[(size_t)b * a.max_cells + pos++] = vv[u];
     if (tid == 0) a.ncell[b] = total;
 }
 
 int flmr_launch_select_cells(const flmr_s0_args& a, hipStream_t st) {
     if ((int64_t)a.nq_cand * a.ncells > 1024) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nq_cand*ncells > 1024");
     switch (nc_bucket(a.ncells)) {
-        case 1: hipLaunchKernelGGL(s0_select_cells<1>, dim3(a.nqueries), dim3(1024), 0, st, a); break;
-        case 2: hipLaunchKernelGGL(s0_select_cells<2>, dim3(a.nqueries), dim3(1024), 0, st, a); break;
-        case 4: hipLaunchKernelGGL(s0_select_cells<4>, dim3(a.nqueries), dim3(1024), 0, st, a); break;
-        default: hipLaunchKernelGGL(s0_select_cells<8>, dim3(a.nqueries), dim3(1024), 0, st, a); break;
+        case 1: hipLaunchKernelGGL(s0_select_cells<1>, dim3(a.nqueries), dim3(64 * SC_WAVES), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(s0_select_cells<2>, dim3(a.nqueries), dim3(64 * SC_WAVES), 0, st, a); break;
+        case 4: hipLaunchKernelGGL(s0_select_cells<4>, dim3(a.nqueries), dim3(64 * SC_WAVES), 0, st, a); break;
+        default: hipLaunchKernelGGL(s0_select_cells<8>, dim3(a.nqueries), dim3(64 * SC_WAVES), 0, st, a); break;
     }
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
