@@ -157,6 +157,29 @@ __global__ __launch_bounds__(256) void s3_split_q(const float* Q, const int32_t*
     }
 }
 
+// the VPB bucket weights of one residual byte with ONE LDS read (b128 / b64): the table is read with random per-lane
+// addresses, and VPB separate 4-byte reads cost VPB times the bank-conflict cycles
+typedef float s3f4 __attribute__((ext_vector_type(4)));
+typedef float s3f2 __attribute__((ext_vector_type(2)));
+template <int VPB>
+__device__ __forceinline__ void s3_lut(const float* wlut_, uint32_t byte, float* w) {
+    const float* wlut = static_cast<const float*>(__builtin_assume_aligned(wlut_, 16));  // the LDS carve starts with the table
+    if constexpr (VPB == 8) {
+        const s3f4 x = reinterpret_cast<const s3f4*>(wlut)[byte * 2], y = reinterpret_cast<const s3f4*>(wlut)[byte * 2 + 1];
+#pragma unroll
+        for (int l = 0; l < 4; l++) { w[l] = x[l]; w[4 + l] = y[l]; }
+    } else if constexpr (VPB == 4) {
+        const s3f4 x = reinterpret_cast<const s3f4*>(wlut)[byte];
+#pragma unroll
+        for (int l = 0; l < 4; l++) w[l] = x[l];
+    } else if constexpr (VPB == 2) {
+        const s3f2 x = reinterpret_cast<const s3f2*>(wlut)[byte];
+        w[0] = x[0]; w[1] = x[1];
+    } else {
+        w[0] = wlut[byte];
+    }
+}
+
 template <int NBITS>
 struct s3_raw {          // one lane's share of one token: half a centroid row (fp16) + its residual bytes
     hf8 c[8];
@@ -271,10 +294,12 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
                         const uint32_t word = e < 4 ? raw.r[wq].x : raw.r[wq].y;
                         const uint32_t byte = (word >> (8 * (e & 3))) & 255u;
                         const int kb = wq * 8 + e;
+                        float wv[VPB];
+                        s3_lut<VPB>(wlut, byte, wv);
 #pragma unroll
                         for (int l = 0; l < VPB; l++) {
                             const int dd = kb * VPB + l;
-                            const float v = raw.valid ? (wlut[byte * VPB + l] + (float)raw.c[dd >> 3][dd & 7]) : 0.0f;
+                            const float v = raw.valid ? (wv[l] + (float)raw.c[dd >> 3][dd & 7]) : 0.0f;
                             d[dd] = v;
                             ss = fmaf(v, v, ss);
                         }
@@ -429,10 +454,12 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_multiq_kernel(flmr_maxsim_a
                             const uint32_t word = e < 4 ? raw.r[wq].x : raw.r[wq].y;
                             const uint32_t byte = (word >> (8 * (e & 3))) & 255u;
                             const int kb = wq * 8 + e;
+                            float wv[VPB];
+                            s3_lut<VPB>(wlut, byte, wv);
 #pragma unroll
                             for (int l = 0; l < VPB; l++) {
                                 const int dd = kb * VPB + l;
-                                const float v = raw.valid ? (wlut[byte * VPB + l] + (float)raw.c[dd >> 3][dd & 7]) : 0.0f;
+                                const float v = raw.valid ? (wv[l] + (float)raw.c[dd >> 3][dd & 7]) : 0.0f;
                                 d[dd] = v;
                                 ss = fmaf(v, v, ss);
                             }
