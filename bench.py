@@ -186,7 +186,7 @@ def main():
     try:
         import csv
         kname = {"s1_filter": "filter_stage1_kernel", "s0_centroid_scores": "s0_centroid_scores_f16", "s3_maxsim": "maxsim_f16_kernel",
-                 "s2_filter_sort": "filter_stage2_kernel"}.get(dom)
+                 "s2_filter_sort": "filter_stage2", "s0_candidates": "cand_mark_score_kernel"}.get(dom)
         with open(os.path.join(ROOT, "profiles", "pmc_summary_latest.csv")) as f:
             for row in csv.DictReader(f):
                 if kname and kname in row["kernel"] and args.passages == 1_000_000 and world == 1:
