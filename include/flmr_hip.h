@@ -145,6 +145,9 @@ int flmr_search_phase3(flmr_searcher_t* searcher, const float* Q, const int32_t*
 /* keys [nqueries, m] (m <= 8192) -> the n largest in descending order, 0 padded; out_counts (nullable) = #non-empty */
 int flmr_topn_keys(const uint64_t* keys, int32_t nqueries, int32_t m, int32_t n, uint64_t* out_keys, int32_t* out_counts,
                    flmr_stream_t stream);
+/* keys [nqueries, m] (any m) -> the n largest of each row, UNORDERED, 0 padded: for the exchange steps whose consumer
+ * (flmr_search_phase2 / phase3) only filters the survivors by shard */
+int flmr_select_keys(const uint64_t* keys, int32_t nqueries, int32_t m, int32_t n, uint64_t* out_keys, flmr_stream_t stream);
 /* descending keys [nqueries, n] -> out_pids i32 / out_scores f32 [nqueries, k] (-1 / 0 padded), out_counts i32[nqueries] */
 int flmr_unpack_keys(const uint64_t* keys, int32_t nqueries, int32_t n, int32_t k, int32_t* out_pids, float* out_scores,
                      int32_t* out_counts, flmr_stream_t stream);

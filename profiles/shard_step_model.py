@@ -54,12 +54,12 @@ for W in WORLDS:
     sc = IndexScorer(device_index=synth.corpus_device_index(sh, pid_base=0), max_batch=B)
     per = -(-B // W)
 
-    def exchange(keys, n):
+    def exchange(keys, n, ordered=False):
         # the other ranks' rows: the same keys with their pids moved into that rank's pid range (same scores, disjoint pids),
         # so that about 1/W of each global survivor set belongs to this shard -- as in a real run
         shift = (torch.arange(W, device="cuda", dtype=torch.int64) * (P // W)).view(W, 1, 1)
         g = torch.where(keys.unsqueeze(0) != 0, keys.unsqueeze(0) + shift, torch.zeros_like(keys).unsqueeze(0))
-        return ops.topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n)
+        return ops.topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n, ordered=ordered)
 
     def step(split):
         if split and W > 1:
@@ -70,7 +70,7 @@ for W in WORLDS:
             k1 = sc.phase1(Q, k, ncells, thr, ndocs, 32)
         s1 = exchange(k1, ndocs)
         s2 = exchange(sc.phase2(s1), ndocs // 4)
-        fin = exchange(sc.phase3(s2), k)
+        fin = exchange(sc.phase3(s2), k, ordered=True)
         return ops.unpack_keys(fin, k)
 
     rec = {"replicated_stage0_ms": timed(lambda: step(False))}

@@ -174,6 +174,7 @@ int flmr_launch_select_topn(const uint64_t* keys, int64_t key_stride, const int3
                             int32_t n, int32_t* out_pids, int64_t out_stride, int32_t* n_out, hipStream_t st,
                             uint64_t* out_keys = nullptr, uint64_t key_add = 0);
 // exact sharded protocol helpers (keys carry GLOBAL pids between ranks; 0 = empty)
+int flmr_launch_select_keys(const uint64_t* keys, int32_t nqueries, int32_t m, int32_t n, uint64_t* out, hipStream_t st);
 int flmr_launch_sort_keys_topn(const uint64_t* keys, int32_t nqueries, int32_t m, int32_t n, uint64_t* out,
                                int32_t* out_counts, hipStream_t st);
 int flmr_launch_filter_local_keys(const uint64_t* keys, int32_t nqueries, int32_t n_in, int64_t pid_base,

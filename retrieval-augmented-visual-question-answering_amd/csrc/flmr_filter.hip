@@ -597,6 +597,34 @@ int flmr_launch_filter_stage2(const flmr_filter_args& f, const int32_t* pids, in
     return FLMR_OK;
 }
 
+// Digit pick of one radix-select pass, by the first wave: the largest digit d whose suffix count sum_{d' >= d} hist[d']
+// reaches `rem`.  Lane l owns digits 4l..4l+3; a shuffle scan gives the counts above each lane's group.  (A single thread
+// walking 256 LDS bins costs ~10 us per pass -- most of the kernel for short lists.)  Returns (digit, count of that digit,
+// keys still needed inside it) in all lanes of the wave.
+__device__ __forceinline__ void sel_pick_digit(const unsigned int* hist, int rem, int lane, int& dsel, int& csel, int& rem_out) {
+    const int h0 = (int)hist[4 * lane], h1 = (int)hist[4 * lane + 1], h2 = (int)hist[4 * lane + 2], h3 = (int)hist[4 * lane + 3];
+    const int mine = h0 + h1 + h2 + h3;
+    int incl = mine;  // inclusive suffix sum over lanes lane..63
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_down(incl, d, 64);
+        if (lane + d < 64) incl += o;
+    }
+    const int above = incl - mine;                  // keys in digits above this lane's group
+    const bool here = above < rem && incl >= rem;   // exactly one lane (when rem <= total)
+    int d = 0, c = 0, r = 0;
+    if (here) {
+        int need = rem - above;
+        if (h3 >= need) { d = 4 * lane + 3; c = h3; r = need; }
+        else if (h3 + h2 >= need) { d = 4 * lane + 2; c = h2; r = need - h3; }
+        else if (h3 + h2 + h1 >= need) { d = 4 * lane + 1; c = h1; r = need - h3 - h2; }
+        else { d = 4 * lane; c = h0; r = need - h3 - h2 - h1; }
+    }
+    const unsigned long long m = __ballot(here);
+    const int src = m ? __builtin_ctzll(m) : 0;
+    dsel = __shfl(d, src, 64); csel = __shfl(c, src, 64); rem_out = __shfl(r, src, 64);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Radix select: the n largest of count[q] 64-bit keys, unordered.  grid = nqueries, block = 1024.
 // Up to 8 passes of 8 bits from the top; the histogram lives in LDS; the leader digit of each wave is
@@ -609,23 +637,23 @@ template <int KPT>
 __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys, int64_t key_stride,
                                                            const int32_t* counts, int32_t n, int32_t* out_pids,
                                                            int64_t out_stride, int32_t* n_out, uint64_t* out_keys,
-                                                           uint64_t key_add) {
+                                                           uint64_t key_add, int32_t fixed_count) {
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long s_prefix;
     __shared__ int s_remaining;
     __shared__ int s_out;
     __shared__ int s_done;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int P = counts[b];
+    const int P = counts ? counts[b] : fixed_count;
     const uint64_t* kb = keys + (size_t)b * key_stride;
-    int32_t* ob = out_pids + (size_t)b * out_stride;
+    int32_t* ob = out_pids ? out_pids + (size_t)b * out_stride : nullptr;  // optional: the selected pids
     uint64_t* okb = out_keys ? out_keys + (size_t)b * out_stride : nullptr;  // optional: the selected keys (+ pid base), 0 padded
     if (P <= n) {
         for (int i = tid; i < n; i += blockDim.x) {
-            if (i < P) ob[i] = flmr_key_pid(kb[i]);
+            if (ob && i < P) ob[i] = flmr_key_pid(kb[i]);
             if (okb) okb[i] = i < P ? kb[i] + key_add : 0ull;
         }
-        if (tid == 0) n_out[b] = P;
+        if (tid == 0 && n_out) n_out[b] = P;
         return;
     }
     uint64_t kreg[KPT];  // keys [0, KPT*1024) of the list; anything beyond streams from global memory in every pass
@@ -653,17 +681,14 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys,
                 if (act) atomicAdd(&hist[(unsigned int)(key >> shift) & 255u], 1u);
             }
             __syncthreads();
-            if (tid == 0) {
-                int rem = s_remaining;
-                int dsel = 0, csel = 0;
-                for (int dgt = 255; dgt >= 0; --dgt) {
-                    const int c = (int)hist[dgt];
-                    if (c >= rem) { dsel = dgt; csel = c; break; }
-                    rem -= c;
+            if (tid < 64) {
+                int dsel, csel, rem;
+                sel_pick_digit(hist, s_remaining, lane, dsel, csel, rem);
+                if (tid == 0) {
+                    s_remaining = rem;
+                    s_prefix = prefix | ((unsigned long long)dsel << shift);
+                    if (csel == rem) s_done = 1;
                 }
-                s_remaining = rem;
-                s_prefix = prefix | ((unsigned long long)dsel << shift);
-                if (csel == rem) s_done = 1;
             }
             __syncthreads();
             continue;
@@ -690,18 +715,15 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys,
             for (int u = 0; u < 4; u++) count(i0 + u * 1024 + tid < P, kk[u]);
         }
         __syncthreads();
-        if (tid == 0) {
-            int rem = s_remaining;
-            int dsel = 0, csel = 0;
-            for (int dgt = 255; dgt >= 0; --dgt) {
-                const int c = (int)hist[dgt];
-                if (c >= rem) { dsel = dgt; csel = c; break; }
-                rem -= c;
+        if (tid < 64) {
+            int dsel, csel, rem;
+            sel_pick_digit(hist, s_remaining, lane, dsel, csel, rem);
+            if (tid == 0) {
+                s_remaining = rem;  // how many keys with the selected digit (and prefix) are still needed
+                s_prefix = prefix | ((unsigned long long)dsel << shift);
+                if (csel == rem) s_done = 1;  // the whole bucket is taken: every key >= the prefix (low bits 0) is selected
+                else if (csel <= SEL_LCAP && pass < 7) s_compact = 1;
             }
-            s_remaining = rem;  // how many keys with the selected digit (and prefix) are still needed
-            s_prefix = prefix | ((unsigned long long)dsel << shift);
-            if (csel == rem) s_done = 1;  // the whole bucket is taken: every key >= the prefix (low bits 0) is selected
-            else if (csel <= SEL_LCAP && pass < 7) s_compact = 1;
         }
         __syncthreads();
         if (s_compact && !s_done) {  // copy the bucket (keys whose top 8*(pass+1) bits equal the new prefix) to LDS
@@ -726,7 +748,7 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys,
     auto emit = [&](bool valid, uint64_t key) {
         if (valid && key >= thr) {
             const int pos = atomicAdd(&s_out, 1);
-            if (pos < n) { ob[pos] = flmr_key_pid(key); if (okb) okb[pos] = key + key_add; }
+            if (pos < n) { if (ob) ob[pos] = flmr_key_pid(key); if (okb) okb[pos] = key + key_add; }
         }
     };
 #pragma unroll
@@ -739,7 +761,7 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys,
         for (int u = 0; u < 4; u++) emit(i0 + u * 1024 + tid < P, kk[u]);
     }
     __syncthreads();
-    if (tid == 0) n_out[b] = s_out < n ? s_out : n;
+    if (tid == 0 && n_out) n_out[b] = s_out < n ? s_out : n;
 }
 
 int flmr_launch_select_topn(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t nqueries,
@@ -748,10 +770,23 @@ int flmr_launch_select_topn(const uint64_t* keys, int64_t key_stride, const int3
     // keys per thread held in registers: sized from the candidate capacity (the tail of longer lists streams)
     if (key_stride <= 16 * 1024)
         hipLaunchKernelGGL(select_topn_kernel<16>, dim3(nqueries), dim3(1024), 0, st, keys, key_stride, counts, n, out_pids,
-                           out_stride, n_out, out_keys, key_add);
+                           out_stride, n_out, out_keys, key_add, 0);
     else
         hipLaunchKernelGGL(select_topn_kernel<24>, dim3(nqueries), dim3(1024), 0, st, keys, key_stride, counts, n, out_pids,
-                           out_stride, n_out, out_keys, key_add);
+                           out_stride, n_out, out_keys, key_add, 0);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
+// keys [nqueries, m] (0 = empty) -> the n largest of each row, UNORDERED, 0 padded (exchange steps of the sharded protocol
+// whose consumers do not care about order: a radix select instead of a full bitonic sort of up to 8192 keys)
+int flmr_launch_select_keys(const uint64_t* keys, int32_t nqueries, int32_t m, int32_t n, uint64_t* out, hipStream_t st) {
+    if (m <= 16 * 1024)
+        hipLaunchKernelGGL(select_topn_kernel<16>, dim3(nqueries), dim3(1024), 0, st, keys, (int64_t)m, nullptr, n, nullptr,
+                           (int64_t)n, nullptr, out, 0ull, m);
+    else
+        hipLaunchKernelGGL(select_topn_kernel<24>, dim3(nqueries), dim3(1024), 0, st, keys, (int64_t)m, nullptr, n, nullptr,
+                           (int64_t)n, nullptr, out, 0ull, m);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }

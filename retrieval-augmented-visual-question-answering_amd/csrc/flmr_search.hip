@@ -432,6 +432,14 @@ extern "C" int flmr_topn_keys(const uint64_t* keys, int32_t nqueries, int32_t m,
     return flmr_launch_sort_keys_topn(keys, nqueries, m, n, out_keys, out_counts, reinterpret_cast<hipStream_t>(stream));
 }
 
+// keys [nqueries, m] -> the n largest, UNORDERED, 0 padded (any m)
+extern "C" int flmr_select_keys(const uint64_t* keys, int32_t nqueries, int32_t m, int32_t n, uint64_t* out_keys,
+                                flmr_stream_t stream) {
+    if (!keys || !out_keys) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    if (m < 1 || n < 1) FLMR_FAIL(FLMR_ERR_INVALID, "bad sizes m=%d n=%d", m, n);
+    return flmr_launch_select_keys(keys, nqueries, m, n, out_keys, reinterpret_cast<hipStream_t>(stream));
+}
+
 // descending keys [nqueries, n] -> pids / scores / counts of the first k
 extern "C" int flmr_unpack_keys(const uint64_t* keys, int32_t nqueries, int32_t n, int32_t k, int32_t* out_pids,
                                 float* out_scores, int32_t* out_counts, flmr_stream_t stream) {

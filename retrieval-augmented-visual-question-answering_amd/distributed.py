@@ -71,9 +71,9 @@ class ShardedSearcher:
 
         gather = gather or default_gather
 
-        def exchange(keys, n):  # [B, m] per rank -> global top-n per query
+        def exchange(keys, n, ordered=False):  # [B, m] per rank -> global top-n per query
             g = gather(keys)                                              # [W, B, m]
-            return ops.topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n)
+            return ops.topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n, ordered=ordered)
 
         k1 = None
         if self.world > 1 and split_stage0 and self._split_ok is not False:
@@ -101,7 +101,7 @@ class ShardedSearcher:
             k1 = self.scorer.phase1(Q, k, ncells, thr, ndocs, nq_cand, q_lens=q_lens)
         s1 = exchange(k1, ndocs)
         s2 = exchange(self.scorer.phase2(s1), ndocs // 4)
-        fin = exchange(self.scorer.phase3(s2), min(k, max(ndocs // 4, 1)))
+        fin = exchange(self.scorer.phase3(s2), min(k, max(ndocs // 4, 1)), ordered=True)
         return ops.unpack_keys(fin, k)
 
     def search_batch(self, Q, k, **kw):

@@ -107,11 +107,15 @@ def merge_topk(scores, pids):
     return os_, op, oc
 
 
-def topn_keys(keys, n):
-    """keys int64 [nq, m] (u64 bit patterns: score bits << 32 | pid, 0 = empty) -> the n largest per row, descending."""
+def topn_keys(keys, n, ordered=True):
+    """keys int64 [nq, m] (u64 bit patterns: score bits << 32 | pid, 0 = empty) -> the n largest per row, descending;
+    ordered=False: the same set in arbitrary order (radix select, any m)."""
     lib = _native.load()
     kd = keys.to("cuda").contiguous()
     out = torch.empty((kd.size(0), n), dtype=torch.int64, device="cuda")
+    if not ordered:
+        _native.check(lib.flmr_select_keys(_p(kd), kd.size(0), kd.size(1), int(n), _p(out), _native.stream_ptr()))
+        return out
     _native.check(lib.flmr_topn_keys(_p(kd), kd.size(0), kd.size(1), int(n), _p(out), None, _native.stream_ptr()))
     return out
 

@@ -445,9 +445,9 @@ def test_query_split_stage0_equals_unsharded(hip, nshards):
     for (k, ncells, thr, ndocs) in [(100, 2, 0.45, 1024), (10, 1, 0.5, 64), (10, 2, -1.0, 64)]:   # thr=-1: every centroid qualifies
         p_ref, s_ref, c_ref = single.search_batch(Q, k, ncells, thr, ndocs, 32)
 
-        def exchange(keys_per_rank, n):
+        def exchange(keys_per_rank, n, ordered=False):   # the intermediate exchanges use the unordered radix select
             g = torch.stack(keys_per_rank)
-            return ops.topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n)
+            return ops.topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n, ordered=ordered)
 
         parts = []
         for r, sh in enumerate(shards):
@@ -462,8 +462,11 @@ def test_query_split_stage0_equals_unsharded(hip, nshards):
             ref_cells = single.tap(pkg._native.TAP_CELLS, 0)
             assert np.array_equal(cells[q, :int(ncell[q])].cpu().numpy(), ref_cells), q
         s1 = exchange([sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32) for sh in shards], ndocs)
+        s1_sorted = exchange([sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32) for sh in shards], ndocs, ordered=True)
+        u = lambda t: t.cpu().numpy().view(np.uint64)                                   # keys are u64 bit patterns
+        assert np.array_equal(np.sort(u(s1), axis=1)[:, ::-1], u(s1_sorted))             # same set as the bitonic top-n
         s2 = exchange([sh.phase2(s1) for sh in shards], ndocs // 4)
-        fin = exchange([sh.phase3(s2) for sh in shards], min(k, ndocs // 4))
+        fin = exchange([sh.phase3(s2) for sh in shards], min(k, ndocs // 4), ordered=True)
         p, s, c = ops.unpack_keys(fin, k)
         assert torch.equal(c, c_ref) and torch.equal(p, p_ref) and torch.equal(s, s_ref), (nshards, k, thr)
 
