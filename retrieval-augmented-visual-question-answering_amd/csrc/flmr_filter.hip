@@ -499,6 +499,132 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_mfma_kernel(flmr_filter_
     }
 }
 
+__global__ __launch_bounds__(256, 2) void filter_stage2_lds_kernel(flmr_filter_args f, const int32_t* pids, int64_t pid_stride,
+                                                                    const int32_t* counts, uint64_t* keys, int64_t key_stride,
+                                                                    const _Float16* __restrict__ cen16,
+                                                                    const _Float16* __restrict__ q_hi,
+                                                                    const _Float16* __restrict__ q_lo) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int cnt = counts[b];
+    const int qlen = f.q_lens ? f.q_lens[b] : f.nq_cand;
+    const int nqc = qlen < f.nq_cand ? qlen : f.nq_cand;  // <= 32 on this path
+    float* tr = reinterpret_cast<float*>(smem) + (size_t)wave * 33;
+    // this wave's row buffer: 32 centroid rows x 256 B, filled by direct global->LDS loads (16-byte pieces XOR-swizzled by row)
+    char* rowbuf = smem + 4 * 33 * sizeof(float) + 16 + (size_t)wave * (32 * 256);
+    const int W = gridDim.y * 4, w = blockIdx.y * 4 + wave;
+    const int ndw = cnt > w ? (cnt - w + W - 1) / W : 0;  // <= 64 documents per wave (launcher)
+    if (ndw == 0) return;
+    int my_pid = 0, my_len = 0;
+    int64_t my_off = 0;
+    if (lane < ndw) {
+        my_pid = pids[(size_t)b * pid_stride + w + lane * W];
+        my_off = f.offsets[my_pid];
+        my_len = (int)doc_len_of(f.doclens, f.offsets, my_pid);
+    }
+    s2h8 bh[8], bl[8];
+    {
+        const s2h8* ph = reinterpret_cast<const s2h8*>(q_hi + ((size_t)b * f.ncol + i) * FLMR_DIM + 64 * h);
+        const s2h8* pl = reinterpret_cast<const s2h8*>(q_lo + ((size_t)b * f.ncol + i) * FLMR_DIM + 64 * h);
+#pragma unroll
+        for (int s = 0; s < 8; s++) { bh[s] = ph[s]; bl[s] = pl[s]; }
+    }
+    auto load_codes = [&](int64_t off, int len, int* cd) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) cd[r] = (lane + 64 * r < len) ? f.codes[off + lane + 64 * r] : 0;
+    };
+    // One gather instruction fetches FOUR WHOLE ROWS straight into LDS (global_load_lds_dwordx4; lane L: row 4g + L/16,
+    // 16-byte piece L%16): 8 cache lines per instruction, each fully used, and no VGPRs held while the loads are in flight.
+    // The register form (lane (i,h) reads its own half row 16 bytes at a time) touches 64 lines per instruction for the same
+    // 1 KB.  The MFMA layout is read back from LDS; piece p of row r is kept at position p ^ (r & 15) so that both the
+    // contiguous DMA writes and the ds_read_b128 are conflict-free.  Measured: 1.04 vs 1.08 ms -- the kernel is bound by the
+    // number of line fills a CU keeps in flight (x latency), see DESIGN.md, so the form of the gather matters little.
+    auto issue_rows = [&](const int* cd, int t, int64_t off, int len) {
+        const int tok = t * 32 + i;
+        int code = 0;
+        if (t < 8) {
+            const int sel = t >> 1;
+            const int reg = sel == 0 ? cd[0] : sel == 1 ? cd[1] : sel == 2 ? cd[2] : cd[3];
+            code = __shfl(reg, (t & 1) * 32 + i, 64);
+        } else if (tok < len) {
+            code = f.codes[off + tok];
+        }
+        const int rl = lane >> 4, pp = lane & 15;
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const int row = 4 * g + rl;
+            const int c = __shfl(code, row, 64);  // lane `row` (< 32) holds token `row`'s code (row 0 for padding tokens)
+            const _Float16* src = cen16 + (size_t)c * FLMR_DIM + ((pp ^ (row & 15)) << 3);
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(rowbuf + g * 1024), 16, 0, 0);
+        }
+    };
+    auto take_rows = [&](s2h8* a) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the tile's DMA loads have landed
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < 8; s++)
+            a[s] = *reinterpret_cast<const s2h8*>(rowbuf + i * 256 + (((8 * h + s) ^ (i & 15)) << 4));
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the buffer may be refilled
+        asm volatile("" ::: "memory");
+    };
+    int cd[4], ncd[4];
+    load_codes(shfl_i64(my_off, 0), __shfl(my_len, 0, 64), cd);
+    bool have_raw = false;
+    for (int j = 0; j < ndw; j++) {
+        const int pid = __shfl(my_pid, j, 64);
+        const int len = __shfl(my_len, j, 64);
+        const int64_t off = shfl_i64(my_off, j);
+        int nlen = 0;
+        int64_t noff = 0;
+        if (j + 1 < ndw) {
+            nlen = __shfl(my_len, j + 1, 64);
+            noff = shfl_i64(my_off, j + 1);
+            load_codes(noff, nlen, ncd);
+        }
+        const int ntiles = (len + 31) >> 5;
+        if (ntiles > 0 && !have_raw) issue_rows(cd, 0, off, len);
+        have_raw = false;
+        float cmax = -9999.0f;  // filter_pids.cpp:30-33: per-token maxima start at -9999
+        for (int t = 0; t < ntiles; t++) {
+            s2h8 av[8];
+            take_rows(av);
+            if (t + 1 < ntiles) {
+                issue_rows(cd, t + 1, off, len);
+            } else if (j + 1 < ndw && nlen > 0) {
+                issue_rows(ncd, 0, noff, nlen);
+                have_raw = true;
+            }
+            f32x16 ah, al;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[s], ah, 0, 0, 0);
+                al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[s], al, 0, 0, 0);
+            }
+            const int nrow = len - t * 32;  // valid token rows in this tile
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+                cmax = fmaxf(cmax, row < nrow ? v : -9999.0f);
+            }
+        }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        if (h == 0) tr[i] = cmax;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            const float sc = flmr_seq_sum(tr, nqc);
+            keys[(size_t)b * key_stride + w + j * W] = flmr_make_key(sc, pid);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; r++) cd[r] = ncd[r];
+    }
+}
+
 int flmr_launch_filter_stage2_mfma(const flmr_filter_args& f, const int32_t* pids, int64_t pid_stride, const int32_t* counts,
                                    int32_t max_count, uint64_t* keys, int64_t key_stride, const _Float16* cen16,
                                    const _Float16* q_hi, const _Float16* q_lo, hipStream_t st) {
@@ -509,8 +635,14 @@ int flmr_launch_filter_stage2_mfma(const flmr_filter_args& f, const int32_t* pid
     if (G < gmin) G = gmin;
     if (G > (int)flmr_ceil_div(max_count, 4)) G = (int)flmr_ceil_div(max_count, 4);
     if (G < 1) G = 1;
-    hipLaunchKernelGGL(filter_stage2_mfma_kernel, dim3(f.nqueries, G), dim3(256), 4 * 33 * sizeof(float), st, f, pids, pid_stride,
-                       counts, keys, key_stride, cen16, q_hi, q_lo);
+    // FLMR_S2_IMPL=regs: the first form of the kernel (per-lane half-row gathers into registers), kept for A/B runs
+    const char* impl = getenv("FLMR_S2_IMPL");
+    if (impl && strcmp(impl, "regs") == 0)
+        hipLaunchKernelGGL(filter_stage2_mfma_kernel, dim3(f.nqueries, G), dim3(256), 4 * 33 * sizeof(float), st, f, pids, pid_stride,
+                           counts, keys, key_stride, cen16, q_hi, q_lo);
+    else
+        hipLaunchKernelGGL(filter_stage2_lds_kernel, dim3(f.nqueries, G), dim3(256), 4 * 33 * sizeof(float) + 16 + 4 * 32 * 256, st,
+                           f, pids, pid_stride, counts, keys, key_stride, cen16, q_hi, q_lo);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }
