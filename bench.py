@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--doclen", type=int, default=128)
     ap.add_argument("--centroids", type=int, default=0, help="0 = 2^floor(log2(16*sqrt(N)))  (collection_indexer.py:93)")
     ap.add_argument("--nbits", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="queries per step")
+    ap.add_argument("--batch", type=int, default=1024, help="queries per step (one batched _search_all_Q-style pass)")
     ap.add_argument("--nq", type=int, default=32)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--cpu-queries", type=int, default=12, help="queries of the batch timed on the CPU baseline (0 = skip)")

@@ -3,7 +3,7 @@
 Rank 0's share of the work (its 1/W passage shard, its 1/W slice of the queries for the query-split stage 0) is executed
 for real; the all-gathers are replaced by repeating rank 0's own buffers W times with the pids shifted into the other ranks' ranges (right sizes and
 survivor shares, made-up contents for the other ranks' parts -- timing only, results are not checked here; tests/test_hip_parity.py does that).  What is missing from the
-figures is only the RCCL time of 4 small all-gathers per step.  Usage: python profiles/shard_step_model.py [passages [worlds, e.g. 1,2,4,8]]
+figures is only the RCCL time of 4 small all-gathers per step.  Usage: python profiles/shard_step_model.py [passages [worlds, e.g. 1,2,4,8 [queries per step]]]
 """
 import sys, time, json
 import torch
@@ -13,7 +13,8 @@ from ravqa_amd import synth, ops
 from ravqa_amd.scorer import IndexScorer
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-DOCLEN, NB, B, NQ, k = 128, 2, 256, 32, 100
+DOCLEN, NB, NQ, k = 128, 2, 32, 100
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 256   # queries per step
 ncells, thr, ndocs = 2, 0.45, 1024
 K = 2 ** int(torch.log2(torch.tensor(16.0 * ((P * DOCLEN) ** 0.5))).floor())
 corpus = synth.make_corpus(P, DOCLEN, K, NB, seed=0, device="cuda")
