@@ -179,6 +179,10 @@ __device__ __forceinline__ int64_t s1s_bcast64(int64_t v, int j) {
     return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 
+// A workgroup takes S1S_CPB consecutive chunks of one query: the list ids and offsets are fetched once, and only the chunk
+// table entry that ends the NEXT chunk's slice is loaded per chunk (a chunk's slice starts where the previous one ended),
+// requested a whole chunk ahead.
+#define S1S_CPB 4
 __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_cand_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* cb = reinterpret_cast<uint32_t*>(smem);                   // candidate bitmap of the chunk
@@ -188,17 +192,33 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     int* acc = reinterpret_cast<int*>(hbase + CAND_CHUNK_WORDS);        // [S1S_SLOTS][S1S_STRIDE]
     __shared__ int scan_lds[17];
     __shared__ int s_base;
-    const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k = lane & 31, h = lane >> 5;
-    cb[tid] = 0u; hb[tid] = 0u;  // CAND_CHUNK_WORDS == blockDim.x
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = lane & 31;
+    const int ch0 = blockIdx.y * S1S_CPB;
+    const int ch_end = ch0 + S1S_CPB < a.nchunks ? ch0 + S1S_CPB : a.nchunks;
     const int nl = a.ncell[b];
     const bool scatter = a.hit_valid[b] != 0;
     const int nq = scatter ? a.nqual[b] : 0;
-    const int pid0 = ch * CAND_CHUNK_PIDS;
-    const s1s_slices mc = s1s_load_slices(a.cells + (size_t)b * a.max_cells, nl, wave, lane, a.ivf_offsets, a.chunk_tab, a.nchunks, ch);
-    const s1s_slices mq = s1s_load_slices(a.qual + (size_t)b * a.qmax, nq, wave, lane, a.ivf_offsets, a.chunk_tab, a.nchunks, ch);
+    s1s_slices mc = s1s_load_slices(a.cells + (size_t)b * a.max_cells, nl, wave, lane, a.ivf_offsets, a.chunk_tab, a.nchunks, ch0);
+    s1s_slices mq = s1s_load_slices(a.qual + (size_t)b * a.qmax, nq, wave, lane, a.ivf_offsets, a.chunk_tab, a.nchunks, ch0);
     const int init = s1s_enc(-9999.0f);
-    if (scatter)  // first window's accumulators, written while the metadata loads are in flight
+    const int qlen = a.q_lens ? a.q_lens[b] : a.nq_cand;
+    const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;  // <= 32 on this path
+    float miss_score = 0.0f;
+    for (int q = 0; q < nqc; q++) miss_score += -9999.0f;
+    const float* cs_b = a.cs + (size_t)b * a.cs_query_stride;
+    uint64_t* keys_b = a.keys + (size_t)b * a.cand_cap;
+
+    for (int ch = ch0; ch < ch_end; ch++) {
+    const int pid0 = ch * CAND_CHUNK_PIDS;
+    // the end of the NEXT chunk's slices, a chunk ahead of its use
+    uint32_t mc_e2 = 0, mq_e2 = 0;
+    if (ch + 1 < ch_end) {
+        if (lane < mc.n) mc_e2 = a.chunk_tab[(size_t)mc.c * (a.nchunks + 1) + ch + 2];
+        if (lane < mq.n) mq_e2 = a.chunk_tab[(size_t)mq.c * (a.nchunks + 1) + ch + 2];
+    }
+    cb[tid] = 0u; hb[tid] = 0u;  // CAND_CHUNK_WORDS == blockDim.x
+    if (scatter)  // first window's accumulators, written while the loads above are in flight
         for (int e = tid; e < S1S_SLOTS * S1S_STRIDE; e += 64 * S1S_WAVES) acc[e] = init;
     __syncthreads();
     // lists are taken four at a time: the first 64 entries of each are requested before any is consumed, and the first
@@ -245,26 +265,22 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
         cw = 0u;
     }
     const uint32_t hcw = cw & hw;
-    int cnt, nh;
-    const int cpos = flmr_block_exclusive_scan(__popc(cw), scan_lds, &cnt);
-    __syncthreads();
-    const int hpos = flmr_block_exclusive_scan(__popc(hcw), scan_lds, &nh);
+    // one block scan for both ranks: candidates in the low half, candidate-and-hit in the high half (<= 32768 each)
+    int tot;
+    const int both = flmr_block_exclusive_scan(__popc(cw) | (__popc(hcw) << 16), scan_lds, &tot);
+    const int cpos = both & 0xffff, hpos = both >> 16;
+    const int cnt = tot & 0xffff, nh = tot >> 16;
     cbase[tid] = (uint16_t)cpos;
     hbase[tid] = (uint16_t)hpos;
+    // where this chunk's keys go: a global atomic whose ~2 us round trip is only awaited right before the keys are written
+    int my_base = 0;
     if (tid == 0) {
         a.chunk_cnt[(size_t)b * a.nchunks + ch] = cnt;
-        s_base = (scatter && cnt) ? atomicAdd(&a.key_count[b], cnt) : 0;
+        if (scatter && cnt) my_base = atomicAdd(&a.key_count[b], cnt);
     }
-    if (!scatter) return;  // this query's stage 1 is done by the scanning kernel (block-uniform)
     __syncthreads();
-    if (cnt == 0) return;
-    const int qlen = a.q_lens ? a.q_lens[b] : a.nq_cand;
-    const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;  // <= 32 on this path
-    float miss_score = 0.0f;
-    for (int q = 0; q < nqc; q++) miss_score += -9999.0f;
-    const float* cs_b = a.cs + (size_t)b * a.cs_query_stride;
-    uint64_t* keys_b = a.keys + (size_t)b * a.cand_cap;
-    const int64_t kbase = s_base;
+    // (queries without `scatter` leave stage 1 to the scanning kernel; both conditions are block-uniform)
+    if (scatter && cnt > 0) {
     for (int win0 = 0; win0 == 0 || win0 < nh; win0 += S1S_SLOTS) {
         const int nslot = (nh - win0) < S1S_SLOTS ? (nh - win0) : S1S_SLOTS;
         if (win0 > 0) {
@@ -272,9 +288,9 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
             __syncthreads();
         }
         // the surviving lists again: (centroid, passage) pairs -> 32-wide max into the passage's slot; four lists at a
-        // time (their score rows and first 64 entries are requested up front)
-        // every lane owns one (centroid, passage) pair and walks the 32 columns itself: 32 ds_max per 64 pairs, no
-        // cross-lane dependency chain; the row value of column q is broadcast from lane q of rowk
+        // time (their score rows and first 64 entries are requested up front).  Every lane owns one (centroid, passage)
+        // pair and walks the 32 columns itself: 32 ds_max per 64 pairs, no cross-lane dependency chain; the row value of
+        // column q is broadcast from lane q of rowk
         auto scatter_pids = [&](int pid, int rowk) {
             int slot = -1;
             if (pid >= 0) {
@@ -290,7 +306,6 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
                 if (on) atomicMax(dst + q, v);
             }
         };
-#ifndef S1S_DIAG_NOSCATTER
         for (int j0 = 0; j0 < mq.n; j0 += 4) {
             int pidv[4], rowv[4];
             int64_t begv[4];
@@ -312,11 +327,9 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
                     scatter_pids(x0 + lane < ev[u] ? a.ivf_pids[begv[u] + x0 + lane] - pid0 : -1, rowv[u]);
             }
         }
-#endif
         __syncthreads();
         // per-slot score = ascending-k sum of the column maxima (filter_pids.cpp:59-63), one thread per slot, kept in the
         // row's padding word
-#ifndef S1S_DIAG_NOSUM
         for (int sl = tid; sl < nslot; sl += 64 * S1S_WAVES) {
             float v[32];
 #pragma unroll
@@ -326,10 +339,11 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
             for (int q = 0; q < 32; q++) sc += q < nqc ? v[q] : 0.0f;
             acc[sl * S1S_STRIDE + 32] = __float_as_int(sc);
         }
-#endif
+        if (tid == 0 && win0 == 0) s_base = my_base;
         __syncthreads();
         // one thread per bitmap word: keys of its candidates (hits of this window; the misses with window 0)
         {
+            const int64_t kbase = s_base;
             uint32_t bits = cw;
             while (bits) {
                 const int bit = __ffs(bits) - 1;
@@ -347,6 +361,12 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
             }
         }
         __syncthreads();
+    }
+    }
+    // next chunk: its slices start where this chunk's ended
+    mc.s = mc.e; mc.e = mc_e2;
+    mq.s = mq.e; mq.e = mq_e2;
+    __syncthreads();  // bitmaps / bases / accumulators are reused
     }
 }
 
@@ -396,7 +416,7 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
                            (size_t)S1S_SLOTS * S1S_STRIDE * sizeof(int);
         FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cand_mark_score_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(cand_mark_score_kernel, dim3(a.nqueries, a.nchunks), dim3(64 * S1S_WAVES), lds, st, a);
+        hipLaunchKernelGGL(cand_mark_score_kernel, dim3(a.nqueries, (a.nchunks + S1S_CPB - 1) / S1S_CPB), dim3(64 * S1S_WAVES), lds, st, a);
     } else {
         hipLaunchKernelGGL(cand_mark_chunks_kernel, dim3(a.nqueries, a.nchunks), dim3(256), 0, st, a.cells, a.ncell, a.max_cells,
                            a.qual, a.nqual, a.qmax, a.hit_valid, a.ivf_pids, a.ivf_offsets, a.chunk_tab, a.nchunks, a.cand_bits,
