@@ -112,9 +112,10 @@ int flmr_search_batch(flmr_searcher_t* searcher, const float* Q, const int32_t* 
  * one small all-gather of keys after each; a key is u64 = order-preserving(score) << 32 | GLOBAL pid, 0 = empty.
  *   phase1: S0..S1 locally            -> out_keys [nqueries, ndocs]    (the shard's top-ndocs stage-1 keys)
  *   gather + flmr_topn_keys(n = ndocs)      = the global stage-1 survivors, identical to the single-index ones
- *   phase2: S2 of the shard's members -> out_keys [nqueries, ndocs]
+ *   phase2: S2 of the shard's members -> out_keys [nqueries, ndocs], SLOT-ALIGNED with the global list given (0 where the
+ *           passage lives on another shard): combine the shards by a SUM all-reduce (or a gather)
  *   gather + flmr_topn_keys(n = ndocs/4)    = the global stage-2 survivors
- *   phase3: S3 of the shard's members -> out_keys [nqueries, ndocs/4]
+ *   phase3: S3 of the shard's members -> out_keys [nqueries, ndocs/4], slot-aligned likewise
  *   gather + flmr_topn_keys(n = k) + flmr_unpack_keys = the final ranking, bit-identical to flmr_search_batch on the
  *   unsharded index.  The same Q / q_lens / params must be passed to all three phases; params->ndocs must equal the
  *   ndocs the searcher was created with.

@@ -179,7 +179,9 @@ int flmr_launch_sort_keys_topn(const uint64_t* keys, int32_t nqueries, int32_t m
                                int32_t* out_counts, hipStream_t st);
 int flmr_launch_filter_local_keys(const uint64_t* keys, int32_t nqueries, int32_t n_in, int64_t pid_base,
                                   int64_t num_passages, int32_t* out_pids, int64_t out_stride, int32_t* out_count,
-                                  hipStream_t st);
+                                  hipStream_t st, int32_t* out_slot = nullptr);
+int flmr_launch_export_keys_slotted(const uint64_t* keys, int64_t key_stride, const int32_t* counts, const int32_t* slot,
+                                    int32_t nqueries, uint64_t key_add, int32_t n, uint64_t* out, hipStream_t st);
 int flmr_launch_export_keys(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t nqueries, uint64_t key_add,
                             int32_t n, uint64_t* out, hipStream_t st);
 int flmr_launch_unpack_keys(const uint64_t* keys, int32_t nqueries, int32_t n, int32_t k, int32_t* out_pids, float* out_scores,

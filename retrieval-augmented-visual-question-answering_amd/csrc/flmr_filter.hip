@@ -998,7 +998,7 @@ int flmr_launch_sort_keys_topn(const uint64_t* keys, int32_t nqueries, int32_t m
 // global keys [nqueries, n_in] -> LOCAL pids of this shard (pid in [pid_base, pid_base + num_passages)), any order
 __global__ __launch_bounds__(256) void filter_local_keys_kernel(const uint64_t* keys, int n_in, int64_t pid_base,
                                                                 int64_t num_passages, int32_t* out_pids, int64_t out_stride,
-                                                                int32_t* out_count) {
+                                                                int32_t* out_count, int32_t* out_slot) {
     __shared__ int cnt;
     const int b = blockIdx.x;
     if (threadIdx.x == 0) cnt = 0;
@@ -1008,7 +1008,10 @@ __global__ __launch_bounds__(256) void filter_local_keys_kernel(const uint64_t* 
         const int64_t pid = (int64_t)(uint32_t)key - pid_base;
         if (key != 0ull && pid >= 0 && pid < num_passages) {
             const int pos = atomicAdd(&cnt, 1);
-            if (pos < out_stride) out_pids[(size_t)b * out_stride + pos] = (int32_t)pid;
+            if (pos < out_stride) {
+                out_pids[(size_t)b * out_stride + pos] = (int32_t)pid;
+                if (out_slot) out_slot[(size_t)b * out_stride + pos] = i;  // where this passage sits in the global list
+            }
         }
     }
     __syncthreads();
@@ -1017,9 +1020,9 @@ __global__ __launch_bounds__(256) void filter_local_keys_kernel(const uint64_t* 
 
 int flmr_launch_filter_local_keys(const uint64_t* keys, int32_t nqueries, int32_t n_in, int64_t pid_base,
                                   int64_t num_passages, int32_t* out_pids, int64_t out_stride, int32_t* out_count,
-                                  hipStream_t st) {
+                                  hipStream_t st, int32_t* out_slot) {
     hipLaunchKernelGGL(filter_local_keys_kernel, dim3(nqueries), dim3(256), 0, st, keys, n_in, pid_base, num_passages, out_pids,
-                       out_stride, out_count);
+                       out_stride, out_count, out_slot);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }
@@ -1030,6 +1033,28 @@ __global__ __launch_bounds__(256) void export_keys_kernel(const uint64_t* keys, 
     const int b = blockIdx.x;
     const int c = counts[b];
     for (int i = threadIdx.x; i < n; i += blockDim.x) out[(size_t)b * n + i] = i < c ? keys[(size_t)b * key_stride + i] + key_add : 0ull;
+}
+
+// the same, SLOT-ALIGNED with the global list the passages were filtered from: out[q][slot[l]] = key of local passage l,
+// 0 everywhere else -- so the shards' outputs can be combined by a SUM all-reduce (one non-zero contributor per slot)
+// as well as by a gather
+__global__ __launch_bounds__(256) void export_keys_slotted_kernel(const uint64_t* keys, int64_t key_stride, const int32_t* counts,
+                                                                  const int32_t* slot, uint64_t key_add, int n, uint64_t* out) {
+    const int b = blockIdx.x;
+    const int c = counts[b];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) out[(size_t)b * n + i] = 0ull;
+    __syncthreads();
+    for (int l = threadIdx.x; l < c; l += blockDim.x) {
+        const int j = slot[(size_t)b * key_stride + l];
+        if (j < n) out[(size_t)b * n + j] = keys[(size_t)b * key_stride + l] + key_add;
+    }
+}
+
+int flmr_launch_export_keys_slotted(const uint64_t* keys, int64_t key_stride, const int32_t* counts, const int32_t* slot,
+                                    int32_t nqueries, uint64_t key_add, int32_t n, uint64_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(export_keys_slotted_kernel, dim3(nqueries), dim3(256), 0, st, keys, key_stride, counts, slot, key_add, n, out);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
 }
 
 int flmr_launch_export_keys(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t nqueries, uint64_t key_add,

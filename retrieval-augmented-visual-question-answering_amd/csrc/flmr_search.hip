@@ -22,6 +22,7 @@ struct flmr_searcher {
     uint64_t* keys2; int32_t* s2_pids; int32_t* s2_count; uint64_t* keys3; float* doc_scores; int32_t* overflow;
     _Float16* q_hi; _Float16* q_lo;
     uint32_t* hit_bits; int32_t* hit_valid; int32_t* key_count;
+    int32_t* s1_slot; int32_t* s2_slot;   // sharded protocol: position of each local survivor / finalist in the global list
     _Float16* q3_hi; _Float16* q3_lo;
     int32_t* qual; int32_t* nqual; int32_t* chunk_cnt; uint8_t* cand_hit; int32_t qmax;
     // last call (for taps)
@@ -105,6 +106,8 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     WS(hit_bits, B * (size_t)s->bitmap_words);
     WS(hit_valid, B);
     WS(key_count, B);
+    WS(s1_slot, B * (size_t)nd);
+    WS(s2_slot, B * (size_t)nd4);
     s->qmax = 1024;
     WS(qual, B * (size_t)s->qmax);
     WS(nqual, B);
@@ -123,7 +126,7 @@ extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
     if (!s) return FLMR_OK;
     void* ptrs[] = {s->cs, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
                     s->keys1, s->s1_pids, s->s1_count, s->keys2, s->s2_pids, s->s2_count, s->keys3, s->doc_scores,
-                    s->overflow, s->q_hi, s->q_lo, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->cand_hit, s->key_count};
+                    s->overflow, s->q_hi, s->q_lo, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot};
     for (void* p : ptrs) (void)hipFree(p);
     for (int i = 0; i <= FLMR_NUM_STAGES; i++)
         if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
@@ -397,32 +400,36 @@ extern "C" int flmr_search_phase1_probed(flmr_searcher_t* s, const float* Q, con
 }
 
 // phase 2: global_s1 [nqueries, n_in] = the GLOBAL top-ndocs stage-1 keys; this shard scores its own members in stage 2
-// -> out_keys [nqueries, ndocs] (global pids, 0 padded).  Q / q_lens / params must be those of phase 1.
+// -> out_keys [nqueries, ndocs], slot j = the key of global_s1[j]'s passage when it lives on this shard, else 0 (so the
+// shards' outputs combine by a SUM all-reduce or by a gather).  Q / q_lens / params must be those of phase 1.
 extern "C" int flmr_search_phase2(flmr_searcher_t* s, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
                                   const flmr_search_params_t* p, const uint64_t* global_s1, int32_t n_in, uint64_t* out_keys,
                                   flmr_stream_t stream) {
     if (!global_s1 || !out_keys) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
     run_ctx c;
     RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
+    if (n_in > p->ndocs) FLMR_FAIL(FLMR_ERR_INVALID, "n_in=%d > ndocs=%d", n_in, p->ndocs);
     RUN(flmr_launch_filter_local_keys(global_s1, nqueries, n_in, s->ix->pid_base, s->ix->num_passages, s->s1_pids, s->maxp.ndocs,
-                                      s->s1_count, c.st));
+                                      s->s1_count, c.st, s->s1_slot));
     RUN(stage_s2(c));
-    return flmr_launch_export_keys(s->keys2, s->maxp.ndocs, s->s1_count, nqueries, (uint64_t)s->ix->pid_base, p->ndocs, out_keys, c.st);
+    return flmr_launch_export_keys_slotted(s->keys2, s->maxp.ndocs, s->s1_count, s->s1_slot, nqueries, (uint64_t)s->ix->pid_base,
+                                           p->ndocs, out_keys, c.st);
 }
 
 // phase 3: global_s2 [nqueries, n_in] = the GLOBAL top-(ndocs/4) stage-2 keys; this shard computes the exact MaxSim of its
-// own members -> out_keys [nqueries, ndocs/4] (global pids, 0 padded).
+// own members -> out_keys [nqueries, ndocs/4], slot-aligned with global_s2 like phase 2.
 extern "C" int flmr_search_phase3(flmr_searcher_t* s, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
                                   const flmr_search_params_t* p, const uint64_t* global_s2, int32_t n_in, uint64_t* out_keys,
                                   flmr_stream_t stream) {
     if (!global_s2 || !out_keys) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
     run_ctx c;
     RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
+    if (n_in > p->ndocs / 4) FLMR_FAIL(FLMR_ERR_INVALID, "n_in=%d > ndocs/4=%d", n_in, p->ndocs / 4);
     RUN(flmr_launch_filter_local_keys(global_s2, nqueries, n_in, s->ix->pid_base, s->ix->num_passages, s->s2_pids,
-                                      s->maxp.ndocs / 4, s->s2_count, c.st));
+                                      s->maxp.ndocs / 4, s->s2_count, c.st, s->s2_slot));
     RUN(stage_s3(c));
-    return flmr_launch_export_keys(s->keys3, s->maxp.ndocs / 4, s->s2_count, nqueries, (uint64_t)s->ix->pid_base, p->ndocs / 4,
-                                   out_keys, c.st);
+    return flmr_launch_export_keys_slotted(s->keys3, s->maxp.ndocs / 4, s->s2_count, s->s2_slot, nqueries,
+                                           (uint64_t)s->ix->pid_base, p->ndocs / 4, out_keys, c.st);
 }
 
 // keys [nqueries, m] -> the n largest, descending, 0 padded (+ optional counts); m <= 8192

@@ -55,10 +55,12 @@ class ShardedSearcher:
         ncells, thr, ndocs = self.k_policy(k)
         return self.scorer.search_batch(Q, k, ncells, thr, ndocs, nq_cand, q_lens=q_lens)
 
-    def search_batch_exact(self, Q, k, nq_cand=32, q_lens=None, gather=None, split_stage0=True):
-        """Exact-parity mode: three phases with one all-gather of u64 keys after each; the result is
+    def search_batch_exact(self, Q, k, nq_cand=32, q_lens=None, gather=None, split_stage0=True, reduce_sum=None):
+        """Exact-parity mode: three phases with one exchange of u64 keys after each; the result is
         bit-identical to searching the unsharded index.  `gather(t)` must return the [world, ...] stack of `t` over the
-        ranks (default: torch.distributed.all_gather_into_tensor on the device)."""
+        ranks (default: torch.distributed.all_gather_into_tensor on the device).  The phase-2/3 outputs are slot-aligned
+        with the global survivor list (one non-zero contributor per slot), so they are combined by a SUM all-reduce --
+        2(W-1)/W of the array per rank instead of W-1 copies; `reduce_sum(t)` overrides it (default: dist.all_reduce)."""
         from . import ops
         ncells, thr, ndocs = self.k_policy(k)
 
@@ -69,11 +71,22 @@ class ShardedSearcher:
             dist.all_gather_into_tensor(g, t.contiguous(), group=self.group)
             return g
 
+        def default_reduce(t):
+            if self.world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return t
+
+        if reduce_sum is None and gather is not None:   # a custom gather (tests, host staging): reduce through it
+            reduce_sum = lambda t: gather(t).sum(dim=0)
+        reduce_sum = reduce_sum or default_reduce
         gather = gather or default_gather
 
-        def exchange(keys, n, ordered=False):  # [B, m] per rank -> global top-n per query
+        # Every rank derives the global lists from the same gathered data, and the phase-2/3 outputs are slot-aligned with
+        # them: the lists must come out in the SAME ORDER on every rank, so they are sorted (the unordered radix select
+        # fills its output through atomics -- same set, rank-dependent order).
+        def exchange(keys, n):  # [B, m] per rank -> global top-n per query, descending
             g = gather(keys)                                              # [W, B, m]
-            return ops.topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n, ordered=ordered)
+            return ops.topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n, ordered=True)
 
         k1 = None
         if self.world > 1 and split_stage0 and self._split_ok is not False:
@@ -100,8 +113,8 @@ class ShardedSearcher:
         if k1 is None:
             k1 = self.scorer.phase1(Q, k, ncells, thr, ndocs, nq_cand, q_lens=q_lens)
         s1 = exchange(k1, ndocs)
-        s2 = exchange(self.scorer.phase2(s1), ndocs // 4)
-        fin = exchange(self.scorer.phase3(s2), min(k, max(ndocs // 4, 1)), ordered=True)
+        s2 = ops.topn_keys(reduce_sum(self.scorer.phase2(s1)), ndocs // 4, ordered=True)
+        fin = ops.topn_keys(reduce_sum(self.scorer.phase3(s2)), min(k, max(ndocs // 4, 1)), ordered=True)
         return ops.unpack_keys(fin, k)
 
     def search_batch(self, Q, k, **kw):

@@ -465,8 +465,11 @@ def test_query_split_stage0_equals_unsharded(hip, nshards):
         s1_sorted = exchange([sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32) for sh in shards], ndocs, ordered=True)
         u = lambda t: t.cpu().numpy().view(np.uint64)                                   # keys are u64 bit patterns
         assert np.array_equal(np.sort(u(s1), axis=1)[:, ::-1], u(s1_sorted))             # same set as the bitonic top-n
-        s2 = exchange([sh.phase2(s1) for sh in shards], ndocs // 4)
-        fin = exchange([sh.phase3(s2) for sh in shards], min(k, ndocs // 4), ordered=True)
+        # phase-2/3 outputs are slot-aligned with the global list: one non-zero contributor per slot -> SUM "all-reduce"
+        parts2 = [sh.phase2(s1) for sh in shards]
+        assert int((torch.stack(parts2) != 0).sum(dim=0).max()) <= 1
+        s2 = ops.topn_keys(torch.stack(parts2).sum(dim=0), ndocs // 4, ordered=False)
+        fin = ops.topn_keys(torch.stack([sh.phase3(s2) for sh in shards]).sum(dim=0), min(k, ndocs // 4), ordered=True)
         p, s, c = ops.unpack_keys(fin, k)
         assert torch.equal(c, c_ref) and torch.equal(p, p_ref) and torch.equal(s, s_ref), (nshards, k, thr)
 
