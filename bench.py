@@ -236,7 +236,7 @@ def main():
             "config": {"workload": f"FLMR late-interaction search, synthetic clustered corpus {args.passages} passages x "
                                    f"{args.doclen} tokens x 128-d, K={K}, nbits={args.nbits}, Nq={args.nq}, k={k} "
                                    f"(ncells={ncells}, thr={thr}, ndocs={ndocs}), {args.batch} queries/step",
-                       "parallelism": (f"index sharded by passage over {world} GPUs, " + (("stage 0 replicated, " if args.replicate_stage0 else "stage 0 split by query + exchange of idx bitsets/cells, ") + "3 all-gathers of (score,pid) keys, result identical to the unsharded index" if args.shard_mode == "exact" else "all-gather of per-shard top-k")) if world > 1 else "1 GPU",
+                       "parallelism": (f"index sharded by passage over {world} GPUs, " + (("stage 0 replicated, " if args.replicate_stage0 else "stage 0 split by query + exchange of idx bitsets/cells, ") + "all-gather of stage-1 keys + SUM all-reduces of slot-aligned stage-2/3 keys, result identical to the unsharded index" if args.shard_mode == "exact" else "all-gather of per-shard top-k")) if world > 1 else "1 GPU",
                        "queries_per_step": args.batch},
             "recall_at_5": recall5,
             "roofline": roof,

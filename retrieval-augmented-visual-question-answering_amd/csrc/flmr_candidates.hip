@@ -10,8 +10,10 @@
 // workgroup reads exactly the list slices it needs -- no global atomics, no bitmap memset, coalesced list reads.
 // The same pass marks a second bitmap from the lists of the centroids that survive the score threshold (the
 // "qualifying" centroids): a candidate outside it provably has no surviving centroid, its stage-1 score is the
-// all-miss value, and stage 1 never reads its codes.  A second kernel turns (bitmap, per-chunk counts) into the
-// ascending pid list with one hit flag per candidate.
+// all-miss value, and stage 1 never reads its codes.  On the default path the same workgroup then COMPUTES stage 1 for
+// the chunk from those lists (cand_mark_score_kernel below: per-passage accumulators in LDS, keys written directly), and
+// the ascending pid list (cand_emit_kernel: bitmap + per-chunk counts -> pids + one hit flag per candidate) is only built
+// for the queries that keep the code-scanning stage 1, or on demand for FLMR_TAP_CANDIDATES.
 #include "flmr_device.h"
 
 #define CAND_CHUNK_WORDS 1024                      // 32768 passages per chunk

@@ -175,6 +175,9 @@ __global__ __launch_bounds__(256) void s0_split_q(const float* Q, const int32_t*
 #ifndef S0_WAVES
 #define S0_WAVES 8               // waves per block (512 threads): two per SIMD, so one wave's MFMAs overlap the other's epilogue
 #endif
+#ifndef S0_OCC
+#define S0_OCC 2                // workgroups per CU the register budget is sized for
+#endif
 #define S0_BROW 136             // halfs per staged B row (128 + 8 pad: conflict-free ds_read_b128 across rows)
 #define S0_LDS_STRIDE 36        // floats per staged row: 16-byte aligned rows for ds_read_b128
 
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256) void s0_split_q(const float* Q, const int32_t*
 // staging + row stores of the dense epilogue.  That halves the kernel's LDS traffic, which at 16 KB of B fragments +
 // 8 KB of staging per (wave, query) was as long as its MFMA time.
 template <bool ARGMAX, bool SPARSE>
-__global__ __launch_bounds__(64 * S0_WAVES, 2) void s0_centroid_scores_f16(flmr_s0_args a) {
+__global__ __launch_bounds__(64 * S0_WAVES, S0_OCC) void s0_centroid_scores_f16(flmr_s0_args a) {
     // dynamic LDS: [4 waves][32 rows][36 f32] staging tiles for the row-contiguous table stores, then the fp16 B
     // operands (q_hi, q_lo) of S0_CH (query, column-tile) items, loaded once per block and shared by its 4 waves.
     // Keeping B out of the global-load path matters: on CDNA4 vmcnt counts loads AND stores and retires in order, so
