@@ -55,7 +55,7 @@ for W in WORLDS:
     sc = IndexScorer(device_index=synth.corpus_device_index(sh, pid_base=0), max_batch=B)
     per = -(-B // W)
 
-    def exchange(keys, n, ordered=True):
+    def exchange(keys, n, ordered=False):
         # the other ranks' rows: the same keys with their pids moved into that rank's pid range (same scores, disjoint pids),
         # so that about 1/W of each global survivor set belongs to this shard -- as in a real run
         shift = (torch.arange(W, device="cuda", dtype=torch.int64) * (P // W)).view(W, 1, 1)
@@ -70,7 +70,7 @@ for W in WORLDS:
         else:
             k1 = sc.phase1(Q, k, ncells, thr, ndocs, 32)
         s1 = exchange(k1, ndocs)
-        s2 = ops.topn_keys(sc.phase2(s1), ndocs // 4, ordered=True)      # (a SUM all-reduce leaves the array size unchanged)
+        s2 = ops.topn_keys(sc.phase2(s1), ndocs // 4, ordered=False)      # (a SUM all-reduce leaves the array size unchanged)
         fin = ops.topn_keys(sc.phase3(s2), k, ordered=True)
         return ops.unpack_keys(fin, k)
 

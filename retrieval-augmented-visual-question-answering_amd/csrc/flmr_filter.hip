@@ -876,11 +876,27 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys,
         }
     }
     // s_prefix is now the n-th largest key (or the floor of the last bucket, taken whole): keep everything >= it
+    // Output positions come from a block scan of per-thread counts, not from an atomic counter: the selected SET is what
+    // matters to the next stage, but a reproducible ORDER (a function of the input only) lets every rank of the sharded
+    // protocol derive the same list from the same gathered keys.
     const unsigned long long thr = s_prefix;
+    __shared__ int sel_scan[17];
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < KPT; j++) mine += (j * 1024 + tid < P && kreg[j] >= thr) ? 1 : 0;
+    for (int i0 = KPT * 1024; i0 < P; i0 += 4 * 1024) {  // (the tail: 4 loads in flight)
+        uint64_t kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) kk[u] = (i0 + u * 1024 + tid < P) ? kb[i0 + u * 1024 + tid] : 0ull;
+#pragma unroll
+        for (int u = 0; u < 4; u++) mine += (i0 + u * 1024 + tid < P && kk[u] >= thr) ? 1 : 0;
+    }
+    int total;
+    int pos = flmr_block_exclusive_scan(mine, sel_scan, &total);
     auto emit = [&](bool valid, uint64_t key) {
         if (valid && key >= thr) {
-            const int pos = atomicAdd(&s_out, 1);
             if (pos < n) { if (ob) ob[pos] = flmr_key_pid(key); if (okb) okb[pos] = key + key_add; }
+            pos++;
         }
     };
 #pragma unroll
@@ -892,8 +908,7 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys,
 #pragma unroll
         for (int u = 0; u < 4; u++) emit(i0 + u * 1024 + tid < P, kk[u]);
     }
-    __syncthreads();
-    if (tid == 0 && n_out) n_out[b] = s_out < n ? s_out : n;
+    if (tid == 0 && n_out) n_out[b] = total < n ? total : n;
 }
 
 int flmr_launch_select_topn(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t nqueries,

@@ -82,11 +82,11 @@ class ShardedSearcher:
         gather = gather or default_gather
 
         # Every rank derives the global lists from the same gathered data, and the phase-2/3 outputs are slot-aligned with
-        # them: the lists must come out in the SAME ORDER on every rank, so they are sorted (the unordered radix select
-        # fills its output through atomics -- same set, rank-dependent order).
-        def exchange(keys, n):  # [B, m] per rank -> global top-n per query, descending
+        # them: the lists must come out in the SAME ORDER on every rank.  The radix select places its output by a block scan
+        # (no atomics), so its order is a function of the input alone and no sort is needed.
+        def exchange(keys, n):  # [B, m] per rank -> global top-n per query (reproducible order)
             g = gather(keys)                                              # [W, B, m]
-            return ops.topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n, ordered=True)
+            return ops.topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n, ordered=False)
 
         k1 = None
         if self.world > 1 and split_stage0 and self._split_ok is not False:
@@ -113,7 +113,7 @@ class ShardedSearcher:
         if k1 is None:
             k1 = self.scorer.phase1(Q, k, ncells, thr, ndocs, nq_cand, q_lens=q_lens)
         s1 = exchange(k1, ndocs)
-        s2 = ops.topn_keys(reduce_sum(self.scorer.phase2(s1)), ndocs // 4, ordered=True)
+        s2 = ops.topn_keys(reduce_sum(self.scorer.phase2(s1)), ndocs // 4, ordered=False)
         fin = ops.topn_keys(reduce_sum(self.scorer.phase3(s2)), min(k, max(ndocs // 4, 1)), ordered=True)
         return ops.unpack_keys(fin, k)
 

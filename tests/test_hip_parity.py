@@ -463,6 +463,9 @@ def test_query_split_stage0_equals_unsharded(hip, nshards):
             assert np.array_equal(cells[q, :int(ncell[q])].cpu().numpy(), ref_cells), q
         s1 = exchange([sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32) for sh in shards], ndocs)
         s1_sorted = exchange([sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32) for sh in shards], ndocs, ordered=True)
+        # every rank derives this list on its own from the same gathered keys: the select must be reproducible
+        for _ in range(3):
+            assert torch.equal(s1, exchange([sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32) for sh in shards], ndocs))
         u = lambda t: t.cpu().numpy().view(np.uint64)                                   # keys are u64 bit patterns
         assert np.array_equal(np.sort(u(s1), axis=1)[:, ::-1], u(s1_sorted))             # same set as the bitonic top-n
         # phase-2/3 outputs are slot-aligned with the global list: one non-zero contributor per slot -> SUM "all-reduce"
