@@ -94,6 +94,19 @@ class IndexArrays:
                            bucket_cutoffs=self.bucket_cutoffs, avg_residual=self.avg_residual,
                            pid_base=self.pid_base + lo, config=self.config)
 
+    def check_ivf_invariant(self):
+        """True iff `ivf[c]` is exactly the sorted set of passages whose codes contain centroid c -- what `optimize_ivf`
+        (colbert/indexing/utils.py:8-53) produces.  Candidate generation (here and in the reference) trusts these lists,
+        and this build's default stage 1 derives the per-passage centroid sets from them instead of scanning the codes."""
+        n = int(self.doclens.shape[0])
+        ntok = int(np.asarray(self.doclens, dtype=np.int64).sum())
+        pid_of = np.repeat(np.arange(n, dtype=np.int64), np.asarray(self.doclens, dtype=np.int64))
+        key = np.unique(np.asarray(self.codes[:ntok], dtype=np.int64) * n + pid_of)
+        lens = np.bincount(key // n, minlength=int(self.centroids.shape[0]))
+        total = int(np.asarray(self.ivf_lengths, dtype=np.int64).sum())
+        return bool(np.array_equal(lens, np.asarray(self.ivf_lengths, dtype=np.int64)) and
+                    np.array_equal((key % n).astype(np.int64), np.asarray(self.ivf[:total], dtype=np.int64)))
+
     def save(self, index_path):
         """Write the reference's on-disk format (single chunk): used by tests and by the synthetic bench."""
         import torch

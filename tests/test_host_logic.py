@@ -183,3 +183,17 @@ def test_build_index_end_to_end_recall_with_oracle(tmp_path):
         pids, _, _ = oi.rank(Q.numpy(), 2, 0.45, 64)
         hits += int(t in pids[:5].tolist())
     assert hits >= 18, hits
+
+
+@pytest.mark.parametrize("name", INDEX_FIXTURES)
+def test_reference_indexes_satisfy_the_ivf_invariant(name):
+    """The fixtures' IVF (written by the reference's optimize_ivf) lists exactly the passages that contain each centroid:
+    the invariant the scatter formulation of stage 1 relies on; shards keep it; a corrupted list is detected."""
+    z = load_golden(name)
+    a = IndexArrays.from_golden(z)
+    assert a.check_ivf_invariant()
+    assert all(a.shard(r, 3).check_ivf_invariant() for r in range(3))
+    bad = IndexArrays.from_golden(z)
+    bad.ivf = bad.ivf.copy()
+    bad.ivf[0] = (bad.ivf[0] + 1) % int(bad.doclens.shape[0])
+    assert not bad.check_ivf_invariant()
