@@ -277,22 +277,23 @@ __global__ __launch_bounds__(64 * S0_WAVES, S0_OCC) void s0_centroid_scores_f16(
             const int rbase = row0 + rt * 32;
             bool staged = true;
             if constexpr (SPARSE) {
-                unsigned long long any = 0ull;
                 // lanes whose column is a real query token (both halves): rows only count those (index_storage.py:116)
                 const unsigned long long colmask = full_cols ? ~0ull : (((1ull << nqc) - 1ull) * 0x100000001ull);
+                // "does any row of this tile survive" == "is any valid lane's maximum over its 16 rows >= thr": the tile
+                // maximum (v_max3 chain) also feeds the column maximum, so the test costs one compare per tile
+                float tmax = FLMR_NEG_INF;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const float v = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
                     if constexpr (ARGMAX) {
                         if (v > cmax) { cmax = v; carg = rbase + (r & 3) + 8 * (r >> 2) + 4 * h; }
-                    } else {
-                        cmax = fmaxf(cmax, v);
                     }
-                    any |= __ballot(v >= a.thr);
+                    tmax = fmaxf(tmax, v);
                 }
+                if constexpr (!ARGMAX) cmax = fmaxf(cmax, tmax);
                 // wave-uniform and rare: some row of this tile survives -> the staged epilogue below stores it and sets
                 // its idx bit (its column max / argmax updates are idempotent)
-                staged = (any & colmask) != 0ull;
+                staged = (__ballot(tmax >= a.thr) & colmask) != 0ull;
             }
             if (staged) {
 #pragma unroll
