@@ -364,20 +364,21 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
 
 // ------------------------------------------------------------------------------------------------
 // S3 for long queries (Nq > 32, e.g. FLMR's 512 text + 32..320 visual rows): same per-wave document pipeline, but the
-// query is walked in CHUNKS of S3_QC tiles of 32 rows that the 4 waves of a workgroup stage once in LDS (fp16 hi/lo,
+// query is walked in CHUNKS of S3_QC tiles of 32 rows that the S3_MQW waves of a workgroup stage once in LDS (fp16 hi/lo,
 // rows padded to 272 B so ds_read_b128 across rows is conflict-free).  Loop order: chunk (outer, block barrier) ->
 // this wave's documents -> token tiles -> the chunk's q-tiles.  The A operand (decompress + normalise + split) is
 // recomputed once per chunk, which costs less than re-reading a 16 KB query tile from L2 per (token tile, q-tile) with
 // the latency exposed, as the short-query kernel would.  Column maxima live in a per-wave LDS row of the chunk's width;
 // at the end of a document within a chunk they are added, k-ascending, to the document's running sum, so the sum is
 // accumulated in exactly the global k order.
-// grid = (nqueries, G), block = 256; dynamic LDS = wlut + S3_QC * 17408 B + 4 waves * (32*S3_QC + 64) floats.
+// grid = (nqueries, G), block = 64 * S3_MQW; dynamic LDS = wlut + S3_QC * 17408 B + S3_MQW * (32*S3_QC + 64) floats.
 // ------------------------------------------------------------------------------------------------
-#define S3_QC 4
+#define S3_QC 8        // q-tiles (of 32 query rows) staged per chunk: the A operand is rebuilt once per chunk
+#define S3_MQW 8       // waves per workgroup sharing the staged chunk (one 512-thread workgroup per CU)
 #define S3_BROW 136
 
 template <int NBITS>
-__global__ __launch_bounds__(256, 2) void maxsim_f16_multiq_kernel(flmr_maxsim_args m, const int32_t* __restrict__ codes,
+__global__ __launch_bounds__(64 * S3_MQW) void maxsim_f16_multiq_kernel(flmr_maxsim_args m, const int32_t* __restrict__ codes,
                                                                    const uint8_t* __restrict__ residuals,
                                                                    const int64_t* __restrict__ doc_offsets,
                                                                    const _Float16* __restrict__ cen16,
@@ -393,8 +394,8 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_multiq_kernel(flmr_maxsim_a
     const int b = blockIdx.x;
     const int cnt = m.counts[b];
     const int qlen = m.q_lens ? m.q_lens[b] : m.nq;
-    for (int t = tid; t < 256 * VPB; t += 256) wlut[t] = wlut_g[t];
-    const int W = gridDim.y * 4, w = blockIdx.y * 4 + wave;
+    for (int t = tid; t < 256 * VPB; t += 64 * S3_MQW) wlut[t] = wlut_g[t];
+    const int W = gridDim.y * S3_MQW, w = blockIdx.y * S3_MQW + wave;
     const int ndw = cnt > w ? (cnt - w + W - 1) / W : 0;  // <= 64 (launcher); idle waves still join the barriers
     int my_pid = 0, my_len = 0;
     int64_t my_off = 0;
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_multiq_kernel(flmr_maxsim_a
     for (int qc0 = 0; qc0 < qlen; qc0 += 32 * S3_QC) {
         const int ntq = ((qlen - qc0 < 32 * S3_QC ? qlen - qc0 : 32 * S3_QC) + 31) >> 5;  // q-tiles in this chunk
         __syncthreads();  // previous chunk fully consumed (also orders the wlut / docsum initialisation)
-        for (int e = tid; e < ntq * 1024; e += 256) {  // 16-byte pieces: [tile][hi|lo][32 rows][16 pieces]
+        for (int e = tid; e < ntq * 1024; e += 64 * S3_MQW) {  // 16-byte pieces: [tile][hi|lo][32 rows][16 pieces]
             const int piece = e & 15, row = (e >> 4) & 31, hl = (e >> 9) & 1, qt = e >> 10;
             const _Float16* src = (hl ? ql_b : qh_b) + (size_t)(qc0 + qt * 32 + row) * FLMR_DIM + piece * 8;  // rows < nqp: zero padded
             *reinterpret_cast<hf8*>(bq + ((qt * 2 + hl) * 32 + row) * S3_BROW + piece * 8) = *reinterpret_cast<const hf8*>(src);
@@ -541,10 +542,15 @@ static int launch_maxsim_f16_t(const flmr_maxsim_args& a, hipStream_t st) {
     if (G < 1) G = 1;
     if (nqp > 32 && getenv("FLMR_S3_NO_MULTIQ") == nullptr) {
         const size_t lds2 = (size_t)256 * (8 / NBITS) * sizeof(float) + (size_t)S3_QC * 2 * 32 * S3_BROW * sizeof(_Float16) +
-                            (size_t)4 * (32 * S3_QC + 64) * sizeof(float);
+                            (size_t)S3_MQW * (32 * S3_QC + 64) * sizeof(float);
+        int G2 = (int)flmr_ceil_div(4096, S3_MQW * (int64_t)a.nqueries);
+        const int g2min = (int)flmr_ceil_div(a.max_count, S3_MQW * 64);
+        if (G2 < g2min) G2 = g2min;
+        if (G2 > (int)flmr_ceil_div(a.max_count, S3_MQW)) G2 = (int)flmr_ceil_div(a.max_count, S3_MQW);
+        if (G2 < 1) G2 = 1;
         FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_f16_multiq_kernel<NBITS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        hipLaunchKernelGGL(maxsim_f16_multiq_kernel<NBITS>, dim3(a.nqueries, G), dim3(256), lds2, st, a, ix->codes,
+        hipLaunchKernelGGL(maxsim_f16_multiq_kernel<NBITS>, dim3(a.nqueries, G2), dim3(64 * S3_MQW), lds2, st, a, ix->codes,
                            ix->residuals, ix->doc_offsets, ix->centroids_f16, ix->wlut, nqp);
     } else {
         hipLaunchKernelGGL(maxsim_f16_kernel<NBITS>, dim3(a.nqueries, G), dim3(256), lds, st, a, ix->codes, ix->residuals,
