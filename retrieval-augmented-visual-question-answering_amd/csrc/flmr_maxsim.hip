@@ -194,19 +194,22 @@ __device__ __forceinline__ void s3_issue_rows(s3_raw<NBITS>& raw, const int* cdr
     constexpr int PACKED = FLMR_DIM * NBITS / 8, NB = 8 * NBITS;
     const int tok = t * 32 + i;
     raw.valid = tok < len;
+    // lanes past the end of the document fetch the document's LAST token instead (finite data, no divergence); their row is
+    // zeroed later by a zero normalisation factor, not by 64 per-element selects
+    const int tokc = raw.valid ? tok : len - 1;
     int code = 0;
     if (t < 8) {  // tokens < 256 were preloaded: register t>>1 of lane (t&1)*32 + i (wave-uniform register choice)
         const int sel = t >> 1;
         const int reg = sel == 0 ? cdreg[0] : sel == 1 ? cdreg[1] : sel == 2 ? cdreg[2] : cdreg[3];
-        code = __shfl(reg, (t & 1) * 32 + i, 64);
-    } else if (raw.valid) {
-        code = codes[off + tok];
+        code = __shfl(reg, (t & 1) * 32 + i, 64);  // (padding lanes read a preloaded 0: centroid row 0)
+    } else {
+        code = codes[off + tokc];
     }
-    if (raw.valid) {
+    {
         const hf8* pc = reinterpret_cast<const hf8*>(cen16 + (size_t)code * FLMR_DIM + 64 * h);
 #pragma unroll
         for (int s = 0; s < 8; s++) raw.c[s] = pc[s];
-        const uint2* pr = reinterpret_cast<const uint2*>(residuals + (size_t)(off + tok) * PACKED + h * NB);
+        const uint2* pr = reinterpret_cast<const uint2*>(residuals + (size_t)(off + tokc) * PACKED + h * NB);
 #pragma unroll
         for (int w = 0; w < NBITS; w++) raw.r[w] = pr[w];
     }
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
 #pragma unroll
                         for (int l = 0; l < VPB; l++) {
                             const int dd = kb * VPB + l;
-                            const float v = raw.valid ? (wv[l] + (float)raw.c[dd >> 3][dd & 7]) : 0.0f;
+                            const float v = wv[l] + (float)raw.c[dd >> 3][dd & 7];
                             d[dd] = v;
                             ss = fmaf(v, v, ss);
                         }
@@ -308,13 +311,15 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
                 ss += __shfl_xor(ss, 32, 64);
                 float nrm = sqrtf(ss);
                 nrm = nrm < 1e-12f ? 1e-12f : nrm;
-                const float inv = 1.0f / nrm;
+                const float inv = raw.valid ? 1.0f / nrm : 0.0f;  // padding rows become exact zeros
 #pragma unroll
                 for (int dd = 0; dd < 64; dd++) {
                     const float v = d[dd] * inv;
                     const _Float16 hi = (_Float16)v;
                     ah[dd >> 3][dd & 7] = hi;
-                    al[dd >> 3][dd & 7] = (_Float16)((v - (float)hi) * 2048.0f);
+                    // (v - hi) * 2048 as one mixed-precision fma on the fp16 register (exactly the same value: v - hi is
+                    // representable, the scalings are powers of two) -- no conversion of hi back to fp32
+                    al[dd >> 3][dd & 7] = (_Float16)fmaf((float)hi, -2048.0f, v * 2048.0f);
                 }
             }
             // ---- prefetch the next tile's rows (this document's next tile, or the next document's first tile) ----
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(64 * S3_MQW) void maxsim_f16_multiq_kernel(flmr_max
 #pragma unroll
                             for (int l = 0; l < VPB; l++) {
                                 const int dd = kb * VPB + l;
-                                const float v = raw.valid ? (wv[l] + (float)raw.c[dd >> 3][dd & 7]) : 0.0f;
+                                const float v = wv[l] + (float)raw.c[dd >> 3][dd & 7];
                                 d[dd] = v;
                                 ss = fmaf(v, v, ss);
                             }
@@ -469,13 +474,13 @@ __global__ __launch_bounds__(64 * S3_MQW) void maxsim_f16_multiq_kernel(flmr_max
                     ss += __shfl_xor(ss, 32, 64);
                     float nrm = sqrtf(ss);
                     nrm = nrm < 1e-12f ? 1e-12f : nrm;
-                    const float inv = 1.0f / nrm;
+                    const float inv = raw.valid ? 1.0f / nrm : 0.0f;  // padding rows become exact zeros
 #pragma unroll
                     for (int dd = 0; dd < 64; dd++) {
                         const float v = d[dd] * inv;
                         const _Float16 hi = (_Float16)v;
                         ah[dd >> 3][dd & 7] = hi;
-                        al[dd >> 3][dd & 7] = (_Float16)((v - (float)hi) * 2048.0f);
+                        al[dd >> 3][dd & 7] = (_Float16)fmaf((float)hi, -2048.0f, v * 2048.0f);  // = (v - hi) * 2048, exactly
                     }
                 }
                 if (t + 1 < ntiles) {
