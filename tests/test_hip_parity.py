@@ -590,3 +590,35 @@ def test_stage1_scatter_equals_code_scan(hip, nbits, doclen, K, npass, policy):
         assert np.array_equal(a[3][q][0], b[3][q][0]), ("stage-1 survivors", q)
         assert np.array_equal(a[3][q][1], b[3][q][1]), ("stage-2 finalists", q)
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+
+@pytest.mark.parametrize("thr,ncells,ndocs", [(0.99, 2, 64), (0.99, 1, 256), (-1.0, 2, 64)])
+def test_degenerate_thresholds_and_empty_passages_vs_oracle(hip, thr, ncells, ndocs):
+    """Edge cases of the pruning stages against the CPU oracle: a threshold no centroid reaches (every candidate gets the
+    all-miss stage-1 score, so the top-ndocs cut is decided by the (score, pid) tie order alone -- the priority-queue order
+    of filter_pids.cpp:24), a threshold every centroid passes (hit_valid = 0: the code-scanning stage 1 runs), and a corpus
+    that contains EMPTY passages (doclen 0) and one-token passages."""
+    from oracle import oracle as orc
+    torch = hip["torch"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    corpus = synth.make_corpus(3000, (0, 12), 256, 2, seed=91, device="cuda")
+    assert int((corpus.doclens == 0).sum()) > 50
+    Q, _ = synth.make_queries(corpus, 6, 32, seed=3)
+    arrays = synth.corpus_to_arrays(corpus)
+    assert arrays.check_ivf_invariant()
+    scorer = IndexScorer(arrays=arrays)
+    oi = orc.OracleIndex(arrays.dim, arrays.nbits, arrays.codes, arrays.residuals, arrays.doclens, arrays.ivf,
+                         arrays.ivf_lengths, arrays.centroids, arrays.bucket_weights)
+    p, s, c = scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32)
+    Qh = Q.cpu().numpy()
+    checked = 0
+    for i in range(Q.size(0)):
+        rp, rs, ncand = oi.rank(Qh[i], ncells, thr, ndocs, 32)
+        n = int(c[i])
+        if ncand < ndocs:   # the reference's behaviour is undefined there (SURVEY 8c); this build keeps every candidate
+            assert n == min(ncand, ndocs // 4)
+            continue
+        tie_aware_equal(rp, rs, p[i, :n].cpu().numpy(), s[i, :n].cpu().numpy(), tol=SCORE_TOL)
+        checked += 1
+    assert checked >= 1
