@@ -50,12 +50,14 @@ int flmr_build_chunk_table(const int32_t* ivf_pids, const int64_t* ivf_offsets, 
 
 // ---- qualifying centroids of each query: compact list of the set bits of idx (if few enough) -------------------------
 // grid = nqueries, block = 1024.  hit_valid[q] = 1 when the list fits and the qualifying lists are not longer than
-// twice the probed-cell lists (otherwise marking would cost more than it saves and stage 1 scans every candidate).
+// `ratio` times the probed-cell lists: 2 when the hit set only prefilters the code-scanning stage 1 (beyond that marking
+// costs more than it saves), 8 when stage 1 itself is computed from those lists (32 LDS atomics per (centroid, passage)
+// pair against ~128 code reads per candidate).
 __global__ __launch_bounds__(1024) void qualifying_kernel(const uint32_t* idx_bits, int idx_words,
                                                           const int64_t* ivf_offsets, const int32_t* cells,
                                                           const int32_t* ncell, int max_cells, int32_t* qual,
                                                           int32_t* nqual, int qmax, int32_t* hit_valid,
-                                                          int32_t* key_count) {
+                                                          int32_t* key_count, int ratio) {
     __shared__ int scan_lds[17];
     __shared__ unsigned long long tot_q, tot_c;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(1024) void qualifying_kernel(const uint32_t* idx_bi
     __syncthreads();
     if (tid == 0) {
         nqual[b] = base < qmax ? base : qmax;
-        hit_valid[b] = (base <= qmax) && (tot_q <= 2ull * tot_c);
+        hit_valid[b] = (base <= qmax) && (tot_q <= (unsigned long long)ratio * tot_c);
         if (key_count) key_count[b] = 0;
     }
 }
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(1024) void cand_emit_kernel(const uint32_t* cand_bi
 
 int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
     hipLaunchKernelGGL(qualifying_kernel, dim3(a.nqueries), dim3(1024), 0, st, a.idx_bits, a.idx_words, a.ivf_offsets, a.cells,
-                       a.ncell, a.max_cells, a.qual, a.nqual, a.qmax, a.hit_valid, a.scatter ? a.key_count : nullptr);
+                       a.ncell, a.max_cells, a.qual, a.nqual, a.qmax, a.hit_valid, a.scatter ? a.key_count : nullptr, a.scatter ? 8 : 2);
     if (a.scatter) {
         const size_t lds = (size_t)CAND_CHUNK_WORDS * (2 * sizeof(uint32_t) + 2 * sizeof(uint16_t)) +
                            (size_t)S1S_SLOTS * S1S_STRIDE * sizeof(int);
