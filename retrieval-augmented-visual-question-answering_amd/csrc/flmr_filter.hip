@@ -893,24 +893,36 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys,
     // Output positions come from a block scan of per-thread counts, not from an atomic counter: the selected SET is what
     // matters to the next stage, but a reproducible ORDER (a function of the input only) lets every rank of the sharded
     // protocol derive the same list from the same gathered keys.
+    // Keys above the threshold are all kept; keys EQUAL to it (one key, or many empty keys = 0 when a row holds fewer than n
+    // real keys) only fill what is left -- otherwise a run of empty keys met first in scan order could displace real ones.
     const unsigned long long thr = s_prefix;
     __shared__ int sel_scan[17];
-    int mine = 0;
+    int mine_gt = 0, mine_eq = 0;
 #pragma unroll
-    for (int j = 0; j < KPT; j++) mine += (j * 1024 + tid < P && kreg[j] >= thr) ? 1 : 0;
+    for (int j = 0; j < KPT; j++) {
+        const bool v = j * 1024 + tid < P;
+        mine_gt += (v && kreg[j] > thr) ? 1 : 0;
+        mine_eq += (v && kreg[j] == thr) ? 1 : 0;
+    }
     for (int i0 = KPT * 1024; i0 < P; i0 += 4 * 1024) {  // (the tail: 4 loads in flight)
         uint64_t kk[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) kk[u] = (i0 + u * 1024 + tid < P) ? kb[i0 + u * 1024 + tid] : 0ull;
 #pragma unroll
-        for (int u = 0; u < 4; u++) mine += (i0 + u * 1024 + tid < P && kk[u] >= thr) ? 1 : 0;
+        for (int u = 0; u < 4; u++) {
+            const bool v = i0 + u * 1024 + tid < P;
+            mine_gt += (v && kk[u] > thr) ? 1 : 0;
+            mine_eq += (v && kk[u] == thr) ? 1 : 0;
+        }
     }
-    int total;
-    int pos = flmr_block_exclusive_scan(mine, sel_scan, &total);
+    int total_gt, total_eq;
+    int pos_gt = flmr_block_exclusive_scan(mine_gt, sel_scan, &total_gt);
+    __syncthreads();
+    int pos_eq = total_gt + flmr_block_exclusive_scan(mine_eq, sel_scan, &total_eq);
     auto emit = [&](bool valid, uint64_t key) {
         if (valid && key >= thr) {
+            const int pos = key > thr ? pos_gt++ : pos_eq++;
             if (pos < n) { if (ob) ob[pos] = flmr_key_pid(key); if (okb) okb[pos] = key + key_add; }
-            pos++;
         }
     };
 #pragma unroll
@@ -922,7 +934,7 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys,
 #pragma unroll
         for (int u = 0; u < 4; u++) emit(i0 + u * 1024 + tid < P, kk[u]);
     }
-    if (tid == 0 && n_out) n_out[b] = total < n ? total : n;
+    if (tid == 0 && n_out) n_out[b] = (total_gt + total_eq) < n ? (total_gt + total_eq) : n;
 }
 
 int flmr_launch_select_topn(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t nqueries,
