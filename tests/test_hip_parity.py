@@ -442,7 +442,8 @@ def test_query_split_stage0_equals_unsharded(hip, nshards):
     Q = torch.stack([torch.from_numpy(z[f"{r}.Q"]) for r in recs]).repeat(4, 1, 1)[:7]   # 7 queries: ragged slices
     B = Q.size(0)
     per = -(-B // nshards)
-    for (k, ncells, thr, ndocs) in [(100, 2, 0.45, 1024), (10, 1, 0.5, 64), (10, 2, -1.0, 64)]:   # thr=-1: every centroid qualifies
+    # thr=-1: every centroid qualifies; ndocs=4096 > #passages: every exchanged list is mostly empty keys
+    for (k, ncells, thr, ndocs) in [(100, 2, 0.45, 1024), (10, 1, 0.5, 64), (10, 2, -1.0, 64), (200, 4, 0.4, 4096)]:
         p_ref, s_ref, c_ref = single.search_batch(Q, k, ncells, thr, ndocs, 32)
 
         def exchange(keys_per_rank, n, ordered=False):   # the intermediate exchanges use the unordered radix select
