@@ -208,6 +208,7 @@ def main():
             nqs = min(args.cpu_queries, args.batch)
             Qh = Q[:nqs].cpu()
             same5 = 0
+            parity_note = ""
             if orc.ref_available():
                 ref = orc.RefCpuScorer(oi)
                 ref.rank(Qh[0], ncells, thr, ndocs)   # warm
@@ -216,6 +217,23 @@ def main():
                 tc = time.perf_counter() - t0
                 kind, cores = "reference", torch.get_num_threads()
                 same5 = sum(res[i][0][:5] == p[i, :5].tolist() for i in range(nqs))
+                # full top-k against the reference: ids position by position, swaps allowed only inside runs of reference
+                # scores closer than 1e-5 (another valid fp32 summation order may swap those); scores by pid
+                samek, maxd = 0, 0.0
+                for i in range(nqs):
+                    rp_, rs_ = res[i][0][:k], res[i][1][:k]
+                    gp_, gs_ = p[i, :k].tolist(), s[i, :k].tolist()
+                    got = dict(zip(gp_, gs_))
+                    ok, a0 = len(rp_) == len(gp_), 0
+                    while ok and a0 < len(rp_):
+                        a1 = a0
+                        while a1 + 1 < len(rp_) and abs(rs_[a1] - rs_[a1 + 1]) <= 1e-5:
+                            a1 += 1
+                        ok = sorted(rp_[a0:a1 + 1]) == sorted(gp_[a0:a1 + 1])
+                        a0 = a1 + 1
+                    samek += int(ok)
+                    maxd = max([maxd] + [abs(got[q_] - v_) for q_, v_ in zip(rp_, rs_) if q_ in got])
+                parity_note = f"; top-{k} ids identical (tie-aware) for {samek}/{nqs}, max |score diff| {maxd:.2e}"
             else:
                 t0 = time.perf_counter()
                 rp, _, _ = oi.search_batch(Qh.numpy(), k, ncells, thr, ndocs)
@@ -224,7 +242,7 @@ def main():
                 same5 = sum(rp[i, :5].tolist() == p[i, :5].tolist() for i in range(nqs))
             cpu = {"value": nqs / tc, "unit": "queries/sec", "cores": cores, "kind": kind,
                    "sample": f"first {nqs} queries of the same batch on the same 1-GPU index, one query per call "
-                             f"(reference semantics); top-5 ids identical to the GPU result for {same5}/{nqs}"}
+                             f"(reference semantics); top-5 ids identical to the GPU result for {same5}/{nqs}" + parity_note}
         except Exception as e:  # the baseline must never take the bench line down
             cpu = {"value": None, "unit": "queries/sec", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
 
