@@ -245,6 +245,8 @@ def test_searcher_dropin_api(hip, tmp_path):
     (2, (200, 420), 32, 32, 1024, (1, 0.5, 64)),        # documents longer than 256 tokens (on-demand code loads), ncells=1
     (2, (1, 60), 32, 32, 1000, (2, 0.45, 256)),         # K not a multiple of 64 -> fp32-MFMA S0 + table path
     (2, 32, 64, 32, 4096, (4, 0.4, 4096)),              # the k > 100 policy of searcher.py:108-118
+    (2, (8, 64), 32, 32, 2048, (8, 0.4, 1024)),         # ncells = 8: the widest per-token cell list the build supports
+    (2, (8, 64), 40, 32, 2048, (3, 0.5, 512)),          # ncells = 3 (runs in the 4-wide instantiation)
 ])
 def test_random_corpus_vs_oracle(hip, nbits, doclen, nq, nq_cand, K, policy):
     """Seeded synthetic corpora at sizes the oracle finishes in seconds: ragged / long docs, Nq != 32, two column tiles,
@@ -442,9 +444,10 @@ def test_query_split_stage0_equals_unsharded(hip, nshards):
     Q = torch.stack([torch.from_numpy(z[f"{r}.Q"]) for r in recs]).repeat(4, 1, 1)[:7]   # 7 queries: ragged slices
     B = Q.size(0)
     per = -(-B // nshards)
+    q_lens = torch.tensor([32, 17, 32, 1, 32, 32, 25], dtype=torch.int32)
     # thr=-1: every centroid qualifies; ndocs=4096 > #passages: every exchanged list is mostly empty keys
     for (k, ncells, thr, ndocs) in [(100, 2, 0.45, 1024), (10, 1, 0.5, 64), (10, 2, -1.0, 64), (200, 4, 0.4, 4096)]:
-        p_ref, s_ref, c_ref = single.search_batch(Q, k, ncells, thr, ndocs, 32)
+        p_ref, s_ref, c_ref = single.search_batch(Q, k, ncells, thr, ndocs, 32, q_lens=q_lens)
 
         def exchange(keys_per_rank, n, ordered=False):   # the intermediate exchanges use the unordered radix select
             g = torch.stack(keys_per_rank)
@@ -453,20 +456,20 @@ def test_query_split_stage0_equals_unsharded(hip, nshards):
         parts = []
         for r, sh in enumerate(shards):
             lo = min(B, r * per)
-            parts.append(sh.probe(Q, k, ncells, thr, ndocs, lo, min(B, lo + per) - lo, 32))
+            parts.append(sh.probe(Q, k, ncells, thr, ndocs, lo, min(B, lo + per) - lo, 32, q_lens=q_lens))
         bits, cells, ncell = (torch.cat([p_[j] for p_ in parts]) for j in range(3))
         # the probe state must equal what the unsharded search computed
         for q in range(B):
-            single.search_batch(Q[q:q + 1], k, ncells, thr, ndocs, 32)
+            single.search_batch(Q[q:q + 1], k, ncells, thr, ndocs, 32, q_lens=q_lens[q:q + 1])
             ref_bits = single.tap(pkg._native.TAP_IDX_BITS, 0).view(np.int32)
             assert np.array_equal(bits[q].cpu().numpy(), ref_bits), q
             ref_cells = single.tap(pkg._native.TAP_CELLS, 0)
             assert np.array_equal(cells[q, :int(ncell[q])].cpu().numpy(), ref_cells), q
-        s1 = exchange([sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32) for sh in shards], ndocs)
-        s1_sorted = exchange([sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32) for sh in shards], ndocs, ordered=True)
+        s1 = exchange([sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32, q_lens=q_lens) for sh in shards], ndocs)
+        s1_sorted = exchange([sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32, q_lens=q_lens) for sh in shards], ndocs, ordered=True)
         # every rank derives this list on its own from the same gathered keys: the select must be reproducible
         for _ in range(3):
-            assert torch.equal(s1, exchange([sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32) for sh in shards], ndocs))
+            assert torch.equal(s1, exchange([sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32, q_lens=q_lens) for sh in shards], ndocs))
         u = lambda t: t.cpu().numpy().view(np.uint64)                                   # keys are u64 bit patterns
         assert np.array_equal(np.sort(u(s1), axis=1)[:, ::-1], u(s1_sorted))             # same set as the bitonic top-n
         # phase-2/3 outputs are slot-aligned with the global list: one non-zero contributor per slot -> SUM "all-reduce"
