@@ -657,3 +657,60 @@ def test_key_selection_kernels_on_crafted_rows(hip):
         assert torch.equal(a, b), (m, n, "reproducible")
         got_set = np.sort(a.cpu().numpy().view(np.uint64), axis=1)[:, ::-1]
         assert np.array_equal(got_set, ref), (m, n, "unordered set")
+
+
+def test_c_abi_reports_errors_instead_of_crashing(hip, scorers):
+    """Boundary behaviour (status codes, no exceptions across the C ABI, thread-local message): out-of-range
+    parameters, NULL pointers and capacity violations return the documented status with a message; nothing is launched."""
+    import ctypes as C
+    torch, nat = hip["torch"], hip["native"]
+    lib = nat.load()
+    z, scorer = scorers["idx_nb2"]
+    ix = scorer.device_index.handle
+    OK, INVALID, UNSUPPORTED, CAPACITY = 0, 1, 2, 5
+
+    def params(k=10, ncells=2, thr=0.45, ndocs=64, nq_cand=32):
+        return nat.SearchParams(k, ncells, thr, ndocs, nq_cand)
+
+    h = C.c_void_p()
+    for bad, want in ((params(ncells=9), UNSUPPORTED), (params(ncells=0), UNSUPPORTED), (params(ndocs=2), UNSUPPORTED),
+                      (params(ndocs=1 << 20), UNSUPPORTED), (params(nq_cand=0), UNSUPPORTED), (params(k=0), INVALID)):
+        assert lib.flmr_searcher_create(ix, 4, 32, C.byref(bad), C.byref(h)) == want
+        assert len(lib.flmr_last_error()) > 0 and not h.value
+    assert lib.flmr_searcher_create(None, 4, 32, C.byref(params()), C.byref(h)) == INVALID
+    assert lib.flmr_searcher_create(ix, 0, 32, C.byref(params()), C.byref(h)) == INVALID
+    assert lib.flmr_searcher_create(ix, 4, 32, C.byref(params()), C.byref(h)) == OK and h.value
+    try:
+        Q = torch.randn(8, 32, 128, device="cuda")
+        out_p = torch.empty((8, 10), dtype=torch.int32, device="cuda")
+        out_s = torch.empty((8, 10), dtype=torch.float32, device="cuda")
+        out_c = torch.empty((8,), dtype=torch.int32, device="cuda")
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        st = nat.stream_ptr()
+        p = params()
+        # more queries / longer queries / wider policy than the workspace was created for
+        assert lib.flmr_search_batch(h, ptr(Q), None, 8, 32, C.byref(p), ptr(out_p), ptr(out_s), ptr(out_c), st) == CAPACITY
+        assert lib.flmr_search_batch(h, ptr(Q), None, 4, 33, C.byref(p), ptr(out_p), ptr(out_s), ptr(out_c), st) == CAPACITY
+        assert lib.flmr_search_batch(h, ptr(Q), None, 4, 32, C.byref(params(ndocs=128)), ptr(out_p), ptr(out_s), ptr(out_c), st) == CAPACITY
+        assert lib.flmr_search_batch(h, ptr(Q), None, 4, 32, C.byref(params(ncells=4)), ptr(out_p), ptr(out_s), ptr(out_c), st) == CAPACITY
+        assert lib.flmr_search_batch(h, None, None, 4, 32, C.byref(p), ptr(out_p), ptr(out_s), ptr(out_c), st) == INVALID
+        assert lib.flmr_search_batch(h, ptr(Q), None, 4, 32, C.byref(p), None, ptr(out_s), ptr(out_c), st) == INVALID
+        assert lib.flmr_search_batch(h, ptr(Q), None, 0, 32, C.byref(p), ptr(out_p), ptr(out_s), ptr(out_c), st) == CAPACITY
+        # the phased protocol insists on ndocs == the workspace's ndocs; the probe slice must lie inside the batch
+        keys = torch.empty((4, 64), dtype=torch.int64, device="cuda")
+        assert lib.flmr_search_phase1(h, ptr(Q), None, 4, 32, C.byref(params(ndocs=32)), ptr(keys), st) == INVALID
+        iw, mc = C.c_int32(0), C.c_int32(0)
+        assert lib.flmr_searcher_probe_dims(h, C.byref(iw), C.byref(mc)) == OK and iw.value > 0 and mc.value == 64
+        bits = torch.empty((4, iw.value), dtype=torch.int32, device="cuda")
+        cells = torch.empty((4, mc.value), dtype=torch.int32, device="cuda")
+        ncell = torch.empty((4,), dtype=torch.int32, device="cuda")
+        assert lib.flmr_search_probe(h, ptr(Q), None, 4, 32, C.byref(p), 2, 3, ptr(bits), ptr(cells), ptr(ncell), st) == INVALID
+        # and a valid call still works afterwards
+        assert lib.flmr_search_batch(h, ptr(Q), None, 4, 32, C.byref(p), ptr(out_p), ptr(out_s), ptr(out_c), st) == OK
+        torch.cuda.synchronize()
+        # op-level entry points
+        assert lib.flmr_select_keys(None, 4, 64, 16, ptr(keys), st) == INVALID
+        assert lib.flmr_select_keys(ptr(keys), 4, 0, 16, ptr(keys), st) == INVALID
+        assert lib.flmr_compress_residuals(ptr(Q), 128, ptr(Q), ptr(out_c), 8, ptr(out_s), 3, ptr(out_p), st) == UNSUPPORTED
+    finally:
+        lib.flmr_searcher_destroy(h)
