@@ -8,53 +8,102 @@ policy INCLUDING its stickiness (the first call's k fixes the values on self.con
 
 What differs: `_search_all_Q` runs all queries as device batches (the reference loops query by query,
 searcher.py:75-79) unless a `filter_fn` is supplied, in which case it stages per query so the callable sees the
-same ascending int32 pid tensor.  Query ENCODING (Checkpoint / BERT forward) is outside this build's scope: pass
-`query_encoder=callable(list[str]) -> Tensor[n, Nq, dim]` if `search()` / `search_all()` on text are needed.
-`config.total_visible_gpus == 0` does NOT mean "stay on the host": the HIP path always runs, with the CPU
-path's numerics.
+same ascending int32 pid tensor.  Query ENCODING (Checkpoint / BERT forward) is outside this build's scope: the
+reference's `Checkpoint` is built lazily on the first `encode()` when its class is available (`ravqa_amd.install()`
+binds it), or pass `query_encoder=callable(list[str]) -> Tensor[n, Nq, dim]`.
+
+Boundary value types are class attributes (`ColBERTConfig`, `Run`, `Collection`, `Queries`, `Ranking`, `Provenance`,
+`IndexScorer`, `Checkpoint`): this module binds this package's own host-side mirrors; `ravqa_amd.dropin.install()`
+derives a subclass bound to the reference package's classes, so that inside the RA-VQA executors the objects that
+go in (`ColBERTConfig`, `Queries`, the `Run()` context) and come out (`Ranking`, `.config`) ARE the reference's.
+
+Numerics: `config.total_visible_gpus == 0` selects the reference's CPU-path numerics (fp32, zero-clamped MaxSim) --
+it does NOT mean "stay on the host", the HIP path always runs.  `total_visible_gpus > 0` selects the reference's
+CUDA-path numerics in the reference (fp16 centroids / embeddings, -9999 padding, `index_storage.py:113-149`); see
+`IndexScorer` for how this build treats that request.
 """
 import os
+import warnings
 
 import torch
 
-from .config import ColBERTConfig, Run
-from .data import Collection, Provenance, Queries, Ranking
-from .scorer import IndexScorer
+from . import config as _config
+from . import data as _data
+from .scorer import IndexScorer as _IndexScorer
 
 
 class Searcher:
+    # boundary types (see module docstring)
+    ColBERTConfig = _config.ColBERTConfig
+    Run = _config.Run
+    Collection = _data.Collection
+    Queries = _data.Queries
+    Ranking = _data.Ranking
+    Provenance = _data.Provenance
+    IndexScorer = _IndexScorer
+    Checkpoint = None   # the reference's colbert.modeling.checkpoint.Checkpoint when installed over the reference package
+
     def __init__(self, index, checkpoint=None, collection=None, config=None, disable_gpu=True, query_encoder=None,
                  max_batch=256):
-        initial_config = ColBERTConfig.from_existing(config, Run().config)
-        if config is not None:
+        cfg_cls = self.ColBERTConfig
+        initial_config = cfg_cls.from_existing(config, self.Run().config)
+        if config is not None:  # searcher.py:27 (the reference dereferences `config` unconditionally)
             initial_config.total_visible_gpus = config.total_visible_gpus
         self.index = os.path.join(initial_config.index_root_, index)
-        self.index_config = ColBERTConfig.load_from_index(self.index)
+        self.index_config = cfg_cls.load_from_index(self.index)
         self.checkpoint = checkpoint or self.index_config.checkpoint
-        self.checkpoint_config = ColBERTConfig.load_from_checkpoint(self.checkpoint) if isinstance(self.checkpoint, str) else None
-        self.config = ColBERTConfig.from_existing(self.checkpoint_config, self.index_config, initial_config)
-        self.collection = Collection.cast(collection if collection is not None else
-                                          (self.config.collection if isinstance(self.config.collection, (str, list)) else None))
-        self.configure(checkpoint=self.checkpoint)
+        self.checkpoint_config = cfg_cls.load_from_checkpoint(self.checkpoint) if isinstance(self.checkpoint, str) else None
+        self.config = cfg_cls.from_existing(self.checkpoint_config, self.index_config, initial_config)
+        self.collection = self._cast_collection(collection if collection is not None else self.config.collection)
+        self.configure(checkpoint=self.checkpoint, collection=self.collection)
         self.query_encoder = query_encoder
-        self.ranker = IndexScorer(self.index, use_gpu=True, max_batch=max_batch)
+        self._checkpoint_model = None
+        use_gpu = (self.config.total_visible_gpus or 0) > 0
+        if use_gpu and config is not None and "total_visible_gpus" in getattr(config, "assigned", {}):
+            # the caller asked for the reference's CUDA branch (searcher.py:42-45): say what it gets instead
+            warnings.warn("total_visible_gpus > 0 selects the reference's CUDA-path numerics (fp16 centroid scores and "
+                          "embeddings, -9999 padding, index_storage.py:113-158); this build always computes the CPU-path "
+                          "numerics (fp32, zero-clamped MaxSim) on the MI355X -- rankings can differ from a reference "
+                          "single-GPU run in near-ties.  Pass total_visible_gpus=0 to silence this.", stacklevel=2)
+        self.ranker = self.IndexScorer(self.index, use_gpu, max_batch=max_batch)
+
+    def _cast_collection(self, obj):
+        """Collection.cast, but lazy: the search path never reads passage text, so a missing / unset collection is not
+        an error here (the reference would fail in Collection.cast(None), searcher.py:39)."""
+        if obj is None:
+            return None
+        if isinstance(obj, str) and not os.path.exists(obj):
+            return obj
+        try:
+            return self.Collection.cast(obj)
+        except AssertionError:
+            return obj
 
     def configure(self, **kw_args):
         self.config.configure(**kw_args)
 
     # ---- text entry points (need an encoder) ------------------------------------------------------------------
     def encode(self, text):
-        if self.query_encoder is None:
-            raise NotImplementedError("query encoding (Checkpoint.queryFromText) is outside the retrieval hot path; "
-                                      "construct Searcher(..., query_encoder=fn) or call _search_all_Q with embeddings")
         queries = text if isinstance(text, list) else [text]
-        return self.query_encoder(queries)
+        if self.query_encoder is not None:
+            return self.query_encoder(queries)
+        if self.Checkpoint is None:
+            raise NotImplementedError("query encoding (Checkpoint.queryFromText) is outside the retrieval hot path; "
+                                      "construct Searcher(..., query_encoder=fn), call ravqa_amd.install() so the "
+                                      "reference's Checkpoint is used, or call _search_all_Q with embeddings")
+        if self._checkpoint_model is None:  # searcher.py:41-45, deferred to the first text query
+            self._checkpoint_model = self.Checkpoint(self.checkpoint, colbert_config=self.config)
+            if torch.cuda.is_available():
+                self._checkpoint_model = self._checkpoint_model.cuda()
+        bsize = 128 if len(queries) > 128 else None
+        self._checkpoint_model.query_tokenizer.query_maxlen = self.config.query_maxlen
+        return self._checkpoint_model.queryFromText(queries, bsize=bsize, to_cpu=True)
 
     def search(self, text, k=10, filter_fn=None):
         return self.dense_search(self.encode(text), k, filter_fn=filter_fn)
 
     def search_all(self, queries, k=10, filter_fn=None):
-        queries = Queries.cast(queries)
+        queries = self.Queries.cast(queries)
         Q = self.encode(list(queries.values()))
         return self._search_all_Q(queries, Q, k, filter_fn=filter_fn)
 
@@ -103,12 +152,12 @@ class Searcher:
             for i, n in enumerate(counts):
                 all_scored.append(list(zip(pids[i, :n].tolist(), range(1, k + 1), scores[i, :n].tolist())))
         data = dict(zip(qids, all_scored))
-        provenance = Provenance()
+        provenance = self.Provenance()
         provenance.source = "Searcher::search_all"
         provenance.queries = queries.provenance() if hasattr(queries, "provenance") else None
         provenance.config = self.config.export()
         provenance.k = k
-        return Ranking(data=data, provenance=provenance)
+        return self.Ranking(data=data, provenance=provenance)
 
     def dense_search(self, Q, k=10, filter_fn=None, remove_zero_tensors=False):
         self._apply_k_policy(k)

@@ -1,0 +1,150 @@
+"""Level-1 drop-in (`ravqa_amd.install()`): the reference's `colbert` package patched in place.
+
+* test_install_over_reference_package: build container only (needs /root/reference).  A fresh interpreter imports the
+  REFERENCE's colbert (with the scratch shims of tests/golden/_shims), calls install(), executes the exact import
+  lines of src/executors/FLMR_executor.py:46-54,99 and src/models/retriever/FLMR.py:7 (read from the checkout at test
+  time), builds the executor's ColBERTConfig, and constructs Searcher(index=..., config=<reference ColBERTConfig>)
+  inside the reference's Run().context up to the point where the native scorer would be created.
+* test_install_mechanics_on_stand_in_package: same bindings against tests/fake_colbert.py (runs anywhere).
+The `-m gpu` counterpart that really searches through the patched names is tests/test_hip_parity.py::
+test_installed_searcher_through_patched_names.
+"""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+REF = os.environ.get("FLMR_REFERENCE_ROOT", "/root/reference")
+HAVE_REF = os.path.isdir(os.path.join(REF, "third_party", "ColBERT", "colbert"))
+
+_SCRIPT = r"""
+import json, os, sys, re
+REF, ROOT, TMP = sys.argv[1], sys.argv[2], sys.argv[3]
+sys.path.insert(0, os.path.join(REF, "third_party", "ColBERT"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden", "_shims"))
+sys.path.insert(0, ROOT)
+import numpy as np, torch, transformers
+if not hasattr(transformers, "AdamW"):
+    transformers.AdamW = torch.optim.AdamW
+import colbert                                   # the REFERENCE package
+ref_searcher, ref_indexer = colbert.Searcher, colbert.Indexer
+import colbert.search.index_storage as ixs
+ref_scorer = ixs.IndexScorer
+import ravqa_amd
+Installed = ravqa_amd.install()
+assert ravqa_amd.install() is Installed           # idempotent
+
+# ---- the executors' own import lines, verbatim from the checkout ----------------------------------------------
+def lines(path, lo, hi):
+    with open(os.path.join(REF, path)) as f:
+        src = f.read().split("\n")
+    return [l.strip() for l in src[lo - 1:hi] if re.match(r"\s*(from colbert|import colbert)", l)]
+imports = lines("src/executors/FLMR_executor.py", 46, 54) + lines("src/executors/FLMR_executor.py", 99, 99) + \
+          lines("src/models/retriever/FLMR.py", 7, 7) + lines("src/models/rag/rag_model_blip.py", 30, 34)
+assert len(imports) >= 8, imports
+ns = {}
+for l in imports:
+    exec(l, ns)
+assert ns["Searcher"] is Installed and colbert.searcher.Searcher is Installed
+assert ns["Indexer"] is ref_indexer                                   # indexing stays with the reference
+assert issubclass(ns["ColBERT"], torch.nn.Module)                      # FLMR.py:7 can still subclass it
+assert ns["ColBERTConfig"].__module__.startswith("colbert.infra")      # the reference's own config class
+assert ixs.IndexScorer is ravqa_amd.IndexScorer and colbert.searcher.IndexScorer is ravqa_amd.IndexScorer
+# FLMR_executor.py:129-134
+cc = ns["ColBERTConfig"](bsize=None, use_ib_negatives=True, checkpoint="bert-base-uncased", rank=0)
+assert cc.use_ib_negatives is True and cc.checkpoint == "bert-base-uncased"
+
+# ---- FLMR_executor.py:774-794 up to the native scorer ------------------------------------------------------------
+Run, RunConfig, ColBERTConfig, Queries = ns["Run"], ns["RunConfig"], ns["ColBERTConfig"], ns["Queries"]
+z = dict(np.load(os.path.join(ROOT, "tests", "golden", "idx_nb2.npz")))
+index_dir = os.path.join(TMP, "temp_index_0", "indexes", "temp_index.nbits=2")
+ravqa_amd.IndexArrays.from_golden(z).save(index_dir)
+calls = []
+class RecordingScorer:
+    def __init__(self, index_path, use_gpu=True, max_batch=256):
+        calls.append((index_path, use_gpu))
+    def search_batch(self, Q, k, ncells, thr, ndocs, nq_cand=32, q_lens=None):
+        calls.append(("search_batch", tuple(Q.shape), k, ncells, thr, ndocs, nq_cand))
+        n = Q.size(0)
+        return (torch.arange(n * k, dtype=torch.int32).view(n, k), torch.ones(n, k), torch.full((n,), k, dtype=torch.int32))
+Installed.IndexScorer = RecordingScorer
+with Run().context(RunConfig(nranks=1, rank=0, root=TMP, experiment="temp_index_0")):
+    config = ColBERTConfig(total_visible_gpus=0)
+    searcher = ns["Searcher"](index="temp_index.nbits=2", config=config)
+    assert calls[0] == (index_dir, False), calls
+    assert isinstance(searcher.config, ColBERTConfig) and searcher.config.nbits == 2 and searcher.config.dim == 128
+    assert searcher.config.total_visible_gpus == 0 and searcher.config.root == TMP
+    queries = Queries(data={7: "what is this", 9: "and this"})
+    ranking = searcher._search_all_Q(queries, torch.zeros(2, 32, 128), k=5)
+    assert type(ranking).__module__.startswith("colbert.data")         # the reference's Ranking comes back
+    d = ranking.todict()
+    assert list(d) == [7, 9] and d[9][0] == (5, 1, 1.0) and len(d[7]) == 5
+    assert calls[1] == ("search_batch", (2, 32, 128), 5, 2, 0.45, 1024, 32), calls
+    assert searcher.config.ndocs == 1024                                 # the policy is sticky on the config (searcher.py:92-118)
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ns["Searcher"](index="temp_index.nbits=2", config=ColBERTConfig(total_visible_gpus=1))
+    assert any("CUDA-path numerics" in str(x.message) for x in w) and calls[-1] == (index_dir, True)
+
+ravqa_amd.uninstall()
+assert colbert.Searcher is ref_searcher and ixs.IndexScorer is ref_scorer and colbert.searcher.IndexScorer is ref_scorer
+
+# ---- level "ops": the four extension attributes --------------------------------------------------------------
+from colbert.search.strided_tensor import StridedTensor
+from colbert.modeling.colbert import ColBERT
+names = ravqa_amd.install(level="ops")
+assert sorted(names) == ["decompress_residuals", "filter_pids", "segmented_lookup", "segmented_maxsim"]
+from ravqa_amd import ops
+assert ixs.IndexScorer.filter_pids is ops.filter_pids and ixs.IndexScorer.decompress_residuals is ops.decompress_residuals
+assert StridedTensor.segmented_lookup is ops.segmented_lookup and ColBERT.segmented_maxsim is ops.segmented_maxsim
+assert ixs.IndexScorer.loaded_extensions and StridedTensor.loaded_extensions and ColBERT.loaded_extensions
+ravqa_amd.uninstall()
+assert "filter_pids" not in ixs.IndexScorer.__dict__ and "loaded_extensions" not in ColBERT.__dict__
+print("DROPIN-OK")
+"""
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="needs the reference checkout (build container only)")
+def test_install_over_reference_package(tmp_path):
+    env = dict(os.environ, TORCH_EXTENSIONS_DIR=str(tmp_path / "ext"), PYTHONPATH="")
+    r = subprocess.run([sys.executable, "-c", _SCRIPT, REF, ROOT, str(tmp_path)], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert r.returncode == 0 and "DROPIN-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_install_mechanics_on_stand_in_package(tmp_path):
+    import fake_colbert
+    import ravqa_amd
+    cleanup = fake_colbert.make(str(tmp_path / "pkg"))
+    try:
+        import colbert
+        import colbert.search.index_storage as ixs
+        ref_searcher = colbert.Searcher
+        late = type(sys)("late_importer")            # a module that did `from colbert import Searcher` before install()
+        late.Searcher = colbert.Searcher
+        sys.modules["late_importer"] = late
+        Installed = ravqa_amd.install()
+        assert colbert.Searcher is Installed and colbert.searcher.Searcher is Installed and late.Searcher is Installed
+        assert ixs.IndexScorer is ravqa_amd.IndexScorer and colbert.Indexer.marker == "reference-indexer"
+        assert issubclass(Installed, ravqa_amd.Searcher) and Installed.reference_class is ref_searcher
+        assert Installed.Queries is colbert.data.Queries and Installed.Run is colbert.infra.Run
+        ravqa_amd.uninstall()
+        assert colbert.Searcher is ref_searcher and late.Searcher is ref_searcher and ixs.IndexScorer.marker == "reference-index-scorer"
+    finally:
+        ravqa_amd.uninstall()
+        sys.modules.pop("late_importer", None)
+        cleanup()
+
+
+def test_install_needs_the_reference_package(tmp_path):
+    import ravqa_amd
+    assert "colbert" not in sys.modules
+    with pytest.raises(ImportError, match="patches that package in place"):
+        ravqa_amd.install(package="colbert_not_there")

@@ -237,6 +237,43 @@ def test_searcher_dropin_api(hip, tmp_path):
         tie_aware_equal(fin[order], ref[order], pids_f, scores_f, tol=SCORE_TOL)
 
 
+def test_installed_searcher_through_patched_names(hip, tmp_path):
+    """Level-1 drop-in on the device: `ravqa_amd.install()` over a `colbert` package tree (the stand-in of
+    tests/fake_colbert.py -- the reference checkout does not exist on the GPU box), then the executor's call sequence
+    (FLMR_executor.py:774-794) through the PATCHED names `colbert.Searcher` / `colbert.search.index_storage.IndexScorer`."""
+    import sys
+    import fake_colbert
+    torch, pkg = hip["torch"], hip["pkg"]
+    cleanup = fake_colbert.make(str(tmp_path / "pkg"))
+    try:
+        pkg.install(require_device=True)
+        from colbert import Searcher
+        from colbert.data import Queries
+        from colbert.infra import ColBERTConfig, Run, RunConfig
+        from colbert.search.index_storage import IndexScorer
+        assert IndexScorer is pkg.IndexScorer and Searcher is pkg.installed()
+        z = load_golden("idx_nb2")
+        root = str(tmp_path / "ckpt")
+        pkg.IndexArrays.from_golden(z).save(os.path.join(root, "temp_index_0", "indexes", "temp_index.nbits=2"))
+        with Run().context(RunConfig(nranks=1, rank=0, root=root, experiment="temp_index_0")):
+            searcher = Searcher(index="temp_index.nbits=2", config=ColBERTConfig(total_visible_gpus=0))
+            assert isinstance(searcher.ranker, pkg.IndexScorer)
+            recs = ["rank0", "rank3"]                       # the k <= 100 policy: ncells=2, thr=0.45, ndocs=1024
+            Q = torch.stack([torch.from_numpy(z[f"{r}.Q"]) for r in recs])
+            ranking = searcher._search_all_Q(Queries(data={i: f"q{i}" for i in range(len(recs))}), Q, k=100)
+            for qid, r in enumerate(recs):
+                pids, ranks, scores = zip(*ranking.todict()[qid])
+                assert list(ranks) == list(range(1, 101))
+                tie_aware_equal(z[f"{r}.final_pids"][:100], z[f"{r}.final_scores"][:100], pids, scores, tol=SCORE_TOL)
+            # the mid-level name: rank() of the patched IndexScorer == the Searcher's own result
+            scorer = IndexScorer(searcher.index, False)
+            p0, s0 = scorer.rank(searcher.config, Q[:1])
+            assert p0[:100] == [t[0] for t in ranking.todict()[0]]
+    finally:
+        pkg.uninstall()
+        cleanup()
+
+
 @pytest.mark.parametrize("nbits,doclen,nq,nq_cand,K,policy", [
     (2, (1, 200), 32, 32, 2048, (2, 0.45, 256)),
     (4, (100, 300), 96, 48, 2048, (2, 0.45, 256)),      # two column tiles -> full table + table-gather stage 2
