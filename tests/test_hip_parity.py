@@ -237,6 +237,25 @@ def test_searcher_dropin_api(hip, tmp_path):
         tie_aware_equal(fin[order], ref[order], pids_f, scores_f, tol=SCORE_TOL)
 
 
+def test_search_reference_written_index(hip):
+    """An index directory written by the reference's own indexer code (two chunks, tests/golden/refindex_2chunk, and
+    its legacy-ivf / fp16-table variant) is loaded from disk and searched; expected = the reference's rank() on it."""
+    from conftest import GOLDEN
+    torch = hip["torch"]
+    exp = dict(np.load(os.path.join(GOLDEN, "refindex.npz")))
+    Q = torch.from_numpy(exp["rank.Q"]).unsqueeze(0)
+    nd = int(exp["rank.ndocs"])
+    scorer = hip["IndexScorer"](os.path.join(GOLDEN, "refindex_2chunk"), False)
+    p, s, c = scorer.search_batch(Q, nd // 4, int(exp["rank.ncells"]), float(exp["rank.thr"]), nd, 32)
+    n = int(c[0])
+    tie_aware_equal(exp["rank.pids"], exp["rank.scores"], p[0, :n].cpu().numpy(), s[0, :n].cpu().numpy(), tol=SCORE_TOL)
+    # legacy variant: same codes / residuals, bucket weights rounded through fp16 -> same ids, scores within the codec's step
+    scorer2 = hip["IndexScorer"](os.path.join(GOLDEN, "refindex_legacy"), False)
+    p2, s2, c2 = scorer2.search_batch(Q, nd // 4, int(exp["rank.ncells"]), float(exp["rank.thr"]), nd, 32)
+    assert int(c2[0]) == n and sorted(p2[0, :n].tolist()) == sorted(p[0, :n].tolist())
+    assert float((s2[0, :n].sort().values - s[0, :n].sort().values).abs().max()) < 5e-3
+
+
 def test_installed_searcher_through_patched_names(hip, tmp_path):
     """Level-1 drop-in on the device: `ravqa_amd.install()` over a `colbert` package tree (the stand-in of
     tests/fake_colbert.py -- the reference checkout does not exist on the GPU box), then the executor's call sequence

@@ -75,6 +75,47 @@ def test_legacy_ivf_conversion(tmp_path):
     assert np.array_equal(a.ivf, b.ivf) and np.array_equal(a.ivf_lengths, b.ivf_lengths)
 
 
+def test_loader_on_reference_written_index():
+    """tests/golden/refindex_2chunk/ was written by the reference's own IndexSaver / CollectionIndexer finalize steps
+    (make_refindex.py); refindex.npz is what the reference's own loader held in memory after reading it back
+    (index_loader.py:31-57, residual.py:134-150, residual_embeddings.py:27-52).  Two chunks, an empty passage, ragged."""
+    from conftest import GOLDEN
+    from oracle import oracle as orc
+    exp = dict(np.load(os.path.join(GOLDEN, "refindex.npz")))
+    a = ravqa_amd.load_index_arrays(os.path.join(GOLDEN, "refindex_2chunk"))
+    assert (a.dim, a.nbits, a.num_centroids) == (128, 2, 32) and int(exp["num_chunks"]) == 2
+    assert a.num_embeddings == int(exp["num_embeddings"]) and a.num_passages == 90
+    for f in ("codes", "residuals", "doclens", "ivf", "ivf_lengths", "centroids", "bucket_weights", "bucket_cutoffs"):
+        got, want = np.asarray(getattr(a, f)), exp[f]
+        if f == "ivf":  # the reference's StridedTensor keeps a zero tail behind the packed lists (strided_tensor_core.py:33-36)
+            want = want[: int(exp["ivf_lengths"].sum())]
+        assert got.dtype == want.dtype or f in ("bucket_cutoffs",), (f, got.dtype, want.dtype)
+        assert np.array_equal(got, want), f
+    assert abs(a.avg_residual - float(exp["avg_residual"])) < 1e-7
+    assert a.check_ivf_invariant()
+    cfg = ColBERTConfig.load_from_index(os.path.join(GOLDEN, "refindex_2chunk"))
+    assert cfg.nbits == 2 and cfg.dim == 128 and cfg.checkpoint == "synthetic-no-checkpoint" and cfg.doc_maxlen == 16
+    # the loaded arrays rank like the reference ranked its own load of the same directory
+    oi = orc.OracleIndex(a.dim, a.nbits, a.codes, a.residuals, a.doclens, a.ivf, a.ivf_lengths, a.centroids, a.bucket_weights)
+    p, s, _ = oi.rank(exp["rank.Q"], int(exp["rank.ncells"]), float(exp["rank.thr"]), int(exp["rank.ndocs"]), 32)
+    from conftest import tie_aware_equal
+    tie_aware_equal(exp["rank.pids"], exp["rank.scores"], p, s)
+
+
+def test_loader_on_legacy_and_gpu_built_variants():
+    """Same chunks, but `ivf.pt` (embedding ids, converted on load like index_loader.py:33-36 -> optimize_ivf), an fp16
+    [dim] `avg_residual.pt` and fp16 `buckets.pt` (what a codec built with total_visible_gpus > 0 saves, residual.py:32-40)."""
+    from conftest import GOLDEN
+    exp = dict(np.load(os.path.join(GOLDEN, "refindex.npz")))
+    b = ravqa_amd.load_index_arrays(os.path.join(GOLDEN, "refindex_legacy"))
+    for f in ("codes", "residuals", "doclens", "ivf", "ivf_lengths", "centroids"):
+        want = exp[f][: int(exp["ivf_lengths"].sum())] if f == "ivf" else exp[f]
+        assert np.array_equal(np.asarray(getattr(b, f)), want), f
+    assert b.bucket_weights.dtype == np.float32
+    assert np.array_equal(b.bucket_weights, exp["bucket_weights"].astype(np.float16).astype(np.float32))  # widened like residual.py:44-45
+    assert abs(b.avg_residual - float(np.float16(exp["avg_residual"]))) < 1e-6
+
+
 def test_shard_arithmetic():
     a = IndexArrays.from_golden(load_golden("idx_nb2"))
     shards = [a.shard(r, 4) for r in range(4)]
