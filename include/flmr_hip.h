@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FLMR_ABI_VERSION 1
+#define FLMR_ABI_VERSION 2
 
 typedef enum flmr_status {
     FLMR_OK = 0,
@@ -46,6 +46,13 @@ int flmr_abi_version(void);
 const char* flmr_last_error(void);
 /* number of visible HIP devices (0 and FLMR_ERR_HIP when the runtime reports none) */
 int flmr_device_count(int* count);
+/* Kernel-variant switches for A/B runs and cross-check tests (FLMR_S0_IMPL, FLMR_FULL_TABLE, FLMR_CAND_IMPL,
+ * FLMR_S1_NO_HITMAP, FLMR_S1_IMPL, FLMR_S2_IMPL, FLMR_S0_STAGED, FLMR_S3_NO_MULTIQ, FLMR_S3_IMPL, FLMR_SCORE_IMPL).  The
+ * environment variables of the same names are read ONCE per process, on first use of the library; afterwards the table
+ * changes only through this call (value NULL or "" clears a switch).  Op-level entry points read the table when they are
+ * called; a searcher snapshots it at flmr_searcher_create and keeps that snapshot.  Nothing on the per-batch launch path
+ * reads the environment.  (The reference has no counterpart: its extensions have one implementation each.) */
+int flmr_set_option(const char* name, const char* value);
 
 /* ------------------------------------------------------------------------------------------------
  * Index residency.  Replaces IndexLoader / ResidualCodec.load / ResidualEmbeddings.load_chunks /
@@ -96,6 +103,12 @@ int flmr_searcher_create(const flmr_index_t* index, int32_t max_queries, int32_t
 int flmr_searcher_destroy(flmr_searcher_t* searcher);
 /* bytes of HBM held by the searcher's workspace */
 int flmr_searcher_workspace_bytes(const flmr_searcher_t* searcher, int64_t* bytes);
+/* Deferred device-side errors.  Two conditions can only be detected on the device: a batch producing more candidates than
+ * the workspace bound (the reference's counterpart is an `assert` inside filter_pids.cpp / an out-of-range write), and
+ * q_lens entries outside [0, nq] (they are clamped before any kernel reads them).  Both raise a flag that is copied to the
+ * host asynchronously after the batch; the NEXT call on the searcher returns FLMR_ERR_CAPACITY / FLMR_ERR_INVALID and
+ * clears it.  flmr_searcher_check waits for the searcher's last batch and reports at once (synchronous). */
+int flmr_searcher_check(flmr_searcher_t* searcher);
 
 /* Q [nqueries, nq, dim] fp32.  q_lens (nullable) i32[nqueries]: number of valid leading rows per query
  * (rows removed by remove_zero_tensors, searcher.py:120-126, are compacted away by the host).
@@ -131,6 +144,11 @@ int flmr_search_phase1(flmr_searcher_t* searcher, const float* Q, const int32_t*
  *   idx_words / max_cells from flmr_searcher_probe_dims.  FLMR_ERR_UNSUPPORTED when the searcher is not on the
  *   sparse-table path (centroids not fp16-exact, K % 64 != 0, or nq_cand > 32): use flmr_search_phase1 then. */
 int flmr_searcher_probe_dims(const flmr_searcher_t* searcher, int32_t* idx_words, int32_t* max_cells);
+/* *supported = 1 iff flmr_search_probe / flmr_search_phase1_probed run for batches of `nq` query tokens with `params` on
+ * this searcher.  The answer depends only on replicated data (centroids, shapes, switches), so every rank of a sharded
+ * job gets the same one: use it to choose between the query-split and the replicated stage 0. */
+int flmr_searcher_probe_supported(const flmr_searcher_t* searcher, int32_t nq, const flmr_search_params_t* params,
+                                  int32_t* supported);
 int flmr_search_probe(flmr_searcher_t* searcher, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
                       const flmr_search_params_t* params, int32_t q_begin, int32_t q_count, uint32_t* out_idx_bits,
                       int32_t* out_cells, int32_t* out_ncell, flmr_stream_t stream);

@@ -18,6 +18,7 @@ HEADERS = ["flmr_common.h", "flmr_device.h"]
 FLMR_MEM_HOST, FLMR_MEM_DEVICE = 0, 1
 (TAP_CENTROID_SCORES, TAP_IDX_BITS, TAP_CELLS, TAP_CANDIDATES, TAP_STAGE1, TAP_STAGE2, TAP_DOC_SCORES) = range(7)
 NUM_STAGES = 9
+ABI_VERSION = 2
 
 
 class FlmrNativeError(RuntimeError):
@@ -65,6 +66,9 @@ _SIGS = {
     "flmr_abi_version": (C.c_int, []),
     "flmr_last_error": (C.c_char_p, []),
     "flmr_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "flmr_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "flmr_searcher_check": (C.c_int, [C.c_void_p]),
+    "flmr_searcher_probe_supported": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(SearchParams), C.POINTER(C.c_int32)]),
     "flmr_index_open": (C.c_int, [C.POINTER(IndexDesc), C.POINTER(C.c_void_p)]),
     "flmr_index_close": (C.c_int, [C.c_void_p]),
     "flmr_searcher_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SearchParams), C.POINTER(C.c_void_p)]),
@@ -123,7 +127,7 @@ def load(require_device=True):
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)  # AttributeError => ABI mismatch, surfaced loudly
             fn.restype, fn.argtypes = res, args
-        if lib.flmr_abi_version() != 1:
+        if lib.flmr_abi_version() != ABI_VERSION:
             raise FlmrNativeError("libflmr_hip.so ABI version mismatch")
         _lib = lib
     if require_device:
@@ -132,6 +136,33 @@ def load(require_device=True):
         if rc != 0 or n.value < 1:
             raise FlmrNativeError("no MI355X / HIP device visible: " + _lib.flmr_last_error().decode())
     return _lib
+
+
+options_epoch = 0  # bumped by set_option(): IndexScorer re-creates its native searcher so the new switches apply
+
+
+def set_option(name, value=None):
+    """flmr_set_option: kernel-variant switch for A/B runs / cross-check tests (value None clears it)."""
+    global options_epoch
+    check(load(False).flmr_set_option(name.encode(), None if value is None else str(value).encode()))
+    options_epoch += 1
+
+
+class options:
+    """`with _native.options(FLMR_S1_IMPL="scan"): ...` -- switches set for the block, cleared afterwards."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            set_option(k, None)
+        return False
 
 
 def check(rc):

@@ -33,6 +33,37 @@ extern thread_local char flmr_err_buf[512];
 
 #define FLMR_LAUNCH_CHECK() FLMR_HIP(hipGetLastError())
 
+// ---- variant switches (A/B runs, cross-check tests) ------------------------------------------------------------------
+// The FLMR_* environment variables are read ONCE per process (first use of the library); afterwards the table changes only
+// through flmr_set_option().  A searcher snapshots the table when it is created and every launch of its batches sees that
+// snapshot (flmr_opt_scope): nothing on the per-batch launch path calls getenv, and the environment cannot flip a running
+// searcher to another kernel path.
+enum flmr_opt_id {
+    FLMR_OPT_S0_IMPL = 0,    // f16 (default when the centroids are fp16-exact) | f32 | mfma | valu
+    FLMR_OPT_FULL_TABLE,     // set: keep the whole centroid-score table
+    FLMR_OPT_CAND_IMPL,      // atomic: first candidate-generation implementation
+    FLMR_OPT_S1_NO_HITMAP,   // set: no hit prefilter
+    FLMR_OPT_S1_IMPL,        // scan: code-scanning stage 1 for every query
+    FLMR_OPT_S2_IMPL,        // regs: per-lane register gathers
+    FLMR_OPT_S0_STAGED,      // set: staged epilogue for every tile
+    FLMR_OPT_S3_NO_MULTIQ,   // set: single-tile MaxSim kernel for long queries too
+    FLMR_OPT_S3_IMPL,        // f32: fp32-MFMA MaxSim kernel
+    FLMR_OPT_SCORE_IMPL,     // valu: plain-FMA padded scorer
+    FLMR_OPT_COUNT
+};
+struct flmr_options {
+    char v[FLMR_OPT_COUNT][16];
+    bool has(int id) const { return v[id][0] != 0; }
+    bool is(int id, const char* x) const { return strcmp(v[id], x) == 0; }
+};
+const flmr_options& flmr_opts();                        // the active snapshot (searcher scope) or the process table
+const flmr_options& flmr_process_options();             // process table (environment resolved on first use)
+struct flmr_opt_scope {                                 // RAII: launches inside the scope see `o`
+    const flmr_options* prev;
+    explicit flmr_opt_scope(const flmr_options* o);
+    ~flmr_opt_scope();
+};
+
 static inline int64_t flmr_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t flmr_round_up(int64_t a, int64_t b) { return flmr_ceil_div(a, b) * b; }
 

@@ -636,8 +636,7 @@ int flmr_launch_filter_stage2_mfma(const flmr_filter_args& f, const int32_t* pid
     if (G > (int)flmr_ceil_div(max_count, 4)) G = (int)flmr_ceil_div(max_count, 4);
     if (G < 1) G = 1;
     // FLMR_S2_IMPL=regs: the first form of the kernel (per-lane half-row gathers into registers), kept for A/B runs
-    const char* impl = getenv("FLMR_S2_IMPL");
-    if (impl && strcmp(impl, "regs") == 0)
+    if (flmr_opts().is(FLMR_OPT_S2_IMPL, "regs"))
         hipLaunchKernelGGL(filter_stage2_mfma_kernel, dim3(f.nqueries, G), dim3(256), 4 * 33 * sizeof(float), st, f, pids, pid_stride,
                            counts, keys, key_stride, cen16, q_hi, q_lo);
     else

@@ -2,12 +2,49 @@
 // Replaces IndexLoader + ResidualCodec.load + ResidualEmbeddings.load_chunks (TPC/search/index_loader.py:14-86,
 // TPC/indexing/codecs/residual.py:134-150, TPC/indexing/codecs/residual_embeddings.py:27-52).
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <vector>
 
 #include "flmr_common.h"
 
 thread_local char flmr_err_buf[512] = {0};
+
+static const char* kOptNames[FLMR_OPT_COUNT] = {"FLMR_S0_IMPL", "FLMR_FULL_TABLE", "FLMR_CAND_IMPL", "FLMR_S1_NO_HITMAP",
+                                                 "FLMR_S1_IMPL", "FLMR_S2_IMPL", "FLMR_S0_STAGED", "FLMR_S3_NO_MULTIQ",
+                                                 "FLMR_S3_IMPL", "FLMR_SCORE_IMPL"};
+static flmr_options g_opts;
+static std::once_flag g_opts_once;
+static thread_local const flmr_options* t_active_opts = nullptr;
+
+static void opts_from_env() {
+    memset(&g_opts, 0, sizeof(g_opts));
+    for (int i = 0; i < FLMR_OPT_COUNT; i++) {
+        const char* e = getenv(kOptNames[i]);
+        if (e) snprintf(g_opts.v[i], sizeof(g_opts.v[i]), "%s", e[0] ? e : "1");
+    }
+}
+const flmr_options& flmr_process_options() {
+    std::call_once(g_opts_once, opts_from_env);
+    return g_opts;
+}
+const flmr_options& flmr_opts() { return t_active_opts ? *t_active_opts : flmr_process_options(); }
+flmr_opt_scope::flmr_opt_scope(const flmr_options* o) : prev(t_active_opts) { t_active_opts = o; }
+flmr_opt_scope::~flmr_opt_scope() { t_active_opts = prev; }
+
+// name = one of the FLMR_* switch names; value NULL or "" clears it.  Affects op-level calls at once and searchers
+// created afterwards (existing searchers keep the snapshot taken at flmr_searcher_create).
+extern "C" int flmr_set_option(const char* name, const char* value) {
+    if (!name) FLMR_FAIL(FLMR_ERR_INVALID, "name is NULL");
+    (void)flmr_process_options();
+    for (int i = 0; i < FLMR_OPT_COUNT; i++)
+        if (strcmp(name, kOptNames[i]) == 0) {
+            if (value && strlen(value) >= sizeof(g_opts.v[i])) FLMR_FAIL(FLMR_ERR_INVALID, "value too long for %s", name);
+            snprintf(g_opts.v[i], sizeof(g_opts.v[i]), "%s", value ? value : "");
+            return FLMR_OK;
+        }
+    FLMR_FAIL(FLMR_ERR_INVALID, "unknown option %s", name);
+}
 
 extern "C" int flmr_abi_version(void) { return FLMR_ABI_VERSION; }
 extern "C" const char* flmr_last_error(void) { return flmr_err_buf; }

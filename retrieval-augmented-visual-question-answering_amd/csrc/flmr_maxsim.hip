@@ -545,7 +545,7 @@ static int launch_maxsim_f16_t(const flmr_maxsim_args& a, hipStream_t st) {
     if (G < gmin) G = gmin;
     if (G > (int)flmr_ceil_div(a.max_count, 4)) G = (int)flmr_ceil_div(a.max_count, 4);
     if (G < 1) G = 1;
-    if (nqp > 32 && getenv("FLMR_S3_NO_MULTIQ") == nullptr) {
+    if (nqp > 32 && !flmr_opts().has(FLMR_OPT_S3_NO_MULTIQ)) {
         const size_t lds2 = (size_t)256 * (8 / NBITS) * sizeof(float) + (size_t)S3_QC * 2 * 32 * S3_BROW * sizeof(_Float16) +
                             (size_t)S3_MQW * (32 * S3_QC + 64) * sizeof(float);
         int G2 = (int)flmr_ceil_div(4096, S3_MQW * (int64_t)a.nqueries);
@@ -582,8 +582,7 @@ static int launch_maxsim_t(const flmr_maxsim_args& a, hipStream_t st) {
 // FLMR_S3_IMPL = f16 (default when the centroids are fp16-exact and split buffers are supplied) | f32
 int flmr_launch_maxsim(const flmr_maxsim_args& a, hipStream_t st) {
     if (a.max_count <= 0) return FLMR_OK;
-    const char* env = getenv("FLMR_S3_IMPL");
-    const bool f16 = a.ix->centroids_f16_exact && a.ix->centroids_f16 && a.q_hi && a.q_lo && !(env && strcmp(env, "f32") == 0);
+    const bool f16 = a.ix->centroids_f16_exact && a.ix->centroids_f16 && a.q_hi && a.q_lo && !flmr_opts().is(FLMR_OPT_S3_IMPL, "f32");
     if (f16) {
         switch (a.ix->nbits) {
             case 1: return launch_maxsim_f16_t<1>(a, st);

@@ -356,8 +356,7 @@ extern "C" int flmr_colbert_score_padded(const float* Q, int32_t q_batch, int32_
     if (B <= 0) return FLMR_OK;
     if ((size_t)nq * 4 > 48 * 1024) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nq=%d too large", nq);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const char* env = getenv("FLMR_SCORE_IMPL");
-    if (dim == FLMR_DIM && !(env && strcmp(env, "valu") == 0)) {
+    if (dim == FLMR_DIM && !flmr_opts().is(FLMR_OPT_SCORE_IMPL, "valu")) {
         scratch sc;
         const int nqp = (int)flmr_round_up(nq, 32);
         _Float16 *qh, *ql;

@@ -19,7 +19,12 @@ struct flmr_searcher {
     int64_t bitmap_words, cand_cap, bytes;
     float* cs; uint32_t* idx_bits; float* part_val; int32_t* part_idx; int32_t* cells; int32_t* ncell;
     uint32_t* bitmap; int32_t* cand; int32_t* cand_count; uint64_t* keys1; int32_t* s1_pids; int32_t* s1_count;
-    uint64_t* keys2; int32_t* s2_pids; int32_t* s2_count; uint64_t* keys3; float* doc_scores; int32_t* overflow;
+    uint64_t* keys2; int32_t* s2_pids; int32_t* s2_count; uint64_t* keys3; float* doc_scores;
+    int32_t* overflow;          // = status: device flags [0] candidate capacity exceeded, [1] q_lens outside [0, nq]
+    int32_t* status_host;       // pinned copy of the two flags, refreshed asynchronously after every batch
+    hipEvent_t status_ev; bool status_pending;
+    int32_t* q_lens_ws;         // [max_queries] query lengths clamped to [0, nq]: what every kernel reads
+    flmr_options opt;           // variant switches, snapshot taken at flmr_searcher_create
     _Float16* q_hi; _Float16* q_lo;
     uint32_t* hit_bits; int32_t* hit_valid; int32_t* key_count;
     int32_t* s1_slot; int32_t* s2_slot;   // sharded protocol: position of each local survivor / finalist in the global list
@@ -66,6 +71,7 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     if (!s) FLMR_FAIL(FLMR_ERR_NOMEM, "host allocation failed");
     memset(s, 0, sizeof(*s));
     s->ix = ix; s->max_queries = max_queries; s->max_nq = max_nq; s->maxp = *maxp;
+    s->opt = flmr_process_options();
     const int nqc = maxp->nq_cand < max_nq ? maxp->nq_cand : max_nq;
     s->ncol_max = (int32_t)flmr_round_up(nqc, 32);
     s->idx_words = (int32_t)flmr_ceil_div(ix->K, 32);
@@ -100,7 +106,8 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     WS(s2_count, B);
     WS(keys3, B * (size_t)nd4);
     WS(doc_scores, B * (size_t)nd4);
-    WS(overflow, 1);
+    WS(overflow, 2);
+    WS(q_lens_ws, B);
     WS(q_hi, B * (size_t)s->ncol_max * FLMR_DIM);
     WS(q_lo, B * (size_t)s->ncol_max * FLMR_DIM);
     WS(hit_bits, B * (size_t)s->bitmap_words);
@@ -116,7 +123,10 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     WS(q3_hi, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
     WS(q3_lo, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
 #undef WS
-    FLMR_HIP(hipMemset(s->overflow, 0, sizeof(int32_t)));
+    FLMR_HIP(hipMemset(s->overflow, 0, 2 * sizeof(int32_t)));
+    FLMR_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->status_host), 2 * sizeof(int32_t), hipHostMallocDefault));
+    s->status_host[0] = s->status_host[1] = 0;
+    FLMR_HIP(hipEventCreateWithFlags(&s->status_ev, hipEventDisableTiming));
     for (int i = 0; i <= FLMR_NUM_STAGES; i++) FLMR_HIP(hipEventCreate(&s->ev[i]));
     *out = s;
     return FLMR_OK;
@@ -126,8 +136,10 @@ extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
     if (!s) return FLMR_OK;
     void* ptrs[] = {s->cs, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
                     s->keys1, s->s1_pids, s->s1_count, s->keys2, s->s2_pids, s->s2_count, s->keys3, s->doc_scores,
-                    s->overflow, s->q_hi, s->q_lo, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot};
+                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot};
     for (void* p : ptrs) (void)hipFree(p);
+    if (s->status_host) (void)hipHostFree(s->status_host);
+    if (s->status_ev) (void)hipEventDestroy(s->status_ev);
     for (int i = 0; i <= FLMR_NUM_STAGES; i++)
         if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
     delete s;
@@ -163,6 +175,8 @@ extern "C" int flmr_searcher_stage_ms(flmr_searcher_t* s, float* ms) {
 
 // ---- one batch = a context (validated parameters + kernel argument blocks) run through stage helpers -----------------
 struct run_ctx {
+    flmr_opt_scope scope;   // every launch of this call sees the searcher's switch snapshot
+    explicit run_ctx(flmr_searcher* s_) : scope(s_ ? &s_->opt : nullptr) {}
     flmr_searcher* s;
     const float* Q;
     const int32_t* q_lens;
@@ -187,10 +201,76 @@ static int mark(run_ctx& c) {
     return FLMR_OK;
 }
 
+// Device-side error flags (candidate capacity, q_lens range) are copied to pinned host memory after every batch without a
+// sync; the next call on the searcher (or flmr_searcher_check, which waits) reports a raised flag and clears it.
+static int poll_status(flmr_searcher* s, bool wait) {
+    if (!s->status_pending) return FLMR_OK;
+    if (wait) {
+        FLMR_HIP(hipEventSynchronize(s->status_ev));
+    } else {
+        const hipError_t e = hipEventQuery(s->status_ev);
+        if (e == hipErrorNotReady) return FLMR_OK;
+        FLMR_HIP(e);
+    }
+    s->status_pending = false;
+    const int32_t ovf = s->status_host[0], bad = s->status_host[1];
+    if (ovf || bad) {
+        s->status_host[0] = s->status_host[1] = 0;
+        FLMR_HIP(hipMemset(s->overflow, 0, 2 * sizeof(int32_t)));
+        if (ovf)
+            FLMR_FAIL(FLMR_ERR_CAPACITY, "an earlier batch produced more candidates than the workspace bound (cand_cap=%lld): its "
+                      "candidate lists were truncated and its results are not reliable (is the IVF consistent with the codes?)",
+                      (long long)s->cand_cap);
+        FLMR_FAIL(FLMR_ERR_INVALID, "an earlier batch passed q_lens outside [0, nq]; they were clamped");
+    }
+    return FLMR_OK;
+}
+
+static int push_status(run_ctx& c) {
+    flmr_searcher* s = c.s;
+    FLMR_HIP(hipMemcpyAsync(s->status_host, s->overflow, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c.st));
+    FLMR_HIP(hipEventRecord(s->status_ev, c.st));
+    s->status_pending = true;
+    return FLMR_OK;
+}
+
+extern "C" int flmr_searcher_check(flmr_searcher_t* s) {
+    if (!s) FLMR_FAIL(FLMR_ERR_INVALID, "NULL searcher");
+    return poll_status(s, true);
+}
+
+__global__ void sanitize_q_lens_kernel(const int32_t* in, int32_t n, int32_t nq, int32_t* out, int32_t* flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t v = in[i];
+    const int32_t c = v < 0 ? 0 : (v > nq ? nq : v);
+    out[i] = c;
+    if (c != v) atomicExch(flag, 1);
+}
+
+// the sparse score table + recomputing stage 2 (and with them the query-split stage 0) need the fp16-split S0 path and
+// a single column tile
+static bool sparse_path(const flmr_searcher* s, int ncol) {
+    const flmr_index* ix = s->ix;
+    const flmr_options& o = s->opt;
+    const bool f16_path = ix->centroids_f16_exact && ix->centroids_f16 && (ix->K % 64 == 0) &&
+                          !(o.has(FLMR_OPT_S0_IMPL) && !o.is(FLMR_OPT_S0_IMPL, "f16"));
+    return f16_path && ncol == 32 && !s->full_table && !o.has(FLMR_OPT_FULL_TABLE);
+}
+
+extern "C" int flmr_searcher_probe_supported(const flmr_searcher_t* s, int32_t nq, const flmr_search_params_t* p,
+                                             int32_t* supported) {
+    if (!s || !p || !supported) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    const int nqc = p->nq_cand < nq ? p->nq_cand : nq;
+    *supported = sparse_path(s, (int)flmr_round_up(nqc, 32)) ? 1 : 0;
+    return FLMR_OK;
+}
+
 static int prepare_ctx(run_ctx& c, flmr_searcher* s, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
                        const flmr_search_params_t* p, flmr_stream_t stream) {
     if (!s || !Q) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
     RUN(check_params(p));
+    RUN(poll_status(s, false));
     if (nqueries < 1 || nqueries > s->max_queries) FLMR_FAIL(FLMR_ERR_CAPACITY, "nqueries=%d > max_queries=%d", nqueries, s->max_queries);
     if (nq < 1 || nq > s->max_nq) FLMR_FAIL(FLMR_ERR_CAPACITY, "nq=%d > max_nq=%d", nq, s->max_nq);
     const int nqc = p->nq_cand < nq ? p->nq_cand : nq;
@@ -201,6 +281,12 @@ static int prepare_ctx(run_ctx& c, flmr_searcher* s, const float* Q, const int32
     c.s = s; c.Q = Q; c.q_lens = q_lens; c.nqueries = nqueries; c.nq = nq; c.nqc = nqc; c.ncol = ncol; c.p = *p;
     c.st = reinterpret_cast<hipStream_t>(stream);
     c.stage = 0;
+    if (q_lens) {  // kernels only ever see lengths inside [0, nq]; a violation is reported by the next status poll
+        hipLaunchKernelGGL(sanitize_q_lens_kernel, dim3((nqueries + 255) / 256), dim3(256), 0, c.st, q_lens, nqueries, nq,
+                           s->q_lens_ws, s->overflow + 1);
+        FLMR_LAUNCH_CHECK();
+        c.q_lens = q_lens = s->q_lens_ws;
+    }
     flmr_s0_args& a0 = c.a0;
     a0.centroids = ix->centroids; a0.Q = Q; a0.q_lens = q_lens;
     a0.K = ix->K; a0.nqueries = nqueries; a0.nq = nq; a0.nq_cand = nqc; a0.ncol = ncol; a0.ncells = p->ncells;
@@ -211,10 +297,7 @@ static int prepare_ctx(run_ctx& c, flmr_searcher* s, const float* Q, const int32
     a0.q_hi = s->q_hi; a0.q_lo = s->q_lo; a0.centroids_f16_exact = ix->centroids_f16_exact;
     a0.centroids_f16 = ix->centroids_f16;
     a0.part_rows = 0;
-    // sparse score table + recomputing stage 2: only on the fp16-split S0 path with a single column tile
-    const char* s0env = getenv("FLMR_S0_IMPL");
-    const bool f16_path = ix->centroids_f16_exact && ix->centroids_f16 && (ix->K % 64 == 0) && !(s0env && strcmp(s0env, "f16") != 0);
-    c.sparse = f16_path && ncol == 32 && !s->full_table && getenv("FLMR_FULL_TABLE") == nullptr;
+    c.sparse = sparse_path(s, ncol);
     a0.full_table = c.sparse ? 0 : 1;
     flmr_filter_args& f = c.f;
     f.cs = s->cs; f.cs_query_stride = (int64_t)ix->K * ncol; f.K = ix->K; f.ncol = ncol; f.nq_cand = nqc;
@@ -243,9 +326,8 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
     const flmr_index* ix = s->ix;
     hipStream_t st = c.st;
     // FLMR_CAND_IMPL=atomic keeps the first implementation (global atomicOr bitmap + separate hit bitmap) for A/B runs
-    const char* cimpl = getenv("FLMR_CAND_IMPL");
-    const bool chunked = !(cimpl && strcmp(cimpl, "atomic") == 0);
-    const bool use_hits = getenv("FLMR_S1_NO_HITMAP") == nullptr;
+    const bool chunked = !s->opt.is(FLMR_OPT_CAND_IMPL, "atomic");
+    const bool use_hits = !s->opt.has(FLMR_OPT_S1_NO_HITMAP);
     bool scatter = false;
     s->last_scatter = false;
     if (chunked) {
@@ -259,8 +341,7 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
         ca.cand = s->cand; ca.cand_hit = s->cand_hit; ca.cand_count = s->cand_count; ca.overflow = s->overflow;
         // stage 1 by scatter over the surviving centroids' IVF lists (single column tile, sparse or full table alike);
         // FLMR_S1_IMPL=scan keeps the code-scanning kernel for every query (A/B runs, cross-check tests)
-        const char* s1impl = getenv("FLMR_S1_IMPL");
-        scatter = use_hits && c.ncol == 32 && !(s1impl && strcmp(s1impl, "scan") == 0);
+        scatter = use_hits && c.ncol == 32 && !s->opt.is(FLMR_OPT_S1_IMPL, "scan");
         ca.scatter = scatter ? 1 : 0;
         ca.cs = s->cs; ca.cs_query_stride = c.f.cs_query_stride; ca.nq_cand = c.nqc; ca.q_lens = c.q_lens;
         ca.keys = s->keys1; ca.key_count = s->key_count;
@@ -286,7 +367,7 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
     RUN(flmr_launch_select_topn(s->keys1, s->cand_cap, s->cand_count, c.nqueries, c.p.ndocs, s->s1_pids, s->maxp.ndocs,
                                 s->s1_count, st, out_keys, (uint64_t)ix->pid_base));
     RUN(mark(c));
-    return FLMR_OK;
+    return push_status(c);
 }
 
 // S2 over s->s1_pids / s1_count -> s->keys2 (slot-aligned with s1_pids)
@@ -316,7 +397,7 @@ extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32
                                  int32_t nq, const flmr_search_params_t* p, int32_t* out_pids, float* out_scores,
                                  int32_t* out_counts, flmr_stream_t stream) {
     if (!out_pids || !out_scores || !out_counts) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
-    run_ctx c;
+    run_ctx c(s);
     RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
     RUN(stage_s0_s1(c, nullptr));
     // ---- S2: full centroid MaxSim over the survivors, keep ndocs/4 in (score,pid) order ----------------
@@ -340,7 +421,7 @@ extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32
 extern "C" int flmr_search_phase1(flmr_searcher_t* s, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
                                   const flmr_search_params_t* p, uint64_t* out_keys, flmr_stream_t stream) {
     if (!out_keys) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
-    run_ctx c;
+    run_ctx c(s);
     RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
     if (s->maxp.ndocs != p->ndocs) FLMR_FAIL(FLMR_ERR_INVALID, "the phased protocol needs ndocs == the searcher's max ndocs (key rows are ndocs wide)");
     s->have_ms = false;
@@ -362,7 +443,7 @@ extern "C" int flmr_search_probe(flmr_searcher_t* s, const float* Q, const int32
                                  const flmr_search_params_t* p, int32_t q_begin, int32_t q_count, uint32_t* out_idx_bits,
                                  int32_t* out_cells, int32_t* out_ncell, flmr_stream_t stream) {
     if (!out_idx_bits || !out_cells || !out_ncell) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
-    run_ctx c;
+    run_ctx c(s);
     RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
     if (!c.sparse) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "query-split stage 0 needs the sparse-table path (fp16-exact centroids, K %% 64 == 0, nq_cand <= 32)");
     if (q_begin < 0 || q_count < 0 || q_begin + q_count > nqueries) FLMR_FAIL(FLMR_ERR_INVALID, "query slice [%d, %d) outside the batch of %d", q_begin, q_begin + q_count, nqueries);
@@ -370,7 +451,7 @@ extern "C" int flmr_search_probe(flmr_searcher_t* s, const float* Q, const int32
     if (q_count == 0) return FLMR_OK;
     flmr_s0_args a0 = c.a0;  // the slice uses workspace slots 0..q_count; its results go straight to the caller's buffers
     a0.Q = Q + (size_t)q_begin * nq * FLMR_DIM;
-    a0.q_lens = q_lens ? q_lens + q_begin : nullptr;
+    a0.q_lens = c.q_lens ? c.q_lens + q_begin : nullptr;
     a0.nqueries = q_count;
     a0.idx_bits = out_idx_bits; a0.cells = out_cells; a0.ncell = out_ncell;
     RUN(flmr_launch_centroid_scores(a0, c.st));
@@ -382,7 +463,7 @@ extern "C" int flmr_search_phase1_probed(flmr_searcher_t* s, const float* Q, con
                                          const int32_t* cells, const int32_t* ncell, uint64_t* out_keys,
                                          flmr_stream_t stream) {
     if (!idx_bits || !cells || !ncell || !out_keys) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
-    run_ctx c;
+    run_ctx c(s);
     RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
     if (!c.sparse) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "query-split stage 0 needs the sparse-table path (fp16-exact centroids, K %% 64 == 0, nq_cand <= 32)");
     if (s->maxp.ndocs != p->ndocs) FLMR_FAIL(FLMR_ERR_INVALID, "the phased protocol needs ndocs == the searcher's max ndocs (key rows are ndocs wide)");
@@ -406,7 +487,7 @@ extern "C" int flmr_search_phase2(flmr_searcher_t* s, const float* Q, const int3
                                   const flmr_search_params_t* p, const uint64_t* global_s1, int32_t n_in, uint64_t* out_keys,
                                   flmr_stream_t stream) {
     if (!global_s1 || !out_keys) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
-    run_ctx c;
+    run_ctx c(s);
     RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
     if (n_in > p->ndocs) FLMR_FAIL(FLMR_ERR_INVALID, "n_in=%d > ndocs=%d", n_in, p->ndocs);
     RUN(flmr_launch_filter_local_keys(global_s1, nqueries, n_in, s->ix->pid_base, s->ix->num_passages, s->s1_pids, s->maxp.ndocs,
@@ -422,7 +503,7 @@ extern "C" int flmr_search_phase3(flmr_searcher_t* s, const float* Q, const int3
                                   const flmr_search_params_t* p, const uint64_t* global_s2, int32_t n_in, uint64_t* out_keys,
                                   flmr_stream_t stream) {
     if (!global_s2 || !out_keys) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
-    run_ctx c;
+    run_ctx c(s);
     RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
     if (n_in > p->ndocs / 4) FLMR_FAIL(FLMR_ERR_INVALID, "n_in=%d > ndocs/4=%d", n_in, p->ndocs / 4);
     RUN(flmr_launch_filter_local_keys(global_s2, nqueries, n_in, s->ix->pid_base, s->ix->num_passages, s->s2_pids,
@@ -460,6 +541,11 @@ extern "C" int flmr_searcher_tap(flmr_searcher_t* s, int32_t what, int32_t q, vo
     if (!s || !host_out || !count) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
     if (q < 0 || q >= s->last_nqueries) FLMR_FAIL(FLMR_ERR_INVALID, "query %d outside the last batch (%d)", q, s->last_nqueries);
     FLMR_HIP(hipStreamSynchronize(s->last_stream));
+    {
+        const int rc = poll_status(s, true);
+        if (rc) return rc;
+    }
+    flmr_opt_scope scope(&s->opt);
     const flmr_index* ix = s->ix;
     const void* src = nullptr;
     int64_t n = 0;

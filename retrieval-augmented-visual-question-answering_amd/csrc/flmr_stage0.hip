@@ -467,7 +467,7 @@ static int launch_s0_t(flmr_s0_args& a, hipStream_t st, int impl) {
         hipLaunchKernelGGL(s0_split_q, dim3((a.ncol * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens,
                            a.nq, a.nq_cand, a.ncol, a.q_hi, a.q_lo);
         const size_t lds = (size_t)S0_WAVES * 32 * S0_LDS_STRIDE * sizeof(float) + (size_t)S0_CH * 2 * 32 * S0_BROW * sizeof(_Float16);
-        const bool sparse = !a.full_table && a.ncol == 32 && getenv("FLMR_S0_STAGED") == nullptr;
+        const bool sparse = !a.full_table && a.ncol == 32 && !flmr_opts().has(FLMR_OPT_S0_STAGED);
         const dim3 grid((a.nblk + S0_WAVES - 1) / S0_WAVES, qsplit), block(64 * S0_WAVES);
         if (sparse) {
             FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_f16<false, true>),
@@ -548,7 +548,8 @@ static int nc_bucket(int ncells) { return ncells <= 1 ? 1 : ncells <= 2 ? 2 : nc
 
 // FLMR_S0_IMPL = f16 (default when every centroid is fp16-exact) | f32 (fp32 MFMA) | valu (plain FMA cross-check)
 int flmr_launch_centroid_scores(flmr_s0_args& a, hipStream_t st) {
-    const char* env = getenv("FLMR_S0_IMPL");
+    const flmr_options& o = flmr_opts();
+    const char* env = o.has(FLMR_OPT_S0_IMPL) ? o.v[FLMR_OPT_S0_IMPL] : nullptr;
     const bool f16_ok = a.centroids_f16_exact && (a.K % (32 * S0_RT) == 0);
     int impl = f16_ok ? S0_F16 : S0_F32;
     if (env && strcmp(env, "valu") == 0) impl = S0_VALU;

@@ -29,7 +29,8 @@ class ShardedSearcher:
     """local_search(Q, k) -> (pids [n,k] GLOBAL ids, -1 padded; scores [n,k]; counts [n]);  merge(scores, pids) ->
     (scores, pids, counts).  Defaults: the HIP IndexScorer on this rank's shard and the HIP merge kernel."""
 
-    def __init__(self, scorer=None, k_policy=None, local_search=None, merge=None, group=None):
+    def __init__(self, scorer=None, k_policy=None, local_search=None, merge=None, group=None, topn_keys=None,
+                 unpack_keys=None):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -40,7 +41,10 @@ class ShardedSearcher:
             from . import ops
             merge = ops.merge_topk
         self._merge = merge
-        self._split_ok = None  # query-split stage 0 supported by the native searcher? (decided on first use)
+        # key selection / unpacking of the exact protocol: the HIP ops by default (tests on CPU inject numpy restatements)
+        self._topn_keys, self._unpack_keys = topn_keys, unpack_keys
+        self._split_ok = {}  # (nq, k, nq_cand) -> query-split stage 0 usable? (capability query, agreed across ranks once)
+        self.timings = None  # set to a dict to collect per-exchange wall times (bench.py --gpus N breakdown)
 
     @classmethod
     def from_arrays(cls, arrays, group=None, max_batch=256):
@@ -61,15 +65,35 @@ class ShardedSearcher:
         ranks (default: torch.distributed.all_gather_into_tensor on the device).  The phase-2/3 outputs are slot-aligned
         with the global survivor list (one non-zero contributor per slot), so they are combined by a SUM all-reduce --
         2(W-1)/W of the array per rank instead of W-1 copies; `reduce_sum(t)` overrides it (default: dist.all_reduce)."""
-        from . import ops
+        if self._topn_keys is None or self._unpack_keys is None:
+            from . import ops
+            self._topn_keys = self._topn_keys or ops.topn_keys
+            self._unpack_keys = self._unpack_keys or ops.unpack_keys
+        topn_keys, unpack_keys = self._topn_keys, self._unpack_keys
         ncells, thr, ndocs = self.k_policy(k)
+        tm = self.timings
+
+        def timed(name, fn, *a):
+            """Run one exchange; with timings enabled, bracket it with device syncs and add its wall time."""
+            if tm is None:
+                return fn(*a)
+            import time
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = fn(*a)
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            tm[name] = tm.get(name, 0.0) + (time.perf_counter() - t0)
+            return out
 
         def default_gather(t):
             if self.world == 1:
                 return t.unsqueeze(0)
-            g = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(g, t.contiguous(), group=self.group)
-            return g
+            # flat in / flat out: the one layout both RCCL and gloo accept for the fused gather
+            g = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(g, t.contiguous().view(-1), group=self.group)
+            return g.view((self.world,) + tuple(t.shape))
 
         def default_reduce(t):
             if self.world > 1:
@@ -85,37 +109,44 @@ class ShardedSearcher:
         # them: the lists must come out in the SAME ORDER on every rank.  The radix select places its output by a block scan
         # (no atomics), so its order is a function of the input alone and no sort is needed.
         def exchange(keys, n):  # [B, m] per rank -> global top-n per query (reproducible order)
-            g = gather(keys)                                              # [W, B, m]
-            return ops.topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n, ordered=False)
+            g = timed("gather_stage1_keys", gather, keys)                 # [W, B, m]
+            return topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n, ordered=False)
 
         k1 = None
-        if self.world > 1 and split_stage0 and self._split_ok is not False:
+        if self.world > 1 and split_stage0 and self._use_query_split(Q, k, ncells, thr, ndocs, nq_cand, gather):
             # stage 0 does not depend on the passage shard: each rank probes 1/W of the queries, the ranks exchange the
-            # idx bitsets + cells (K/8 bytes + a few ints per query) and rebuild the table rows they need locally
+            # idx bitsets + cells (K/8 bytes + a few ints per query) and rebuild the table rows they need locally.
+            # Errors raised in here are real failures (the shape was declared supported): they propagate.
             B = Q.size(0)
             per = -(-B // self.world)
             lo = min(B, self.rank * per)
             cnt = min(B, lo + per) - lo
-            try:
-                iw, mc = self.scorer.probe_dims(Q, k, ncells, thr, ndocs, nq_cand)
-                bufs = (torch.zeros((per, iw), dtype=torch.int32, device="cuda"),
-                        torch.zeros((per, mc), dtype=torch.int32, device="cuda"),
-                        torch.zeros((per,), dtype=torch.int32, device="cuda"))
-                self.scorer.probe(Q, k, ncells, thr, ndocs, lo, cnt, nq_cand, q_lens=q_lens, out=bufs)
-                self._split_ok = True
-            except RuntimeError:
-                if self._split_ok:  # it worked before: a real failure, not an unsupported shape
-                    raise
-                self._split_ok = False  # same decision on every rank: it depends only on the replicated centroids / shape
-            if self._split_ok:
-                bits, cells, ncell = (gather(t).reshape((-1,) + tuple(t.shape[1:])) for t in bufs)
-                k1 = self.scorer.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, nq_cand, q_lens=q_lens)
+            iw, mc = self.scorer.probe_dims(Q, k, ncells, thr, ndocs, nq_cand)
+            dev = self.scorer.probe_device if hasattr(self.scorer, "probe_device") else "cuda"
+            bufs = (torch.zeros((per, iw), dtype=torch.int32, device=dev),
+                    torch.zeros((per, mc), dtype=torch.int32, device=dev),
+                    torch.zeros((per,), dtype=torch.int32, device=dev))
+            self.scorer.probe(Q, k, ncells, thr, ndocs, lo, cnt, nq_cand, q_lens=q_lens, out=bufs)
+            bits, cells, ncell = (timed("gather_probe_state", gather, t).reshape((-1,) + tuple(t.shape[1:])) for t in bufs)
+            k1 = self.scorer.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, nq_cand, q_lens=q_lens)
         if k1 is None:
             k1 = self.scorer.phase1(Q, k, ncells, thr, ndocs, nq_cand, q_lens=q_lens)
         s1 = exchange(k1, ndocs)
-        s2 = ops.topn_keys(reduce_sum(self.scorer.phase2(s1)), ndocs // 4, ordered=False)
-        fin = ops.topn_keys(reduce_sum(self.scorer.phase3(s2)), min(k, max(ndocs // 4, 1)), ordered=True)
-        return ops.unpack_keys(fin, k)
+        s2 = topn_keys(timed("reduce_stage2_keys", reduce_sum, self.scorer.phase2(s1)), ndocs // 4, ordered=False)
+        fin = topn_keys(timed("reduce_stage3_keys", reduce_sum, self.scorer.phase3(s2)), min(k, max(ndocs // 4, 1)), ordered=True)
+        return unpack_keys(fin, k)
+
+    def _use_query_split(self, Q, k, ncells, thr, ndocs, nq_cand, gather):
+        """Capability query (flmr_searcher_probe_supported: depends only on replicated data), then -- once per batch shape
+        -- the MIN of the answers over the ranks, so that a rank can never take a different branch of the protocol (and
+        issue different collectives) than the others."""
+        key = (int(Q.size(1)), int(k), int(nq_cand))
+        if key not in self._split_ok:
+            ok = bool(self.scorer.supports_query_split(Q, k, ncells, thr, ndocs, nq_cand))
+            dev = self.scorer.probe_device if hasattr(self.scorer, "probe_device") else "cuda"
+            votes = gather(torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev))
+            self._split_ok[key] = bool(int(votes.min()) == 1)
+        return self._split_ok[key]
 
     def search_batch(self, Q, k, **kw):
         pids, scores, counts = self._local(Q, k, **kw)

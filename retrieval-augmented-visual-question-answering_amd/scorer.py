@@ -79,6 +79,7 @@ class IndexScorer:
         self.max_batch = int(max_batch)
         self._searcher = None
         self._searcher_key = None
+        self._searcher_epoch = 0
         if isinstance(self.arrays, IndexArrays):
             self.codec = _Codec(self.arrays)
             self.embeddings = _Embeddings(self.arrays)
@@ -89,6 +90,8 @@ class IndexScorer:
     # ---- native searcher (workspace) management ---------------------------------------------------------
     def _get_searcher(self, nqueries, nq, p):
         key = (max(nqueries, 1), nq, p.ncells, p.ndocs, p.nq_cand)
+        if self._searcher is not None and self._searcher_epoch != _native.options_epoch:
+            self.close_searcher()  # a switch changed (flmr_set_option): the native searcher snapshots them at creation
         cur = self._searcher_key
         if cur is None or key[0] > cur[0] or key[1] > cur[1] or key[2] > cur[2] or key[3] > cur[3] or key[4] > cur[4]:
             grown = key if cur is None else tuple(max(a, b) for a, b in zip(key, cur))
@@ -96,13 +99,27 @@ class IndexScorer:
             h = C.c_void_p()
             mp = _params(1, grown[2], 0.0, grown[3], grown[4])
             _native.check(self._lib.flmr_searcher_create(self.device_index.handle, grown[0], grown[1], C.byref(mp), C.byref(h)))
-            self._searcher, self._searcher_key = h, grown
+            self._searcher, self._searcher_key, self._searcher_epoch = h, grown, _native.options_epoch
         return self._searcher
 
     def close_searcher(self):
         if self._searcher is not None:
             self._lib.flmr_searcher_destroy(self._searcher)
             self._searcher, self._searcher_key = None, None
+
+    def check(self):
+        """Wait for the last batch and raise FlmrNativeError if it overflowed the candidate bound or was handed q_lens
+        outside [0, nq] (flmr_searcher_check); without this call the error surfaces on the next batch."""
+        if self._searcher is not None:
+            _native.check(self._lib.flmr_searcher_check(self._searcher))
+
+    def supports_query_split(self, Q, k, ncells, thr, ndocs, nq_cand=32):
+        """True iff the query-split stage 0 (probe / phase1_probed) runs for this batch shape; depends only on
+        replicated data, so every rank of a sharded job gets the same answer (flmr_searcher_probe_supported)."""
+        _, _, _, nq, p, s = self._phase_args(Q, k, ncells, thr, ndocs, nq_cand, None)
+        ok = C.c_int32(0)
+        _native.check(self._lib.flmr_searcher_probe_supported(s, nq, C.byref(p), C.byref(ok)))
+        return bool(ok.value)
 
     def workspace_bytes(self):
         b = C.c_int64(0)
@@ -254,6 +271,7 @@ class IndexScorer:
                 p, s, c = self.search_batch(Q[:1], kk, config.ncells, config.centroid_score_threshold, config.ndocs,
                                             config.query_maxlen)
                 n = int(c[0])
+                self.check()
                 return p[0, :n].tolist(), s[0, :n].tolist()
             # per-query staging so the callable sees the same ascending int32 pid tensor (index_storage.py:90-91)
             pids, centroid_scores = self.retrieve(config, Q)

@@ -148,6 +148,8 @@ class Searcher:
             pids, scores, counts = self.ranker.search_batch(Qb, kk, c.ncells, c.centroid_score_threshold, c.ndocs,
                                                             c.query_maxlen, q_lens=q_lens)
             pids, scores, counts = pids.cpu(), scores.cpu(), counts.cpu().tolist()
+            if hasattr(self.ranker, "check"):
+                self.ranker.check()   # deferred device-side errors of the batches above (candidate bound, q_lens range)
             all_scored = []
             for i, n in enumerate(counts):
                 all_scored.append(list(zip(pids[i, :n].tolist(), range(1, k + 1), scores[i, :n].tolist())))

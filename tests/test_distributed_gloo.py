@@ -91,3 +91,101 @@ def test_two_rank_sharded_search(tmp_path):
     z = dict(np.load(os.path.join(ROOT, "tests", "golden", "idx_nb2.npz")))
     for qi, rec in enumerate(("rank0", "rank3")):
         assert int(z[f"{rec}.final_pids"][0]) in res[0]["pids"][qi].tolist()
+
+
+# ---- exact-parity mode: three phases, real collectives, 2 and 3 ranks ------------------------------------------
+def _exact_worker(rank, world, port, out_path, query_split, use_q_lens):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ravqa_amd
+    from ravqa_amd.distributed import ShardedSearcher
+    import oracle_shard_scorer as oss
+    z = dict(np.load(os.path.join(ROOT, "tests", "golden", "idx_nb2.npz")))
+    full = ravqa_amd.IndexArrays.from_golden(z)
+    scorer = oss.OracleShardScorer(full.shard(rank, world), query_split=query_split)
+    policy = {100: (2, 0.45, 1024), 10: (1, 0.5, 64)}
+    ss = ShardedSearcher(scorer=scorer, k_policy=lambda k: policy[k], topn_keys=oss.topn_keys, unpack_keys=oss.unpack_keys)
+    ss.timings = {}
+    # 5 queries: with 2 ranks the slices are 3 + 2, with 3 ranks 2 + 2 + 1 (ragged last slice)
+    Q = torch.stack([torch.from_numpy(z[f"rank{i}.Q"]) for i in (0, 3, 1, 4, 2)])
+    q_lens = torch.tensor([32, 20, 32, 7, 32], dtype=torch.int32) if use_q_lens else None
+    res = {}
+    for k in (100, 10):
+        p, s, c = ss.search_batch_exact(Q, k, nq_cand=32, q_lens=q_lens)   # default gather / all_reduce: real gloo collectives
+        res[k] = (p, s, c)
+    torch.save({"res": res, "calls": scorer.calls, "timings": ss.timings, "split_ok": dict(ss._split_ok)}, f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,query_split,use_q_lens", [(2, True, False), (3, True, True), (2, False, True)])
+def test_exact_protocol_multirank_equals_unsharded(tmp_path, world, query_split, use_q_lens):
+    """ShardedSearcher.search_batch_exact over real gloo collectives (all_gather_into_tensor of the probe state and of the
+    stage-1 keys, SUM all-reduce of the slot-aligned stage-2/3 keys): every rank ends with the ranking of the UNSHARDED
+    index, bit for bit -- ids, scores, counts -- for both k-policies, with a ragged last query slice, with per-query
+    lengths, and with the replicated-stage-0 fallback (capability vote = no)."""
+    from oracle import oracle as orc
+    import ravqa_amd
+    port, out = _free_port(), str(tmp_path / "res")
+    mp.spawn(_exact_worker, args=(world, port, out, query_split, use_q_lens), nprocs=world, join=True)
+    res = [torch.load(f"{out}.{r}") for r in range(world)]
+    z = dict(np.load(os.path.join(ROOT, "tests", "golden", "idx_nb2.npz")))
+    oi = orc.OracleIndex.from_golden(z)
+    Q = np.stack([z[f"rank{i}.Q"] for i in (0, 3, 1, 4, 2)])
+    q_lens = [32, 20, 32, 7, 32] if use_q_lens else [32] * 5
+    for k, (ncells, thr, ndocs) in {100: (2, 0.45, 1024), 10: (1, 0.5, 64)}.items():
+        for r in range(1, world):   # all ranks agree
+            for a, b in zip(res[0]["res"][k], res[r]["res"][k]):
+                assert torch.equal(a, b), (k, r)
+        p, s, c = res[0]["res"][k]
+        for b in range(5):
+            rp, rs, ncand = oi.rank(Q[b][: q_lens[b]], ncells, thr, ndocs, 32)
+            n = int(c[b])
+            assert n == min(k, len(rp)), (k, b, n, len(rp))
+            if ncand < ndocs:
+                continue   # the reference's undefined case (filter_pids.cpp:119-123); defined here, covered elsewhere
+            assert p[b, :n].tolist() == rp[:n].tolist(), (k, b)
+            assert np.array_equal(s[b, :n].numpy().view(np.uint32), rs[:n].view(np.uint32)), (k, b)
+    for r in range(world):
+        calls = [c[0] for c in res[r]["calls"]]
+        if query_split:
+            per = -(-5 // world)
+            lo = min(5, r * per)
+            assert ("probe", lo, min(5, lo + per) - lo) in res[r]["calls"] and "phase1_probed" in calls and "phase1" not in calls
+            assert "gather_probe_state" in res[r]["timings"]
+        else:
+            assert "phase1" in calls and "probe" not in calls and "gather_probe_state" not in res[r]["timings"]
+        assert list(res[r]["split_ok"].values()) == [query_split] * len(res[r]["split_ok"])
+        assert {"gather_stage1_keys", "reduce_stage2_keys", "reduce_stage3_keys"} <= set(res[r]["timings"])
+
+
+def _vote_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ravqa_amd
+    from ravqa_amd.distributed import ShardedSearcher
+    import oracle_shard_scorer as oss
+    z = dict(np.load(os.path.join(ROOT, "tests", "golden", "idx_nb2.npz")))
+    full = ravqa_amd.IndexArrays.from_golden(z)
+    scorer = oss.OracleShardScorer(full.shard(rank, world), query_split=(rank == 0))   # the ranks DISAGREE
+    ss = ShardedSearcher(scorer=scorer, k_policy=lambda k: (1, 0.5, 64), topn_keys=oss.topn_keys, unpack_keys=oss.unpack_keys)
+    Q = torch.stack([torch.from_numpy(z[f"rank{i}.Q"]) for i in (0, 3)])
+    p, s, c = ss.search_batch_exact(Q, 10)
+    torch.save({"p": p, "calls": [c_[0] for c_ in scorer.calls]}, f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_that_disagree_on_the_capability_take_the_same_branch(tmp_path):
+    """One rank says the query-split stage 0 is supported, the other does not: the MIN vote sends BOTH down the replicated
+    branch (no probe anywhere, identical results) instead of issuing mismatched collectives."""
+    world, port, out = 2, _free_port(), str(tmp_path / "res")
+    mp.spawn(_vote_worker, args=(world, port, out), nprocs=world, join=True)
+    res = [torch.load(f"{out}.{r}") for r in range(world)]
+    assert torch.equal(res[0]["p"], res[1]["p"])
+    for r in res:
+        assert "probe" not in r["calls"] and "phase1_probed" not in r["calls"] and "phase1" in r["calls"]

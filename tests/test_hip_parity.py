@@ -126,14 +126,11 @@ def test_score_pids_fused_vs_oracle(hip, scorers, name):
         Qd = torch.from_numpy(Q).cuda()
         pd = torch.from_numpy(pids).cuda()
         for impl in ("f16", "f32"):  # fp16-split wave-per-document kernel (default) and the fp32-MFMA kernel
-            os.environ["FLMR_S3_IMPL"] = impl
-            try:
+            with hip["native"].options(FLMR_S3_IMPL=impl):
                 out = torch.empty(len(pids), dtype=torch.float32, device="cuda")
                 hip["native"].check(scorer._lib.flmr_score_pids(scorer.device_index.handle, C.c_void_p(Qd.data_ptr()), Q.shape[0],
                                                                  C.c_void_p(pd.data_ptr()), len(pids), C.c_void_p(out.data_ptr()),
                                                                  hip["native"].stream_ptr()))
-            finally:
-                os.environ.pop("FLMR_S3_IMPL", None)
             assert np.max(np.abs(out.cpu().numpy() - ref)) <= SCORE_TOL / 4, (r, impl)
 
 
@@ -145,12 +142,9 @@ def test_s0_kernel_variants_agree(hip, scorers):
         z, scorer = scorers[name]
         taps = {}
         for impl in ("f16", "f32", "valu"):
-            os.environ["FLMR_S0_IMPL"] = impl
-            try:
+            with nat.options(FLMR_S0_IMPL=impl):
                 _search_one(hip, scorer, z, rec, full_table=True)
                 taps[impl] = [scorer.tap(t) for t in (nat.TAP_CENTROID_SCORES, nat.TAP_IDX_BITS, nat.TAP_CELLS, nat.TAP_CANDIDATES)]
-            finally:
-                os.environ.pop("FLMR_S0_IMPL", None)
         for impl in ("f16", "f32"):
             assert np.max(np.abs(taps[impl][0] - taps["valu"][0])) <= 5e-7, (name, rec, impl)
             for a, b in zip(taps[impl][1:], taps["valu"][1:]):
@@ -376,13 +370,9 @@ def test_candidate_generation_variants_agree(hip, scorers):
     z, scorer = scorers["idx_nb2"]
     outs = {}
     for tag, env in (("chunked", {}), ("atomic", {"FLMR_CAND_IMPL": "atomic"}), ("nohit", {"FLMR_S1_NO_HITMAP": "1"})):
-        os.environ.update(env)
-        try:
+        with nat.options(**env):
             pids, scores = _search_one(hip, scorer, z, "rank3")
             outs[tag] = (scorer.tap(nat.TAP_CANDIDATES), np.sort(scorer.tap(nat.TAP_STAGE1)), scorer.tap(nat.TAP_STAGE2), pids, scores)
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
     for tag in ("atomic", "nohit"):
         for a, b in zip(outs["chunked"], outs[tag]):
             assert np.array_equal(a, b), tag
@@ -449,11 +439,8 @@ def test_colbert_score_padded_mfma_vs_oracle(hip):
         ref = orc.colbert_score_padded(Q.numpy(), D.numpy(), mask.numpy())
         got = ops.colbert_score_padded(Q, D, mask).cpu().numpy()
         assert np.max(np.abs(got - ref) / (1.0 + np.abs(ref))) <= 2e-6
-        os.environ["FLMR_SCORE_IMPL"] = "valu"
-        try:
+        with hip["native"].options(FLMR_SCORE_IMPL="valu"):
             got2 = ops.colbert_score_padded(Q, D, mask).cpu().numpy()
-        finally:
-            os.environ.pop("FLMR_SCORE_IMPL", None)
         assert np.max(np.abs(got2 - ref) / (1.0 + np.abs(ref))) <= 2e-6
         assert got[4] == np.float32(-9999.0) * Q.shape[1] or abs(got[4] + 9999.0 * Q.shape[1]) < 1.0
 
@@ -636,15 +623,11 @@ def test_stage1_scatter_equals_code_scan(hip, nbits, doclen, K, npass, policy):
     ncells, thr, ndocs = policy
     outs = {}
     for tag, env in (("scatter", {}), ("scan", {"FLMR_S1_IMPL": "scan"})):
-        os.environ.update(env)
-        try:
+        with nat.options(**env):
             p, s, c = scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=q_lens)
             torch.cuda.synchronize()
             taps = [(np.sort(scorer.tap(nat.TAP_STAGE1, q)), scorer.tap(nat.TAP_STAGE2, q)) for q in range(Q.size(0))]
             outs[tag] = (p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), taps)
-        finally:
-            for k_ in env:
-                os.environ.pop(k_, None)
     a, b = outs["scatter"], outs["scan"]
     for q in range(Q.size(0)):
         assert np.array_equal(a[3][q][0], b[3][q][0]), ("stage-1 survivors", q)
@@ -770,3 +753,71 @@ def test_c_abi_reports_errors_instead_of_crashing(hip, scorers):
         assert lib.flmr_compress_residuals(ptr(Q), 128, ptr(Q), ptr(out_c), 8, ptr(out_s), 3, ptr(out_p), st) == UNSUPPORTED
     finally:
         lib.flmr_searcher_destroy(h)
+
+
+def test_deferred_device_errors_and_q_lens_clamp(hip, scorers):
+    """q_lens outside [0, nq] cannot be seen by the host without a sync: the kernels read a clamped copy (so the batch runs
+    memory-safe and equals the run with the clamped lengths), a device flag is raised, and the NEXT call on the searcher --
+    or flmr_searcher_check at once -- returns FLMR_ERR_INVALID and clears it (include/flmr_hip.h: flmr_searcher_check)."""
+    torch, nat = hip["torch"], hip["native"]
+    z, scorer = scorers["idx_nb2"]
+    Q = torch.stack([torch.from_numpy(z[f"rank{i}.Q"]) for i in (0, 3, 1)])
+    good = torch.tensor([32, 20, 0], dtype=torch.int32)
+    bad = torch.tensor([77, 20, -5], dtype=torch.int32)       # 77 -> 32, -5 -> 0
+    ref = scorer.search_batch(Q, 16, 2, 0.45, 64, 32, q_lens=good)
+    scorer.check()
+    got = scorer.search_batch(Q, 16, 2, 0.45, 64, 32, q_lens=bad)
+    torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    with pytest.raises(nat.FlmrNativeError, match="q_lens"):
+        scorer.check()
+    scorer.check()                                             # reported once, then clear
+    # without an explicit check the error surfaces on the next batch call
+    scorer.search_batch(Q, 16, 2, 0.45, 64, 32, q_lens=bad)
+    torch.cuda.synchronize()
+    with pytest.raises(nat.FlmrNativeError, match="q_lens"):
+        scorer.search_batch(Q, 16, 2, 0.45, 64, 32, q_lens=good)
+    scorer.search_batch(Q, 16, 2, 0.45, 64, 32, q_lens=good)
+    scorer.check()
+
+
+def test_switches_are_snapshotted_not_read_from_the_environment(hip, scorers):
+    """FLMR_* switches: the environment is read once per process; later changes go through flmr_set_option, and a native
+    searcher keeps the snapshot it was created with (nothing on the launch path calls getenv)."""
+    import ctypes as C
+    torch, nat = hip["torch"], hip["native"]
+    lib = nat.load()
+    z, scorer = scorers["idx_nb2"]
+    assert lib.flmr_set_option(b"FLMR_NOT_A_SWITCH", b"1") == 1 and b"unknown option" in lib.flmr_last_error()
+    assert lib.flmr_set_option(b"FLMR_S1_IMPL", b"x" * 40) == 1
+    Q = torch.from_numpy(z["rank0.Q"]).unsqueeze(0)
+    p = nat.SearchParams(8, 2, 0.45, 64, 32)
+    ok = C.c_int32(-1)
+
+    def supported():
+        h = C.c_void_p()
+        nat.check(lib.flmr_searcher_create(scorer.device_index.handle, 1, 32, C.byref(p), C.byref(h)))
+        nat.check(lib.flmr_searcher_probe_supported(h, 32, C.byref(p), C.byref(ok)))
+        return h, ok.value
+
+    h1, s1 = supported()
+    os.environ["FLMR_FULL_TABLE"] = "1"                      # too late: the environment was resolved at first use
+    try:
+        h2, s2 = supported()
+        nat.set_option("FLMR_FULL_TABLE", "1")              # the API does change what NEW searchers see ...
+        h3, s3 = supported()
+        nat.check(lib.flmr_searcher_probe_supported(h1, 32, C.byref(p), C.byref(ok)))   # ... and old ones keep theirs
+        assert (s1, s2, s3, ok.value) == (1, 1, 0, 1)
+    finally:
+        os.environ.pop("FLMR_FULL_TABLE", None)
+        nat.set_option("FLMR_FULL_TABLE", None)
+        for h in (h1, h2, h3):
+            lib.flmr_searcher_destroy(h)
+    # nq_cand > 32 -> two column tiles -> no sparse table -> no query split
+    p2 = nat.SearchParams(8, 2, 0.45, 64, 48)
+    h = C.c_void_p()
+    nat.check(lib.flmr_searcher_create(scorer.device_index.handle, 1, 96, C.byref(p2), C.byref(h)))
+    nat.check(lib.flmr_searcher_probe_supported(h, 96, C.byref(p2), C.byref(ok)))
+    lib.flmr_searcher_destroy(h)
+    assert ok.value == 0
