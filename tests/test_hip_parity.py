@@ -762,8 +762,8 @@ def test_deferred_device_errors_and_q_lens_clamp(hip, scorers):
     torch, nat = hip["torch"], hip["native"]
     z, scorer = scorers["idx_nb2"]
     Q = torch.stack([torch.from_numpy(z[f"rank{i}.Q"]) for i in (0, 3, 1)])
-    good = torch.tensor([32, 20, 0], dtype=torch.int32)
-    bad = torch.tensor([77, 20, -5], dtype=torch.int32)       # 77 -> 32, -5 -> 0
+    good = torch.tensor([32, 20, 32], dtype=torch.int32)
+    bad = torch.tensor([77, 20, 1 << 30], dtype=torch.int32)  # both out-of-range entries clamp to nq = 32
     ref = scorer.search_batch(Q, 16, 2, 0.45, 64, 32, q_lens=good)
     scorer.check()
     got = scorer.search_batch(Q, 16, 2, 0.45, 64, 32, q_lens=bad)
