@@ -1,0 +1,105 @@
+"""`-m gpu` parity at BASELINE.json's shapes, against the reference's own compiled C++ stages where they are available
+(oracle/_ref via RefCpuScorer -- the .so files travel to the GPU box) and the C restatement otherwise.
+
+  cfg2  10 k passages x 128 tokens, K = 16384                    (BASELINE.json configs[1])
+  cfg3  160 k passages, K = 65536, nbits = 8, Nq in {320, 832}  (configs[2]: PreFLMR's long queries + PQ decompress)
+  cfg4  1 M passages x 128 tokens, K = 131072, nbits 2 and 8, fixed and ragged doclens   (configs[3], one GPU's view)
+
+Policies follow searcher.py:92-118: k <= 100 -> (ncells 2, thr 0.45, ndocs 1024); k = 500 -> (4, 0.4, 4096).
+Bars: ranked ids identical position by position except inside runs of reference scores closer than `gap` (another valid
+fp32 summation order may swap those); scores within `tol`.  For Nq = 32: gap 1e-5, tol 1e-4 (north_star).  For
+long queries the score itself grows with Nq (hundreds), and one fp32 ulp of the score exceeds 1e-5, so both bars are
+stated in ulps of the score magnitude: gap = 4 ulp, tol = 16 ulp (>= the Nq = 32 values).
+"""
+import numpy as np
+import pytest
+
+from conftest import tie_aware_equal
+
+pytestmark = pytest.mark.gpu
+
+POLICY = {100: (2, 0.45, 1024), 500: (4, 0.4, 4096)}   # searcher.py:92-118
+EPS32 = float(np.finfo(np.float32).eps)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    import ravqa_amd
+    from ravqa_amd import _native
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    _native.load(require_device=True)
+    return dict(torch=torch, pkg=ravqa_amd)
+
+
+def _reference_ranker(arrays):
+    """rank(Q numpy [Nq,128], ncells, thr, ndocs) -> (pids, scores, ncand): the reference's compiled stages when
+    oracle/_ref is present, else the C restatement (pinned to them by tests/test_oracle_golden.py)."""
+    import torch
+    from oracle import oracle as orc
+    oi = orc.OracleIndex(arrays.dim, arrays.nbits, arrays.codes, arrays.residuals, arrays.doclens, arrays.ivf,
+                         arrays.ivf_lengths, arrays.centroids, arrays.bucket_weights)
+    if orc.ref_available():
+        ref = orc.RefCpuScorer(oi)
+        return lambda Q, ncells, thr, ndocs: ref.rank(torch.from_numpy(Q), ncells, thr, ndocs), "reference"
+    return lambda Q, ncells, thr, ndocs: oi.rank(Q, ncells, thr, ndocs, 32), "port"
+
+
+def _check(hip, corpus, nq, n_queries, ks, seed=2, max_batch=32):
+    torch = hip["torch"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=max_batch)
+    rank, kind = _reference_ranker(synth.corpus_to_arrays(corpus))
+    Q, targets = synth.make_queries(corpus, max(n_queries.values()), nq, seed=seed)
+    Qh = Q.cpu().numpy()
+    checked = 0
+    for k in ks:
+        ncells, thr, ndocs = POLICY[k]
+        n = n_queries[k]
+        p, s, c = scorer.search_batch(Q[:n], ndocs // 4, ncells, thr, ndocs, 32)
+        scorer.check()
+        p, s, c = p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy()
+        for i in range(n):
+            rp, rs, ncand = rank(Qh[i], ncells, thr, ndocs)
+            if ncand < ndocs:       # the reference's undefined case (filter_pids.cpp:119-123): defined here, tested elsewhere
+                continue
+            mag = max(1.0, float(np.max(np.abs(rs))))
+            gap, tol = max(1e-5, 4 * EPS32 * mag), max(1e-4, 16 * EPS32 * mag)
+            m = int(c[i])
+            assert m == len(rp) == ndocs // 4, (k, i, m, len(rp))
+            tie_aware_equal(rp, rs, p[i, :m], s[i, :m], gap=gap, tol=tol)
+            if all(abs(rs[j] - rs[j + 1]) > gap for j in range(5)):   # no near-tie among the first six: top-5 ids bit-exact
+                assert p[i, :5].tolist() == [int(x) for x in rp[:5]], (k, i)
+            checked += 1
+        if k <= 100:
+            hit = (torch.from_numpy(p[:, :5].astype(np.int64)) == targets[:n].cpu().unsqueeze(1)).any(dim=1).float().mean()
+            assert float(hit) >= 0.95, float(hit)
+    assert checked >= sum(n_queries[k] for k in ks) // 2, (checked, kind)
+    scorer.close_searcher()
+    return kind
+
+
+@pytest.mark.parametrize("nbits", [2, 8])
+def test_cfg2_10k_passages(hip, nbits):
+    from ravqa_amd import synth
+    corpus = synth.make_corpus(10_000, 128, 16384, nbits, seed=11, device="cuda")
+    _check(hip, corpus, 32, {100: 32, 500: 8}, ks=(100, 500))
+
+
+@pytest.mark.parametrize("nq", [320, 832])
+def test_cfg3_160k_passages_long_queries_nbits8(hip, nq):
+    """PreFLMR-sized queries (Nq = 320 / 832 > query_maxlen = 32): candidate generation uses the first 32 tokens
+    (index_storage.py:77), the exact MaxSim all of them -- the LDS-chunked long-query kernel at the size it exists for."""
+    from ravqa_amd import synth
+    corpus = synth.make_corpus(160_000, 128, 65536, 8, seed=12, device="cuda")
+    _check(hip, corpus, nq, {100: 8}, ks=(100,), max_batch=8)
+
+
+@pytest.mark.parametrize("nbits,doclen", [(2, 128), (8, 128), (2, (32, 224)), (8, (32, 224))])
+def test_cfg4_1m_passages_headline_shape(hip, nbits, doclen):
+    """BASELINE's headline corpus on one GPU: 1 M passages, K = 131072 -- 32 queries at the k <= 100 policy and 4 at the
+    k = 500 policy, every ranked list checked against the reference's CPU stages."""
+    from ravqa_amd import synth
+    corpus = synth.make_corpus(1_000_000, doclen, 131072, nbits, seed=0, device="cuda")
+    _check(hip, corpus, 32, {100: 32, 500: 4}, ks=(100, 500))
