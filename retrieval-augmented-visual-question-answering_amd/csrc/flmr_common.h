@@ -44,7 +44,7 @@ enum flmr_opt_id {
     FLMR_OPT_CAND_IMPL,      // atomic: first candidate-generation implementation
     FLMR_OPT_S1_NO_HITMAP,   // set: no hit prefilter
     FLMR_OPT_S1_IMPL,        // scan: code-scanning stage 1 for every query
-    FLMR_OPT_S2_IMPL,        // regs: per-lane register gathers
+    FLMR_OPT_S2_IMPL,        // walk | lds | regs: force the dense walk / the LDS-DMA gather / the register gather (default: cost model)
     FLMR_OPT_S0_STAGED,      // set: staged epilogue for every tile
     FLMR_OPT_S3_NO_MULTIQ,   // set: single-tile MaxSim kernel for long queries too
     FLMR_OPT_S3_IMPL,        // f32: fp32-MFMA MaxSim kernel
@@ -110,7 +110,9 @@ struct flmr_index {
     int32_t centroids_f16_exact;  // every centroid value is representable in fp16 (true for reference-format indexes)
     uint32_t* ivf_chunk_tab;      // [K][nchunks+1]: first entry of each IVF list with pid >= chunk*32768
     int32_t nchunks;
+    int32_t* codes_sorted;        // [N] per-passage ascending copy of `codes` (stage-2 walk); NULL when a passage is too long
 };
+int flmr_build_sorted_codes(flmr_index* ix);
 
 // build the fused byte -> (8/nbits) fp32 decode table from the codec tables (host)
 void flmr_build_wlut(int nbits, const float* bucket_weights, const uint8_t* reversed_bit_map,
@@ -200,6 +202,11 @@ int flmr_launch_filter_stage2(const flmr_filter_args& f, const int32_t* pids, in
 int flmr_launch_filter_stage2_mfma(const flmr_filter_args& f, const int32_t* pids, int64_t pid_stride, const int32_t* counts,
                                    int32_t max_count, uint64_t* keys, int64_t key_stride, const _Float16* cen16,
                                    const _Float16* q_hi, const _Float16* q_lo, hipStream_t st);
+// stage 2 as a query-stationary dense walk over the centroid table (flmr_stage2_walk.hip): same keys, bit for bit
+int flmr_launch_filter_stage2_walk(const flmr_filter_args& f, const int32_t* pids, int64_t pid_stride, const int32_t* counts,
+                                   int32_t max_count, uint64_t* keys, int64_t key_stride, const _Float16* cen16,
+                                   const _Float16* q_hi, const _Float16* q_lo, const int32_t* codes_sorted, hipStream_t st);
+bool flmr_stage2_walk_pays(const flmr_index* ix, int nqueries, int max_count);
 // top-n of count[q] keys, unordered output (radix select); n_out[q] = min(n, count[q])
 int flmr_launch_select_topn(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t nqueries,
                             int32_t n, int32_t* out_pids, int64_t out_stride, int32_t* n_out, hipStream_t st,

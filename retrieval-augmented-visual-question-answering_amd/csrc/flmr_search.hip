@@ -371,10 +371,20 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
 }
 
 // S2 over s->s1_pids / s1_count -> s->keys2 (slot-aligned with s1_pids)
-static int stage_s2(run_ctx& c) {
+// `whole_batch`: the survivors are the full top-ndocs lists of a single-index search (flmr_search_batch).  Phase 2 of the
+// sharded protocol scores only this shard's members (a fraction of ndocs per query): the table walk, whose cost does not
+// shrink with the number of survivors, is then the wrong form unless forced.
+static int stage_s2(run_ctx& c, bool whole_batch) {
     flmr_searcher* s = c.s;
     const flmr_index* ix = s->ix;
-    if (c.sparse)
+    const flmr_options& o = s->opt;
+    const bool walk = c.sparse && ix->codes_sorted &&
+                      (o.is(FLMR_OPT_S2_IMPL, "walk") ||
+                       (!o.has(FLMR_OPT_S2_IMPL) && whole_batch && flmr_stage2_walk_pays(ix, c.nqueries, c.p.ndocs)));
+    if (walk)
+        RUN(flmr_launch_filter_stage2_walk(c.f, s->s1_pids, s->maxp.ndocs, s->s1_count, c.p.ndocs, s->keys2, s->maxp.ndocs,
+                                           ix->centroids_f16, s->q_hi, s->q_lo, ix->codes_sorted, c.st));
+    else if (c.sparse)
         RUN(flmr_launch_filter_stage2_mfma(c.f, s->s1_pids, s->maxp.ndocs, s->s1_count, c.p.ndocs, s->keys2, s->maxp.ndocs,
                                            ix->centroids_f16, s->q_hi, s->q_lo, c.st));
     else
@@ -401,7 +411,7 @@ extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32
     RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
     RUN(stage_s0_s1(c, nullptr));
     // ---- S2: full centroid MaxSim over the survivors, keep ndocs/4 in (score,pid) order ----------------
-    RUN(stage_s2(c));
+    RUN(stage_s2(c, true));
     RUN(flmr_launch_sort_topn(s->keys2, s->maxp.ndocs, s->s1_count, p->ndocs, nqueries, p->ndocs / 4, s->s2_pids,
                               nullptr, s->maxp.ndocs / 4, s->s2_count, 0, 0, c.st));
     RUN(mark(c));
@@ -492,7 +502,7 @@ extern "C" int flmr_search_phase2(flmr_searcher_t* s, const float* Q, const int3
     if (n_in > p->ndocs) FLMR_FAIL(FLMR_ERR_INVALID, "n_in=%d > ndocs=%d", n_in, p->ndocs);
     RUN(flmr_launch_filter_local_keys(global_s1, nqueries, n_in, s->ix->pid_base, s->ix->num_passages, s->s1_pids, s->maxp.ndocs,
                                       s->s1_count, c.st, s->s1_slot));
-    RUN(stage_s2(c));
+    RUN(stage_s2(c, false));
     return flmr_launch_export_keys_slotted(s->keys2, s->maxp.ndocs, s->s1_count, s->s1_slot, nqueries, (uint64_t)s->ix->pid_base,
                                            p->ndocs, out_keys, c.st);
 }

@@ -821,3 +821,58 @@ def test_switches_are_snapshotted_not_read_from_the_environment(hip, scorers):
     nat.check(lib.flmr_searcher_probe_supported(h, 96, C.byref(p2), C.byref(ok)))
     lib.flmr_searcher_destroy(h)
     assert ok.value == 0
+
+
+@pytest.mark.parametrize("nbits,doclen,K,npass,policy", [
+    (2, (1, 200), 2048, 6000, (2, 0.45, 256)),      # ragged passages incl. one-token ones, fewer survivors than a work item holds
+    (2, 64, 512, 70_000, (2, 0.3, 1024)),           # K = one LDS slice: many tokens of a passage fall into the same slice
+    (4, (10, 90), 1024, 40_000, (4, 0.4, 4096)),    # ndocs = 4096: four work items per query
+    (2, (300, 420), 4096, 3000, (2, 0.45, 256)),    # passages longer than 256 tokens, several code windows per slice
+])
+def test_stage2_walk_equals_gather(hip, nbits, doclen, K, npass, policy):
+    """Stage 2 as the query-stationary table walk (flmr_stage2_walk.hip, FLMR_S2_IMPL=walk: sorted per-passage codes, score
+    slices in LDS, running maxima in registers) vs the row-gather kernel (FLMR_S2_IMPL=lds): the stage-2 finalists IN ORDER,
+    and the final ids, scores (as bits) and counts must be identical -- max is exact, so the token order cannot matter."""
+    nat = hip["native"]
+    torch = hip["torch"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    corpus = synth.make_corpus(npass, doclen, K, nbits, seed=41, device="cuda")
+    Q, _ = synth.make_queries(corpus, 9, 32, seed=6)
+    q_lens = torch.tensor([32, 32, 20, 32, 1, 32, 32, 7, 32], dtype=torch.int32)
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=16)
+    ncells, thr, ndocs = policy
+    outs = {}
+    for impl in ("lds", "walk"):
+        with nat.options(FLMR_S2_IMPL=impl):
+            for tag, ql in (("full", None), ("ragged", q_lens)):
+                p, s, c = scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=ql)
+                torch.cuda.synchronize()
+                taps = [scorer.tap(nat.TAP_STAGE2, q) for q in range(Q.size(0))]
+                outs[impl, tag] = (p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), taps)
+            scorer.check()
+    for tag in ("full", "ragged"):
+        a, b = outs["lds", tag], outs["walk", tag]
+        for q in range(Q.size(0)):
+            assert np.array_equal(a[3][q], b[3][q]), ("stage-2 finalists", tag, q)
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), tag
+
+
+def test_stage2_walk_on_golden_fixture(hip, scorers):
+    """The walk against the reference's own stage-2 output (golden `filtered_pids`, produced by filter_pids.cpp) -- as a set, and
+    in order against the oracle's pruning run on the GPU's own score table (like test_search_stages_vs_golden does for the
+    default kernel)."""
+    from oracle import oracle as orc
+    nat = hip["native"]
+    z, scorer = scorers["idx_nb2"]
+    oi = orc.OracleIndex.from_golden(z)
+    for r in ("rank0", "rank3"):
+        with nat.options(FLMR_S2_IMPL="walk"):
+            _search_one(hip, scorer, z, r, full_table=False)
+            got = scorer.tap(nat.TAP_STAGE2)
+            cand = scorer.tap(nat.TAP_CANDIDATES)
+        _search_one(hip, scorer, z, r, full_table=True)
+        table = scorer.tap(nat.TAP_CENTROID_SCORES)
+        fin = oi.filter_pids(cand, table, table.max(axis=1) >= np.float32(z[f"{r}.thr"]), int(z[f"{r}.ndocs"]))
+        assert np.array_equal(got, fin), r
+        assert sorted(got.tolist()) == sorted(z[f"{r}.filtered_pids"].tolist()), r
