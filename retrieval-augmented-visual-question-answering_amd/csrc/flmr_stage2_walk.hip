@@ -44,6 +44,15 @@ __device__ __forceinline__ int w2_enc(float v) {
 }
 __device__ __forceinline__ float w2_dec(int e) { return __int_as_float(e ^ ((e >> 31) & 0x7fffffff)); }
 
+// -DW2_PROFILE (profiles/microbench/s2_walk_probe.hip): per-wave cycle counts of the three phases of a slice
+#ifdef W2_PROFILE
+#define W2_CLK(x) const long long x = __builtin_readcyclecounter()
+#define W2_ACC(k, v) prof_acc[k] += (v)
+#else
+#define W2_CLK(x)
+#define W2_ACC(k, v)
+#endif
+
 #define W2_SLICE 512                 // centroid rows per LDS buffer
 #define W2_STRIDE 36                 // floats per staged score row: 144 B, so that the rows random lanes read start in 16
                                      // different bank groups and every ds_read_b128 stays 16-byte aligned (2 x 72 KB of LDS)
@@ -105,7 +114,14 @@ int flmr_build_sorted_codes(flmr_index* ix) {
 __global__ __launch_bounds__(64 * W2_WAVES, 2) void filter_stage2_walk_kernel(
     flmr_filter_args f, const int32_t* __restrict__ pids, int64_t pid_stride, const int32_t* __restrict__ counts,
     uint64_t* __restrict__ keys, int64_t key_stride, const _Float16* __restrict__ cen16, const _Float16* __restrict__ q_hi,
-    const _Float16* __restrict__ q_lo, const int32_t* __restrict__ codes_sorted, int nchunks, int nitems) {
+    const _Float16* __restrict__ q_lo, const int32_t* __restrict__ codes_sorted, int nchunks, int nitems
+#ifdef W2_PROFILE
+    , long long* prof
+#endif
+    ) {
+#ifdef W2_PROFILE
+    long long prof_acc[3] = {0, 0, 0};
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* const buf = reinterpret_cast<int*>(smem);  // [2][W2_SLICE + 1][W2_STRIDE] score images (w2_enc)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -133,12 +149,15 @@ __global__ __launch_bounds__(64 * W2_WAVES, 2) void filter_stage2_walk_kernel(
         }
 
         // this lane's two passages: slots base + wave*128 + {0, 64} + lane of the survivor list.  Their ascending codes are
-        // streamed through two 4-entry register windows (current, next): `pos` is the array index of cw[0], `pn` the index
-        // the next window starts at.  Windows are fetched with one unconditional 16-byte load each -- entries past the
-        // passage's end are garbage and are never looked at (`pos < end` guards every use); codes_sorted carries 8 words
-        // of padding so the last passage's windows stay inside the allocation.
+        // streamed through 4-entry register windows.  `ps` is the array index of the next unread code (= cw.x), cw holds
+        // [ps, cwe), nw holds [cwe, nwe) (nwe == cwe: none).  A third window `st` is in flight: it is requested once per
+        // slice, BEFORE the slice's MFMA work, from the position behind nw, and becomes nw at the end of the slice if nw was
+        // used up meanwhile -- so the consumer loops contain no memory loads (a load inside their divergent flow costs a
+        // full-wave gather, merge copies and a vmcnt(0) that also waits for the prefetched A tile).  Windows are fetched
+        // with one unconditional 16-byte load; entries past the passage's end are garbage and are never looked at
+        // (`ps < end` guards every use); codes_sorted carries 8 words of padding.
         int pid[2];
-        uint32_t pos[2], pn[2], end[2];
+        uint32_t ps[2], cwe[2], nwe[2], end[2];
         w2i4 cw[2], nw[2];
         int m[2][32];              // running column maxima, w2_enc images (filter_pids.cpp:30-33: they start at -9999)
         auto load4 = [&](uint32_t p) { return *reinterpret_cast<const w2i4u*>(codes_sorted + p); };
@@ -146,16 +165,17 @@ __global__ __launch_bounds__(64 * W2_WAVES, 2) void filter_stage2_walk_kernel(
         for (int d = 0; d < 2; d++) {
             const int slot = base + wave * 128 + d * 64 + lane;
             pid[d] = -1;
-            pos[d] = end[d] = 0u;
+            ps[d] = end[d] = 0u;
             if (slot < cnt) {
                 pid[d] = pids[(size_t)b * pid_stride + slot];
                 const int64_t off = f.offsets[pid[d]];
-                pos[d] = (uint32_t)off;
+                ps[d] = (uint32_t)off;
                 end[d] = (uint32_t)(off + (f.doclens ? f.doclens[pid[d]] : (f.offsets[pid[d] + 1] - off)));
             }
-            cw[d] = load4(pos[d]);
-            pn[d] = pos[d] + 4u;
-            nw[d] = load4(pn[d]);
+            cw[d] = load4(ps[d]);
+            cwe[d] = ps[d] + 4u;
+            nw[d] = load4(cwe[d]);
+            nwe[d] = cwe[d] + 4u;
 #pragma unroll
             for (int c = 0; c < 32; c++) m[d][c] = w2_enc(-9999.0f);
         }
@@ -202,12 +222,10 @@ __global__ __launch_bounds__(64 * W2_WAVES, 2) void filter_stage2_walk_kernel(
         // the smallest image) instead, so the 32 running maxima are updated in place by every trip of the wave-uniform loop
         // (with an `if (active)` around them the compiler carries two copies of all 64 maxima through the loop's phi nodes;
         // with the test at the loop head it splits their live ranges and copies them on every trip -- hence guard + do/while).
-        // The window refill is a wave-uniform branch around one unconditional load, so the loaded window is not touched --
-        // and not waited for -- until it becomes the current one.
-        auto consume = [&](const int* src, int sb, int se, w2i4& cwd, w2i4& nwd, uint32_t& ps, uint32_t& pnx, const uint32_t e,
-                           int* md) {
-            if (__ballot(ps < e && cwd.x < se) != 0ull) do {
-                const bool act = ps < e && cwd.x < se;
+        auto consume = [&](const int* src, int sb, int se, w2i4& cwd, const w2i4& nwd, uint32_t& p, uint32_t& ce, const uint32_t ne,
+                           const uint32_t e, int* md) {
+            if (__ballot(p < ce && p < e && cwd.x < se) != 0ull) do {
+                const bool act = p < ce && p < e && cwd.x < se;
                 const int* rowp = src + (act ? (cwd.x - sb) : W2_SLICE) * W2_STRIDE;
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
@@ -217,34 +235,56 @@ __global__ __launch_bounds__(64 * W2_WAVES, 2) void filter_stage2_walk_kernel(
                     md[4 * j + 2] = max(md[4 * j + 2], t.z);
                     md[4 * j + 3] = max(md[4 * j + 3], t.w);
                 }
-                cwd.x = act ? cwd.y : cwd.x;
-                cwd.y = act ? cwd.z : cwd.y;
-                cwd.z = act ? cwd.w : cwd.z;
-                ps += act ? 1u : 0u;
-                const bool refill = ps == pnx;   // the current window is used up: the prefetched one takes over
-                if (__ballot(refill) != 0ull) {
-                    cwd.x = refill ? nwd.x : cwd.x;
-                    cwd.y = refill ? nwd.y : cwd.y;
-                    cwd.z = refill ? nwd.z : cwd.z;
-                    cwd.w = refill ? nwd.w : cwd.w;
-                    pnx += refill ? 4u : 0u;
-                    nwd = load4(pnx);            // every lane (re)loads its next window: no divergence, no merge copies
-                }
-            } while (__ballot(ps < e && cwd.x < se) != 0ull);
+                p += act ? 1u : 0u;
+                const bool promote = p == ce && ne != ce;   // cw used up and nw present: nw becomes the current window
+                cwd.x = promote ? nwd.x : (act ? cwd.y : cwd.x);
+                cwd.y = promote ? nwd.y : (act ? cwd.z : cwd.y);
+                cwd.z = promote ? nwd.z : (act ? cwd.w : cwd.z);
+                cwd.w = promote ? nwd.w : cwd.w;
+                ce = promote ? ne : ce;
+            } while (__ballot(p < ce && p < e && cwd.x < se) != 0ull);
         };
 
         // ---- the walk ------------------------------------------------------------------------------------------------
+        W2_CLK(t0);
         load_a(0, 2 * wave);
         produce(0, buf);
         __syncthreads();
         for (int s = 0; s < nslices; s++) {
             int* const cur = buf + (size_t)(s & 1) * W2_BUF;
             int* const nxt = buf + (size_t)((s + 1) & 1) * W2_BUF;
+            W2_CLK(t1);
+            // request the window behind nw (position nwe) for both passages: it lands during the MFMA work below
+            const uint32_t sta0 = nwe[0], sta1 = nwe[1];
+            const w2i4 st0 = load4(sta0), st1 = load4(sta1);
             if (s + 1 < nslices) produce(s + 1, nxt);
+            W2_CLK(t2);
             const int sb = s * W2_SLICE, se = sb + W2_SLICE;
-            consume(cur, sb, se, cw[0], nw[0], pos[0], pn[0], end[0], m[0]);
-            consume(cur, sb, se, cw[1], nw[1], pos[1], pn[1], end[1], m[1]);
+            while (true) {
+                consume(cur, sb, se, cw[0], nw[0], ps[0], cwe[0], nwe[0], end[0], m[0]);
+                consume(cur, sb, se, cw[1], nw[1], ps[1], cwe[1], nwe[1], end[1], m[1]);
+                // a passage with more than 4 .. 8 codes inside one slice runs out of buffered codes (rare): fetch its next
+                // window now (exposed latency) and go round again
+                const bool starved0 = ps[0] == cwe[0] && ps[0] < end[0], starved1 = ps[1] == cwe[1] && ps[1] < end[1];
+                if (__ballot(starved0 || starved1) == 0ull) break;
+                const w2i4 x0 = load4(cwe[0]), x1 = load4(cwe[1]);
+                if (starved0) { cw[0] = x0; cwe[0] += 4u; nwe[0] = cwe[0]; }
+                if (starved1) { cw[1] = x1; cwe[1] += 4u; nwe[1] = cwe[1]; }
+            }
+            // nw was promoted during this slice -> the staged window (it starts where nw ended) is the new nw
+            {
+                const bool take0 = nwe[0] == cwe[0] && sta0 == cwe[0], take1 = nwe[1] == cwe[1] && sta1 == cwe[1];
+                nw[0].x = take0 ? st0.x : nw[0].x; nw[0].y = take0 ? st0.y : nw[0].y;
+                nw[0].z = take0 ? st0.z : nw[0].z; nw[0].w = take0 ? st0.w : nw[0].w;
+                nw[1].x = take1 ? st1.x : nw[1].x; nw[1].y = take1 ? st1.y : nw[1].y;
+                nw[1].z = take1 ? st1.z : nw[1].z; nw[1].w = take1 ? st1.w : nw[1].w;
+                nwe[0] += take0 ? 4u : 0u;
+                nwe[1] += take1 ? 4u : 0u;
+            }
+            W2_CLK(t3);
             __syncthreads();  // `nxt` is complete, `cur` may be overwritten
+            W2_CLK(t4);
+            W2_ACC(0, t2 - t1); W2_ACC(1, t3 - t2); W2_ACC(2, t4 - t3);
         }
 
         // ---- k-ascending fp32 sum (filter_pids.cpp:59-63) and the (score, pid) key, slot-aligned with the survivor list
@@ -259,6 +299,10 @@ __global__ __launch_bounds__(64 * W2_WAVES, 2) void filter_stage2_walk_kernel(
             }
         }
     }
+#ifdef W2_PROFILE
+    if (lane == 0 && prof)
+        for (int k = 0; k < 3; k++) atomicAdd(reinterpret_cast<unsigned long long*>(prof) + k, (unsigned long long)prof_acc[k]);
+#endif
 }
 
 static int cu_count() {
@@ -294,7 +338,11 @@ int flmr_launch_filter_stage2_walk(const flmr_filter_args& f, const int32_t* pid
     const size_t lds = (size_t)2 * W2_BUF * sizeof(float);
     FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_stage2_walk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(filter_stage2_walk_kernel, dim3(grid), dim3(64 * W2_WAVES), lds, st, f, pids, pid_stride, counts, keys,
-                       key_stride, cen16, q_hi, q_lo, codes_sorted, nchunks, (int)nitems);
+                       key_stride, cen16, q_hi, q_lo, codes_sorted, nchunks, (int)nitems
+#ifdef W2_PROFILE
+                       , nullptr
+#endif
+    );
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }
