@@ -40,7 +40,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_keys, (size_t)NQ * ND * 8)); CK(hipMalloc(&d_prof, 64)); CK(hipMemset(d_prof, 0, 64));
     flmr_filter_args f{};
     f.K = K; f.ncol = 32; f.nq_cand = 32; f.nqueries = NQ; f.q_lens = nullptr; f.codes = d_codes; f.doclens = nullptr; f.offsets = d_off;
-    const size_t lds = (size_t)2 * W2_BUF * sizeof(int);
+    const size_t lds = (size_t)W2_BUF * sizeof(int) + 8192;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_stage2_walk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = NQ < cu_count() ? NQ : cu_count();
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

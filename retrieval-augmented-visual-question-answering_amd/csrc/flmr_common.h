@@ -111,8 +111,10 @@ struct flmr_index {
     uint32_t* ivf_chunk_tab;      // [K][nchunks+1]: first entry of each IVF list with pid >= chunk*32768
     int32_t nchunks;
     int32_t* codes_sorted;        // [N] per-passage ascending copy of `codes` (stage-2 walk); NULL when a passage is too long
+    _Float16* centroids_f16_tiled;  // centroids_f16 in MFMA A-operand order, one contiguous 1 KB run per (tile, k-step) (stage-2 walk)
 };
 int flmr_build_sorted_codes(flmr_index* ix);
+int flmr_build_tiled_centroids(flmr_index* ix);
 
 // build the fused byte -> (8/nbits) fp32 decode table from the codec tables (host)
 void flmr_build_wlut(int nbits, const float* bucket_weights, const uint8_t* reversed_bit_map,

@@ -378,12 +378,12 @@ static int stage_s2(run_ctx& c, bool whole_batch) {
     flmr_searcher* s = c.s;
     const flmr_index* ix = s->ix;
     const flmr_options& o = s->opt;
-    const bool walk = c.sparse && ix->codes_sorted &&
+    const bool walk = c.sparse && ix->codes_sorted && ix->centroids_f16_tiled &&
                       (o.is(FLMR_OPT_S2_IMPL, "walk") ||
                        (!o.has(FLMR_OPT_S2_IMPL) && whole_batch && flmr_stage2_walk_pays(ix, c.nqueries, c.p.ndocs)));
     if (walk)
         RUN(flmr_launch_filter_stage2_walk(c.f, s->s1_pids, s->maxp.ndocs, s->s1_count, c.p.ndocs, s->keys2, s->maxp.ndocs,
-                                           ix->centroids_f16, s->q_hi, s->q_lo, ix->codes_sorted, c.st));
+                                           ix->centroids_f16_tiled, s->q_hi, s->q_lo, ix->codes_sorted, c.st));
     else if (c.sparse)
         RUN(flmr_launch_filter_stage2_mfma(c.f, s->s1_pids, s->maxp.ndocs, s->s1_count, c.p.ndocs, s->keys2, s->maxp.ndocs,
                                            ix->centroids_f16, s->q_hi, s->q_lo, c.st));

@@ -16,17 +16,26 @@
 //
 // One workgroup (8 waves) owns a (query, block of 1024 survivors) item.  Every lane owns TWO passages and keeps their 32
 // running column maxima in registers (2 x 32 VGPRs) -- no atomics, no LDS accumulators.  The table is walked in slices of
-// 512 centroids: the waves compute the slice's [512 x 32] fp32 score tile with exactly the MFMA sequence of stage 0
-// (2 x v_mfma_f32_32x32x16_f16 per 16 dims against q_hi / q_lo, then fma(lo, 2^-11, hi): bitwise the values stage 0
-// produces) into one of two 72 KB LDS buffers while the lanes consume the previous slice from the other one: a lane walks
-// its passage's codes in ASCENDING order (`codes_sorted`, built once at flmr_index_open) and, for every code inside the
-// slice, reads that row from LDS (8 x ds_read_b128 at immediate offsets from one address; rows are 144 bytes apart so that
-// random rows spread over the banks) and folds it into its maxima.  max is exact, so the token order does not matter: the maxima -- and the
-// k-ascending fp32 sum -- are bit-identical to the gather kernels'.  One barrier per slice.
+// 1024 centroids, each in two strict phases separated by barriers:
+//   produce  every wave computes four 32-row tiles of the slice's [1024 x 32] fp32 score tile with exactly the MFMA sequence
+//            of stage 0 (2 x v_mfma_f32_32x32x16_f16 per 16 dims against q_hi / q_lo, then fma(lo, 2^-11, hi): bitwise the
+//            values stage 0 produces) and stores them to the 144 KB LDS buffer; the A operand comes from a copy of the
+//            table laid out in MFMA order (one contiguous 1 KB load per k-step), tile t+1 in flight behind tile t's MFMAs;
+//   consume  a lane walks its passages' codes in ASCENDING order (`codes_sorted`, built once at flmr_index_open) and, for
+//            every code inside the slice, reads that row from LDS (8 x ds_read_b128 at immediate offsets from one address;
+//            rows are 144 bytes apart so that random rows spread over the banks) and folds it into its maxima.
+// max is exact, so the token order does not matter: the maxima -- and the k-ascending fp32 sum -- are bit-identical to the
+// gather kernels'.  (A double-buffered variant with 512-row slices that overlaps the phases fits the 160 KB of LDS too, but
+// a lane then meets half as many of its codes per slice and the consumer loop -- whose trip count is the LONGEST per-lane
+// run in the wave -- runs at 15 % lane utilisation instead of 22 %; measured slower.)
 //
-// Bound: the consumer's VALU work (32 v_max per token, issued for the longest per-lane token run of each wave and slice)
-// and the MFMA pipe are of the same size; HBM is not involved (the 33.5 MB table is L2 / Infinity-Cache resident, the
-// sorted codes of the survivors are 0.5 MB per query).
+// Bound: the L2 -> CU stream of the table in the produce phase (one pass over all K rows per item: 256 KB per 1024-row slice
+// per CU; 34 TB/s chip-wide is the measured ceiling of that stream, = the MFMA time of the slice) and LDS instruction issue in
+// the consume phase.  Measured with profiles/microbench/s2_walk_probe (K = 131072, 1024 queries x 1024 survivors x 128
+// codes): 5.1 ms per launch -- per 1024-row slice and wave 11.4 k cycles produce, 6.1 k consume, 3.5 k barrier wait --
+// against 4.06 ms for the gather kernel on the same shape, so at BASELINE's shape (tokens per query == K) the gather stays
+// the default.  The walk's cost is proportional to K, the gather's to the survivors' token count: the cost model below
+// picks the walk when the table is the shorter of the two (the 10 k / 160 k-passage corpora with K = 16384 / 65536).
 #include "flmr_device.h"
 
 typedef _Float16 w2h8 __attribute__((ext_vector_type(8)));
@@ -53,10 +62,11 @@ __device__ __forceinline__ float w2_dec(int e) { return __int_as_float(e ^ ((e >
 #define W2_ACC(k, v)
 #endif
 
-#define W2_SLICE 512                 // centroid rows per LDS buffer
-#define W2_STRIDE 36                 // floats per staged score row: 144 B, so that the rows random lanes read start in 16
-                                     // different bank groups and every ds_read_b128 stays 16-byte aligned (2 x 72 KB of LDS)
 #define W2_WAVES 8
+#define W2_SLICE 1024                // centroid rows per slice (the LDS score buffer)
+#define W2_TPW (W2_SLICE / 32 / W2_WAVES)   // tiles per wave and slice
+#define W2_STRIDE 36                 // floats per staged score row: 144 B, so that the rows random lanes read start in 16
+                                     // different bank groups and every ds_read_b128 stays 16-byte aligned (144 KB of LDS)
 #define W2_DOCS (W2_WAVES * 128)     // passages per work item: two per lane
 #define W2_BUF ((W2_SLICE + 1) * W2_STRIDE)   // words per buffer: the score rows + one dummy row (the smallest image)
 #define W2_INF 0x7fffffff
@@ -94,6 +104,36 @@ __global__ __launch_bounds__(64) void sort_doc_codes_kernel(const int32_t* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// centroids_f16_tiled: the fp16 centroid table re-laid in the MFMA A-operand order.  Lane (i, h) of a wave needs dims
+// 64h .. 64h+63 of row i of a 32-row tile -- its own 128-byte line of the row-major table -- so loading a tile straight into
+// registers takes 8 instructions that EACH touch all 64 lines of the tile: the texture-address unit retires about one line per
+// cycle and the first version of the walk spent 9 000 of its 14 000 cycles per slice there (the LDS-DMA form of the same
+// tile is no faster: ~6.4 TB/s chip-wide, MI355X_MICROARCH.md).  In this copy 16-byte unit [(tile*8 + s)*64 + lane] holds
+// dims 64h+8s .. 64h+8s+7 of row tile*32 + i (lane = 32h + i), so step s of a tile is ONE fully contiguous 1 KB load that
+// lands in MFMA layout.  33.5 MB at K = 131072, built once at flmr_index_open.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tile_centroids_kernel(const _Float16* __restrict__ cen16, int K, uint4* __restrict__ out) {
+    const size_t n = (size_t)K * 16;  // 16-byte units
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(u & 63), s = (int)((u >> 6) & 7);
+        const size_t tile = u >> 9;
+        const int i = lane & 31, h = lane >> 5;
+        out[u] = *reinterpret_cast<const uint4*>(cen16 + (tile * 32 + i) * FLMR_DIM + 64 * h + 8 * s);
+    }
+}
+
+int flmr_build_tiled_centroids(flmr_index* ix) {
+    ix->centroids_f16_tiled = nullptr;
+    if (!ix->centroids_f16 || ix->K % 32 != 0) return FLMR_OK;
+    FLMR_HIP(hipMalloc(reinterpret_cast<void**>(&ix->centroids_f16_tiled), (size_t)ix->K * FLMR_DIM * sizeof(_Float16)));
+    hipLaunchKernelGGL(tile_centroids_kernel, dim3(2048), dim3(256), 0, 0, ix->centroids_f16, ix->K,
+                       reinterpret_cast<uint4*>(ix->centroids_f16_tiled));
+    FLMR_LAUNCH_CHECK();
+    FLMR_HIP(hipDeviceSynchronize());
+    return FLMR_OK;
+}
+
 int flmr_build_sorted_codes(flmr_index* ix) {
     ix->codes_sorted = nullptr;
     if (ix->max_doclen > W2_MAX_DOCLEN || ix->N >= 0x7fffffffLL || ix->num_passages <= 0 || ix->N <= 0) return FLMR_OK;
@@ -109,11 +149,11 @@ int flmr_build_sorted_codes(flmr_index* ix) {
 
 // ------------------------------------------------------------------------------------------------
 // The walk.  grid = min(#items, #CUs) persistent workgroups of 512 threads, item = (query, block of 1024 survivors);
-// dynamic LDS = 2 x W2_SLICE x W2_STRIDE floats (144 KB).
+// dynamic LDS = the score buffer (144 KB) + 8 KB for q_lo.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * W2_WAVES, 2) void filter_stage2_walk_kernel(
     flmr_filter_args f, const int32_t* __restrict__ pids, int64_t pid_stride, const int32_t* __restrict__ counts,
-    uint64_t* __restrict__ keys, int64_t key_stride, const _Float16* __restrict__ cen16, const _Float16* __restrict__ q_hi,
+    uint64_t* __restrict__ keys, int64_t key_stride, const _Float16* __restrict__ cen16t, const _Float16* __restrict__ q_hi,
     const _Float16* __restrict__ q_lo, const int32_t* __restrict__ codes_sorted, int nchunks, int nitems
 #ifdef W2_PROFILE
     , long long* prof
@@ -123,13 +163,13 @@ __global__ __launch_bounds__(64 * W2_WAVES, 2) void filter_stage2_walk_kernel(
     long long prof_acc[3] = {0, 0, 0};
 #endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* const buf = reinterpret_cast<int*>(smem);  // [2][W2_SLICE + 1][W2_STRIDE] score images (w2_enc)
+    int* const buf = reinterpret_cast<int*>(smem);  // [W2_SLICE + 1][W2_STRIDE] score images (w2_enc)
+    w2h8* const blds = reinterpret_cast<w2h8*>(smem + (size_t)W2_BUF * sizeof(int));  // [8 steps][64 lanes] q_lo in MFMA order
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int K = f.K;
     const int nslices = (K + W2_SLICE - 1) / W2_SLICE;
-    if (threadIdx.x < 2 * W2_STRIDE)  // the dummy row behind each buffer's 512 score rows
-        buf[(size_t)(threadIdx.x / W2_STRIDE) * W2_BUF + W2_SLICE * W2_STRIDE + threadIdx.x % W2_STRIDE] = (int)0x80000000;
+    if (threadIdx.x < W2_STRIDE) buf[W2_SLICE * W2_STRIDE + threadIdx.x] = (int)0x80000000;  // the dummy row behind the score rows
 
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int b = item / nchunks, chunk = item - b * nchunks;
@@ -139,14 +179,19 @@ __global__ __launch_bounds__(64 * W2_WAVES, 2) void filter_stage2_walk_kernel(
         const int qlen = f.q_lens ? f.q_lens[b] : f.nq_cand;
         const int nqc = qlen < f.nq_cand ? qlen : f.nq_cand;  // <= 32 on this path
 
-        // B operand: this query's fp16 split, lane (i, h) holds dims 64h .. 64h+63 of query token i
-        w2h8 bh[8], bl[8];
+        // B operand: this query's fp16 split, lane (i, h) holds dims 64h .. 64h+63 of query token i.  q_hi stays in registers
+        // (32 VGPRs); q_lo lives in LDS in MFMA order ([step][lane] 16-byte units, 8 KB, the same for every wave) and is read
+        // one step ahead of its MFMA -- with both halves in registers the kernel does not fit the 256-VGPR budget of two
+        // waves per SIMD next to the two A tiles, the accumulators and the 64 running maxima.
+        w2h8 bh[8];
         {
             const w2h8* ph = reinterpret_cast<const w2h8*>(q_hi + ((size_t)b * f.ncol + i) * FLMR_DIM + 64 * h);
-            const w2h8* pl = reinterpret_cast<const w2h8*>(q_lo + ((size_t)b * f.ncol + i) * FLMR_DIM + 64 * h);
 #pragma unroll
-            for (int s = 0; s < 8; s++) { bh[s] = ph[s]; bl[s] = pl[s]; }
+            for (int s = 0; s < 8; s++) bh[s] = ph[s];
+            const int u = threadIdx.x, us = u >> 6, ui = u & 31, uh = (u >> 5) & 1;   // 512 threads <-> 512 units
+            blds[u] = *reinterpret_cast<const w2h8*>(q_lo + ((size_t)b * f.ncol + ui) * FLMR_DIM + 64 * uh + 8 * us);
         }
+        __syncthreads();
 
         // this lane's two passages: slots base + wave*128 + {0, 64} + lane of the survivor list.  Their ascending codes are
         // streamed through 4-entry register windows.  `ps` is the array index of the next unread code (= cw.x), cw holds
@@ -158,7 +203,8 @@ __global__ __launch_bounds__(64 * W2_WAVES, 2) void filter_stage2_walk_kernel(
         // (`ps < end` guards every use); codes_sorted carries 8 words of padding.
         int pid[2];
         uint32_t ps[2], cwe[2], nwe[2], end[2];
-        w2i4 cw[2], nw[2];
+        int cwx[2], cwy[2], cwz[2], cww[2], nwx[2], nwy[2], nwz[2], nww[2];  // (scalars: element-wise selects on vector types
+                                                                             //  compile to index-compare chains)
         int m[2][32];              // running column maxima, w2_enc images (filter_pids.cpp:30-33: they start at -9999)
         auto load4 = [&](uint32_t p) { return *reinterpret_cast<const w2i4u*>(codes_sorted + p); };
 #pragma unroll
@@ -172,120 +218,157 @@ __global__ __launch_bounds__(64 * W2_WAVES, 2) void filter_stage2_walk_kernel(
                 ps[d] = (uint32_t)off;
                 end[d] = (uint32_t)(off + (f.doclens ? f.doclens[pid[d]] : (f.offsets[pid[d] + 1] - off)));
             }
-            cw[d] = load4(ps[d]);
+            const w2i4 w0 = load4(ps[d]);
+            cwx[d] = w0.x; cwy[d] = w0.y; cwz[d] = w0.z; cww[d] = w0.w;
             cwe[d] = ps[d] + 4u;
-            nw[d] = load4(cwe[d]);
+            const w2i4 w1 = load4(cwe[d]);
+            nwx[d] = w1.x; nwy[d] = w1.y; nwz[d] = w1.z; nww[d] = w1.w;
             nwe[d] = cwe[d] + 4u;
 #pragma unroll
             for (int c = 0; c < 32; c++) m[d][c] = w2_enc(-9999.0f);
         }
 
         // ---- producer pieces ------------------------------------------------------------------------------------
-        w2h8 a[8];  // A operand of the next tile to multiply: lane (i, h) holds dims 64h .. 64h+63 of centroid row i of the tile
-        auto load_a = [&](int slice, int tile) {
-            int row = slice * W2_SLICE + tile * 32 + i;
-            row = row < K ? row : 0;  // rows past the table are never referenced by a code
-            const w2h8* pc = reinterpret_cast<const w2h8*>(cen16 + (size_t)row * FLMR_DIM + 64 * h);
+        w2h8 a[8], a1[8];  // A operands of two tiles (ping-pong): lane (i, h) holds dims 64h .. 64h+63 of centroid row i
+        auto load_a = [&](w2h8* a, int slice, int tile) {  // from the tiled copy: step s is one contiguous 1 KB load (see above)
+            int t = slice * (W2_SLICE / 32) + tile;
+            t = t * 32 < K ? t : 0;  // tiles past the table are never referenced by a code
+            const w2h8* pc = reinterpret_cast<const w2h8*>(cen16t) + (size_t)t * 512 + lane;
 #pragma unroll
-            for (int s = 0; s < 8; s++) a[s] = pc[s];
+            for (int s = 0; s < 8; s++) a[s] = pc[s * 64];
         };
         f32x16 ah, al;
-        auto mfma_tile = [&]() {
+        auto mfma_tile = [&](const w2h8* a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
+            w2h8 blo[2] = {blds[lane], blds[64 + lane]};   // q_lo, two steps ahead of its MFMA
 #pragma unroll
             for (int s = 0; s < 8; s++) {
+                const w2h8 cur_lo = blo[s & 1];
+                if (s + 2 < 8) blo[s & 1] = blds[(s + 2) * 64 + lane];
                 ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bh[s], ah, 0, 0, 0);
-                al = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bl[s], al, 0, 0, 0);
+                al = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], cur_lo, al, 0, 0, 0);
             }
         };
         // C/D layout of the 32x32 MFMA: register r of lane (i, h) is row (r&3) + 8*(r>>2) + 4h, column i.  One lane-dependent
         // address, everything else is an immediate offset.
-        const int wbase = ((2 * wave) * 32 + 4 * h) * W2_STRIDE + i;
-        auto store_tile = [&](int* dst, int tile_rel) {
+        const int wbase = ((W2_TPW * wave) * 32 + 4 * h) * W2_STRIDE + i;
+        auto store_tile = [&](int tile_rel) {
 #pragma unroll
             for (int r = 0; r < 16; r++)
-                dst[wbase + (tile_rel * 32 + (r & 3) + 8 * (r >> 2)) * W2_STRIDE] = w2_enc(fmaf(al[r], 1.0f / 2048.0f, ah[r]));
+                buf[wbase + (tile_rel * 32 + (r & 3) + 8 * (r >> 2)) * W2_STRIDE] = w2_enc(fmaf(al[r], 1.0f / 2048.0f, ah[r]));
         };
-        // slice `s` into buffer `dst`; on return `a` holds tile 2*wave of slice s+1 (prefetched across the consumer phase)
-        auto produce = [&](int s, int* dst) {
-            mfma_tile();
-            load_a(s, 2 * wave + 1);
-            store_tile(dst, 0);
-            mfma_tile();
-            if (s + 1 < nslices) load_a(s + 1, 2 * wave);
-            store_tile(dst, 1);
+        // this wave's four tiles of slice `s`.  `a` already holds the first (requested before the previous consumer phase);
+        // every further tile is requested as soon as the registers it lands in have been read by the MFMAs of the tile
+        // before last, and the first tile of slice s+1 goes out behind the third.
+        auto produce = [&](int s) {
+            load_a(a1, s, W2_TPW * wave + 1);
+            mfma_tile(a);
+            load_a(a, s, W2_TPW * wave + 2);
+            store_tile(0);
+            mfma_tile(a1);
+            load_a(a1, s, W2_TPW * wave + 3);
+            store_tile(1);
+            mfma_tile(a);
+            if (s + 1 < nslices) load_a(a, s + 1, W2_TPW * wave);
+            store_tile(2);
+            mfma_tile(a1);
+            store_tile(3);
         };
 
-        // ---- consumer: fold the rows of this passage's codes that lie in [sb, se) -----------------------------------
-        // No control flow around the maxima: a lane without a token in the slice reads the buffer's dummy row (row W2_SLICE,
-        // the smallest image) instead, so the 32 running maxima are updated in place by every trip of the wave-uniform loop
+        // ---- consumer: fold the rows of both passages' codes that lie in [sb, se) --------------------------------------
+        // ONE wave-uniform loop serves both passages of a lane per trip (two independent LDS read streams in flight, half the
+        // trips of two loops).  No control flow around the maxima: a passage without a token in the slice reads the buffer's
+        // dummy row (row W2_SLICE, the smallest image) instead, so the running maxima are updated in place on every trip
         // (with an `if (active)` around them the compiler carries two copies of all 64 maxima through the loop's phi nodes;
         // with the test at the loop head it splits their live ranges and copies them on every trip -- hence guard + do/while).
-        auto consume = [&](const int* src, int sb, int se, w2i4& cwd, const w2i4& nwd, uint32_t& p, uint32_t& ce, const uint32_t ne,
-                           const uint32_t e, int* md) {
-            if (__ballot(p < ce && p < e && cwd.x < se) != 0ull) do {
-                const bool act = p < ce && p < e && cwd.x < se;
-                const int* rowp = src + (act ? (cwd.x - sb) : W2_SLICE) * W2_STRIDE;
+        // The loop contains no memory loads: a load inside its divergent flow costs a full-wave gather, merge copies and a
+        // vmcnt(0) that also waits for the prefetched A tile.
+#define W2_ACT(d) ((ps[d] < cwe[d]) & (ps[d] < end[d]) & (cwx[d] < se))   /* `&`, not `&&`: no short-circuit branches */
+#define W2_STEP(d, act)                                                                                          \
+    {                                                                                                            \
+        cwx[d] = (act) ? cwy[d] : cwx[d];                                                                        \
+        cwy[d] = (act) ? cwz[d] : cwy[d];                                                                        \
+        cwz[d] = (act) ? cww[d] : cwz[d];                                                                        \
+        ps[d] += (act) ? 1u : 0u;                                                                                \
+        const bool promote = (ps[d] == cwe[d]) & (nwe[d] != cwe[d]); /* cw used up, nw present: nw takes over */ \
+        cwx[d] = promote ? nwx[d] : cwx[d];                                                                      \
+        cwy[d] = promote ? nwy[d] : cwy[d];                                                                      \
+        cwz[d] = promote ? nwz[d] : cwz[d];                                                                      \
+        cww[d] = promote ? nww[d] : cww[d];                                                                      \
+        cwe[d] = promote ? nwe[d] : cwe[d];                                                                      \
+    }
+        auto consume = [&](const int* src, int sb, int se) {
+            if (__ballot(W2_ACT(0) | W2_ACT(1)) != 0ull) do {
+                const bool act0 = W2_ACT(0), act1 = W2_ACT(1);
+                const int* r0 = src + (act0 ? (cwx[0] - sb) : W2_SLICE) * W2_STRIDE;
+                const int* r1 = src + (act1 ? (cwx[1] - sb) : W2_SLICE) * W2_STRIDE;
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const w2i4 t = *reinterpret_cast<const w2i4*>(rowp + 4 * j);
-                    md[4 * j + 0] = max(md[4 * j + 0], t.x);
-                    md[4 * j + 1] = max(md[4 * j + 1], t.y);
-                    md[4 * j + 2] = max(md[4 * j + 2], t.z);
-                    md[4 * j + 3] = max(md[4 * j + 3], t.w);
+                    const w2i4 t = *reinterpret_cast<const w2i4*>(r0 + 4 * j);
+                    m[0][4 * j + 0] = max(m[0][4 * j + 0], t.x);
+                    m[0][4 * j + 1] = max(m[0][4 * j + 1], t.y);
+                    m[0][4 * j + 2] = max(m[0][4 * j + 2], t.z);
+                    m[0][4 * j + 3] = max(m[0][4 * j + 3], t.w);
                 }
-                p += act ? 1u : 0u;
-                const bool promote = p == ce && ne != ce;   // cw used up and nw present: nw becomes the current window
-                cwd.x = promote ? nwd.x : (act ? cwd.y : cwd.x);
-                cwd.y = promote ? nwd.y : (act ? cwd.z : cwd.y);
-                cwd.z = promote ? nwd.z : (act ? cwd.w : cwd.z);
-                cwd.w = promote ? nwd.w : cwd.w;
-                ce = promote ? ne : ce;
-            } while (__ballot(p < ce && p < e && cwd.x < se) != 0ull);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const w2i4 t = *reinterpret_cast<const w2i4*>(r1 + 4 * j);
+                    m[1][4 * j + 0] = max(m[1][4 * j + 0], t.x);
+                    m[1][4 * j + 1] = max(m[1][4 * j + 1], t.y);
+                    m[1][4 * j + 2] = max(m[1][4 * j + 2], t.z);
+                    m[1][4 * j + 3] = max(m[1][4 * j + 3], t.w);
+                }
+                W2_STEP(0, act0)
+                W2_STEP(1, act1)
+            } while (__ballot(W2_ACT(0) | W2_ACT(1)) != 0ull);
         };
 
         // ---- the walk ------------------------------------------------------------------------------------------------
-        W2_CLK(t0);
-        load_a(0, 2 * wave);
-        produce(0, buf);
-        __syncthreads();
+        load_a(a, 0, W2_TPW * wave);
         for (int s = 0; s < nslices; s++) {
-            int* const cur = buf + (size_t)(s & 1) * W2_BUF;
-            int* const nxt = buf + (size_t)((s + 1) & 1) * W2_BUF;
             W2_CLK(t1);
-            // request the window behind nw (position nwe) for both passages: it lands during the MFMA work below
+            // request the window behind nw (position nwe) for both passages: it lands during the MFMA work below and becomes
+            // nw at the end of the consumer phase if nw was used up meanwhile
             const uint32_t sta0 = nwe[0], sta1 = nwe[1];
             const w2i4 st0 = load4(sta0), st1 = load4(sta1);
-            if (s + 1 < nslices) produce(s + 1, nxt);
+            produce(s);
             W2_CLK(t2);
+            __syncthreads();  // the slice is complete
+            W2_CLK(t3);
             const int sb = s * W2_SLICE, se = sb + W2_SLICE;
             while (true) {
-                consume(cur, sb, se, cw[0], nw[0], ps[0], cwe[0], nwe[0], end[0], m[0]);
-                consume(cur, sb, se, cw[1], nw[1], ps[1], cwe[1], nwe[1], end[1], m[1]);
+                consume(buf, sb, se);
                 // a passage with more than 4 .. 8 codes inside one slice runs out of buffered codes (rare): fetch its next
                 // window now (exposed latency) and go round again
-                const bool starved0 = ps[0] == cwe[0] && ps[0] < end[0], starved1 = ps[1] == cwe[1] && ps[1] < end[1];
-                if (__ballot(starved0 || starved1) == 0ull) break;
+                const bool starved0 = (ps[0] == cwe[0]) & (ps[0] < end[0]), starved1 = (ps[1] == cwe[1]) & (ps[1] < end[1]);
+                if (__ballot(starved0 | starved1) == 0ull) break;
                 const w2i4 x0 = load4(cwe[0]), x1 = load4(cwe[1]);
-                if (starved0) { cw[0] = x0; cwe[0] += 4u; nwe[0] = cwe[0]; }
-                if (starved1) { cw[1] = x1; cwe[1] += 4u; nwe[1] = cwe[1]; }
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), here: keeps the wait out of the consumer loop
+                cwx[0] = starved0 ? x0.x : cwx[0]; cwy[0] = starved0 ? x0.y : cwy[0];
+                cwz[0] = starved0 ? x0.z : cwz[0]; cww[0] = starved0 ? x0.w : cww[0];
+                cwx[1] = starved1 ? x1.x : cwx[1]; cwy[1] = starved1 ? x1.y : cwy[1];
+                cwz[1] = starved1 ? x1.z : cwz[1]; cww[1] = starved1 ? x1.w : cww[1];
+                cwe[0] += starved0 ? 4u : 0u; cwe[1] += starved1 ? 4u : 0u;
+                nwe[0] = starved0 ? cwe[0] : nwe[0]; nwe[1] = starved1 ? cwe[1] : nwe[1];
             }
             // nw was promoted during this slice -> the staged window (it starts where nw ended) is the new nw
             {
-                const bool take0 = nwe[0] == cwe[0] && sta0 == cwe[0], take1 = nwe[1] == cwe[1] && sta1 == cwe[1];
-                nw[0].x = take0 ? st0.x : nw[0].x; nw[0].y = take0 ? st0.y : nw[0].y;
-                nw[0].z = take0 ? st0.z : nw[0].z; nw[0].w = take0 ? st0.w : nw[0].w;
-                nw[1].x = take1 ? st1.x : nw[1].x; nw[1].y = take1 ? st1.y : nw[1].y;
-                nw[1].z = take1 ? st1.z : nw[1].z; nw[1].w = take1 ? st1.w : nw[1].w;
+                const bool take0 = (nwe[0] == cwe[0]) & (sta0 == cwe[0]), take1 = (nwe[1] == cwe[1]) & (sta1 == cwe[1]);
+                nwx[0] = take0 ? st0.x : nwx[0]; nwy[0] = take0 ? st0.y : nwy[0];
+                nwz[0] = take0 ? st0.z : nwz[0]; nww[0] = take0 ? st0.w : nww[0];
+                nwx[1] = take1 ? st1.x : nwx[1]; nwy[1] = take1 ? st1.y : nwy[1];
+                nwz[1] = take1 ? st1.z : nwz[1]; nww[1] = take1 ? st1.w : nww[1];
                 nwe[0] += take0 ? 4u : 0u;
                 nwe[1] += take1 ? 4u : 0u;
             }
-            W2_CLK(t3);
-            __syncthreads();  // `nxt` is complete, `cur` may be overwritten
             W2_CLK(t4);
-            W2_ACC(0, t2 - t1); W2_ACC(1, t3 - t2); W2_ACC(2, t4 - t3);
+            __syncthreads();  // the buffer may be overwritten
+            W2_CLK(t5);
+            W2_ACC(0, t2 - t1); W2_ACC(1, t4 - t3); W2_ACC(2, (t3 - t2) + (t5 - t4));
         }
+#undef W2_ACT
+#undef W2_STEP
 
         // ---- k-ascending fp32 sum (filter_pids.cpp:59-63) and the (score, pid) key, slot-aligned with the survivor list
 #pragma unroll
@@ -318,16 +401,16 @@ static int cu_count() {
 // true when the walk is the cheaper form for this launch: it needs the sorted code copy, a chip's worth of items (an item
 // occupies one CU for the whole table walk), and a table that is not much longer than the token runs it replaces
 bool flmr_stage2_walk_pays(const flmr_index* ix, int nqueries, int max_count) {
-    if (!ix->codes_sorted || max_count <= 0) return false;
+    if (!ix->codes_sorted || !ix->centroids_f16_tiled || max_count <= 0) return false;
     const int nchunks = (int)flmr_ceil_div(max_count, W2_DOCS);
     const int64_t nitems = (int64_t)nqueries * nchunks;
     if (nitems * 2 < cu_count()) return false;
     const double tokens = (double)max_count * ((double)ix->N / (double)(ix->num_passages > 0 ? ix->num_passages : 1));
-    return (double)ix->K * nchunks <= 1.5 * tokens;
+    return (double)ix->K * nchunks <= 0.6 * tokens;   // measured break-even: K = 0.8 x tokens (see the header)
 }
 
 int flmr_launch_filter_stage2_walk(const flmr_filter_args& f, const int32_t* pids, int64_t pid_stride, const int32_t* counts,
-                                   int32_t max_count, uint64_t* keys, int64_t key_stride, const _Float16* cen16,
+                                   int32_t max_count, uint64_t* keys, int64_t key_stride, const _Float16* cen16_tiled,
                                    const _Float16* q_hi, const _Float16* q_lo, const int32_t* codes_sorted, hipStream_t st) {
     if (max_count <= 0) return FLMR_OK;
     if (f.ncol != 32) FLMR_FAIL(FLMR_ERR_INVALID, "stage-2 walk needs one column tile");
@@ -335,10 +418,10 @@ int flmr_launch_filter_stage2_walk(const flmr_filter_args& f, const int32_t* pid
     const int nchunks = (int)flmr_ceil_div(max_count, W2_DOCS);
     const int64_t nitems = (int64_t)f.nqueries * nchunks;
     const int grid = (int)(nitems < cu_count() ? nitems : cu_count());
-    const size_t lds = (size_t)2 * W2_BUF * sizeof(float);
+    const size_t lds = (size_t)W2_BUF * sizeof(int) + 8192;
     FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_stage2_walk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(filter_stage2_walk_kernel, dim3(grid), dim3(64 * W2_WAVES), lds, st, f, pids, pid_stride, counts, keys,
-                       key_stride, cen16, q_hi, q_lo, codes_sorted, nchunks, (int)nitems
+                       key_stride, cen16_tiled, q_hi, q_lo, codes_sorted, nchunks, (int)nitems
 #ifdef W2_PROFILE
                        , nullptr
 #endif
