@@ -1,13 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- queries/sec (+ Recall@5) of the FLMR late-interaction search path on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched with
-torch.distributed.run, one rank per GPU (RCCL).  A "step" = one pass of the whole hot path (S0..S4) over one batch of
-`--batch` synthetic queries (Nq=32, d=128) against the synthetic clustered corpus of BASELINE.md section 3
-(1 M passages x 128 tokens, K=131072, nbits=2), index and queries already resident in HBM.  For N > 1 the index is
-sharded by passage (BASELINE.json configs[3]): every rank searches its shard for every query, then ONE all-gather of
-the per-shard top-k over xGMI and a merge; the total work is fixed, so `scaling` is "strong".
-Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched with torch.distributed.run,
+one rank per GPU (RCCL).  A "step" = one pass of the whole hot path (S0..S4) over one batch of `--batch` synthetic queries
+(Nq=32, d=128) against the synthetic clustered corpus of BASELINE.md section 3 / SURVEY 8(d) (1 M passages x 128 tokens,
+K=131072, nbits=2), index and queries already resident in HBM.  The steps ROTATE over `--query-batches` distinct batches
+(4 x 1024 = 4096 queries by default), so no step re-reads the cache lines of the one before.  For N > 1 the index is
+sharded by passage (BASELINE.json configs[3]); the total work is fixed, so `scaling` is "strong".  Rank 0 prints ONE JSON
+line.
+
+Besides the contract's keys the line carries (N = 1):
+  roofline      the dominant kernel (largest per-stage HIP-event time inside the timed region) against its roof, from the
+                kernel's OWN compulsory bytes / flops (SURVEY 8(d) counts intermediates as 0); `per_kernel` does the same
+                for every stage; `whole_path` = the bytes this build must move per query against the HBM peak;
+  cpu_baseline  the reference's compiled C++ stages + torch-CPU glue (oracle/_ref), >= 64 queries on all host threads and
+                a second sample on 8 threads, with the ranked lists compared to the GPU's in the same run;
+  sub_results   the same path at k=5, nbits=8, ragged passages and Nq=832 (short runs);
+  hbm_copy_GBs  measured device copy bandwidth (read + write), next to the 8 TB/s spec used as `peak`.
+N > 1: `exchange_ms` = wall time of each collective of the exact sharded protocol, measured in separate un-timed steps.
 """
 import argparse
 import json
@@ -18,24 +28,29 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-FP32_MFMA_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+F16_MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA peak (no sparsity)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.csv")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--passages", type=int, default=1_000_000)
     ap.add_argument("--doclen", type=int, default=128)
+    ap.add_argument("--ragged", action="store_true", help="doclens ~ U{32..224} (mean 128) instead of a fixed length")
     ap.add_argument("--centroids", type=int, default=0, help="0 = 2^floor(log2(16*sqrt(N)))  (collection_indexer.py:93)")
     ap.add_argument("--nbits", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="queries per step (one batched _search_all_Q-style pass)")
+    ap.add_argument("--query-batches", type=int, default=4, help="distinct query batches the steps rotate over")
     ap.add_argument("--nq", type=int, default=32)
     ap.add_argument("--k", type=int, default=100)
-    ap.add_argument("--cpu-queries", type=int, default=12, help="queries of the batch timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-queries", type=int, default=64, help="queries timed on the CPU baseline at all threads (0 = skip)")
+    ap.add_argument("--cpu-queries-8t", type=int, default=16, help="queries timed on the CPU baseline at 8 threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the k=5 / nbits=8 / ragged / Nq=832 sub-results")
     ap.add_argument("--replicate-stage0", action="store_true",
                     help="exact shard mode: every rank runs stage 0 for the whole batch instead of 1/N of the queries + an exchange")
     ap.add_argument("--shard-mode", choices=["exact", "fast"], default="exact",
@@ -47,12 +62,55 @@ def parse():
     return ap.parse_args()
 
 
+def k_policy(k):
+    return (2, 0.45, 1024) if k <= 100 else (4, 0.4, max(4 * k, 4096))   # searcher.py:92-118
+
+
+def num_centroids(n_tok):
+    import math
+    return 2 ** int(math.floor(math.log2(16.0 * math.sqrt(n_tok))))       # collection_indexer.py:93
+
+
+def shard_of(corpus, rank, world, synth, torch):
+    """Passage shard `rank` of `world` of a device-resident corpus: contiguous pid range, IVF restricted."""
+    P, K = corpus.doclens.numel(), corpus.K
+    lo, hi = (P * rank) // world, (P * (rank + 1)) // world
+    tlo, thi = int(corpus.doc_offsets[lo]), int(corpus.doc_offsets[hi])
+    keep = (corpus.ivf >= lo) & (corpus.ivf < hi)
+    owner = torch.repeat_interleave(torch.arange(K, device="cuda"), corpus.ivf_lengths)
+    sh = synth.SyntheticCorpus()
+    sh.dim, sh.nbits, sh.K, sh.sigma = corpus.dim, corpus.nbits, K, corpus.sigma
+    sh.centroids, sh.bucket_weights, sh.bucket_cutoffs = corpus.centroids, corpus.bucket_weights, corpus.bucket_cutoffs
+    sh.codes, sh.residuals = corpus.codes[tlo:thi].contiguous(), corpus.residuals[tlo:thi].contiguous()
+    sh.doclens = corpus.doclens[lo:hi].contiguous()
+    sh.doc_offsets = (corpus.doc_offsets[lo:hi + 1] - tlo).contiguous()
+    sh.ivf = (corpus.ivf[keep] - lo).to(torch.int32).contiguous()
+    sh.ivf_lengths = torch.bincount(owner[keep], minlength=K).long()
+    sh.ivf_offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), torch.cumsum(sh.ivf_lengths, 0)])
+    return sh, lo
+
+
+def tie_aware_same(ref_p, ref_s, got_p, gap=1e-5):
+    """ids position by position, swaps allowed only inside runs of reference scores closer than `gap`."""
+    if len(ref_p) != len(got_p):
+        return False
+    a0 = 0
+    while a0 < len(ref_p):
+        a1 = a0
+        while a1 + 1 < len(ref_p) and abs(ref_s[a1] - ref_s[a1 + 1]) <= gap:
+            a1 += 1
+        if sorted(ref_p[a0:a1 + 1]) != sorted(got_p[a0:a1 + 1]):
+            return False
+        a0 = a1 + 1
+    return True
+
+
 def main():
     args = parse()
     import torch
     import torch.distributed as dist
-    import ravqa_amd
-    from ravqa_amd import synth, ops
+    import ravqa_amd  # noqa: F401
+    from ravqa_amd import _native, ops, synth
     from ravqa_amd.scorer import IndexScorer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -68,202 +126,295 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    N_tok = args.passages * args.doclen
-    K = args.centroids or 2 ** int(torch.log2(torch.tensor(16.0 * (N_tok ** 0.5))).floor())
+    doclen = (32, 224) if args.ragged else args.doclen
+    K = args.centroids or num_centroids(args.passages * args.doclen)
     k = args.k
-    ncells, thr, ndocs = (2, 0.45, 1024) if k <= 100 else (4, 0.4, max(4 * k, 4096))   # searcher.py:92-118
-
-    # ---- synthetic corpus, generated on the GPU, identical on every rank; then this rank's passage shard --------
-    t0 = time.time()
-    corpus = synth.make_corpus(args.passages, args.doclen, K, args.nbits, seed=0, device="cuda")
-    Q, targets = synth.make_queries(corpus, args.batch, args.nq, seed=2)
-    if world > 1:
-        lo, hi = (args.passages * rank) // world, (args.passages * (rank + 1)) // world
-        tlo, thi = int(corpus.doc_offsets[lo]), int(corpus.doc_offsets[hi])
-        keep = (corpus.ivf >= lo) & (corpus.ivf < hi)
-        owner = torch.repeat_interleave(torch.arange(K, device="cuda"), corpus.ivf_lengths)
-        shard = synth.SyntheticCorpus()
-        shard.dim, shard.nbits, shard.K, shard.sigma = corpus.dim, corpus.nbits, K, corpus.sigma
-        shard.centroids, shard.bucket_weights, shard.bucket_cutoffs = corpus.centroids, corpus.bucket_weights, corpus.bucket_cutoffs
-        shard.codes, shard.residuals = corpus.codes[tlo:thi].contiguous(), corpus.residuals[tlo:thi].contiguous()
-        shard.doclens = corpus.doclens[lo:hi].contiguous()
-        shard.doc_offsets = (corpus.doc_offsets[lo:hi + 1] - tlo).contiguous()
-        shard.ivf = (corpus.ivf[keep] - lo).to(torch.int32).contiguous()
-        shard.ivf_lengths = torch.bincount(owner[keep], minlength=K).long()
-        shard.ivf_offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), torch.cumsum(shard.ivf_lengths, 0)])
-        local, pid_base = shard, lo
-    else:
-        local, pid_base = corpus, 0
-    scorer = IndexScorer(device_index=synth.corpus_device_index(local, pid_base=pid_base), max_batch=args.batch)
-    torch.cuda.synchronize()
-    t_build = time.time() - t0
-
-    from ravqa_amd.distributed import ShardedSearcher
-    sharded = ShardedSearcher(scorer=scorer) if world > 1 else None
-
-    def host_gather(t):  # --single-device-smoke only: gloo cannot gather device tensors
-        parts = [torch.empty_like(t, device="cpu") for _ in range(world)]
-        dist.all_gather(parts, t.cpu())
-        return torch.stack(parts).cuda()
-
-    def step(profile=False):
-        if world > 1 and args.shard_mode == "exact":
-            return sharded.search_batch_exact(Q, k, nq_cand=32, gather=host_gather if args.single_device_smoke else None,
-                                              split_stage0=not args.replicate_stage0)
-        p, s, c = scorer.search_batch(Q, k, ncells, thr, ndocs, 32, profile=profile)  # query_maxlen = 32 (index_storage.py:77)
-        if world > 1:
-            gs = torch.empty((world,) + tuple(s.shape), dtype=s.dtype, device="cuda")
-            gp = torch.empty((world,) + tuple(p.shape), dtype=p.dtype, device="cuda")
-            if args.single_device_smoke:
-                hs, hp = [torch.empty_like(s, device="cpu") for _ in range(world)], [torch.empty_like(p, device="cpu") for _ in range(world)]
-                dist.all_gather(hs, s.cpu())
-                dist.all_gather(hp, p.cpu())
-                gs, gp = torch.stack(hs).cuda(), torch.stack(hp).cuda()
-            else:
-                dist.all_gather_into_tensor(gs, s)
-                dist.all_gather_into_tensor(gp, p)
-            s, p, c = ops.merge_topk(gs, gp)
-        return p, s, c
+    ncells, thr, ndocs = k_policy(k)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    stage_sum = {}
-    barrier()
-    t0 = time.perf_counter()
-    staged = world > 1 and args.shard_mode == "exact"   # the phased protocol has no per-stage event set
-    for _ in range(args.steps):
-        p, s, c = step(profile=True)
-        if not staged:
-            for name, ms in scorer.stage_ms().items():   # HIP events on the launch stream, recorded inside the timed region
-                stage_sum[name] = stage_sum.get(name, 0.0) + ms
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cpu" if args.single_device_smoke else "cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def host_gather(t):  # --single-device-smoke only: gloo cannot gather device tensors
+        parts = [torch.empty_like(t, device="cpu") for _ in range(world)]
+        dist.all_gather(parts, t.cpu())
+        return torch.stack(parts).cuda()
+
+    # ---- synthetic corpus, generated on the GPU, identical on every rank; then this rank's passage shard -----------
+    t0 = time.time()
+    corpus = synth.make_corpus(args.passages, doclen, K, args.nbits, seed=0, device="cuda")
+    nb = max(1, args.query_batches)
+    Qs, tgts = [], []
+    for j in range(nb):
+        Qj, tj = synth.make_queries(corpus, args.batch, args.nq, seed=2 + j)
+        Qs.append(Qj)
+        tgts.append(tj)
+    local, pid_base = shard_of(corpus, rank, world, synth, torch) if world > 1 else (corpus, 0)
+    scorer = IndexScorer(device_index=synth.corpus_device_index(local, pid_base=pid_base), max_batch=args.batch)
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+
+    from ravqa_amd.distributed import ShardedSearcher
+    sharded = ShardedSearcher(scorer=scorer) if world > 1 else None
+    exact = world > 1 and args.shard_mode == "exact"
+
+    def run_step(sc, Q, kk, pol, profile=False):
+        if exact:
+            return sharded.search_batch_exact(Q, kk, nq_cand=32, gather=host_gather if args.single_device_smoke else None,
+                                              split_stage0=not args.replicate_stage0)
+        p, s, c = sc.search_batch(Q, kk, pol[0], pol[1], pol[2], 32, profile=profile)   # query_maxlen = 32 (index_storage.py:77)
+        if world > 1:
+            if args.single_device_smoke:
+                gs, gp = host_gather(s), host_gather(p)
+            else:
+                gs = torch.empty((world,) + tuple(s.shape), dtype=s.dtype, device="cuda")
+                gp = torch.empty((world,) + tuple(p.shape), dtype=p.dtype, device="cuda")
+                dist.all_gather_into_tensor(gs, s)
+                dist.all_gather_into_tensor(gp, p)
+            s, p, c = ops.merge_topk(gs, gp)
+        return p, s, c
+
+    def timed(sc, batches, targets, kk, pol, steps, warmup, collect_stages):
+        for i in range(warmup):
+            run_step(sc, batches[i % len(batches)], kk, pol)
+        stage_sum, last = {}, {}
+        barrier()
+        t0_ = time.perf_counter()
+        for i in range(steps):
+            j = i % len(batches)
+            last[j] = run_step(sc, batches[j], kk, pol, profile=collect_stages)
+            if collect_stages:
+                for name, ms in sc.stage_ms().items():   # HIP events on the launch stream, inside the timed region
+                    stage_sum[name] = stage_sum.get(name, 0.0) + ms
+        barrier()
+        dt = time.perf_counter() - t0_
+        if world > 1:
+            t = torch.tensor([dt], device="cpu" if args.single_device_smoke else "cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        sc.check()
+        hits = [float((last[j][0][:, :5] == targets[j].unsqueeze(1).to(torch.int32)).any(dim=1).float().mean()) for j in last]
+        return dt, {n: v / steps for n, v in stage_sum.items()}, sum(hits) / len(hits), last
+
+    dt, stage_ms, recall5, last = timed(scorer, Qs, tgts, k, (ncells, thr, ndocs), args.steps, args.warmup,
+                                        collect_stages=not exact)
     ms_per_step = dt / args.steps * 1e3
     qps = args.batch * args.steps / dt
-    stage_ms = {n: v / args.steps for n, v in stage_sum.items()}
 
-    # ---- workload statistics of the last batch (outside the timed region) --------------------------------------------
-    from ravqa_amd import _native
-    P = [len(scorer.tap(_native.TAP_CANDIDATES, q)) for q in range(0, args.batch, max(1, args.batch // 32))]
-    ncell = [len(scorer.tap(_native.TAP_CELLS, q)) for q in range(0, args.batch, max(1, args.batch // 32))]
-    P_mean, ncell_mean = sum(P) / len(P), sum(ncell) / len(ncell)
-    recall5 = float((p[:, :5] == targets.unsqueeze(1).to(torch.int32)).any(dim=1).float().mean())
-    d, B = 128, 128 * args.nbits // 8
-    nfin_tok = (ndocs // 4) * args.doclen
-    ivf_mean_len = float(local.ivf_lengths.float().mean())
-    # SURVEY 8(d) algorithmic bytes per query (per shard): IVF lists + (doclen,offset) + S1 code scan + residuals of
-    # the finalists + their centroid rows + Q + output + centroid matrix amortised over the batch
-    alg_bytes = (4 * ncell_mean * ivf_mean_len + 16 * P_mean + 4 * P_mean * args.doclen + B * nfin_tok
-                 + 4 * d * min(K, nfin_tok) + 4 * d * args.nq + 8 * k + 4 * d * K / args.batch)
-    s1_bytes = 16 * P_mean + 4 * P_mean * args.doclen
-    s0_flops = 2.0 * K * d * min(args.nq, 32)
-    if not stage_ms:  # phased multi-GPU run: per-stage events are a single-GPU measurement (see the N=1 line)
-        stage_ms = {"whole_step": ms_per_step}
-    dom = max(stage_ms, key=stage_ms.get)
-    dom_ms_per_query = stage_ms[dom] / args.batch
-    if dom == "s0_centroid_scores":
-        ach = s0_flops / (dom_ms_per_query * 1e-3) / 1e12
-        roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None}
-    else:
-        nbytes = {"s1_filter": s1_bytes, "s3_maxsim": B * nfin_tok + 4 * d * min(K, nfin_tok) + 4 * nfin_tok,
-                  "s2_filter_sort": 4 * ndocs * args.doclen + 4 * 32 * ndocs * args.doclen}.get(dom, alg_bytes)
-        ach = nbytes / (dom_ms_per_query * 1e-3) / 1e9
-        roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None}
-    roof["launch_ms"] = stage_ms[dom]
-    # HBM bytes per launch of the dominant kernel from the PMC passes (profiles/pmc_passes.sh: FETCH_SIZE doubled as the
-    # gfx950 guide prescribes, + WRITE_SIZE), when a summary for this round has been committed next to this file
-    try:
-        import csv
-        kname = {"s1_filter": "filter_stage1_kernel", "s0_centroid_scores": "s0_centroid_scores_f16", "s3_maxsim": "maxsim_f16_kernel",
-                 "s2_filter_sort": "filter_stage2", "s0_candidates": "cand_mark_score_kernel"}.get(dom)
-        with open(os.path.join(ROOT, "profiles", "pmc_summary_latest.csv")) as f:
-            for row in csv.DictReader(f):
-                if kname and kname in row["kernel"] and args.passages == 1_000_000 and world == 1:
-                    roof["traffic"] = (2.0 * float(row["FETCH_SIZE"]) + float(row["WRITE_SIZE"])) * 1024.0
-                    roof["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/)"
-    except Exception:
-        pass
-    roof["whole_path_algorithmic_GBs"] = alg_bytes * qps / 1e9
-    roof["whole_path_frac_of_hbm_peak"] = alg_bytes * qps / 1e9 / HBM_PEAK_GBS
+    # ---- N > 1: wall time of every collective of the exact protocol, in separate un-timed steps ------------------------
+    exchange_ms = None
+    if exact:
+        sharded.timings = {}
+        nprobe = 3
+        for i in range(nprobe):
+            run_step(scorer, Qs[i % nb], k, (ncells, thr, ndocs))
+        barrier()
+        exchange_ms = {n: v / nprobe * 1e3 for n, v in sharded.timings.items()}
+        sharded.timings = None
 
-    # ---- CPU baseline (rank 0, N=1 only): the reference's own C++ stages + torch-CPU glue, bounded sample ----------
-    cpu = None
+    out = None
+    if rank == 0:
+        # ---- workload statistics of the last batch (outside the timed region) ----------------------------------------
+        P = [len(scorer.tap(_native.TAP_CANDIDATES, q)) for q in range(0, args.batch, max(1, args.batch // 32))]
+        ncell = [len(scorer.tap(_native.TAP_CELLS, q)) for q in range(0, args.batch, max(1, args.batch // 32))]
+        P_mean, ncell_mean = sum(P) / len(P), sum(ncell) / len(ncell)
+        d, B = 128, 128 * args.nbits // 8
+        mean_len = float(local.doclens.float().mean())
+        nfin_tok, ns_tok = (ndocs // 4) * mean_len, ndocs * mean_len
+        ivf_mean_len = float(local.ivf_lengths.float().mean())
+        nq_s0 = min(args.nq, 32)
+        # the reference formulation's compulsory bytes per query (kept for comparison with round 1) ...
+        alg_ref = (4 * ncell_mean * ivf_mean_len + 16 * P_mean + 4 * P_mean * mean_len + B * nfin_tok
+                   + 4 * d * min(K, nfin_tok) + 4 * d * args.nq + 8 * k + 4 * d * K / args.batch)
+        # ... and what THIS build must move per query: probed + surviving IVF lists (stage 1 is computed from them, the
+        # candidates' codes are never read), the survivors' codes (stage 2), the finalists' codes, residual bytes and fp16
+        # centroid rows (stage 3), Q, the output, and per batch: the fp32 table once for stage 0, the fp16 table once for
+        # stage 2
+        per_kernel_bytes = {
+            "s0_centroid_scores": 4 * d * K / args.batch + 2 * 2 * d * nq_s0 + 4 * nq_s0 * K / 64,
+            "s0_candidates": 2 * 4 * ncell_mean * ivf_mean_len + 8 * P_mean,
+            "s2_filter_sort": 4 * ns_tok + 2 * d * K / args.batch + 16 * ndocs,
+            "s3_maxsim": (4 + B + 2 * d) * nfin_tok + 2 * 2 * d * args.nq,
+        }
+        per_kernel_flops = {
+            "s0_centroid_scores": 2.0 * 2 * K * d * nq_s0,                # hi + lo products
+            "s2_filter_sort": 2.0 * 2 * ns_tok * d * nq_s0,
+            "s3_maxsim": 3.0 * 2 * nfin_tok * d * args.nq,                # hi.hi + hi.lo + lo.hi
+        }
+        alg_build = sum(per_kernel_bytes.values()) + 4 * d * args.nq + 8 * k + 8 * P_mean
+        if not stage_ms:  # phased multi-GPU run: per-stage events are a single-GPU measurement (see the N=1 line)
+            stage_ms = {"whole_step": ms_per_step}
+        pmc = {}
+        try:
+            import csv
+            with open(PMC_SUMMARY) as f:
+                for row in csv.DictReader(f):
+                    pmc[row["kernel"]] = row
+        except Exception:
+            pass
+        kname = {"s0_centroid_scores": "s0_centroid_scores_f16", "s3_maxsim": "maxsim_f16_kernel",
+                 "s2_filter_sort": "filter_stage2", "s0_candidates": "cand_mark_score_kernel"}
+
+        def roof_of(stage):
+            t_s = stage_ms[stage] * 1e-3
+            nbytes = per_kernel_bytes.get(stage, alg_build) * args.batch
+            r = {"kernel": stage, "launch_ms": stage_ms[stage], "compulsory_GB_per_launch": nbytes / 1e9,
+                 "hbm_frac": nbytes / t_s / 1e9 / HBM_PEAK_GBS}
+            if stage in per_kernel_flops:
+                r["TFLOPs"] = per_kernel_flops[stage] * args.batch / t_s / 1e12
+                r["mfma_frac"] = r["TFLOPs"] / F16_MFMA_PEAK_TFLOPS
+            for kn, row in pmc.items():
+                if stage in kname and kname[stage] in kn and args.passages == 1_000_000 and world == 1 and args.nbits == 2:
+                    r["traffic"] = (2.0 * float(row["FETCH_SIZE"]) + float(row["WRITE_SIZE"])) * 1024.0
+            return r
+
+        per_kernel = [roof_of(sname) for sname in sorted(stage_ms, key=stage_ms.get, reverse=True) if stage_ms[sname] > 0.05]
+        dom = per_kernel[0]
+        mfma_bound = dom.get("mfma_frac", 0.0) > dom["hbm_frac"]
+        roof = {"kernel": dom["kernel"], "bound": "mfma" if mfma_bound else "hbm",
+                "achieved": dom["TFLOPs"] if mfma_bound else dom["compulsory_GB_per_launch"] / (dom["launch_ms"] * 1e-3),
+                "peak": F16_MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                "frac": dom["mfma_frac"] if mfma_bound else dom["hbm_frac"], "traffic": dom.get("traffic"),
+                "traffic_source": ("static: profiles/r02_pmc_summary.csv (rocprofv3 --pmc of this workload, 2*FETCH_SIZE + "
+                                   "WRITE_SIZE, bytes per launch; not measured in this run)") if dom.get("traffic") else None,
+                "launch_ms": dom["launch_ms"],
+                "note": ("achieved = the kernel's own compulsory bytes (or split-MFMA flops) per launch / its HIP-event time; "
+                         "stage 2 (gather form) is limited by neither roof but by the fabric: one 256-byte fp16 centroid "
+                         "row per survivor token from the Infinity Cache, measured gather ceiling 9.3-9.6 TB/s "
+                         "(profiles/microbench)"),
+                "gathered_row_GBs": (2 * d * ns_tok * args.batch / (dom["launch_ms"] * 1e-3) / 1e9) if dom["kernel"] == "s2_filter_sort" else None,
+                "per_kernel": per_kernel,
+                "whole_path": {"compulsory_bytes_per_query": alg_build, "GBs": alg_build * qps / 1e9,
+                               "frac_of_hbm_peak": alg_build * qps / 1e9 / HBM_PEAK_GBS,
+                               "reference_formulation_bytes_per_query": alg_ref}}
+
+        # ---- measured device copy bandwidth (read + write), next to the spec used as `peak` ---------------------------
+        src = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        for _ in range(10):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        copy_gbs = 10 * 2 * src.numel() * 4 / (time.perf_counter() - t0_) / 1e9
+        del src, dst
+
+        out = {
+            "metric": "queries/sec", "value": qps, "unit": "queries/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 (fp16-split MFMA products, fp32 accumulate; ids / keys int32 / u64)", "data": "synthetic",
+            "config": {"workload": f"FLMR late-interaction search, synthetic clustered corpus {args.passages} passages x "
+                                   f"{'U{32..224}' if args.ragged else args.doclen} tokens x 128-d, K={K}, nbits={args.nbits}, "
+                                   f"Nq={args.nq}, k={k} (ncells={ncells}, thr={thr}, ndocs={ndocs}), {args.batch} queries/step, "
+                                   f"{nb} query batches in rotation",
+                       "parallelism": (f"index sharded by passage over {world} GPUs, " + (("stage 0 replicated, " if args.replicate_stage0 else "stage 0 split by query + exchange of idx bitsets/cells, ") + "all-gather of stage-1 keys + SUM all-reduces of slot-aligned stage-2/3 keys, result identical to the unsharded index" if exact else "all-gather of per-shard top-k")) if world > 1 else "1 GPU",
+                       "queries_per_step": args.batch},
+            "recall_at_5": recall5, "roofline": roof, "cpu_baseline": None, "stage_ms_per_step": stage_ms,
+            "candidates_per_query": P_mean, "cells_per_query": ncell_mean,
+            "hbm_copy_GBs": copy_gbs, "index_build_s": t_build, "workspace_GB": scorer.workspace_bytes() / 1e9,
+        }
+        if exchange_ms is not None:
+            out["exchange_ms"] = exchange_ms
+            out["exchange_ms_note"] = ("wall time per collective of one step (device-synchronised around each call, separate "
+                                       "un-timed steps): the rest of ms_per_step is per-rank compute")
+
+    # ---- CPU baseline (rank 0, N=1 only): the reference's own C++ stages + torch-CPU glue, bounded samples ----------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_queries > 0:
         try:
             from oracle import oracle as orc
             arrays = synth.corpus_to_arrays(corpus)
             oi = orc.OracleIndex(arrays.dim, arrays.nbits, arrays.codes, arrays.residuals, arrays.doclens, arrays.ivf,
                                  arrays.ivf_lengths, arrays.centroids, arrays.bucket_weights)
+            p_gpu, s_gpu, _ = last[0]
+            Qh = Qs[0].cpu()
             nqs = min(args.cpu_queries, args.batch)
-            Qh = Q[:nqs].cpu()
-            same5 = 0
-            parity_note = ""
+            all_threads = torch.get_num_threads()
             if orc.ref_available():
                 ref = orc.RefCpuScorer(oi)
                 ref.rank(Qh[0], ncells, thr, ndocs)   # warm
-                t0 = time.perf_counter()
+                t0_ = time.perf_counter()
                 res = [ref.rank(Qh[i], ncells, thr, ndocs) for i in range(nqs)]
-                tc = time.perf_counter() - t0
-                kind, cores = "reference", torch.get_num_threads()
-                same5 = sum(res[i][0][:5] == p[i, :5].tolist() for i in range(nqs))
-                # full top-k against the reference: ids position by position, swaps allowed only inside runs of reference
-                # scores closer than 1e-5 (another valid fp32 summation order may swap those); scores by pid
+                tc = time.perf_counter() - t0_
+                same5 = sum(res[i][0][:5] == p_gpu[i, :5].tolist() for i in range(nqs))
                 samek, maxd = 0, 0.0
                 for i in range(nqs):
                     rp_, rs_ = res[i][0][:k], res[i][1][:k]
-                    gp_, gs_ = p[i, :k].tolist(), s[i, :k].tolist()
+                    gp_, gs_ = p_gpu[i, :k].tolist(), s_gpu[i, :k].tolist()
+                    samek += int(tie_aware_same(rp_, rs_, gp_))
                     got = dict(zip(gp_, gs_))
-                    ok, a0 = len(rp_) == len(gp_), 0
-                    while ok and a0 < len(rp_):
-                        a1 = a0
-                        while a1 + 1 < len(rp_) and abs(rs_[a1] - rs_[a1 + 1]) <= 1e-5:
-                            a1 += 1
-                        ok = sorted(rp_[a0:a1 + 1]) == sorted(gp_[a0:a1 + 1])
-                        a0 = a1 + 1
-                    samek += int(ok)
                     maxd = max([maxd] + [abs(got[q_] - v_) for q_, v_ in zip(rp_, rs_) if q_ in got])
-                parity_note = f"; top-{k} ids identical (tie-aware) for {samek}/{nqs}, max |score diff| {maxd:.2e}"
+                n8 = min(args.cpu_queries_8t, nqs)
+                qps8 = None
+                if n8 > 0:
+                    torch.set_num_threads(8)
+                    ref.rank(Qh[0], ncells, thr, ndocs)
+                    t0_ = time.perf_counter()
+                    for i in range(n8):
+                        ref.rank(Qh[i], ncells, thr, ndocs)
+                    qps8 = n8 / (time.perf_counter() - t0_)
+                    torch.set_num_threads(all_threads)
+                out["cpu_baseline"] = {
+                    "value": nqs / tc, "unit": "queries/sec", "cores": all_threads, "kind": "reference",
+                    "sample": (f"first {nqs} queries of batch 0 on the same 1-GPU index, one query per call (reference semantics), "
+                               f"{all_threads} threads; top-5 ids identical to the GPU result for {same5}/{nqs}; top-{k} ids identical "
+                               f"(tie-aware) for {samek}/{nqs}, max |score diff| {maxd:.2e}"),
+                    "value_8_threads": qps8, "sample_8_threads": f"first {n8} queries, torch.set_num_threads(8)"}
             else:
-                t0 = time.perf_counter()
-                rp, _, _ = oi.search_batch(Qh.numpy(), k, ncells, thr, ndocs)
-                tc = time.perf_counter() - t0
-                kind, cores = "port", os.cpu_count()
-                same5 = sum(rp[i, :5].tolist() == p[i, :5].tolist() for i in range(nqs))
-            cpu = {"value": nqs / tc, "unit": "queries/sec", "cores": cores, "kind": kind,
-                   "sample": f"first {nqs} queries of the same batch on the same 1-GPU index, one query per call "
-                             f"(reference semantics); top-5 ids identical to the GPU result for {same5}/{nqs}" + parity_note}
+                t0_ = time.perf_counter()
+                rp, _, _ = oi.search_batch(Qh[:nqs].numpy(), k, ncells, thr, ndocs)
+                tc = time.perf_counter() - t0_
+                same5 = sum(rp[i, :5].tolist() == p_gpu[i, :5].tolist() for i in range(nqs))
+                out["cpu_baseline"] = {"value": nqs / tc, "unit": "queries/sec", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"first {nqs} queries of batch 0 (C restatement, OpenMP over queries); top-5 ids "
+                                                 f"identical to the GPU result for {same5}/{nqs}"}
+            del arrays, oi
         except Exception as e:  # the baseline must never take the bench line down
-            cpu = {"value": None, "unit": "queries/sec", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+            out["cpu_baseline"] = {"value": None, "unit": "queries/sec", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+
+    # ---- sub-results (N = 1): the same path at the other operating points SURVEY 8(d) names -----------------------------
+    if rank == 0 and world == 1 and not args.no_extras:
+        subs = []
+
+        def sub(name, sc, batches, targets, kk, note):
+            try:
+                pol = k_policy(kk)
+                dt_, _, rec, _ = timed(sc, batches, targets, kk, pol, 6, 2, collect_stages=False)
+                subs.append({"name": name, "value": args.batch * 6 / dt_, "unit": "queries/sec", "ms_per_step": dt_ / 6 * 1e3,
+                             "recall_at_5": rec, "note": note})
+            except Exception as e:
+                subs.append({"name": name, "value": None, "note": f"failed: {e!r}"})
+
+        sub("k5", scorer, Qs, tgts, 5, "same index, k=5 (same pruning policy as k=100, searcher.py:92-107; 5 results returned)")
+        sub("k500", scorer, Qs, tgts, 500, "same index, k=500 policy (ncells=4, thr=0.4, ndocs=4096)")
+        try:
+            Q8, t8 = zip(*[synth.make_queries(corpus, args.batch, 832, seed=40 + j) for j in range(2)])
+            sc8 = IndexScorer(device_index=scorer.device_index, max_batch=256)
+            sub("nq832", sc8, list(Q8), list(t8), k, "same index, PreFLMR-sized queries (Nq=832, candidate generation on the first 32 tokens)")
+            sc8.close_searcher()
+            del Q8, t8, sc8
+        except Exception as e:
+            subs.append({"name": "nq832", "value": None, "note": f"failed: {e!r}"})
+        scorer.close_searcher()
+        del scorer, corpus, local
+        torch.cuda.empty_cache()
+        for name, nbits_, dl_, note in (("nbits8", 8, args.doclen, "nbits=8 (the FLMR configs' setting), fixed doclen"),
+                                        ("ragged", args.nbits, (32, 224), "doclens ~ U{32..224}, mean 128")):
+            try:
+                c2 = synth.make_corpus(args.passages, dl_, K, nbits_, seed=0, device="cuda")
+                Q2, t2 = zip(*[synth.make_queries(c2, args.batch, args.nq, seed=2 + j) for j in range(2)])
+                sc2 = IndexScorer(device_index=synth.corpus_device_index(c2), max_batch=args.batch)
+                sub(name, sc2, list(Q2), list(t2), k, note)
+                sc2.close_searcher()
+                del sc2, c2, Q2, t2
+                torch.cuda.empty_cache()
+            except Exception as e:
+                subs.append({"name": name, "value": None, "note": f"failed: {e!r}"})
+        out["sub_results"] = subs
 
     if rank == 0:
-        out = {
-            "metric": "queries/sec", "value": qps, "unit": "queries/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"FLMR late-interaction search, synthetic clustered corpus {args.passages} passages x "
-                                   f"{args.doclen} tokens x 128-d, K={K}, nbits={args.nbits}, Nq={args.nq}, k={k} "
-                                   f"(ncells={ncells}, thr={thr}, ndocs={ndocs}), {args.batch} queries/step",
-                       "parallelism": (f"index sharded by passage over {world} GPUs, " + (("stage 0 replicated, " if args.replicate_stage0 else "stage 0 split by query + exchange of idx bitsets/cells, ") + "all-gather of stage-1 keys + SUM all-reduces of slot-aligned stage-2/3 keys, result identical to the unsharded index" if args.shard_mode == "exact" else "all-gather of per-shard top-k")) if world > 1 else "1 GPU",
-                       "queries_per_step": args.batch},
-            "recall_at_5": recall5,
-            "roofline": roof,
-            "cpu_baseline": cpu,
-            "stage_ms_per_step": stage_ms,
-            "candidates_per_query": P_mean, "cells_per_query": ncell_mean,
-            "algorithmic_bytes_per_query": alg_bytes,
-            "index_build_s": t_build, "workspace_GB": scorer.workspace_bytes() / 1e9,
-        }
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -9,7 +9,7 @@ KREGEX='s0_|filter_stage|maxsim|select_topn|sort_topn|s1_|cand_|qualifying'
 run() { # name, counters...
   name=$1; shift
   timeout 600 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "$KREGEX" --output-format csv -d "$OUT/$name" -o p -- \
-      python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/$name.log" 2>&1
+      python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/$name.log" 2>&1
 }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA
 run sq2 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS
