@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--nq", type=int, default=32)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--cpu-queries", type=int, default=64, help="queries timed on the CPU baseline at all threads (0 = skip)")
-    ap.add_argument("--cpu-queries-8t", type=int, default=16, help="queries timed on the CPU baseline at 8 threads")
+    ap.add_argument("--cpu-queries-8t", type=int, default=64, help="queries timed on the CPU baseline at 8 threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the k=5 / nbits=8 / ragged / Nq=832 sub-results")
     ap.add_argument("--replicate-stage0", action="store_true",
@@ -258,9 +258,10 @@ def main():
 
         def roof_of(stage):
             t_s = stage_ms[stage] * 1e-3
-            nbytes = per_kernel_bytes.get(stage, alg_build) * args.batch
-            r = {"kernel": stage, "launch_ms": stage_ms[stage], "compulsory_GB_per_launch": nbytes / 1e9,
-                 "hbm_frac": nbytes / t_s / 1e9 / HBM_PEAK_GBS}
+            r = {"kernel": stage, "launch_ms": stage_ms[stage]}
+            if stage in per_kernel_bytes or stage == "whole_step":
+                nbytes = per_kernel_bytes.get(stage, alg_build) * args.batch
+                r.update({"compulsory_GB_per_launch": nbytes / 1e9, "hbm_frac": nbytes / t_s / 1e9 / HBM_PEAK_GBS})
             if stage in per_kernel_flops:
                 r["TFLOPs"] = per_kernel_flops[stage] * args.batch / t_s / 1e12
                 r["mfma_frac"] = r["TFLOPs"] / F16_MFMA_PEAK_TFLOPS
@@ -271,6 +272,8 @@ def main():
 
         per_kernel = [roof_of(sname) for sname in sorted(stage_ms, key=stage_ms.get, reverse=True) if stage_ms[sname] > 0.05]
         dom = per_kernel[0]
+        dom.setdefault("compulsory_GB_per_launch", alg_build * args.batch / 1e9)
+        dom.setdefault("hbm_frac", dom["compulsory_GB_per_launch"] / (dom["launch_ms"] * 1e-3) / HBM_PEAK_GBS)
         mfma_bound = dom.get("mfma_frac", 0.0) > dom["hbm_frac"]
         roof = {"kernel": dom["kernel"], "bound": "mfma" if mfma_bound else "hbm",
                 "achieved": dom["TFLOPs"] if mfma_bound else dom["compulsory_GB_per_launch"] / (dom["launch_ms"] * 1e-3),
@@ -347,6 +350,7 @@ def main():
                     got = dict(zip(gp_, gs_))
                     maxd = max([maxd] + [abs(got[q_] - v_) for q_, v_ in zip(rp_, rs_) if q_ in got])
                 n8 = min(args.cpu_queries_8t, nqs)
+                qps_all = nqs / tc
                 qps8 = None
                 if n8 > 0:
                     torch.set_num_threads(8)
@@ -356,12 +360,17 @@ def main():
                         ref.rank(Qh[i], ncells, thr, ndocs)
                     qps8 = n8 / (time.perf_counter() - t0_)
                     torch.set_num_threads(all_threads)
+                # the reference spawns at::get_num_threads() pthreads per extension call (filter_pids.cpp:97-101): on a
+                # 128-thread host that overhead dominates, so the 8-thread run is the faster one -- report the better
+                best8 = qps8 is not None and qps8 > qps_all
                 out["cpu_baseline"] = {
-                    "value": nqs / tc, "unit": "queries/sec", "cores": all_threads, "kind": "reference",
-                    "sample": (f"first {nqs} queries of batch 0 on the same 1-GPU index, one query per call (reference semantics), "
-                               f"{all_threads} threads; top-5 ids identical to the GPU result for {same5}/{nqs}; top-{k} ids identical "
-                               f"(tie-aware) for {samek}/{nqs}, max |score diff| {maxd:.2e}"),
-                    "value_8_threads": qps8, "sample_8_threads": f"first {n8} queries, torch.set_num_threads(8)"}
+                    "value": qps8 if best8 else qps_all, "unit": "queries/sec", "cores": 8 if best8 else all_threads,
+                    "kind": "reference",
+                    "sample": (f"first {n8 if best8 else nqs} queries of batch 0 on the same 1-GPU index, one query per call (reference "
+                               f"semantics); parity on the first {nqs}: top-5 ids identical to the GPU result for {same5}/{nqs}, top-{k} "
+                               f"ids identical (tie-aware) for {samek}/{nqs}, max |score diff| {maxd:.2e}"),
+                    "value_all_threads": qps_all, "threads_all": all_threads, "queries_all_threads": nqs,
+                    "value_8_threads": qps8, "queries_8_threads": n8}
             else:
                 t0_ = time.perf_counter()
                 rp, _, _ = oi.search_batch(Qh[:nqs].numpy(), k, ncells, thr, ndocs)
