@@ -13,7 +13,7 @@ from .index import DeviceIndex, IndexArrays, codec_tables, load_index_arrays
 
 __all__ = ["ColBERTConfig", "RunConfig", "Run", "Queries", "Ranking", "Collection", "Provenance", "IndexArrays",
            "DeviceIndex", "load_index_arrays", "codec_tables", "build_native", "FlmrNativeError", "Searcher",
-           "IndexScorer", "install", "uninstall", "installed"]
+           "IndexScorer", "install", "uninstall", "installed", "Indexer", "FLMRModelForRetrieval"]
 
 
 def __getattr__(name):  # torch-dependent pieces are imported lazily
@@ -23,4 +23,10 @@ def __getattr__(name):  # torch-dependent pieces are imported lazily
     if name == "IndexScorer":
         from .scorer import IndexScorer
         return IndexScorer
+    if name == "Indexer":
+        from .indexer import Indexer
+        return Indexer
+    if name == "FLMRModelForRetrieval":
+        from .flmr import FLMRModelForRetrieval
+        return FLMRModelForRetrieval
     raise AttributeError(name)

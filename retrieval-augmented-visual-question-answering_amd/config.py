@@ -27,6 +27,11 @@ _COLBERT_FIELDS = dict(_RUN_FIELDS, **{
     "query_maxlen": 32, "attend_to_mask_tokens": False, "interaction": "colbert",
     "index_path": None, "nbits": 1, "kmeans_niters": 4, "resume": False,
     "ncells": None, "centroid_score_threshold": None, "ndocs": None,
+    # TrainingSettings (settings.py:114-144): never read by the search path, but the executors construct ColBERTConfig with
+    # them (FLMR_executor.py:129-134: bsize, use_ib_negatives) and index metadata carries them
+    "similarity": "cosine", "bsize": 32, "accumsteps": 1, "lr": 3e-06, "maxsteps": 500_000, "save_every": None,
+    "warmup": None, "warmup_bert": None, "relu": False, "nway": 2, "use_ib_negatives": False, "reranker": False,
+    "distillation_alpha": 1.0, "ignore_scores": False,
 })
 
 

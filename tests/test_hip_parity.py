@@ -876,3 +876,32 @@ def test_stage2_walk_on_golden_fixture(hip, scorers):
         fin = oi.filter_pids(cand, table, table.max(axis=1) >= np.float32(z[f"{r}.thr"]), int(z[f"{r}.ndocs"]))
         assert np.array_equal(got, fin), r
         assert sorted(got.tolist()) == sorted(z[f"{r}.filtered_pids"].tolist()), r
+
+
+def test_flmr_model_surface_score_and_forward(hip):
+    """FLMRModelForRetrieval.score / forward (ravqa_amd/flmr.py; names of TPC/modeling/colbert.py:64-80,217-224) with
+    injected encoders: the HIP padded scorer behind `score`, `forward` = query -> doc -> repeat_interleave(nway) -> score,
+    against the CPU oracle's padded MaxSim on the same encodings; autograd use is refused, not silently dropped."""
+    from oracle import oracle as orc
+    from types import SimpleNamespace
+    from ravqa_amd.flmr import FLMRModelForRetrieval
+    torch = hip["torch"]
+    g = torch.Generator().manual_seed(2)
+    table = torch.randn(60, 128, generator=g)
+    enc = lambda ids, am: (table.to(ids.device)[ids] * am.unsqueeze(-1))
+    model = FLMRModelForRetrieval(enc, colbert_config=SimpleNamespace(nway=3, use_ib_negatives=True, similarity="cosine",
+                                                                     interaction="colbert"), mask_punctuation_ids=[7])
+    B, nway, Lq, Ld = 4, 3, 12, 20
+    qi = torch.randint(1, 60, (B, Lq), generator=g)
+    di = torch.randint(0, 60, (B * nway, Ld), generator=g)
+    di[:, 0] = 5
+    with torch.no_grad():
+        scores = model.forward((qi, (qi != 0).long()), (di, (di != 0).long()))
+        Q = model.query(qi, (qi != 0).long())
+        D, mask = model.doc(di, (di != 0).long(), keep_dims="return_mask")
+    assert scores.shape == (B * nway,) and scores.is_cuda
+    ref = orc.colbert_score_padded(Q.repeat_interleave(nway, dim=0).cpu().numpy(), D.cpu().numpy(), mask.squeeze(-1).cpu().numpy())
+    assert np.max(np.abs(scores.cpu().numpy() - ref)) <= SCORE_TOL
+    Qg = Q.clone().requires_grad_(True)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        model.score(Qg.repeat_interleave(nway, dim=0), D, mask)

@@ -238,3 +238,103 @@ def test_reference_indexes_satisfy_the_ivf_invariant(name):
     bad.ivf = bad.ivf.copy()
     bad.ivf[0] = (bad.ivf[0] + 1) % int(bad.doclens.shape[0])
     assert not bad.check_ivf_invariant()
+
+
+def test_config_accepts_the_executors_constructor_calls():
+    """FLMR_executor.py:129-134 builds ColBERTConfig(bsize=None, use_ib_negatives=True, checkpoint=..., rank=...); :786
+    ColBERTConfig(total_visible_gpus=...).  The host-side mirror must take both (round 1 raised TypeError on the first)."""
+    c = ColBERTConfig(bsize=None, use_ib_negatives=True, checkpoint="bert-base-uncased", rank=0)
+    assert c.use_ib_negatives is True and c.bsize == 32 and "bsize" not in c.assigned and c.nway == 2
+    assert ColBERTConfig(total_visible_gpus=0).total_visible_gpus == 0
+    with pytest.raises(TypeError):
+        ColBERTConfig(not_a_field=1)
+
+
+def test_indexer_entry_point_builds_a_reference_format_index(tmp_path):
+    """Indexer(checkpoint, config).index(name, collection, overwrite) (TPC/indexer.py:58-76) over indexing.build_index, on
+    host tensors: path resolution under Run().context, overwrite semantics, and the written directory loads back and ranks
+    the planted passages first (CPU oracle)."""
+    from oracle import oracle as orc
+    from ravqa_amd.indexer import Indexer
+    g = torch.Generator().manual_seed(0)
+    P, K = 300, 64
+    protos = torch.nn.functional.normalize(torch.randn(K, 128, generator=g), dim=-1)
+    doclens = torch.randint(4, 20, (P,), generator=g)
+    codes = torch.randint(0, K, (int(doclens.sum()),), generator=g)
+    embs = torch.nn.functional.normalize(protos[codes] + 0.05 * torch.randn(len(codes), 128, generator=g), dim=-1)
+    passages = [f"passage {i}" for i in range(P)]
+    calls = []
+
+    def doc_encoder(ps):
+        calls.append(len(ps))
+        return embs, doclens
+
+    with Run().context(RunConfig(nranks=1, rank=0, root=str(tmp_path), experiment="exp")):
+        ix = Indexer(checkpoint=None, config=ColBERTConfig(nbits=4, kmeans_niters=4), doc_encoder=doc_encoder)
+        path = ix.index("my.index", passages, overwrite=False)
+        assert path == os.path.join(str(tmp_path), "exp", "indexes/", "my.index") == ix.get_index() and calls == [P]
+        with pytest.raises(AssertionError):
+            ix.index("my.index", passages, overwrite=False)               # exists: the reference asserts (indexer.py:67)
+        assert ix.index("my.index", passages, overwrite="reuse") == path and calls == [P]      # reused, not rebuilt
+        ix.index("my.index", (embs, doclens), overwrite=True)            # erased + rebuilt from an (embeddings, doclens) pair
+        assert calls == [P]
+        with pytest.raises(NotImplementedError):
+            Indexer(checkpoint=None, config=ColBERTConfig(nbits=4)).index("other", passages)
+    a = ravqa_amd.load_index_arrays(path)
+    assert (a.nbits, a.num_passages, a.num_embeddings) == (4, P, int(doclens.sum())) and a.check_ivf_invariant()
+    oi = orc.OracleIndex(a.dim, a.nbits, a.codes, a.residuals, a.doclens, a.ivf, a.ivf_lengths, a.centroids, a.bucket_weights)
+    offs = np.concatenate([[0], np.cumsum(doclens.numpy())])
+    hits = 0
+    for t in (3, 77, 150, 299):
+        q = embs[offs[t]:offs[t + 1]][torch.arange(32) % int(doclens[t])].numpy()
+        p, _, _ = oi.rank(q, 2, 0.45, 64)
+        hits += int(t in p[:3].tolist())
+    assert hits >= 3
+
+
+def test_flmr_model_surface_host_logic():
+    """FLMRModelForRetrieval (ravqa_amd/flmr.py): query / doc / mask with injected encoders vs the torch expressions of
+    FLMR.query (src/models/retriever/FLMR.py:73-99) and ColBERT.doc (TPC/modeling/colbert.py:194-215) -- the parts that are
+    host logic (masking, visual-token concatenation, normalisation, keep_dims); the MaxSim `score` is covered on the GPU."""
+    from ravqa_amd.flmr import FLMRModelForRetrieval
+    g = torch.Generator().manual_seed(1)
+    B, L, dim, nvis = 3, 7, 128, 2
+    table = torch.randn(50, dim, generator=g)
+    enc = lambda ids, am: table[ids] * am.unsqueeze(-1)
+    W = torch.randn(16, nvis * dim, generator=g)
+    model = FLMRModelForRetrieval(enc, vision_projection=lambda f: f @ W, mask_punctuation_ids=[5, 9], device="cpu")
+    ids = torch.tensor([[2, 5, 7, 0, 0, 0, 0], [3, 9, 9, 4, 11, 0, 0], [1, 2, 3, 4, 5, 6, 7]])
+    am = (ids != 0).long()
+    feats = torch.randn(B, 16, generator=g)
+    Q = model.query(ids, am, feats)
+    ref = torch.cat([table[ids] * am.unsqueeze(-1) * (ids != 0).unsqueeze(-1), (feats @ W).reshape(B, nvis, dim)], dim=1)
+    assert Q.shape == (B, L + nvis, dim) and torch.allclose(Q, torch.nn.functional.normalize(ref, p=2, dim=2))
+    assert torch.all(Q[0, 3:L].abs().sum(-1) == 0)                     # padded text tokens stay zero rows
+    D, mask = model.doc(ids, am, keep_dims="return_mask")
+    keep = (ids != 0) & (ids != 5) & (ids != 9)                         # punctuation ids are masked out of documents
+    assert torch.equal(mask.squeeze(-1), keep) and torch.all(D[~keep].abs().sum(-1) == 0)
+    assert torch.allclose(D[keep].norm(dim=-1), torch.ones(int(keep.sum())), atol=1e-6)
+    flat = model.doc(ids, am, keep_dims=False)
+    assert [d.shape[0] for d in flat] == keep.sum(1).tolist() and torch.allclose(flat[1], D[1][keep[1]])
+    assert model.doc(ids, am).shape == (B, L, dim)
+    assert model.mask(ids, skiplist=[]) == (ids != 0).tolist()
+
+
+def test_metrics_match_the_reference_processors():
+    """tests/golden/metrics.json: records + the numbers the REFERENCE's compute_DPR_scores / compute_DPR_scores_with_pos_ids
+    (src/metrics/metrics_processors.py:481-601) computed for them (make_metrics_golden.py).  evaluation.py must reproduce
+    every metric exactly, including the early-out when records carry no answers."""
+    import json
+    from conftest import GOLDEN
+    from ravqa_amd import evaluation
+    g = json.load(open(os.path.join(GOLDEN, "metrics.json")))
+    got = evaluation.recall_pseudo_relevance(g["records"], g["Ks"])
+    assert set(got) == set(g["pseudo_relevance"]) and len(got) == 4 * len(g["Ks"])
+    for key, want in g["pseudo_relevance"].items():
+        assert abs(got[key] - want) < 1e-12, key
+    got = evaluation.recall_with_pos_ids(g["records"], g["Ks"])
+    assert set(got) == set(g["pos_ids"])
+    for key, want in g["pos_ids"].items():
+        assert abs(got[key] - want) < 1e-12, key
+    stripped = [{k: v for k, v in r.items() if k not in ("answers", "gold_answer")} for r in g["records"]]
+    assert evaluation.recall_pseudo_relevance(stripped, g["Ks"]) == g["pseudo_relevance_without_answers"] == {}
