@@ -179,6 +179,10 @@ __global__ __launch_bounds__(256) void s0_split_q(const float* Q, const int32_t*
 #define S0_OCC 2                // workgroups per CU the register budget is sized for
 #endif
 #define S0_BROW 136             // halfs per staged B row (128 + 8 pad: conflict-free ds_read_b128 across rows)
+#ifndef S0_DMA_B
+#define S0_DMA_B 1              // 1: B operands DMA-ed into two alternating LDS buffers of S0_DCH items each (global_load_lds,
+#endif                          //    rows unpadded, 16-byte pieces XOR-swizzled by row), the next chunk in flight while the
+#define S0_DCH 3                //    current one is multiplied; 0: staged through registers, one buffer of S0_CH items
 #define S0_LDS_STRIDE 36        // floats per staged row: 16-byte aligned rows for ds_read_b128
 
 // ARGMAX = true (index build, flmr_nearest_centroids): additionally tracks the row index of every block maximum in
@@ -223,6 +227,51 @@ __global__ __launch_bounds__(64 * S0_WAVES, S0_OCC) void s0_centroid_scores_f16(
     uint32_t idxw[S0_RT];  // the 32-bit idx word of each row tile, OR-ed over the column tiles of one query
 #pragma unroll
     for (int rt = 0; rt < S0_RT; rt++) idxw[rt] = 0u;
+#if S0_DMA_B
+    // B staging by LDS-DMA, double-buffered: piece z of a chunk is 1 KB = rows 4g .. 4g+3 of one (item, hi|lo) image, contiguous
+    // in q_hi / q_lo; wave w issues pieces 6w .. 6w+5 of the 48.  One barrier per chunk: behind it every wave's pieces of THIS
+    // chunk have landed (each wave waits for its own with vmcnt(0) first) and every wave is done reading the OTHER buffer, which
+    // the next chunk's DMA then overwrites while this one is multiplied.  (Staged through registers -- the S0_DMA_B=0 path --
+    // the load latency and the LDS writes of every chunk were exposed between two barriers: a third of the wave cycles of this
+    // kernel were spent parked, profiles/r02_pmc_summary.csv.)
+    static_assert(S0_WAVES * 6 == S0_DCH * 16, "piece assignment assumes 48 pieces per chunk over 8 waves");
+    char* const bqb = reinterpret_cast<char*>(bq);
+    auto dma_chunk = [&](int c0, int buf) {
+#pragma unroll
+        for (int kz = 0; kz < 6; kz++) {
+            const int z = wave * 6 + kz, item = z >> 4, hl = (z >> 3) & 1, g = z & 7;
+            const int itx = c0 + item;
+            if (itx < niter) {  // wave-uniform
+                const int bb = blockIdx.y + (itx / T) * gridDim.y, row = 4 * g + (lane >> 4);
+                const _Float16* src = (hl ? a.q_lo : a.q_hi) + ((size_t)bb * a.ncol + (itx % T) * 32 + row) * FLMR_DIM +
+                                      (((lane & 15) ^ (row & 15)) << 3);
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(bqb + (((buf * S0_DCH + item) * 2 + hl) * 8192 + g * 1024)),
+                                                 16, 0, 0);
+            }
+        }
+    };
+    dma_chunk(0, 0);
+    for (int c0 = 0, cit = 0; c0 < niter; c0 += S0_DCH, cit++) {
+      const int nch = (niter - c0) < S0_DCH ? (niter - c0) : S0_DCH;
+      const int buf = cit & 1;
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of the chunk (and its older stores) are done
+      __syncthreads();
+      if (c0 + S0_DCH < niter) dma_chunk(c0 + S0_DCH, buf ^ 1);
+      if (active)
+      for (int j = 0; j < nch; j++) {
+        const int it = c0 + j;
+        const int b = blockIdx.y + (it / T) * gridDim.y, ct = it % T;
+        f16x8 bh[8], bl[8];
+        {
+            const char* ph = bqb + (((buf * S0_DCH + j) * 2 + 0) * 8192) + i * 256;
+            const char* pl = bqb + (((buf * S0_DCH + j) * 2 + 1) * 8192) + i * 256;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                bh[s] = *reinterpret_cast<const f16x8*>(ph + (((8 * h + s) ^ (i & 15)) << 4));
+                bl[s] = *reinterpret_cast<const f16x8*>(pl + (((8 * h + s) ^ (i & 15)) << 4));
+            }
+        }
+#else
     for (int c0 = 0; c0 < niter; c0 += S0_CH) {
       const int nch = (niter - c0) < S0_CH ? (niter - c0) : S0_CH;
       __syncthreads();  // every wave is done reading the previous chunk
@@ -244,6 +293,7 @@ __global__ __launch_bounds__(64 * S0_WAVES, S0_OCC) void s0_centroid_scores_f16(
             bh[s] = *reinterpret_cast<const f16x8*>(bq + ((j * 2 + 0) * 32 + i) * S0_BROW + 64 * h + 8 * s);
             bl[s] = *reinterpret_cast<const f16x8*>(bq + ((j * 2 + 1) * 32 + i) * S0_BROW + 64 * h + 8 * s);
         }
+#endif
         const int qlen = a.q_lens ? a.q_lens[b] : a.nq;
         const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;
         float* cs_b = a.cs + (size_t)b * a.K * a.ncol;
@@ -466,7 +516,7 @@ static int launch_s0_t(flmr_s0_args& a, hipStream_t st, int impl) {
     if (impl == S0_F16) {
         hipLaunchKernelGGL(s0_split_q, dim3((a.ncol * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens,
                            a.nq, a.nq_cand, a.ncol, a.q_hi, a.q_lo);
-        const size_t lds = (size_t)S0_WAVES * 32 * S0_LDS_STRIDE * sizeof(float) + (size_t)S0_CH * 2 * 32 * S0_BROW * sizeof(_Float16);
+        const size_t lds = (size_t)S0_WAVES * 32 * S0_LDS_STRIDE * sizeof(float) + (S0_DMA_B ? (size_t)2 * S0_DCH * 2 * 8192 : (size_t)S0_CH * 2 * 32 * S0_BROW * sizeof(_Float16));
         const bool sparse = !a.full_table && a.ncol == 32 && !flmr_opts().has(FLMR_OPT_S0_STAGED);
         const dim3 grid((a.nblk + S0_WAVES - 1) / S0_WAVES, qsplit), block(64 * S0_WAVES);
         if (sparse) {
@@ -528,7 +578,7 @@ int flmr_launch_centroid_argmax(flmr_s0_args& a, int32_t* out_codes, hipStream_t
     const int qsplit = a.nqueries < 8 ? a.nqueries : 8;
     hipLaunchKernelGGL(s0_split_q, dim3((a.ncol * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens, a.nq,
                        a.nq_cand, a.ncol, a.q_hi, a.q_lo);
-    const size_t lds = (size_t)S0_WAVES * 32 * S0_LDS_STRIDE * sizeof(float) + (size_t)S0_CH * 2 * 32 * S0_BROW * sizeof(_Float16);
+    const size_t lds = (size_t)S0_WAVES * 32 * S0_LDS_STRIDE * sizeof(float) + (S0_DMA_B ? (size_t)2 * S0_DCH * 2 * 8192 : (size_t)S0_CH * 2 * 32 * S0_BROW * sizeof(_Float16));
     FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_f16<true, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((s0_centroid_scores_f16<true, true>), dim3((a.nblk + S0_WAVES - 1) / S0_WAVES, qsplit), dim3(64 * S0_WAVES), lds, st, a);
