@@ -45,6 +45,53 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint4* __restrict__ t
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = acc.x;
 }
 
+// the same gather, but the block's rows come from slice (blockIdx.x % 8) of the table only: workgroups are dealt to the 8 XCDs
+// round-robin, so each XCD's L2 (4 MB) sees one slice of table/8 bytes -- a 32 MB table becomes eight L2-resident 4 MB slices
+template <int DEPTH>
+__global__ __launch_bounds__(256) void gather_sliced_kernel(const uint4* __restrict__ table, uint32_t slice_rows, int iters, uint32_t* sink) {
+    const int lane = threadIdx.x & 63;
+    uint32_t seed = (blockIdx.x * 256 + threadIdx.x) / 64 * 2654435761u + 12345u;
+    const uint32_t base = (blockIdx.x & 7) * slice_rows;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (int it = 0; it < iters; it += DEPTH) {
+        uint4 v[DEPTH][8];
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+#pragma unroll
+            for (int g = 0; g < 8; g++) {
+                uint32_t s2 = seed + (uint32_t)(it + d) * 97u + (uint32_t)(4 * g + (lane >> 4)) * 7919u;
+                const uint32_t row = base + ((lcg(s2) >> 8) & (slice_rows - 1));
+                v[d][g] = table[(size_t)row * 16 + (lane & 15)];
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++)
+#pragma unroll
+            for (int g = 0; g < 8; g++) { acc.x ^= v[d][g].x; acc.y += v[d][g].y; acc.z ^= v[d][g].z; acc.w += v[d][g].w; }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = acc.x;
+}
+
+// the sliced gather again, rows going straight to LDS (global_load_lds_dwordx4: 1 KB = four rows per instruction) as the
+// stage-2 kernels do: two 8 KB tiles in flight per wave, vmcnt(8) before a buffer is reused
+__global__ __launch_bounds__(256) void gather_sliced_dma_kernel(const uint4* __restrict__ table, uint32_t slice_rows, int iters, uint32_t* sink) {
+    __shared__ __attribute__((aligned(16))) char buf[4][2][8192];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t seed = (blockIdx.x * 256 + threadIdx.x) / 64 * 2654435761u + 12345u;
+    const uint32_t base = (blockIdx.x & 7) * slice_rows;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            uint32_t s2 = seed + (uint32_t)it * 97u + (uint32_t)(4 * g + (lane >> 4)) * 7919u;
+            const uint32_t row = base + ((lcg(s2) >> 8) & (slice_rows - 1));
+            __builtin_amdgcn_global_load_lds(table + (size_t)row * 16 + (lane & 15), (__attribute__((address_space(3))) void*)(&buf[wave][it & 1][g * 1024]), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (buf[wave][0][lane] == 0x7b && iters < 0) sink[0] = 1;
+}
+
 // every wave walks tiles (start + it) % ntiles with the same `start` per block group -> shared through L2
 __global__ __launch_bounds__(256) void stream_kernel(const uint4* __restrict__ table, uint32_t ntiles, int iters, int shared, uint32_t* sink) {
     const int lane = threadIdx.x & 63;
@@ -119,6 +166,25 @@ int main() {
             run(name, bytes, "GB/s", [&] { hipLaunchKernelGGL(gather_kernel<1>, dim3(blocks), dim3(256), 0, 0, table, nrows - 1, iters, sink); });
             snprintf(name, sizeof name, "gather 256B rows, table %3zu MB, %2d waves/CU, depth 2", mb, wpc);
             run(name, bytes, "GB/s", [&] { hipLaunchKernelGGL(gather_kernel<2>, dim3(blocks), dim3(256), 0, 0, table, nrows - 1, iters, sink); });
+        }
+    }
+    // ---- gather, table cut into one slice per XCD ---------------------------------------------------------------------------
+    for (int wpc : {8, 16}) {
+        const int blocks = ncu * wpc / 4, iters = 512;
+        for (size_t mb : {8, 16, 32, 64}) {
+            const uint32_t slice_rows = (uint32_t)((mb << 20) / 256 / 8);
+            const double bytes = (double)blocks * 4 * iters * 8192.0;
+            snprintf(name, sizeof name, "gather 256B rows, table %3zu MB in 8 XCD slices, %2d waves/CU, depth 2", mb, wpc);
+            run(name, bytes, "GB/s", [&] { hipLaunchKernelGGL(gather_sliced_kernel<2>, dim3(blocks), dim3(256), 0, 0, table, slice_rows, iters, sink); });
+        }
+    }
+    for (int wpc : {8, 16}) {
+        const int blocks = ncu * wpc / 4, iters = 512;
+        for (size_t mb : {8, 32, 64}) {
+            const uint32_t slice_rows = (uint32_t)((mb << 20) / 256 / 8);
+            const double bytes = (double)blocks * 4 * iters * 8192.0;
+            snprintf(name, sizeof name, "gather -> LDS (DMA), table %3zu MB in 8 XCD slices, %2d waves/CU", mb, wpc);
+            run(name, bytes, "GB/s", [&] { hipLaunchKernelGGL(gather_sliced_dma_kernel, dim3(blocks), dim3(256), 0, 0, table, slice_rows, iters, sink); });
         }
     }
     // ---- stream ------------------------------------------------------------------------------------------------------

@@ -44,10 +44,10 @@ enum flmr_opt_id {
     FLMR_OPT_CAND_IMPL,      // atomic: first candidate-generation implementation
     FLMR_OPT_S1_NO_HITMAP,   // set: no hit prefilter
     FLMR_OPT_S1_IMPL,        // scan: code-scanning stage 1 for every query
-    FLMR_OPT_S2_IMPL,        // walk | lds | regs: force the dense walk / the LDS-DMA gather / the register gather (default: cost model)
+    FLMR_OPT_S2_IMPL,        // xcd | walk | lds | ldsb | regs: force the XCD-sliced gather / the dense walk / the LDS-DMA gather (4-wave blocks; 16-wave blocks with the query operand in LDS) / the register gather (default: cost model)
     FLMR_OPT_S0_STAGED,      // set: staged epilogue for every tile
     FLMR_OPT_S3_NO_MULTIQ,   // set: single-tile MaxSim kernel for long queries too
-    FLMR_OPT_S3_IMPL,        // f32: fp32-MFMA MaxSim kernel
+    FLMR_OPT_S3_IMPL,        // f32: fp32-MFMA MaxSim kernel; dma: fp16-split kernel with LDS-DMA row gathers two tiles ahead (default: register gathers)
     FLMR_OPT_SCORE_IMPL,     // valu: plain-FMA padded scorer
     FLMR_OPT_COUNT
 };
@@ -112,9 +112,12 @@ struct flmr_index {
     int32_t nchunks;
     int32_t* codes_sorted;        // [N] per-passage ascending copy of `codes` (stage-2 walk); NULL when a passage is too long
     _Float16* centroids_f16_tiled;  // centroids_f16 in MFMA A-operand order, one contiguous 1 KB run per (tile, k-step) (stage-2 walk)
+    uint16_t* doc_splits;         // [num_passages][8]: codes_sorted position of the first code >= s * slice_rows (XCD-sliced stage 2)
+    int32_t slice_rows;           // ceil(K / 8)
 };
 int flmr_build_sorted_codes(flmr_index* ix);
 int flmr_build_tiled_centroids(flmr_index* ix);
+int flmr_build_doc_splits(flmr_index* ix);
 
 // build the fused byte -> (8/nbits) fp32 decode table from the codec tables (host)
 void flmr_build_wlut(int nbits, const float* bucket_weights, const uint8_t* reversed_bit_map,
@@ -209,6 +212,13 @@ int flmr_launch_filter_stage2_walk(const flmr_filter_args& f, const int32_t* pid
                                    int32_t max_count, uint64_t* keys, int64_t key_stride, const _Float16* cen16,
                                    const _Float16* q_hi, const _Float16* q_lo, const int32_t* codes_sorted, hipStream_t st);
 bool flmr_stage2_walk_pays(const flmr_index* ix, int nqueries, int max_count);
+// stage 2 with the centroid table cut into one L2-resident slice per XCD (flmr_stage2_xcd.hip): same keys, bit for bit;
+// `part`: workspace of flmr_stage2_xcd_part_floats(max_queries, part_stride) floats
+int flmr_launch_filter_stage2_xcd(const flmr_filter_args& f, const int32_t* pids, int64_t pid_stride, const int32_t* counts,
+                                  int32_t max_count, uint64_t* keys, int64_t key_stride, const flmr_index* ix,
+                                  const _Float16* q_hi, const _Float16* q_lo, float* part, int64_t part_stride, hipStream_t st);
+bool flmr_stage2_xcd_pays(const flmr_index* ix);
+size_t flmr_stage2_xcd_part_floats(int64_t nqueries, int64_t ndocs);
 // top-n of count[q] keys, unordered output (radix select); n_out[q] = min(n, count[q])
 int flmr_launch_select_topn(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t nqueries,
                             int32_t n, int32_t* out_pids, int64_t out_stride, int32_t* n_out, hipStream_t st,

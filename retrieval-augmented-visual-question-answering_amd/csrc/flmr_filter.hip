@@ -499,7 +499,11 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_mfma_kernel(flmr_filter_
     }
 }
 
-__global__ __launch_bounds__(256, 2) void filter_stage2_lds_kernel(flmr_filter_args f, const int32_t* pids, int64_t pid_stride,
+// WAVES = 4, B_LDS = false: the query's fp16 hi/lo operand (64 VGPRs) stays in registers -> 217 VGPRs, 2 waves per SIMD.
+// WAVES = 16, B_LDS = true: one 1024-thread block per CU shares the operand through LDS (16 KB, stored in the lane order of the
+// MFMA B operand: conflict-free ds_read_b128) -> <= 128 VGPRs, 4 waves per SIMD to hide the row-gather latency.
+template <int WAVES, bool B_LDS>
+__global__ __launch_bounds__(64 * WAVES, B_LDS ? 1 : 2) void filter_stage2_lds_kernel(flmr_filter_args f, const int32_t* pids, int64_t pid_stride,
                                                                     const int32_t* counts, uint64_t* keys, int64_t key_stride,
                                                                     const _Float16* __restrict__ cen16,
                                                                     const _Float16* __restrict__ q_hi,
@@ -513,8 +517,19 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_lds_kernel(flmr_filter_a
     const int nqc = qlen < f.nq_cand ? qlen : f.nq_cand;  // <= 32 on this path
     float* tr = reinterpret_cast<float*>(smem) + (size_t)wave * 33;
     // this wave's row buffer: 32 centroid rows x 256 B, filled by direct global->LDS loads (16-byte pieces XOR-swizzled by row)
-    char* rowbuf = smem + 4 * 33 * sizeof(float) + 16 + (size_t)wave * (32 * 256);
-    const int W = gridDim.y * 4, w = blockIdx.y * 4 + wave;
+    constexpr size_t TR_BYTES = (WAVES * 33 * sizeof(float) + 15) / 16 * 16;
+    char* rowbuf = smem + TR_BYTES + (size_t)wave * (32 * 256);
+    const s2h8* const Bh = reinterpret_cast<const s2h8*>(smem + TR_BYTES + (size_t)WAVES * (32 * 256));  // [8][64], then Bl [8][64]
+    if constexpr (B_LDS) {
+        s2h8* Bw = reinterpret_cast<s2h8*>(smem + TR_BYTES + (size_t)WAVES * (32 * 256));
+        for (int t = threadIdx.x; t < 1024; t += 64 * WAVES) {
+            const int lo = t >> 9, sidx = (t >> 6) & 7, ln = t & 63;
+            const _Float16* src = (lo ? q_lo : q_hi) + ((size_t)b * f.ncol + (ln & 31)) * FLMR_DIM + 64 * (ln >> 5) + 8 * sidx;
+            Bw[t] = *reinterpret_cast<const s2h8*>(src);
+        }
+        __syncthreads();
+    }
+    const int W = gridDim.y * WAVES, w = blockIdx.y * WAVES + wave;
     const int ndw = cnt > w ? (cnt - w + W - 1) / W : 0;  // <= 64 documents per wave (launcher)
     if (ndw == 0) return;
     int my_pid = 0, my_len = 0;
@@ -524,8 +539,8 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_lds_kernel(flmr_filter_a
         my_off = f.offsets[my_pid];
         my_len = (int)doc_len_of(f.doclens, f.offsets, my_pid);
     }
-    s2h8 bh[8], bl[8];
-    {
+    s2h8 bh[B_LDS ? 1 : 8], bl[B_LDS ? 1 : 8];
+    if constexpr (!B_LDS) {
         const s2h8* ph = reinterpret_cast<const s2h8*>(q_hi + ((size_t)b * f.ncol + i) * FLMR_DIM + 64 * h);
         const s2h8* pl = reinterpret_cast<const s2h8*>(q_lo + ((size_t)b * f.ncol + i) * FLMR_DIM + 64 * h);
 #pragma unroll
@@ -601,8 +616,13 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_lds_kernel(flmr_filter_a
             for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
 #pragma unroll
             for (int s = 0; s < 8; s++) {
-                ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[s], ah, 0, 0, 0);
-                al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[s], al, 0, 0, 0);
+                if constexpr (B_LDS) {
+                    ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], Bh[s * 64 + lane], ah, 0, 0, 0);
+                    al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], Bh[512 + s * 64 + lane], al, 0, 0, 0);
+                } else {
+                    ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[s], ah, 0, 0, 0);
+                    al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[s], al, 0, 0, 0);
+                }
             }
             const int nrow = len - t * 32;  // valid token rows in this tile
 #pragma unroll
@@ -639,8 +659,20 @@ int flmr_launch_filter_stage2_mfma(const flmr_filter_args& f, const int32_t* pid
     if (flmr_opts().is(FLMR_OPT_S2_IMPL, "regs"))
         hipLaunchKernelGGL(filter_stage2_mfma_kernel, dim3(f.nqueries, G), dim3(256), 4 * 33 * sizeof(float), st, f, pids, pid_stride,
                            counts, keys, key_stride, cen16, q_hi, q_lo);
-    else
-        hipLaunchKernelGGL(filter_stage2_lds_kernel, dim3(f.nqueries, G), dim3(256), 4 * 33 * sizeof(float) + 16 + 4 * 32 * 256, st,
+    else if (flmr_opts().is(FLMR_OPT_S2_IMPL, "ldsb")) {
+        // 16-wave blocks sharing the query operand through LDS
+        int G16 = (int)flmr_ceil_div(8192, 16 * (int64_t)f.nqueries);
+        const int g16min = (int)flmr_ceil_div(max_count, 16 * 64);
+        if (G16 < g16min) G16 = g16min;
+        if (G16 > (int)flmr_ceil_div(max_count, 16)) G16 = (int)flmr_ceil_div(max_count, 16);
+        if (G16 < 1) G16 = 1;
+        const size_t lds16 = (16 * 33 * sizeof(float) + 15) / 16 * 16 + (size_t)16 * 32 * 256 + 16384;
+        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_stage2_lds_kernel<16, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+        hipLaunchKernelGGL((filter_stage2_lds_kernel<16, true>), dim3(f.nqueries, G16), dim3(1024), lds16, st, f, pids, pid_stride,
+                           counts, keys, key_stride, cen16, q_hi, q_lo);
+    } else
+        hipLaunchKernelGGL((filter_stage2_lds_kernel<4, false>), dim3(f.nqueries, G), dim3(256), (4 * 33 * sizeof(float) + 15) / 16 * 16 + 4 * 32 * 256, st,
                            f, pids, pid_stride, counts, keys, key_stride, cen16, q_hi, q_lo);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;

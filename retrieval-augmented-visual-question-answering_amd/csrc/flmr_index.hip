@@ -167,6 +167,7 @@ extern "C" int flmr_index_open(const flmr_index_desc_t* d, flmr_index_t** out) {
     }
     FLMR_TRY(flmr_build_sorted_codes(ix));
     FLMR_TRY(flmr_build_tiled_centroids(ix));
+    FLMR_TRY(flmr_build_doc_splits(ix));
     FLMR_TRY(flmr_build_chunk_table(ix->ivf_pids, ix->ivf_offsets, K, ix->num_passages, &ix->ivf_chunk_tab, &ix->nchunks));
     // fused decode table (always built on the host from the host bucket_weights)
     {
@@ -197,6 +198,7 @@ extern "C" int flmr_index_close(flmr_index_t* ix) {
     (void)hipFree(ix->ivf_chunk_tab);
     (void)hipFree(ix->codes_sorted);
     (void)hipFree(ix->centroids_f16_tiled);
+    (void)hipFree(ix->doc_splits);
     delete[] ix->ivf_len_prefix;
     delete ix;
     return FLMR_OK;

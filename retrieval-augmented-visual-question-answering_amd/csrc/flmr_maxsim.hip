@@ -180,6 +180,81 @@ __device__ __forceinline__ void s3_lut(const float* wlut_, uint32_t byte, float*
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One lane's half row (64 dims): decode (centroid fp16 + bucket weight), normalise, split into the fp16 hi / lo MFMA A operand.
+//   x   = w + (float)c                       one v_fma_mix_f32 (c * 1.0 + w: the fp16 source is read in place -- same single rounding)
+//   ss += x * x                              k-ascending, one fp32 chain (decompress + normalise order of the oracle)
+//   v   = x * inv, vs = v * 2048             packed fp32 multiplies
+//   hi  = fp16(v)                            v_cvt_pk_f16_f32 (two per instruction, round to nearest even)
+//   lo  = fp16(fma(hi, -2048, vs))           v_fma_mixlo/mixhi_f16: hi is read from the packed register, the result lands in its
+//                                            half of the packed lo register -- (v - hi) * 2048 exactly (v - hi is representable,
+//                                            the scalings are powers of two), so lo is the fp16 rounding of the exact remainder
+// The mixed-precision forms do what the plain C expressions say (fp32 fma, then one conversion), bit for bit; written as
+// instructions because the compiler otherwise converts hi back to fp32 and packs the halves separately (520 -> ~340 VALU
+// operations per tile in a kernel that is bound by VALU issue, PMC: profiles/r02_pmc_summary.csv).
+// `word(wi)`: wi-th 32-bit word of the lane's 8 * NBITS residual bytes.
+// ------------------------------------------------------------------------------------------------
+typedef uint32_t s3u4 __attribute__((ext_vector_type(4)));
+typedef float s3v2 __attribute__((ext_vector_type(2)));
+typedef _Float16 s3h2 __attribute__((ext_vector_type(2)));
+
+template <int HALF>
+__device__ __forceinline__ float s3_add_f16(uint32_t cpk, float w) {  // w + (float)half HALF of cpk
+    float r;
+    if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(cpk), "v"(w));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(cpk), "v"(w));
+    return r;
+}
+
+template <int NBITS, typename WordFn>
+__device__ __forceinline__ void s3_decode_split(const float* wlut, WordFn word, const hf8 (&c)[8], bool valid, hf8 (&ah)[8], hf8 (&al)[8]) {
+    constexpr int VPB = 8 / NBITS;
+    float d[64];
+    float ss = 0.0f;
+#pragma unroll
+    for (int wq = 0; wq < NBITS; wq++) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t byte = (word(wq * 2 + (e >> 2)) >> (8 * (e & 3))) & 255u;
+            const int kb = wq * 8 + e;
+            float wv[VPB];
+            s3_lut<VPB>(wlut, byte, wv);
+#pragma unroll
+            for (int l = 0; l < VPB; l++) {
+                const int dd = kb * VPB + l;
+                const uint32_t cpk = __builtin_bit_cast(s3u4, c[dd >> 3])[(dd & 7) >> 1];
+                const float v = (dd & 1) ? s3_add_f16<1>(cpk, wv[l]) : s3_add_f16<0>(cpk, wv[l]);
+                d[dd] = v;
+                ss = fmaf(v, v, ss);
+            }
+        }
+    }
+    ss += __shfl_xor(ss, 32, 64);
+    float nrm = sqrtf(ss);
+    nrm = nrm < 1e-12f ? 1e-12f : nrm;
+    const float inv = valid ? 1.0f / nrm : 0.0f;  // padding rows become exact zeros
+    const float m2048 = -2048.0f;
+#pragma unroll
+    for (int s8 = 0; s8 < 8; s8++) {
+        s3u4 hpk, lpk;
+#pragma unroll
+        for (int pr = 0; pr < 4; pr++) {
+            const int dd = s8 * 8 + 2 * pr;
+            s3v2 v = {d[dd], d[dd + 1]};
+            v *= inv;
+            const s3v2 vs = v * 2048.0f;
+            const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, s3h2));
+            uint32_t lo;
+            asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(m2048), "v"(vs[0]));
+            asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(m2048), "v"(vs[1]));
+            hpk[pr] = hi;
+            lpk[pr] = lo;
+        }
+        ah[s8] = __builtin_bit_cast(hf8, hpk);
+        al[s8] = __builtin_bit_cast(hf8, lpk);
+    }
+}
+
 template <int NBITS>
 struct s3_raw {          // one lane's share of one token: half a centroid row (fp16) + its residual bytes
     hf8 c[8];
@@ -287,41 +362,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
         for (int t = 0; t < ntiles; t++) {
             // ---- decompress this lane's half row, normalise, split into fp16 hi/lo (the MFMA A operand) ----
             hf8 ah[8], al[8];
-            {
-                float d[64];
-                float ss = 0.0f;
-#pragma unroll
-                for (int wq = 0; wq < NBITS; wq++) {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const uint32_t word = e < 4 ? raw.r[wq].x : raw.r[wq].y;
-                        const uint32_t byte = (word >> (8 * (e & 3))) & 255u;
-                        const int kb = wq * 8 + e;
-                        float wv[VPB];
-                        s3_lut<VPB>(wlut, byte, wv);
-#pragma unroll
-                        for (int l = 0; l < VPB; l++) {
-                            const int dd = kb * VPB + l;
-                            const float v = wv[l] + (float)raw.c[dd >> 3][dd & 7];
-                            d[dd] = v;
-                            ss = fmaf(v, v, ss);
-                        }
-                    }
-                }
-                ss += __shfl_xor(ss, 32, 64);
-                float nrm = sqrtf(ss);
-                nrm = nrm < 1e-12f ? 1e-12f : nrm;
-                const float inv = raw.valid ? 1.0f / nrm : 0.0f;  // padding rows become exact zeros
-#pragma unroll
-                for (int dd = 0; dd < 64; dd++) {
-                    const float v = d[dd] * inv;
-                    const _Float16 hi = (_Float16)v;
-                    ah[dd >> 3][dd & 7] = hi;
-                    // (v - hi) * 2048 as one mixed-precision fma on the fp16 register (exactly the same value: v - hi is
-                    // representable, the scalings are powers of two) -- no conversion of hi back to fp32
-                    al[dd >> 3][dd & 7] = (_Float16)fmaf((float)hi, -2048.0f, v * 2048.0f);
-                }
-            }
+            s3_decode_split<NBITS>(wlut, [&](int wi) { return (wi & 1) ? raw.r[wi >> 1].y : raw.r[wi >> 1].x; }, raw.c, raw.valid, ah, al);
             // ---- prefetch the next tile's rows (this document's next tile, or the next document's first tile) ----
             if (t + 1 < ntiles) {
                 s3_issue_rows<NBITS>(raw, cd, t + 1, off, len, i, h, codes, residuals, cen16);
@@ -365,6 +406,233 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
 #pragma unroll
         for (int r = 0; r < 4; r++) cd[r] = ncd[r];
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S3, fp16-split, centroid rows by LDS-DMA with TWO token tiles in flight (FLMR_S3_IMPL=dma; Nq <= 32).
+// maxsim_f16_kernel above keeps one tile's rows in flight in registers (32 VGPRs per lane, requested after the current
+// tile has been decompressed): a row gather from the Infinity Cache takes ~2 us, the MFMA phase it overlaps with ~0.3 us,
+// and at 250 VGPRs there is no room for a second register buffer -- per tile the wave sits out most of the latency
+// (4.5 TB/s of row gathers against the 9.3-9.6 TB/s this chip delivers for 256-byte rows).  Here the rows go straight to LDS
+// (global_load_lds_dwordx4: four whole rows per instruction, 16-byte pieces XOR-swizzled by row like stage 2's), two 8 KB
+// buffers per wave, requested TWO tiles ahead; the lane's half row is read back (8 x ds_read_b128) when its tile comes up.
+// The tiles of all of a wave's documents form one flat sequence, so the pipeline runs across document boundaries.
+//
+// vmcnt retires in order and the compiler's own wait insertion assumes it sees every outstanding operation; a wait it
+// places for one register load would also drain the DMA issued before it.  So every VMEM load inside the loop is issued
+// from inline assembly (invisible to that pass) and waited for by hand:
+//   * a step issues, in this order: code of tile g+3 (1), residual bytes of tile g+2 (RL), DMA of tile g+2 (8);
+//   * top of step g: everything older than step g-1's issues must have landed (rows + residual bytes of tile g):
+//     vmcnt(9 + RL) when step g-1 issued its full set, vmcnt(8 + RL) when it had no code to load, else vmcnt(0);
+//   * before the DMA of tile g+2: its code (first issue of step g-1) -- younger than it are the rest of step g-1 (RL + 8)
+//     and this step's code + residual loads: vmcnt(2 RL + 8 + [tile g+3 exists]).
+// A wait count is safe whenever it does not exceed the number of operations issued after the awaited one; the compiler's
+// own stores (keys) only add to that number.  Registers alternate by tile parity, so no value is copied while its load is
+// in flight, and each awaited register passes through an empty asm after the wait so its uses cannot be scheduled above it.
+// Same arithmetic as maxsim_f16_kernel in the same order: bit-identical scores.
+// grid = (nqueries, G), block = 256; dynamic LDS = wlut + 4 * nqp floats + 4 waves x 16 KB.
+// ------------------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <int N>
+__device__ __forceinline__ void s3_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// residual bytes of one lane's half row: 8 * NBITS bytes
+template <int NBITS>
+struct s3_res {
+    u32x4 q[(NBITS + 1) / 2];  // NBITS == 1: only .xy of q[0]
+    __device__ __forceinline__ void issue(const uint8_t* p) {  // asynchronous: wait, then touch(), before any use
+        if constexpr (NBITS == 1) {
+            u32x2 t;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(t) : "v"(p) : "memory");
+            q[0].x = t.x; q[0].y = t.y;
+        } else {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q[0]) : "v"(p) : "memory");
+            if constexpr (NBITS >= 4) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(q[1]) : "v"(p) : "memory");
+            if constexpr (NBITS >= 8) {
+                asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(q[2]) : "v"(p) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(q[3]) : "v"(p) : "memory");
+            }
+        }
+    }
+    __device__ __forceinline__ void touch() {
+#pragma unroll
+        for (int k = 0; k < (NBITS + 1) / 2; k++) asm volatile("" : "+v"(q[k])::"memory");
+    }
+    __device__ __forceinline__ uint32_t word(int wi) const { return q[wi >> 2][wi & 3]; }
+};
+
+template <int NBITS>
+__global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args m, const int32_t* __restrict__ codes,
+                                                                const uint8_t* __restrict__ residuals,
+                                                                const int64_t* __restrict__ doc_offsets,
+                                                                const _Float16* __restrict__ cen16,
+                                                                const float* __restrict__ wlut_g, int nqp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int VPB = 8 / NBITS, PACKED = FLMR_DIM * NBITS / 8, NB = 8 * NBITS;
+    constexpr int RL = NBITS == 1 ? 1 : NBITS / 2;  // residual load instructions per tile
+    float* wlut = reinterpret_cast<float*>(smem);  // [256 * VPB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    float* colmax = wlut + 256 * VPB + (size_t)wave * nqp;  // this wave's running maxima [nqp] (nqp == 32 here)
+    char* const rowbuf = smem + ((256 * VPB + 4 * (size_t)nqp) * sizeof(float) + 15) / 16 * 16 + (size_t)wave * 16384;
+    const uint32_t rowbuf_lds =
+        __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)rowbuf);
+    const int b = blockIdx.x;
+    const int cnt = m.counts[b];
+    const int qlen = m.q_lens ? m.q_lens[b] : m.nq;
+    for (int t = tid; t < 256 * VPB; t += 256) wlut[t] = wlut_g[t];
+    for (int t = lane; t < nqp; t += 64) colmax[t] = 0.0f;
+    __syncthreads();
+
+    const int W = gridDim.y * 4, w = blockIdx.y * 4 + wave;
+    const int ndw = cnt > w ? (cnt - w + W - 1) / W : 0;  // documents of this wave (<= 64, guaranteed by the launcher)
+    if (ndw == 0) return;
+    int my_pid = 0, my_len = 0;
+    int64_t my_off = 0;
+    if (lane < ndw) {
+        my_pid = m.pids[(size_t)b * m.pid_stride + w + lane * W];
+        my_off = doc_offsets[my_pid];
+        my_len = (int)(doc_offsets[my_pid + 1] - my_off);
+        if (my_len <= 0) {  // an empty passage has no tile: its score is the empty sum (segmented_maxsim.cpp: all maxima 0)
+            if (m.keys) m.keys[(size_t)b * m.key_stride + w + lane * W] = flmr_make_key(0.0f, my_pid);
+            if (m.scores) m.scores[(size_t)b * m.key_stride + w + lane * W] = 0.0f;
+        }
+    }
+    hf8 bh[8], bl[8];
+    {
+        const hf8* ph = reinterpret_cast<const hf8*>(m.q_hi + ((size_t)b * nqp + i) * FLMR_DIM + 64 * h);
+        const hf8* pl = reinterpret_cast<const hf8*>(m.q_lo + ((size_t)b * nqp + i) * FLMR_DIM + 64 * h);
+#pragma unroll
+        for (int s = 0; s < 8; s++) { bh[s] = ph[s]; bl[s] = pl[s]; }
+    }
+    const int my_off_lo = (int)(uint32_t)my_off, my_off_hi = (int)(uint32_t)((uint64_t)my_off >> 32);
+    // flat tile sequence over (document j, tile t); j == ndw: past the end
+    auto normalize = [&](int& j, int& t) {
+        while (j < ndw && t >= ((__shfl(my_len, j, 64) + 31) >> 5)) { j++; t = 0; }
+    };
+    auto next_of = [&](int j, int t, int& nj, int& nt) {
+        nj = j; nt = t + 1;
+        if (j < ndw) normalize(nj, nt); else nj = ndw;
+    };
+    // array position of this lane's token in tile (j, t); padding lanes take the document's last token
+    auto tokpos = [&](int j, int t, bool& valid) {
+        const int len = __shfl(my_len, j, 64);
+        const int64_t off = ((int64_t)__shfl(my_off_hi, j, 64) << 32) | (uint32_t)__shfl(my_off_lo, j, 64);
+        const int tok = t * 32 + i;
+        valid = tok < len;
+        return off + (valid ? tok : len - 1);
+    };
+    auto issue_code = [&](int64_t pos, int& c) {
+        asm volatile("global_load_dword %0, %1, off" : "=v"(c) : "v"(codes + pos) : "memory");
+    };
+    auto dma_rows = [&](int code, int buf) {  // 32 rows -> rowbuf[buf]: piece p of row r at position p ^ (r & 15)
+        const int rl = lane >> 4, pp = lane & 15;
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const int row = 4 * g + rl;
+            const int c = __shfl(code, row, 64);
+            const _Float16* src = cen16 + (size_t)c * FLMR_DIM + ((pp ^ (row & 15)) << 3);
+            const uint32_t dst = rowbuf_lds + buf * 8192 + g * 1024;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+        }
+    };
+
+    // tiles g (being consumed), g+1, g+2, g+3 of the sequence
+    int j0 = 0, t0 = 0, j1, t1, j2, t2, j3, t3;
+    normalize(j0, t0);
+    next_of(j0, t0, j1, t1);
+    next_of(j1, t1, j2, t2);
+    next_of(j2, t2, j3, t3);
+    s3_res<NBITS> rE, rO;              // residual bytes of the even / odd tile in flight
+    bool vE = false, vO = false, vtmp;
+    int cE = 0, cO = 0;                // code of tile g+2 (parity of g) / g+3
+    // prologue, issue order: code of tile 2, then residual bytes + DMA of tile 0, of tile 1
+    {
+        int64_t p0 = 0, p1 = 0;
+        int c0 = 0, c1 = 0;
+        if (j0 < ndw) { p0 = tokpos(j0, t0, vE); c0 = codes[p0]; }
+        if (j1 < ndw) { p1 = tokpos(j1, t1, vO); c1 = codes[p1]; }
+        // every compiler-visible load lands here, before the first hand-counted one is issued
+        asm volatile("" : "+v"(c0), "+v"(c1)::"memory");
+#pragma unroll
+        for (int s = 0; s < 8; s++) asm volatile("" : "+v"(bh[s]), "+v"(bl[s])::"memory");
+        if (j2 < ndw) issue_code(tokpos(j2, t2, vtmp), cE);
+        if (j0 < ndw) { rE.issue(residuals + (size_t)p0 * PACKED + h * NB); dma_rows(c0, 0); }
+        if (j1 < ndw) { rO.issue(residuals + (size_t)p1 * PACKED + h * NB); dma_rows(c1, 1); }
+    }
+
+    // one step: consume tile g from buffer `buf` with residual bytes r / validity v; c2 holds the code of tile g+2, c3 receives
+    // the code of tile g+3; afterwards r / v belong to tile g+2
+    auto step = [&](int buf, s3_res<NBITS>& r, bool& v, int& c2, int& c3, bool first) {
+        // ---- tile g's rows and residual bytes: wait, read this lane's half row out of LDS, release the buffer ----
+        if (j1 >= ndw) s3_wait_vm<0>();
+        else if (first || j2 >= ndw) s3_wait_vm<8 + RL>();
+        else s3_wait_vm<9 + RL>();
+        r.touch();
+        hf8 c[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++)
+            c[s] = *reinterpret_cast<const hf8*>(rowbuf + buf * 8192 + i * 256 + (((8 * h + s) ^ (i & 15)) << 4));
+        // ---- decompress this lane's half row, normalise, split into fp16 hi/lo (the MFMA A operand) ----
+        hf8 ah[8], al[8];
+        s3_decode_split<NBITS>(wlut, [&](int wi) { return r.word(wi); }, c, v, ah, al);
+        const bool last_of_doc = (j1 != j0);
+        const int pid = __shfl(my_pid, j0, 64), dslot = w + j0 * W;
+        // ---- keep the pipeline full, in this order: code of tile g+3, residual bytes of tile g+2, DMA of tile g+2 ----
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the row buffer has been read: it may be refilled
+        if (j3 < ndw) issue_code(tokpos(j3, t3, vtmp), c3);
+        if (j2 < ndw) {
+            r.issue(residuals + (size_t)tokpos(j2, t2, v) * PACKED + h * NB);
+            if (j3 < ndw) s3_wait_vm<2 * RL + 9>(); else s3_wait_vm<2 * RL + 8>();
+            asm volatile("" : "+v"(c2)::"memory");
+            dma_rows(c2, buf);
+        }
+        // ---- 32 tokens x 32 query tokens ----
+        {
+            f32x16 acch, accl;
+#pragma unroll
+            for (int q = 0; q < 16; q++) { acch[q] = 0.0f; accl[q] = 0.0f; }
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[s], acch, 0, 0, 0);
+                accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[s], accl, 0, 0, 0);
+                accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s], accl, 0, 0, 0);
+            }
+            float mx = 0.0f;  // segmented_maxsim.cpp:58-59: the running max starts at zero
+#pragma unroll
+            for (int q = 0; q < 16; q++) mx = fmaxf(mx, fmaf(accl[q], 1.0f / 2048.0f, acch[q]));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (h == 0 && i < qlen) colmax[i] = fmaxf(colmax[i], mx);
+        }
+        if (last_of_doc) {  // k-ascending sum of the column maxima, reset for the next document
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                float sc = 0.0f;
+                for (int k = 0; k < qlen; k++) sc += colmax[k];
+                if (m.keys) m.keys[(size_t)b * m.key_stride + dslot] = flmr_make_key(sc, pid);
+                if (m.scores) m.scores[(size_t)b * m.key_stride + dslot] = sc;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int t = lane; t < nqp; t += 64) colmax[t] = 0.0f;
+        }
+        // ---- advance the window of tile positions ----
+        j0 = j1; t0 = t1; j1 = j2; t1 = t2; j2 = j3; t2 = t3;
+        next_of(j2, t2, j3, t3);
+    };
+    bool first = true;
+    while (j0 < ndw) {
+        step(0, rE, vE, cE, cO, first);   // even tile: DMA of tile g+2 uses cE, the code of tile g+3 lands in cO
+        first = false;
+        if (j0 >= ndw) break;
+        step(1, rO, vO, cO, cE, false);   // odd tile: roles swapped
+    }
+    s3_wait_vm<0>();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -450,39 +718,7 @@ __global__ __launch_bounds__(64 * S3_MQW) void maxsim_f16_multiq_kernel(flmr_max
             have_raw = false;
             for (int t = 0; t < ntiles; t++) {
                 hf8 ah[8], al[8];
-                {
-                    float d[64];
-                    float ss = 0.0f;
-#pragma unroll
-                    for (int wq = 0; wq < NBITS; wq++) {
-#pragma unroll
-                        for (int e = 0; e < 8; e++) {
-                            const uint32_t word = e < 4 ? raw.r[wq].x : raw.r[wq].y;
-                            const uint32_t byte = (word >> (8 * (e & 3))) & 255u;
-                            const int kb = wq * 8 + e;
-                            float wv[VPB];
-                            s3_lut<VPB>(wlut, byte, wv);
-#pragma unroll
-                            for (int l = 0; l < VPB; l++) {
-                                const int dd = kb * VPB + l;
-                                const float v = wv[l] + (float)raw.c[dd >> 3][dd & 7];
-                                d[dd] = v;
-                                ss = fmaf(v, v, ss);
-                            }
-                        }
-                    }
-                    ss += __shfl_xor(ss, 32, 64);
-                    float nrm = sqrtf(ss);
-                    nrm = nrm < 1e-12f ? 1e-12f : nrm;
-                    const float inv = raw.valid ? 1.0f / nrm : 0.0f;  // padding rows become exact zeros
-#pragma unroll
-                    for (int dd = 0; dd < 64; dd++) {
-                        const float v = d[dd] * inv;
-                        const _Float16 hi = (_Float16)v;
-                        ah[dd >> 3][dd & 7] = hi;
-                        al[dd >> 3][dd & 7] = (_Float16)fmaf((float)hi, -2048.0f, v * 2048.0f);  // = (v - hi) * 2048, exactly
-                    }
-                }
+                s3_decode_split<NBITS>(wlut, [&](int wi) { return (wi & 1) ? raw.r[wi >> 1].y : raw.r[wi >> 1].x; }, raw.c, raw.valid, ah, al);
                 if (t + 1 < ntiles) {
                     s3_issue_rows<NBITS>(raw, cd, t + 1, off, len, i, h, codes, residuals, cen16);
                 } else if (j + 1 < ndw && nlen > 0) {
@@ -557,6 +793,12 @@ static int launch_maxsim_f16_t(const flmr_maxsim_args& a, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(maxsim_f16_multiq_kernel<NBITS>, dim3(a.nqueries, G2), dim3(64 * S3_MQW), lds2, st, a, ix->codes,
                            ix->residuals, ix->doc_offsets, ix->centroids_f16, ix->wlut, nqp);
+    } else if (nqp == 32 && flmr_opts().is(FLMR_OPT_S3_IMPL, "dma")) {
+        const size_t lds3 = ((size_t)256 * (8 / NBITS) * sizeof(float) + (size_t)4 * nqp * sizeof(float) + 15) / 16 * 16 + 4 * 16384;
+        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_f16_dma_kernel<NBITS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+        hipLaunchKernelGGL(maxsim_f16_dma_kernel<NBITS>, dim3(a.nqueries, G), dim3(256), lds3, st, a, ix->codes, ix->residuals,
+                           ix->doc_offsets, ix->centroids_f16, ix->wlut, nqp);
     } else {
         hipLaunchKernelGGL(maxsim_f16_kernel<NBITS>, dim3(a.nqueries, G), dim3(256), lds, st, a, ix->codes, ix->residuals,
                            ix->doc_offsets, ix->centroids_f16, ix->wlut, nqp);

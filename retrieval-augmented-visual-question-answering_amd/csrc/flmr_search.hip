@@ -28,6 +28,7 @@ struct flmr_searcher {
     _Float16* q_hi; _Float16* q_lo;
     uint32_t* hit_bits; int32_t* hit_valid; int32_t* key_count;
     int32_t* s1_slot; int32_t* s2_slot;   // sharded protocol: position of each local survivor / finalist in the global list
+    float* s2_part;             // XCD-sliced stage 2: per (query, slice, survivor) column maxima (NULL when the index has no split table)
     _Float16* q3_hi; _Float16* q3_lo;
     int32_t* qual; int32_t* nqual; int32_t* chunk_cnt; uint8_t* cand_hit; int32_t qmax;
     // last call (for taps)
@@ -115,6 +116,8 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     WS(key_count, B);
     WS(s1_slot, B * (size_t)nd);
     WS(s2_slot, B * (size_t)nd4);
+    if (ix->doc_splits && s->ncol_max == 32 && (flmr_stage2_xcd_pays(ix) || s->opt.is(FLMR_OPT_S2_IMPL, "xcd")))
+        WS(s2_part, flmr_stage2_xcd_part_floats((int64_t)B, nd));
     s->qmax = 1024;
     WS(qual, B * (size_t)s->qmax);
     WS(nqual, B);
@@ -136,7 +139,7 @@ extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
     if (!s) return FLMR_OK;
     void* ptrs[] = {s->cs, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
                     s->keys1, s->s1_pids, s->s1_count, s->keys2, s->s2_pids, s->s2_count, s->keys3, s->doc_scores,
-                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot};
+                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part};
     for (void* p : ptrs) (void)hipFree(p);
     if (s->status_host) (void)hipHostFree(s->status_host);
     if (s->status_ev) (void)hipEventDestroy(s->status_ev);
@@ -381,7 +384,12 @@ static int stage_s2(run_ctx& c, bool whole_batch) {
     const bool walk = c.sparse && ix->codes_sorted && ix->centroids_f16_tiled &&
                       (o.is(FLMR_OPT_S2_IMPL, "walk") ||
                        (!o.has(FLMR_OPT_S2_IMPL) && whole_batch && flmr_stage2_walk_pays(ix, c.nqueries, c.p.ndocs)));
-    if (walk)
+    const bool xcd = !walk && c.sparse && s->s2_part && c.f.ncol == 32 &&
+                     (o.is(FLMR_OPT_S2_IMPL, "xcd") || (!o.has(FLMR_OPT_S2_IMPL) && flmr_stage2_xcd_pays(ix)));
+    if (xcd)
+        RUN(flmr_launch_filter_stage2_xcd(c.f, s->s1_pids, s->maxp.ndocs, s->s1_count, c.p.ndocs, s->keys2, s->maxp.ndocs, ix,
+                                          s->q_hi, s->q_lo, s->s2_part, s->maxp.ndocs, c.st));
+    else if (walk)
         RUN(flmr_launch_filter_stage2_walk(c.f, s->s1_pids, s->maxp.ndocs, s->s1_count, c.p.ndocs, s->keys2, s->maxp.ndocs,
                                            ix->centroids_f16_tiled, s->q_hi, s->q_lo, ix->codes_sorted, c.st));
     else if (c.sparse)

@@ -858,6 +858,85 @@ def test_stage2_walk_equals_gather(hip, nbits, doclen, K, npass, policy):
         assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), tag
 
 
+@pytest.mark.parametrize("nbits,doclen,npids", [
+    (1, (0, 70), 3000), (2, (0, 12), 5000), (2, (1, 300), 777), (4, (30, 34), 4096), (8, (0, 200), 2500), (2, 128, 1),
+])
+def test_s3_dma_kernel_equals_register_kernel(hip, nbits, doclen, npids):
+    """S3's default kernel (centroid rows by LDS-DMA two tiles ahead, hand-counted vmcnt waits; flmr_maxsim.hip) vs the register
+    row-gather kernel (FLMR_S3_IMPL=regs): same arithmetic in the same order, so the scores must agree bit for bit -- over
+    empty passages, one-token passages, passages of several tiles, tile counts that end the pipeline at every phase, ragged
+    query lengths via the search path, and a single document."""
+    import ctypes as C
+    nat = hip["native"]
+    torch = hip["torch"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    corpus = synth.make_corpus(6000, doclen, 512, nbits, seed=77 + nbits, device="cuda")
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=8)
+    Q, _ = synth.make_queries(corpus, 6, 32, seed=9)
+    g = torch.Generator().manual_seed(5)
+    pids = torch.randperm(6000, generator=g)[:npids].to(torch.int32).cuda()
+    outs = {}
+    for impl in ("regs", "dma"):
+        with nat.options(FLMR_S3_IMPL=impl):
+            res = []
+            for nq in (32, 17):
+                Qd = Q[0, :nq].contiguous()
+                out = torch.full((npids,), -7.0, dtype=torch.float32, device="cuda")
+                nat.check(scorer._lib.flmr_score_pids(scorer.device_index.handle, C.c_void_p(Qd.data_ptr()), nq,
+                                                      C.c_void_p(pids.data_ptr()), npids, C.c_void_p(out.data_ptr()),
+                                                      nat.stream_ptr()))
+                res.append(out.cpu().numpy())
+            q_lens = torch.tensor([32, 5, 32, 1, 20, 32], dtype=torch.int32)
+            for ql in (None, q_lens):
+                p, s, c = scorer.search_batch(Q, 64, 2, 0.3, 256, 32, q_lens=ql)
+                scorer.check()
+                res += [p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy()]
+            outs[impl] = res
+    for a, b in zip(outs["regs"], outs["dma"]):
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+    assert not np.any(outs["dma"][0] == -7.0)
+
+
+@pytest.mark.parametrize("nbits,doclen,K,npass,policy", [
+    (2, (0, 200), 2048, 6000, (2, 0.45, 256)),      # ragged passages incl. empty and one-token ones; most (passage, slice) runs < 8 tokens
+    (2, 64, 512, 70_000, (2, 0.3, 1024)),           # 64-code slices: runs of several octets, four survivor groups per query
+    (4, (10, 90), 1000, 40_000, (4, 0.4, 4096)),    # K not a multiple of 8 slices; ndocs = 4096: sixteen waves per (query, slice)
+    (2, (300, 420), 4096, 3000, (2, 0.45, 256)),    # passages longer than 256 tokens
+    (2, 128, 32768, 20_000, (2, 0.45, 1024)),       # a table beyond one L2: the kernel is the DEFAULT here (no switch set)
+])
+def test_stage2_xcd_sliced_equals_gather(hip, nbits, doclen, K, npass, policy):
+    """Stage 2 with the centroid table cut into one slice per XCD (flmr_stage2_xcd.hip: sorted per-passage codes, 8-token
+    octets, per-slice column maxima + combine) vs the row-gather kernel (FLMR_S2_IMPL=lds): the stage-2 finalists IN ORDER,
+    and the final ids, scores (as bits) and counts must be identical -- max is exact, so neither the token order nor the
+    cut into slices can matter."""
+    nat = hip["native"]
+    torch = hip["torch"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    corpus = synth.make_corpus(npass, doclen, K, nbits, seed=43, device="cuda")
+    Q, _ = synth.make_queries(corpus, 9, 32, seed=6)
+    q_lens = torch.tensor([32, 32, 20, 32, 1, 32, 32, 7, 32], dtype=torch.int32)
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=16)
+    ncells, thr, ndocs = policy
+    outs = {}
+    impls = ("lds", "xcd", "ldsb") if K < 32768 else ("lds", None)
+    for impl in impls:
+        with nat.options(**({"FLMR_S2_IMPL": impl} if impl else {})):
+            for tag, ql in (("full", None), ("ragged", q_lens)):
+                p, s, c = scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=ql)
+                torch.cuda.synchronize()
+                taps = [scorer.tap(nat.TAP_STAGE2, q) for q in range(Q.size(0))]
+                outs[impl, tag] = (p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), taps)
+            scorer.check()
+    for other in impls[1:]:
+        for tag in ("full", "ragged"):
+            a, b = outs[impls[0], tag], outs[other, tag]
+            for q in range(Q.size(0)):
+                assert np.array_equal(a[3][q], b[3][q]), ("stage-2 finalists", other, tag, q)
+            assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), (other, tag)
+
+
 def test_stage2_walk_on_golden_fixture(hip, scorers):
     """The walk against the reference's own stage-2 output (golden `filtered_pids`, produced by filter_pids.cpp) -- as a set, and
     in order against the oracle's pruning run on the GPU's own score table (like test_search_stages_vs_golden does for the
