@@ -283,9 +283,10 @@ def main():
                                    "WRITE_SIZE, bytes per launch; not measured in this run)") if dom.get("traffic") else None,
                 "launch_ms": dom["launch_ms"],
                 "note": ("achieved = the kernel's own compulsory bytes (or split-MFMA flops) per launch / its HIP-event time; "
-                         "stage 2 (gather form) is limited by neither roof but by the fabric: one 256-byte fp16 centroid "
-                         "row per survivor token from the Infinity Cache, measured gather ceiling 9.3-9.6 TB/s "
-                         "(profiles/microbench)"),
+                         "stage 2 is limited by neither roof: it moves one 256-byte fp16 centroid row per survivor token "
+                         "(gathered_row_GBs) -- from the Infinity Cache in the gather form (measured ceiling 9.3-9.6 TB/s), "
+                         "from an L2-resident table slice per XCD in the default sliced form (69 % L2 hits, ceiling 23-32 TB/s, "
+                         "profiles/microbench) whose time goes to per-wave set-up and instruction issue (DESIGN.md section 4)"),
                 "gathered_row_GBs": (2 * d * ns_tok * args.batch / (dom["launch_ms"] * 1e-3) / 1e9) if dom["kernel"] == "s2_filter_sort" else None,
                 "per_kernel": per_kernel,
                 "whole_path": {"compulsory_bytes_per_query": alg_build, "GBs": alg_build * qps / 1e9,

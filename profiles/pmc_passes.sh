@@ -5,7 +5,7 @@ set -u
 OUT=$(readlink -f "$1"); mkdir -p "$OUT"
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-KREGEX='s0_|filter_stage|maxsim|select_topn|sort_topn|s1_|cand_|qualifying'
+KREGEX='s0_|filter_stage|s2_combine|maxsim|select_topn|sort_topn|s1_|cand_|qualifying'
 run() { # name, counters...
   name=$1; shift
   timeout 600 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "$KREGEX" --output-format csv -d "$OUT/$name" -o p -- \
