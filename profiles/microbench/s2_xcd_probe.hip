@@ -47,6 +47,15 @@ int main(int argc, char** argv) {
 #endif
     flmr_filter_args f{};
     f.K = K; f.ncol = 32; f.nq_cand = 32; f.nqueries = NQ; f.q_lens = nullptr; f.codes = nullptr; f.doclens = nullptr; f.offsets = ix.doc_offsets;
+    {
+        int nb = 0;
+        const size_t lds = (size_t)X2_WAVES * X2_WAVE_LDS;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_stage2_xcd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, filter_stage2_xcd_kernel, 64 * X2_WAVES, lds));
+        hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+        printf("dynamic LDS per block %zu B, resident blocks per CU %d (LDS per CU %zu B, per block max %zu B)\n", lds, nb,
+               (size_t)prop.maxSharedMemoryPerMultiProcessor, (size_t)prop.sharedMemPerBlockOptin);
+    }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 3; rep++) {
 #ifdef X2_PROFILE
