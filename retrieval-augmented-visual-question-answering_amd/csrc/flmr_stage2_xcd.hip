@@ -232,8 +232,12 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
             asm volatile("" ::: "memory");
             issue_rows(0);
             issue_rows(1);
-            int jcur = -1;       // passage whose column maxima `cm` carries
+            int jcur = -1;       // passage whose column maxima `cm` carries (per lane: over the rows of its own half-wave)
             float cm = -9999.0f;
+            auto flush = [&](int j) {
+                const float v = x2_max(cm, __shfl_xor(cm, 32, 64));
+                if (h == 0) prow[(size_t)j * 32 + i] = v;
+            };
             for (int t = 0; t < ntiles; t++) {
                 // ---- tile t's rows ----
                 if (t == 0) x2_wait_vm<8>(); else x2_wait_vm<9>();
@@ -266,26 +270,28 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
                     ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[s], ah, 0, 0, 0);
                     al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[s], al, 0, 0, 0);
                 }
-                // rows 8k .. 8k+7 (octet k) live in registers 4k .. 4k+3 of the two half-waves
+                // rows 8k .. 8k+7 (octet k) live in registers 4k .. 4k+3 of the two half-waves: each lane keeps the maximum over
+                // ITS four rows; the two halves are only combined when a passage is flushed (one LDS-crossbar op per passage
+                // instead of four per tile)
                 float mq[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const float v0 = fmaf(al[4 * k], 1.0f / 2048.0f, ah[4 * k]), v1 = fmaf(al[4 * k + 1], 1.0f / 2048.0f, ah[4 * k + 1]);
                     const float v2 = fmaf(al[4 * k + 2], 1.0f / 2048.0f, ah[4 * k + 2]), v3 = fmaf(al[4 * k + 3], 1.0f / 2048.0f, ah[4 * k + 3]);
-                    const float m = x2_max(x2_max3(v0, v1, v2), v3);
-                    mq[k] = x2_max(m, __shfl_xor(m, 32, 64));
+                    mq[k] = x2_max(x2_max3(v0, v1, v2), v3);
                 }
 #ifdef X2_PROFILE
                 asm volatile("" : "+v"(mq[0]), "+v"(mq[1]), "+v"(mq[2]), "+v"(mq[3]));
 #endif
                 X2_STAMP(6);
                 // ---- fold the octets into their passages (wave-uniform control flow) ----
+                const int nvalid = ntot - 4 * t;  // >= 4 except in the last tile
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    if (4 * t + k < ntot) {
+                    if (k < nvalid) {
                         const int j = __builtin_amdgcn_readlane(om, k);
                         if (j != jcur) {
-                            if (jcur >= 0 && h == 0) prow[(size_t)jcur * 32 + i] = cm;
+                            if (jcur >= 0) flush(jcur);
                             cm = -9999.0f;  // filter_pids.cpp:30-33
                             jcur = j;
                         }
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
                 }
                 X2_STAMP(7);
             }
-            if (h == 0) prow[(size_t)jcur * 32 + i] = cm;
+            flush(jcur);
             x2_wait_vm<0>();  // (also: the DMA writes of the tiles requested past the end have landed before the LDS is reused)
             asm volatile("" ::: "memory");
         }
