@@ -102,6 +102,18 @@ __device__ __forceinline__ void flmr_bitonic_sort_desc(T* s, int n) {
 // (filter_pids.cpp:59-63): kept strictly k-ascending so pruning decisions are bit-identical to the CPU path.
 __device__ __forceinline__ float flmr_seq_sum(const float* v, int n) {
     float s = 0.0f;
+    if (n <= 32) {
+        // the common case (one column tile): all loads are issued before the first add -- a loop of dependent LDS reads costs
+        // one LDS round trip per column (~3000 cycles per passage, as much as a token tile), the adds alone ~250.  Columns
+        // >= n contribute +0.0f, which leaves the sum's bits unchanged (x + 0.0f == x for every x but -0.0f, which a sum
+        // that started from +0.0f never is).
+        float x[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) x[k] = k < n ? v[k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 32; k++) s += x[k];
+        return s;
+    }
     for (int k = 0; k < n; k++) s += v[k];
     return s;
 }

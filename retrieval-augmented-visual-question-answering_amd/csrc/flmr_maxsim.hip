@@ -394,8 +394,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
-            float sc = 0.0f;
-            for (int k = 0; k < qlen; k++) sc += colmax[k];
+            const float sc = flmr_seq_sum(colmax, qlen);
             const int dslot = w + j * W;
             if (m.keys) m.keys[(size_t)b * m.key_stride + dslot] = flmr_make_key(sc, pid);
             if (m.scores) m.scores[(size_t)b * m.key_stride + dslot] = sc;
@@ -612,8 +611,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) {
-                float sc = 0.0f;
-                for (int k = 0; k < qlen; k++) sc += colmax[k];
+                const float sc = flmr_seq_sum(colmax, qlen);
                 if (m.keys) m.keys[(size_t)b * m.key_stride + dslot] = flmr_make_key(sc, pid);
                 if (m.scores) m.scores[(size_t)b * m.key_stride + dslot] = sc;
             }
