@@ -420,11 +420,14 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
 // vmcnt retires in order and the compiler's own wait insertion assumes it sees every outstanding operation; a wait it
 // places for one register load would also drain the DMA issued before it.  So every VMEM load inside the loop is issued
 // from inline assembly (invisible to that pass) and waited for by hand:
-//   * a step issues, in this order: code of tile g+3 (1), residual bytes of tile g+2 (RL), DMA of tile g+2 (8);
+//   * a step issues, in this order: codes of tile g+6 (1 operation: global -> LDS ring, ALWAYS issued -- past the end the
+//     last position is repeated), residual bytes of tile g+2 (RL), row DMA of tile g+2 (8);
 //   * top of step g: everything older than step g-1's issues must have landed (rows + residual bytes of tile g):
-//     vmcnt(9 + RL) when step g-1 issued its full set, vmcnt(8 + RL) when it had no code to load, else vmcnt(0);
-//   * before the DMA of tile g+2: its code (first issue of step g-1) -- younger than it are the rest of step g-1 (RL + 8)
-//     and this step's code + residual loads: vmcnt(2 RL + 8 + [tile g+3 exists]).
+//     vmcnt(9 + RL) when tile g+1 exists (8 + RL for g = 0, where the prologue's second tile comes last), else vmcnt(0);
+//   * before the DMA of tile g+2: its codes -- the first operation of step g-4 -- must have landed: younger than them are
+//     the rest of that step (RL + 8), three full steps and this step's code + residual requests: vmcnt(36 + 5 RL).
+// (The first form requested the codes one step before their rows; that left the codes' HBM latency on every step's path.
+// Neither form changes S3's time -- see DESIGN.md section 4.)
 // A wait count is safe whenever it does not exceed the number of operations issued after the awaited one; the compiler's
 // own stores (keys) only add to that number.  Registers alternate by tile parity, so no value is copied while its load is
 // in flight, and each awaited register passes through an empty asm after the wait so its uses cannot be scheduled above it.
@@ -480,6 +483,8 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args
     char* const rowbuf = smem + ((256 * VPB + 4 * (size_t)nqp) * sizeof(float) + 15) / 16 * 16 + (size_t)wave * 16384;
     const uint32_t rowbuf_lds =
         __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)rowbuf);
+    char* const ring = smem + ((256 * VPB + 4 * (size_t)nqp) * sizeof(float) + 15) / 16 * 16 + 4 * 16384 + (size_t)wave * 2048;
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring);
     const int b = blockIdx.x;
     const int cnt = m.counts[b];
     const int qlen = m.q_lens ? m.q_lens[b] : m.nq;
@@ -525,51 +530,79 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args
         valid = tok < len;
         return off + (valid ? tok : len - 1);
     };
-    auto issue_code = [&](int64_t pos, int& c) {
-        asm volatile("global_load_dword %0, %1, off" : "=v"(c) : "v"(codes + pos) : "memory");
-    };
-    auto dma_rows = [&](int code, int buf) {  // 32 rows -> rowbuf[buf]: piece p of row r at position p ^ (r & 15)
-        const int rl = lane >> 4, pp = lane & 15;
+    uint32_t piece_off[8];  // byte offset, inside its row, of the 16-byte piece this lane moves in DMA instruction gq
 #pragma unroll
-        for (int g = 0; g < 8; g++) {
-            const int row = 4 * g + rl;
-            const int c = __shfl(code, row, 64);
-            const _Float16* src = cen16 + (size_t)c * FLMR_DIM + ((pp ^ (row & 15)) << 3);
-            const uint32_t dst = rowbuf_lds + buf * 8192 + g * 1024;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+    for (int gq = 0; gq < 8; gq++) piece_off[gq] = (uint32_t)(((lane & 15) ^ ((4 * gq + (lane >> 4)) & 15)) << 4);
+    // codes of the tile at array positions `pos` (lane i: row i; lanes 32..63 repeat) -> ring slot g % 8, straight to LDS
+    auto issue_codes = [&](int64_t pos, int g) {
+        const uint32_t dst = ring_lds + (g & 7) * 256;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(codes + pos), "s"(dst) : "memory", "m0");
+    };
+    // 32 rows of tile g -> rowbuf[g & 1]: piece p of row r at position p ^ (r & 15); codes from the ring
+    auto dma_rows = [&](int g) {
+        const int* cr = reinterpret_cast<const int*>(ring + (g & 7) * 256) + (lane >> 4);
+        int c[8];
+#pragma unroll
+        for (int gq = 0; gq < 8; gq++) c[gq] = cr[4 * gq];
+#pragma unroll
+        for (int gq = 0; gq < 8; gq++) {
+            const uint32_t dst = rowbuf_lds + (g & 1) * 8192 + gq * 1024;
+            uint32_t voff;
+            asm volatile("s_mov_b32 m0, %2\n\tv_lshl_add_u32 %0, %3, 8, %4\n\tglobal_load_lds_dwordx4 %0, %1"
+                         : "=&v"(voff)
+                         : "s"(cen16), "s"(dst), "v"(c[gq]), "v"(piece_off[gq])
+                         : "memory", "m0");
         }
     };
 
-    // tiles g (being consumed), g+1, g+2, g+3 of the sequence
-    int j0 = 0, t0 = 0, j1, t1, j2, t2, j3, t3;
+    // tiles g (being consumed), g+1, g+2 of the sequence, and the cursor of the code requests (tile g+6)
+    int j0 = 0, t0 = 0, j1, t1, j2, t2, jc, tc;
     normalize(j0, t0);
     next_of(j0, t0, j1, t1);
     next_of(j1, t1, j2, t2);
-    next_of(j2, t2, j3, t3);
+    jc = j0; tc = t0;
     s3_res<NBITS> rE, rO;              // residual bytes of the even / odd tile in flight
     bool vE = false, vO = false, vtmp;
-    int cE = 0, cO = 0;                // code of tile g+2 (parity of g) / g+3
-    // prologue, issue order: code of tile 2, then residual bytes + DMA of tile 0, of tile 1
+    int64_t cpos = 0;                  // last valid position of the code cursor (requests past the end repeat it)
+    auto next_code_pos = [&]() -> int64_t {
+        if (jc < ndw) { cpos = tokpos(jc, tc, vtmp); next_of(jc, tc, jc, tc); }
+        return cpos;
+    };
+    // VMEM issue order:  prologue  C0 .. C5, res0, R0 (8), res1, R1 (8)      Ct = codes of tile t (1 operation, ALWAYS issued:
+    //                    step g    C(g+6), res(g+2) (RL), R(g+2) (8)          past the end the last position is repeated)
+    // top of step g: R(g) and res(g) must have landed; younger are the operations of step g-1 (the prologue's second tile
+    // for g = 0): 1 + RL + 8, or just the code request when tile g+1 does not exist.
+    // before R(g+2) is issued: C(g+2) -- the first operation of step g-4 -- must have landed; younger than it are the rest of
+    // that step (RL + 8), three full steps (27 + 3 RL), this step's C and res (1 + RL): 36 + 5 RL; from the prologue (g = 0, 1):
+    // 20 + 3 RL, 28 + 4 RL.
     {
-        int64_t p0 = 0, p1 = 0;
-        int c0 = 0, c1 = 0;
-        if (j0 < ndw) { p0 = tokpos(j0, t0, vE); c0 = codes[p0]; }
-        if (j1 < ndw) { p1 = tokpos(j1, t1, vO); c1 = codes[p1]; }
-        // every compiler-visible load lands here, before the first hand-counted one is issued
-        asm volatile("" : "+v"(c0), "+v"(c1)::"memory");
 #pragma unroll
         for (int s = 0; s < 8; s++) asm volatile("" : "+v"(bh[s]), "+v"(bl[s])::"memory");
-        if (j2 < ndw) issue_code(tokpos(j2, t2, vtmp), cE);
-        if (j0 < ndw) { rE.issue(residuals + (size_t)p0 * PACKED + h * NB); dma_rows(c0, 0); }
-        if (j1 < ndw) { rO.issue(residuals + (size_t)p1 * PACKED + h * NB); dma_rows(c1, 1); }
+        int64_t p0 = 0, p1 = 0;
+        for (int g = 0; g < 6; g++) {
+            const int64_t p = next_code_pos();
+            if (g == 0) p0 = p;
+            if (g == 1) p1 = p;
+            issue_codes(p, g);
+        }
+        s3_wait_vm<4>();  // C0, C1
+        asm volatile("" ::: "memory");
+        (void)tokpos(j0, t0, vE);
+        rE.issue(residuals + (size_t)p0 * PACKED + h * NB);
+        dma_rows(0);
+        if (j1 < ndw) {
+            (void)tokpos(j1, t1, vO);
+            rO.issue(residuals + (size_t)p1 * PACKED + h * NB);
+            dma_rows(1);
+        }
     }
 
-    // one step: consume tile g from buffer `buf` with residual bytes r / validity v; c2 holds the code of tile g+2, c3 receives
-    // the code of tile g+3; afterwards r / v belong to tile g+2
-    auto step = [&](int buf, s3_res<NBITS>& r, bool& v, int& c2, int& c3, bool first) {
+    // one step: consume tile g with residual bytes r / validity v; afterwards r / v belong to tile g+2
+    auto step = [&](int g, s3_res<NBITS>& r, bool& v) {
+        const int buf = g & 1;
         // ---- tile g's rows and residual bytes: wait, read this lane's half row out of LDS, release the buffer ----
-        if (j1 >= ndw) s3_wait_vm<0>();
-        else if (first || j2 >= ndw) s3_wait_vm<8 + RL>();
+        if (j1 >= ndw) s3_wait_vm<(0)>();
+        else if (g == 0) s3_wait_vm<8 + RL>();
         else s3_wait_vm<9 + RL>();
         r.touch();
         hf8 c[8];
@@ -581,14 +614,13 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args
         s3_decode_split<NBITS>(wlut, [&](int wi) { return r.word(wi); }, c, v, ah, al);
         const bool last_of_doc = (j1 != j0);
         const int pid = __shfl(my_pid, j0, 64), dslot = w + j0 * W;
-        // ---- keep the pipeline full, in this order: code of tile g+3, residual bytes of tile g+2, DMA of tile g+2 ----
+        // ---- keep the pipeline full, in this order: codes of tile g+6, residual bytes of tile g+2, rows of tile g+2 ----
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the row buffer has been read: it may be refilled
-        if (j3 < ndw) issue_code(tokpos(j3, t3, vtmp), c3);
+        issue_codes(next_code_pos(), g + 6);
         if (j2 < ndw) {
             r.issue(residuals + (size_t)tokpos(j2, t2, v) * PACKED + h * NB);
-            if (j3 < ndw) s3_wait_vm<2 * RL + 9>(); else s3_wait_vm<2 * RL + 8>();
-            asm volatile("" : "+v"(c2)::"memory");
-            dma_rows(c2, buf);
+            if (g == 0) s3_wait_vm<20 + 3 * RL>(); else if (g == 1) s3_wait_vm<28 + 4 * RL>(); else s3_wait_vm<36 + 5 * RL>();
+            dma_rows(g + 2);
         }
         // ---- 32 tokens x 32 query tokens ----
         {
@@ -620,15 +652,13 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args
             for (int t = lane; t < nqp; t += 64) colmax[t] = 0.0f;
         }
         // ---- advance the window of tile positions ----
-        j0 = j1; t0 = t1; j1 = j2; t1 = t2; j2 = j3; t2 = t3;
-        next_of(j2, t2, j3, t3);
+        j0 = j1; t0 = t1; j1 = j2; t1 = t2;
+        next_of(j1, t1, j2, t2);
     };
-    bool first = true;
-    while (j0 < ndw) {
-        step(0, rE, vE, cE, cO, first);   // even tile: DMA of tile g+2 uses cE, the code of tile g+3 lands in cO
-        first = false;
+    for (int g = 0; j0 < ndw; g += 2) {
+        step(g, rE, vE);
         if (j0 >= ndw) break;
-        step(1, rO, vO, cO, cE, false);   // odd tile: roles swapped
+        step(g + 1, rO, vO);
     }
     s3_wait_vm<0>();
 }
@@ -792,7 +822,7 @@ static int launch_maxsim_f16_t(const flmr_maxsim_args& a, hipStream_t st) {
         hipLaunchKernelGGL(maxsim_f16_multiq_kernel<NBITS>, dim3(a.nqueries, G2), dim3(64 * S3_MQW), lds2, st, a, ix->codes,
                            ix->residuals, ix->doc_offsets, ix->centroids_f16, ix->wlut, nqp);
     } else if (nqp == 32 && flmr_opts().is(FLMR_OPT_S3_IMPL, "dma")) {
-        const size_t lds3 = ((size_t)256 * (8 / NBITS) * sizeof(float) + (size_t)4 * nqp * sizeof(float) + 15) / 16 * 16 + 4 * 16384;
+        const size_t lds3 = ((size_t)256 * (8 / NBITS) * sizeof(float) + (size_t)4 * nqp * sizeof(float) + 15) / 16 * 16 + 4 * 16384 + 4 * 2048;
         FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_f16_dma_kernel<NBITS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
         hipLaunchKernelGGL(maxsim_f16_dma_kernel<NBITS>, dim3(a.nqueries, G), dim3(256), lds3, st, a, ix->codes, ix->residuals,
