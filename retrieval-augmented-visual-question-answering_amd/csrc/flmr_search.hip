@@ -376,7 +376,9 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
 // S2 over s->s1_pids / s1_count -> s->keys2 (slot-aligned with s1_pids)
 // `whole_batch`: the survivors are the full top-ndocs lists of a single-index search (flmr_search_batch).  Phase 2 of the
 // sharded protocol scores only this shard's members (a fraction of ndocs per query): the table walk, whose cost does not
-// shrink with the number of survivors, is then the wrong form unless forced.
+// shrink with the number of survivors, is then the wrong form unless forced; so is the XCD-sliced kernel, whose waves each take
+// one eighth of 64 survivors' tokens (per-rank compute of a step at 8 shards, profiles/shard_step_model.py: 2.16 ms sliced,
+// 1.92 ms gather).
 static int stage_s2(run_ctx& c, bool whole_batch) {
     flmr_searcher* s = c.s;
     const flmr_index* ix = s->ix;
@@ -385,7 +387,7 @@ static int stage_s2(run_ctx& c, bool whole_batch) {
                       (o.is(FLMR_OPT_S2_IMPL, "walk") ||
                        (!o.has(FLMR_OPT_S2_IMPL) && whole_batch && flmr_stage2_walk_pays(ix, c.nqueries, c.p.ndocs)));
     const bool xcd = !walk && c.sparse && s->s2_part && c.f.ncol == 32 &&
-                     (o.is(FLMR_OPT_S2_IMPL, "xcd") || (!o.has(FLMR_OPT_S2_IMPL) && flmr_stage2_xcd_pays(ix)));
+                     (o.is(FLMR_OPT_S2_IMPL, "xcd") || (!o.has(FLMR_OPT_S2_IMPL) && whole_batch && flmr_stage2_xcd_pays(ix)));
     if (xcd)
         RUN(flmr_launch_filter_stage2_xcd(c.f, s->s1_pids, s->maxp.ndocs, s->s1_count, c.p.ndocs, s->keys2, s->maxp.ndocs, ix,
                                           s->q_hi, s->q_lo, s->s2_part, s->maxp.ndocs, c.st));
