@@ -47,7 +47,7 @@ enum flmr_opt_id {
     FLMR_OPT_S2_IMPL,        // xcd | walk | lds | ldsb | regs: force the XCD-sliced gather / the dense walk / the LDS-DMA gather (4-wave blocks; 16-wave blocks with the query operand in LDS) / the register gather (default: cost model)
     FLMR_OPT_S0_STAGED,      // set: staged epilogue for every tile
     FLMR_OPT_S3_NO_MULTIQ,   // set: single-tile MaxSim kernel for long queries too
-    FLMR_OPT_S3_IMPL,        // f32: fp32-MFMA MaxSim kernel; dma: fp16-split kernel with LDS-DMA row gathers two tiles ahead (default: register gathers)
+    FLMR_OPT_S3_IMPL,        // f32: fp32-MFMA MaxSim kernel; dma / regs: fp16-split kernel with LDS-DMA row gathers two tiles ahead / register gathers (default: dma for nbits = 8, else regs)
     FLMR_OPT_SCORE_IMPL,     // valu: plain-FMA padded scorer
     FLMR_OPT_COUNT
 };

@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// S3, fp16-split, centroid rows by LDS-DMA with TWO token tiles in flight (FLMR_S3_IMPL=dma; Nq <= 32).
+// S3, fp16-split, centroid rows by LDS-DMA with TWO token tiles in flight (Nq <= 32; default for nbits = 8, FLMR_S3_IMPL=dma).
 // maxsim_f16_kernel above keeps one tile's rows in flight in registers (32 VGPRs per lane, requested after the current
 // tile has been decompressed): a row gather from the Infinity Cache takes ~2 us, the MFMA phase it overlaps with ~0.3 us,
 // and at 250 VGPRs there is no room for a second register buffer -- per tile the wave sits out most of the latency
@@ -821,7 +821,8 @@ static int launch_maxsim_f16_t(const flmr_maxsim_args& a, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(maxsim_f16_multiq_kernel<NBITS>, dim3(a.nqueries, G2), dim3(64 * S3_MQW), lds2, st, a, ix->codes,
                            ix->residuals, ix->doc_offsets, ix->centroids_f16, ix->wlut, nqp);
-    } else if (nqp == 32 && flmr_opts().is(FLMR_OPT_S3_IMPL, "dma")) {
+    } else if (nqp == 32 && (flmr_opts().is(FLMR_OPT_S3_IMPL, "dma") || (NBITS == 8 && !flmr_opts().has(FLMR_OPT_S3_IMPL)))) {
+        // (measured, 1 M passages: nbits = 2  2.03 vs 2.04 ms for the register form; nbits = 8  2.31 vs 2.43 ms)
         const size_t lds3 = ((size_t)256 * (8 / NBITS) * sizeof(float) + (size_t)4 * nqp * sizeof(float) + 15) / 16 * 16 + 4 * 16384 + 4 * 2048;
         FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_f16_dma_kernel<NBITS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));

@@ -361,7 +361,8 @@ long long* x2_prof_buffer = nullptr;  // set by the stand-alone harness (profile
 
 // the sliced form pays when the centroid table does not fit an XCD's L2 anyway (the gather kernel then reads it from the fabric)
 bool flmr_stage2_xcd_pays(const flmr_index* ix) {
-    return ix->doc_splits && ix->codes_sorted && (size_t)ix->K * FLMR_DIM * sizeof(_Float16) > ((size_t)6 << 20);
+    const size_t table = (size_t)ix->K * FLMR_DIM * sizeof(_Float16);
+    return ix->doc_splits && ix->codes_sorted && table > ((size_t)6 << 20) && table < ((size_t)1 << 32);  // 32-bit row offsets
 }
 
 size_t flmr_stage2_xcd_part_floats(int64_t nqueries, int64_t ndocs) { return (size_t)nqueries * X2_SLICES * ndocs * 32; }
@@ -372,6 +373,7 @@ int flmr_launch_filter_stage2_xcd(const flmr_filter_args& f, const int32_t* pids
     if (max_count <= 0) return FLMR_OK;
     if (f.ncol != 32) FLMR_FAIL(FLMR_ERR_INVALID, "stage-2 recompute needs one column tile");
     if (!ix->doc_splits || !ix->codes_sorted || !part) FLMR_FAIL(FLMR_ERR_INVALID, "stage-2 sliced kernel needs the sorted codes and their split table");
+    if ((size_t)ix->K * FLMR_DIM * sizeof(_Float16) >= ((size_t)1 << 32)) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "stage-2 sliced kernel: centroid table >= 4 GB");
     const int G = (int)flmr_ceil_div(max_count, X2_WAVES * X2_DOCS);
     const int64_t grid = (int64_t)X2_SLICES * f.nqueries * G;
     if (grid > 0x7fffffffLL) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "stage-2 grid too large");

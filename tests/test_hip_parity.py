@@ -347,6 +347,13 @@ def test_full_size_properties(hip):
                                                          C.c_void_p(p[i].data_ptr()), 100, C.c_void_p(out.data_ptr()),
                                                          hip["native"].stream_ptr()))
         assert torch.equal(out, s[i])
+    # every stage-2 form gives the same bits at this size too (default here: the XCD-sliced kernel; K = 32768 -> 8 MB table)
+    ref = (p.cpu(), s.cpu(), c.cpu())
+    for impl in ("lds", "xcd", "walk"):
+        with hip["native"].options(FLMR_S2_IMPL=impl):
+            p2, s2, c2 = scorer.search_batch(Q, 100, 2, 0.45, 1024, 32)
+            scorer.check()
+        assert torch.equal(p2.cpu(), ref[0]) and torch.equal(s2.cpu().view(torch.int32), ref[1].view(torch.int32)) and torch.equal(c2.cpu(), ref[2]), impl
 
 
 def test_merge_topk(hip):
@@ -935,6 +942,25 @@ def test_stage2_xcd_sliced_equals_gather(hip, nbits, doclen, K, npass, policy):
             for q in range(Q.size(0)):
                 assert np.array_equal(a[3][q], b[3][q]), ("stage-2 finalists", other, tag, q)
             assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), (other, tag)
+
+
+def test_stage2_xcd_on_golden_fixture(hip, scorers):
+    """The sliced stage 2 against the reference's own stage-2 output (golden `filtered_pids`, produced by filter_pids.cpp) -- as a
+    set, and in order against the oracle's pruning run on the GPU's own score table."""
+    from oracle import oracle as orc
+    nat = hip["native"]
+    z, scorer = scorers["idx_nb2"]
+    oi = orc.OracleIndex.from_golden(z)
+    for r in ("rank0", "rank3"):
+        with nat.options(FLMR_S2_IMPL="xcd"):
+            _search_one(hip, scorer, z, r, full_table=False)
+            got = scorer.tap(nat.TAP_STAGE2)
+            cand = scorer.tap(nat.TAP_CANDIDATES)
+        _search_one(hip, scorer, z, r, full_table=True)
+        table = scorer.tap(nat.TAP_CENTROID_SCORES)
+        fin = oi.filter_pids(cand, table, table.max(axis=1) >= np.float32(z[f"{r}.thr"]), int(z[f"{r}.ndocs"]))
+        assert np.array_equal(got, fin), r
+        assert sorted(got.tolist()) == sorted(z[f"{r}.filtered_pids"].tolist()), r
 
 
 def test_stage2_walk_on_golden_fixture(hip, scorers):
