@@ -98,6 +98,24 @@ __device__ __forceinline__ void flmr_bitonic_sort_desc(T* s, int n) {
     }
 }
 
+// Both half-waves' values of a register (lanes L and L ^ 32) without an LDS round trip: v_permlane32_swap exchanges the upper
+// half of one copy with the lower half of another, leaving {v[L & 31], v[(L & 31) + 32]} in every lane (a VALU op; the
+// ds_bpermute form of __shfl_xor(v, 32) costs an LDS-crossbar round trip on the critical path of every tile).
+__device__ __forceinline__ void flmr_both_halves(float v, float& lo, float& hi) {
+    float a = v, b = v;
+    // (written as an instruction: the compiler's builtin returned the first result twice; two read-write operands also keep
+    // the copies in two registers -- with one register for both the instruction swaps it with itself)
+    // volatile: the instruction reads lanes of BOTH halves, so it must not be sunk into a branch that only one half takes
+    // (its only consumer often is: `if (h == 0) store`)
+    // The wait states are the compiler's job for instructions it knows; inside an asm block they are ours: the operands are
+    // usually written by the VALU instruction just before (DPP-class hazard), and read by the one just after.
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    lo = a;
+    hi = b;
+}
+__device__ __forceinline__ float flmr_xhalf_max(float v) { float a, b; flmr_both_halves(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float flmr_xhalf_sum(float v) { float a, b; flmr_both_halves(v, a, b); return a + b; }  // = v + other half's v
+
 // sequential fp32 sum of per-column maxima, the reference's `score += per_doc_approx_scores[k]` order
 // (filter_pids.cpp:59-63): kept strictly k-ascending so pruning decisions are bit-identical to the CPU path.
 __device__ __forceinline__ float flmr_seq_sum(const float* v, int n) {

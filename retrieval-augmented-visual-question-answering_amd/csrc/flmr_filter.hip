@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_mfma_kernel(flmr_filter_
                 cmax = fmaxf(cmax, row < nrow ? v : -9999.0f);
             }
         }
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        cmax = flmr_xhalf_max(cmax);
         if (h == 0) tr[i] = cmax;
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(64 * WAVES, B_LDS ? 1 : 2) void filter_stage2_lds_k
                 cmax = fmaxf(cmax, row < nrow ? v : -9999.0f);
             }
         }
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        cmax = flmr_xhalf_max(cmax);
         if (h == 0) tr[i] = cmax;
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {

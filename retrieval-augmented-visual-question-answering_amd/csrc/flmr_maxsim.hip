@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void maxsim_kernel(flmr_maxsim_args m, const i
         float ss = 0.0f;
 #pragma unroll
         for (int t = 0; t < 64; t++) ss = fmaf(a[t], a[t], ss);
-        ss += __shfl_xor(ss, 32, 64);
+        ss = flmr_xhalf_sum(ss);
         float nrm = sqrtf(ss);
         nrm = nrm < 1e-12f ? 1e-12f : nrm;
         const float inv = 1.0f / nrm;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void maxsim_kernel(flmr_maxsim_args m, const i
                 const float inv_r = __shfl(inv, row, 64);
                 mx = fmaxf(mx, acc[r] * inv_r);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = flmr_xhalf_max(mx);
             if (h == 0 && col < qlen) atomicMax(&colmax[col], __float_as_int(mx));
         }
     }
@@ -229,7 +229,7 @@ __device__ __forceinline__ void s3_decode_split(const float* wlut, WordFn word, 
             }
         }
     }
-    ss += __shfl_xor(ss, 32, 64);
+    ss = flmr_xhalf_sum(ss);
     float nrm = sqrtf(ss);
     nrm = nrm < 1e-12f ? 1e-12f : nrm;
     const float inv = valid ? 1.0f / nrm : 0.0f;  // padding rows become exact zeros
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
                 float mx = 0.0f;  // segmented_maxsim.cpp:58-59: the running max starts at zero
 #pragma unroll
                 for (int r = 0; r < 16; r++) mx = fmaxf(mx, fmaf(accl[r], 1.0f / 2048.0f, acch[r]));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = flmr_xhalf_max(mx);
                 const int col = q0 + i;
                 if (h == 0 && col < qlen) colmax[col] = fmaxf(colmax[col], mx);
             }
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args
             float mx = 0.0f;  // segmented_maxsim.cpp:58-59: the running max starts at zero
 #pragma unroll
             for (int q = 0; q < 16; q++) mx = fmaxf(mx, fmaf(accl[q], 1.0f / 2048.0f, acch[q]));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = flmr_xhalf_max(mx);
             if (h == 0 && i < qlen) colmax[i] = fmaxf(colmax[i], mx);
         }
         if (last_of_doc) {  // k-ascending sum of the column maxima, reset for the next document
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(64 * S3_MQW) void maxsim_f16_multiq_kernel(flmr_max
                     float mx = 0.0f;  // segmented_maxsim.cpp:58-59: the running max starts at zero
 #pragma unroll
                     for (int r = 0; r < 16; r++) mx = fmaxf(mx, fmaf(accl[r] + accm[r], 1.0f / 2048.0f, acch[r]));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    mx = flmr_xhalf_max(mx);
                     if (h == 0) colmax[qt * 32 + i] = fmaxf(colmax[qt * 32 + i], mx);
                 }
             }

@@ -394,7 +394,7 @@ __global__ __launch_bounds__(64 * S0_WAVES, S0_OCC) void s0_centroid_scores_f16(
             if (ov > cmax || (ov == cmax && oa < carg)) { cmax = ov; carg = oa; }
             if (lane < 32) a.part_idx[((size_t)b * a.nblk + wtile) * a.ncol + col] = carg;
         } else {
-            cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+            cmax = flmr_xhalf_max(cmax);
         }
         if (lane < 32) a.part_val[((size_t)b * a.nblk + wtile) * a.ncol + col] = (col < nqc) ? cmax : FLMR_NEG_INF;
         if (ct == T - 1) {

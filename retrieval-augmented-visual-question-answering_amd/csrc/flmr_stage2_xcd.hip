@@ -223,8 +223,8 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
             //   prologue  C0 .. C5, R0 (8), R1 (8)          Ct = codes of tile t (1 operation), Rt = rows of tile t (8 operations)
             //   step t    C(t+6), R(t+2)
             // top of step t: Rt must have landed; younger than it are R1 (t = 0) or all of step t-1: vmcnt(8) / vmcnt(9).
-            // before R(t+2) is issued: C(t+2) must have landed; it was the first operation of step t-4, so younger than it are
-            // the 8 + 27 operations of steps t-4 .. t-1 and this step's C: vmcnt(36); for t = 0, 1 (codes from the prologue) 20, 28.
+            // R(t+2) needs C(t+2), the first operation of step t-4 (or of the prologue): at least 19 operations older than the
+            // youngest, so the wait at the top of the step has already covered it.
             // (The compiler's own stores of column maxima only add to the number of younger operations: a count stays safe.)
 #pragma unroll
             for (int t = 0; t < X2_AHEAD; t++) issue_codes(t);
@@ -235,13 +235,15 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
             int jcur = -1;       // passage whose column maxima `cm` carries (per lane: over the rows of its own half-wave)
             float cm = -9999.0f;
             auto flush = [&](int j) {
-                const float v = x2_max(cm, __shfl_xor(cm, 32, 64));
+                const float v = flmr_xhalf_max(cm);
                 if (h == 0) prow[(size_t)j * 32 + i] = v;
             };
             for (int t = 0; t < ntiles; t++) {
                 // ---- tile t's rows ----
                 if (t == 0) x2_wait_vm<8>(); else x2_wait_vm<9>();
                 X2_STAMP(1);
+                // ONE LDS round trip per step: this tile's rows, its octets' passages, the codes of tile t+2 (their request, four
+                // steps old, is older than anything the wait above lets through) and the octet entries of tile t+6
                 x2h8 av[8];
 #pragma unroll
                 for (int s = 0; s < 8; s++)
@@ -252,14 +254,31 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
                     o = o < ntot ? o : ntot - 1;
                     om = ometa[o] >> 3;
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the row buffer has been read: it may be refilled
+                int c[8];
+                {
+                    const int* cr = reinterpret_cast<const int*>(ring + ((t + 2) & (X2_RING - 1)) * 256) + (lane >> 4);
+#pragma unroll
+                    for (int gq = 0; gq < 8; gq++) c[gq] = cr[4 * gq];
+                }
+                const uint32_t cpos = tile_pos(t + X2_AHEAD);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the row buffer has been read: it may be refilled)
                 X2_STAMP(2);
                 // ---- keep the pipeline full: codes of tile t+6, rows of tile t+2 ----
-                issue_codes(t + X2_AHEAD);
+                {
+                    const uint32_t dst = ring_lds + ((t + X2_AHEAD) & (X2_RING - 1)) * 256;
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(codes_sorted + cpos), "s"(dst) : "memory", "m0");
+                }
                 X2_STAMP(3);
-                if (t == 0) x2_wait_vm<20>(); else if (t == 1) x2_wait_vm<28>(); else x2_wait_vm<36>();
                 X2_STAMP(4);
-                issue_rows(t + 2);
+#pragma unroll
+                for (int gq = 0; gq < 8; gq++) {
+                    const uint32_t dst = rowbuf_lds + (t & 1) * 8192 + gq * 1024;
+                    uint32_t voff;
+                    asm volatile("s_mov_b32 m0, %2\n\tv_lshl_add_u32 %0, %3, 8, %4\n\tglobal_load_lds_dwordx4 %0, %1"
+                                 : "=&v"(voff)
+                                 : "s"(cen16), "s"(dst), "v"(c[gq]), "v"(piece_off[gq])
+                                 : "memory", "m0");
+                }
                 X2_STAMP(5);
                 // ---- 32 tokens x 32 query tokens, fp16-split: same MFMA sequence as stage 0 and the gather kernel ----
                 x2f16 ah, al;
