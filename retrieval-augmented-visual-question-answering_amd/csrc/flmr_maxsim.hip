@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void maxsim_kernel(flmr_maxsim_args m, const i
         float ss = 0.0f;
 #pragma unroll
         for (int t = 0; t < 64; t++) ss = fmaf(a[t], a[t], ss);
-        ss = flmr_xhalf_sum(ss);
+        ss += __shfl_xor(ss, 32, 64);
         float nrm = sqrtf(ss);
         nrm = nrm < 1e-12f ? 1e-12f : nrm;
         const float inv = 1.0f / nrm;
@@ -229,7 +229,7 @@ __device__ __forceinline__ void s3_decode_split(const float* wlut, WordFn word, 
             }
         }
     }
-    ss = flmr_xhalf_sum(ss);
+    ss += __shfl_xor(ss, 32, 64);
     float nrm = sqrtf(ss);
     nrm = nrm < 1e-12f ? 1e-12f : nrm;
     const float inv = valid ? 1.0f / nrm : 0.0f;  // padding rows become exact zeros
@@ -253,6 +253,18 @@ __device__ __forceinline__ void s3_decode_split(const float* wlut, WordFn word, 
         ah[s8] = __builtin_bit_cast(hf8, hpk);
         al[s8] = __builtin_bit_cast(hf8, lpk);
     }
+}
+
+// maximum over a lane's 16 accumulator rows of hi + lo / 2048, zero floor (segmented_maxsim.cpp:58-59), as a tree
+__device__ __forceinline__ float s3_tile_max(const f32x16& acch, const f32x16& accl) {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = fmaf(accl[r], 1.0f / 2048.0f, acch[r]);
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = fmaxf(v[r], v[r + 8]);
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], v[r + 4]);
+    return fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), 0.0f);
 }
 
 template <int NBITS>
@@ -343,6 +355,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
     }
     s3_raw<NBITS> raw;
     bool have_raw = false;
+    float cmx = 0.0f;  // single q-tile: this lane's column maximum over its own half's rows of the current document
     for (int j = 0; j < ndw; j++) {
         const int pid = __shfl(my_pid, j, 64);
         const int len = __shfl(my_len, j, 64);
@@ -382,15 +395,22 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
                     accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[s], accl, 0, 0, 0);
                     accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s], accl, 0, 0, 0);
                 }
-                float mx = 0.0f;  // segmented_maxsim.cpp:58-59: the running max starts at zero
-#pragma unroll
-                for (int r = 0; r < 16; r++) mx = fmaxf(mx, fmaf(accl[r], 1.0f / 2048.0f, acch[r]));
-                mx = flmr_xhalf_max(mx);
-                const int col = q0 + i;
-                if (h == 0 && col < qlen) colmax[col] = fmaxf(colmax[col], mx);
+                const float mx = s3_tile_max(acch, accl);  // over this lane's 16 rows
+                if (single_qt) {
+                    cmx = fmaxf(cmx, mx);  // one column per lane pair: kept in a register until the document ends
+                } else {
+                    const float mxx = flmr_xhalf_max(mx);
+                    const int col = q0 + i;
+                    if (h == 0 && col < qlen) colmax[col] = fmaxf(colmax[col], mxx);
+                }
             }
         }
         // ---- document done: k-ascending sum of the column maxima, reset for the next document ----
+        if (single_qt) {
+            const float v = flmr_xhalf_max(cmx);  // the two half-waves hold the maxima over their own rows
+            if (h == 0) colmax[i] = v;
+            cmx = 0.0f;  // segmented_maxsim.cpp:58-59: the running max starts at zero
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
@@ -597,6 +617,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args
         }
     }
 
+    float cmx = 0.0f;
     // one step: consume tile g with residual bytes r / validity v; afterwards r / v belong to tile g+2
     auto step = [&](int g, s3_res<NBITS>& r, bool& v) {
         const int buf = g & 1;
@@ -633,13 +654,14 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args
                 accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[s], accl, 0, 0, 0);
                 accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s], accl, 0, 0, 0);
             }
-            float mx = 0.0f;  // segmented_maxsim.cpp:58-59: the running max starts at zero
-#pragma unroll
-            for (int q = 0; q < 16; q++) mx = fmaxf(mx, fmaf(accl[q], 1.0f / 2048.0f, acch[q]));
-            mx = flmr_xhalf_max(mx);
-            if (h == 0 && i < qlen) colmax[i] = fmaxf(colmax[i], mx);
+            cmx = fmaxf(cmx, s3_tile_max(acch, accl));  // this lane's column, over its own half's rows, kept in a register
         }
         if (last_of_doc) {  // k-ascending sum of the column maxima, reset for the next document
+            {
+                const float v = flmr_xhalf_max(cmx);
+                if (h == 0) colmax[i] = v;
+                cmx = 0.0f;  // segmented_maxsim.cpp:58-59: the running max starts at zero
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) {
