@@ -51,7 +51,12 @@ int flmr_device_count(int* count);
  * environment variables of the same names are read ONCE per process, on first use of the library; afterwards the table
  * changes only through this call (value NULL or "" clears a switch).  Op-level entry points read the table when they are
  * called; a searcher snapshots it at flmr_searcher_create and keeps that snapshot.  Nothing on the per-batch launch path
- * reads the environment.  (The reference has no counterpart: its extensions have one implementation each.) */
+ * reads the environment.  (The reference has no counterpart: its extensions have one implementation each.)
+ * Values with a measured use: FLMR_S2_IMPL = xcd | lds | ldsb | walk | regs (stage 2: one L2-resident table slice per XCD --
+ * the default for whole batches when the fp16 centroid table exceeds an L2 -- / row gather with 4-wave or 16-wave blocks /
+ * dense table walk / register gather); FLMR_S3_IMPL = regs | dma | f32 (fused MaxSim for Nq <= 32: register row gathers /
+ * LDS-DMA two tiles ahead, the default for nbits = 8 / fp32-MFMA kernel).  Every variant is bit-identical to the default
+ * (tests/test_hip_parity.py). */
 int flmr_set_option(const char* name, const char* value);
 
 /* ------------------------------------------------------------------------------------------------

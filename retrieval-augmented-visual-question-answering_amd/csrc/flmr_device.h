@@ -109,7 +109,7 @@ __device__ __forceinline__ void flmr_both_halves(float v, float& lo, float& hi) 
     // (its only consumer often is: `if (h == 0) store`)
     // The wait states are the compiler's job for instructions it knows; inside an asm block they are ours: the operands are
     // usually written by the VALU instruction just before (DPP-class hazard), and read by the one just after.
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    asm volatile("s_nop 3\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
     lo = a;
     hi = b;
 }
