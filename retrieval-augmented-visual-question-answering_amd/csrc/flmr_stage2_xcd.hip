@@ -19,7 +19,7 @@
 //     into a small ring, so that no step waits for a code; both from inline assembly with hand-counted vmcnt waits (see maxsim_f16_dma_kernel in flmr_maxsim.hip for the rules and why the compiler's own wait
 //     insertion cannot be used with a deep DMA pipeline).
 //   * Per (passage, slice) the wave writes the 32 column maxima ("partial", -9999 start as filter_pids.cpp:30-33) to
-//     part[query][slice][slot][32]; s2_combine_kernel takes the maximum over the slices that hold tokens and sums the columns
+//     part[query][slot][slice][32]; s2_combine_kernel takes the maximum over the slices that hold tokens and sums the columns
 //     k-ascending exactly like the gather kernel.  max is exact and every token's 32 scores come from the same MFMA sequence as
 //     in the gather kernel (one output row depends on its own A row only), so the keys are bit-identical.
 //
@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
     // every compiler-visible load lands here, before the first hand-counted one is issued
 #pragma unroll
     for (int s = 0; s < 8; s++) asm volatile("" : "+v"(bh[s]), "+v"(bl[s])::"memory");
-    float* const prow = part + (((size_t)b * X2_SLICES + sl) * part_stride + slot0) * 32;
+    // part[query][survivor slot][slice][32]: the eight partial rows of a survivor are one contiguous KB for the combine kernel
+    float* const prow = part + (((size_t)b * part_stride + slot0) * X2_SLICES + sl) * 32;
     uint32_t piece_off[8];  // byte offset, inside its row, of the 16-byte piece this lane moves in DMA instruction gq
 #pragma unroll
     for (int gq = 0; gq < 8; gq++) piece_off[gq] = (uint32_t)(((lane & 15) ^ ((4 * gq + (lane >> 4)) & 15)) << 4);
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
             float cm = -9999.0f;
             auto flush = [&](int j) {
                 const float v = flmr_xhalf_max(cm);
-                if (h == 0) prow[(size_t)j * 32 + i] = v;
+                if (h == 0) prow[(size_t)j * (X2_SLICES * 32) + i] = v;
             };
             for (int t = 0; t < ntiles; t++) {
                 // ---- tile t's rows ----
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(256) void s2_combine_kernel(flmr_filter_args f, con
         // all eight rows are requested before the first is used (a slice without tokens was never written: its row is read and dropped)
         float v[X2_SLICES];
 #pragma unroll
-        for (int s = 0; s < X2_SLICES; s++) v[s] = __builtin_nontemporal_load(part + (((size_t)b * X2_SLICES + s) * part_stride + d) * 32 + i);
+        for (int s = 0; s < X2_SLICES; s++) v[s] = __builtin_nontemporal_load(part + (((size_t)b * part_stride + d) * X2_SLICES + s) * 32 + i);
 #pragma unroll
         for (int s = 0; s < X2_SLICES; s++) {
             const int start = (int)((w[s >> 1] >> (16 * (s & 1))) & 0xffffu);
