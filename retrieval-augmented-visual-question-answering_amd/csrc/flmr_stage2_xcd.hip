@@ -233,7 +233,8 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
             asm volatile("" ::: "memory");
             issue_rows(0);
             issue_rows(1);
-            int jcur = -1;       // passage whose column maxima `cm` carries (per lane: over the rows of its own half-wave)
+            // passage whose column maxima `cm` carries (per lane: over the rows of its own half-wave); starts at the first octet's
+            int jcur = __builtin_amdgcn_readfirstlane((int)(ometa[0] >> 3));
             float cm = -9999.0f;
             auto flush = [&](int j) {
                 const float v = flmr_xhalf_max(cm);
@@ -305,18 +306,17 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
 #endif
                 X2_STAMP(6);
                 // ---- fold the octets into their passages (wave-uniform control flow) ----
-                const int nvalid = ntot - 4 * t;  // >= 4 except in the last tile
+                // (octets past the end of the stream -- last tile only -- repeat the last octet, passage and tokens alike: folding
+                // them again changes nothing, so no octet needs a validity test)
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    if (k < nvalid) {
-                        const int j = __builtin_amdgcn_readlane(om, k);
-                        if (j != jcur) {
-                            if (jcur >= 0) flush(jcur);
-                            cm = -9999.0f;  // filter_pids.cpp:30-33
-                            jcur = j;
-                        }
-                        cm = x2_max(cm, mq[k]);
+                    const int j = __builtin_amdgcn_readlane(om, k);
+                    if (j != jcur) {
+                        flush(jcur);
+                        cm = -9999.0f;  // filter_pids.cpp:30-33
+                        jcur = j;
                     }
+                    cm = x2_max(cm, mq[k]);
                 }
                 X2_STAMP(7);
             }
