@@ -113,7 +113,12 @@ __device__ __forceinline__ void flmr_both_halves(float v, float& lo, float& hi) 
     lo = a;
     hi = b;
 }
-__device__ __forceinline__ float flmr_xhalf_max(float v) { float a, b; flmr_both_halves(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float flmr_xhalf_max(float v) {
+    float a, b, r;
+    flmr_both_halves(v, a, b);
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));  // (fmaxf would first canonicalise both asm outputs: two more VALU ops)
+    return r;
+}
 __device__ __forceinline__ float flmr_xhalf_sum(float v) { float a, b; flmr_both_halves(v, a, b); return a + b; }  // = v + other half's v
 
 // sequential fp32 sum of per-column maxima, the reference's `score += per_doc_approx_scores[k]` order
