@@ -39,7 +39,7 @@ extern thread_local char flmr_err_buf[512];
 // snapshot (flmr_opt_scope): nothing on the per-batch launch path calls getenv, and the environment cannot flip a running
 // searcher to another kernel path.
 enum flmr_opt_id {
-    FLMR_OPT_S0_IMPL = 0,    // f16 (default when the centroids are fp16-exact) | f32 | mfma | valu
+    FLMR_OPT_S0_IMPL = 0,    // f16 (default when the centroids are fp16-exact; query-stationary on the sparse path) | f16rs (row-stationary fp16 kernel) | f32 | mfma | valu
     FLMR_OPT_FULL_TABLE,     // set: keep the whole centroid-score table
     FLMR_OPT_CAND_IMPL,      // atomic: first candidate-generation implementation
     FLMR_OPT_S1_NO_HITMAP,   // set: no hit prefilter

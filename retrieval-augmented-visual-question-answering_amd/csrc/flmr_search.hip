@@ -261,7 +261,7 @@ static bool sparse_path(const flmr_searcher* s, int ncol) {
     const flmr_index* ix = s->ix;
     const flmr_options& o = s->opt;
     const bool f16_path = ix->centroids_f16_exact && ix->centroids_f16 && (ix->K % 64 == 0) &&
-                          !(o.has(FLMR_OPT_S0_IMPL) && !o.is(FLMR_OPT_S0_IMPL, "f16"));
+                          !(o.has(FLMR_OPT_S0_IMPL) && !o.is(FLMR_OPT_S0_IMPL, "f16") && !o.is(FLMR_OPT_S0_IMPL, "f16rs"));
     return f16_path && ncol == 32 && !s->full_table && !o.has(FLMR_OPT_FULL_TABLE);
 }
 

@@ -408,6 +408,162 @@ __global__ __launch_bounds__(64 * S0_WAVES, S0_OCC) void s0_centroid_scores_f16(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// S0a, QUERY-stationary form (default on the sparse path: one column tile, only surviving rows stored).
+// s0_centroid_scores_f16 keeps 64 centroid rows per wave in registers and streams the queries' B operands from LDS: 16 KB of
+// ds_read_b128 per (wave, query) for 32 MFMAs -- with 16 waves per CU the LDS pipe is as busy as the matrix pipe.  Here the
+// operand that is REUSED stays in registers instead: a wave holds the fp16 hi/lo images of S0Q_QT = 2 queries (128 VGPRs) for
+// the whole kernel and the centroid tiles stream through LDS, 8 KB per 32-row tile shared by the 8 waves of the workgroup
+// (16 queries): 8 KB of LDS reads per wave for the same 32 MFMAs, a third of the traffic.  The tiles go global -> LDS by DMA
+// (one 1 KB piece per wave and tile, XOR-swizzled like stage 2's), S0Q_AHEAD tiles ahead, one block barrier per tile.
+// Same MFMA sequence per (row, column) as the row-stationary kernel: every value is bitwise the same.
+//
+// vmcnt: a step's VMEM operations are fixed so that the wait for a tile's piece can leave the younger STORES outstanding
+// (stores retire slowly and share the counter): step t issues the DMA of tile t + AHEAD first, then one idx-word store per
+// query, and after odd tiles one block-maximum store per query -- 3 operations after an even tile, 5 after an odd one.
+// The piece of tile t was the first operation of step t - AHEAD = t - 3: younger are the rest of that step and two full
+// steps: 4 + 3 + 5 = 12 for even t, 2 + 5 + 3 = 10 for odd t.  (The rare dense epilogue's row stores only add to that.)
+// grid = (ceil(nqueries / 16), slices), block = 512; dynamic LDS = 8 x 4.5 KB staging + S0Q_NBUF x 8 KB tiles.
+// ------------------------------------------------------------------------------------------------
+#define S0Q_QT 2
+#define S0Q_AHEAD 3
+#define S0Q_NBUF 4
+
+template <int N>
+__device__ __forceinline__ void s0q_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__global__ __launch_bounds__(512, 1) void s0_centroid_scores_qs(flmr_s0_args a, int rows_per_slice) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    float* stage = reinterpret_cast<float*>(smem) + wave * 32 * S0_LDS_STRIDE;
+    char* const abuf = smem + 8 * 32 * S0_LDS_STRIDE * sizeof(float);
+    const uint32_t abuf_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)abuf);
+    const int row_begin = blockIdx.y * rows_per_slice;
+    const int row_end = row_begin + rows_per_slice < a.K ? row_begin + rows_per_slice : a.K;  // multiples of 64
+    const int ntiles = (row_end - row_begin) >> 5;
+    if (ntiles <= 0) return;
+    // this wave's queries (a query past the end repeats the last one: same values to the same addresses)
+    int bq[S0Q_QT], nqc[S0Q_QT];
+    f16x8 bh[S0Q_QT][8], bl[S0Q_QT][8];
+#pragma unroll
+    for (int q = 0; q < S0Q_QT; q++) {
+        const int b = (blockIdx.x * 8 + wave) * S0Q_QT + q;
+        bq[q] = b < a.nqueries ? b : a.nqueries - 1;
+        const int qlen = a.q_lens ? a.q_lens[bq[q]] : a.nq;
+        nqc[q] = qlen < a.nq_cand ? qlen : a.nq_cand;
+        const f16x8* ph = reinterpret_cast<const f16x8*>(a.q_hi + ((size_t)bq[q] * a.ncol + i) * FLMR_DIM + 64 * h);
+        const f16x8* pl = reinterpret_cast<const f16x8*>(a.q_lo + ((size_t)bq[q] * a.ncol + i) * FLMR_DIM + 64 * h);
+#pragma unroll
+        for (int s = 0; s < 8; s++) { bh[q][s] = ph[s]; bl[q][s] = pl[s]; }
+    }
+    // every compiler-visible load lands here, before the first hand-counted operation
+#pragma unroll
+    for (int q = 0; q < S0Q_QT; q++)
+#pragma unroll
+        for (int s = 0; s < 8; s++) asm volatile("" : "+v"(bh[q][s]), "+v"(bl[q][s])::"memory");
+
+    // tile t (rows row_begin + 32 t ...) -> buffer t % NBUF; this wave moves rows 4*wave .. 4*wave+3: piece p of row r at
+    // position p ^ (r & 15).  Tiles past the end repeat the last tile (the counts above need every step's DMA).
+    const int prow = 4 * wave + (lane >> 4);
+    const uint32_t poff = (uint32_t)((((lane & 15) ^ (prow & 15)) << 4));
+    auto dma_tile = [&](int t) {
+        const int tt = t < ntiles ? t : ntiles - 1;
+        const uint32_t voff = (uint32_t)(row_begin + 32 * tt + prow) * 256u + poff;  // K * 256 < 4 GB (checked by the launcher)
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(abuf_lds + (t % S0Q_NBUF) * 8192 + wave * 1024);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(voff), "s"(dst), "s"(a.centroids_f16) : "memory", "m0");
+    };
+#pragma unroll
+    for (int t = 0; t < S0Q_AHEAD; t++) dma_tile(t);
+
+    float cmax[S0Q_QT];
+#pragma unroll
+    for (int q = 0; q < S0Q_QT; q++) cmax[q] = FLMR_NEG_INF;
+    const int c4 = (lane & 7) * 4;  // first of the 4 columns this lane stores in the dense epilogue
+
+    auto step = [&](int t, bool odd) {
+        // ---- tile t: this wave's piece has landed, then everybody's ----
+        if (t < S0Q_AHEAD) {  // the prologue's pieces: younger are the later prologue pieces and the steps so far
+            if (t == 0) s0q_wait_vm<S0Q_AHEAD - 1>();
+            else if (t == 1) s0q_wait_vm<S0Q_AHEAD - 2 + 3>();
+            else s0q_wait_vm<S0Q_AHEAD - 3 + 3 + 5>();
+        } else if (odd) {
+            s0q_wait_vm<10>();
+        } else {
+            s0q_wait_vm<12>();
+        }
+        __syncthreads();
+        dma_tile(t + S0Q_AHEAD);  // (its buffer was read two steps ago at the latest: every wave has passed this barrier since)
+        f16x8 av[8];
+        {
+            const char* pa = abuf + (t % S0Q_NBUF) * 8192 + i * 256;
+#pragma unroll
+            for (int s = 0; s < 8; s++) av[s] = *reinterpret_cast<const f16x8*>(pa + (((8 * h + s) ^ (i & 15)) << 4));
+        }
+        const int rbase = row_begin + 32 * t;
+#pragma unroll
+        for (int q = 0; q < S0Q_QT; q++) {
+            f32x16 ah, al;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[q][s], ah, 0, 0, 0);
+                al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[q][s], al, 0, 0, 0);
+            }
+            const int b = bq[q];
+            const bool full_cols = nqc[q] >= 32;
+            const unsigned long long colmask = full_cols ? ~0ull : (((1ull << nqc[q]) - 1ull) * 0x100000001ull);
+            float tmax = FLMR_NEG_INF;
+#pragma unroll
+            for (int r = 0; r < 16; r++) tmax = fmaxf(tmax, fmaf(al[r], 1.0f / 2048.0f, ah[r]));
+            cmax[q] = fmaxf(cmax[q], tmax);
+            uint32_t idxw = 0u;
+            if ((__ballot(tmax >= a.thr) & colmask) != 0ull) {  // wave-uniform and rare: some row of this tile survives
+                float* cs_b = a.cs + (size_t)b * a.K * a.ncol;
+                const int nvalid4 = nqc[q] - c4;
+#pragma unroll
+                for (int r = 0; r < 16; r++) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * S0_LDS_STRIDE + i] = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int mrow = 0; mrow < 4; mrow++) {
+                    const int R = (lane >> 3) + 8 * mrow;
+                    const float4 v4 = *reinterpret_cast<const float4*>(stage + R * S0_LDS_STRIDE + c4);
+                    float m4;
+                    if (full_cols) {
+                        m4 = fmaxf(fmaxf(v4.x, v4.y), fmaxf(v4.z, v4.w));
+                    } else {
+                        m4 = nvalid4 > 0 ? v4.x : FLMR_NEG_INF;
+                        m4 = fmaxf(m4, nvalid4 > 1 ? v4.y : FLMR_NEG_INF);
+                        m4 = fmaxf(m4, nvalid4 > 2 ? v4.z : FLMR_NEG_INF);
+                        m4 = fmaxf(m4, nvalid4 > 3 ? v4.w : FLMR_NEG_INF);
+                    }
+                    unsigned long long bal = __ballot(m4 >= a.thr);  // byte j of `bal` = the 8 lanes of row 8*mrow + j
+                    bal |= bal >> 4; bal |= bal >> 2; bal |= bal >> 1;
+                    bal &= 0x0101010101010101ull;
+                    const uint32_t byte = (uint32_t)((bal * 0x0102040810204080ull) >> 56);
+                    idxw |= byte << (8 * mrow);
+                    if ((byte >> (lane >> 3)) & 1u) *reinterpret_cast<float4*>(cs_b + (size_t)(rbase + R) * a.ncol + c4) = v4;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (lane == 0) a.idx_bits[(size_t)b * a.idx_words + (rbase >> 5)] = idxw;
+            if (odd) {  // end of a 64-row block: its column maxima, for the cell selection
+                const float m = flmr_xhalf_max(cmax[q]);
+                if (lane < 32) a.part_val[((size_t)b * a.nblk + (rbase >> 6)) * a.ncol + i] = (i < nqc[q]) ? m : FLMR_NEG_INF;
+                cmax[q] = FLMR_NEG_INF;
+            }
+        }
+    };
+    for (int t = 0; t < ntiles; t += 2) {
+        step(t, false);
+        step(t + 1, true);  // (ntiles is even: slices are multiples of 64 rows)
+    }
+    s0q_wait_vm<0>();  // the DMA of the repeated tiles past the end must have landed before the LDS is released
+}
+
 __global__ void check_f16_exact_kernel(const float* x, size_t n, int* flag) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const float v = x[e];
@@ -519,7 +675,20 @@ static int launch_s0_t(flmr_s0_args& a, hipStream_t st, int impl) {
         const size_t lds = (size_t)S0_WAVES * 32 * S0_LDS_STRIDE * sizeof(float) + (S0_DMA_B ? (size_t)2 * S0_DCH * 2 * 8192 : (size_t)S0_CH * 2 * 32 * S0_BROW * sizeof(_Float16));
         const bool sparse = !a.full_table && a.ncol == 32 && !flmr_opts().has(FLMR_OPT_S0_STAGED);
         const dim3 grid((a.nblk + S0_WAVES - 1) / S0_WAVES, qsplit), block(64 * S0_WAVES);
-        if (sparse) {
+        const bool qs = sparse && a.centroids_f16 && (int64_t)a.K * 256 < (1ll << 32) && !flmr_opts().is(FLMR_OPT_S0_IMPL, "f16rs");
+        if (qs) {
+            // query-stationary: 16 queries per workgroup, the table cut into as many slices (multiples of 64 rows) as fill the chip
+            const int ngroups = (int)flmr_ceil_div(a.nqueries, 8 * S0Q_QT);
+            int slices = (int)flmr_ceil_div(512, ngroups);
+            const int max_slices = a.K / 64;
+            if (slices > max_slices) slices = max_slices;
+            if (slices < 1) slices = 1;
+            const int rows_per_slice = (int)flmr_round_up(flmr_ceil_div(a.K, slices), 64);
+            slices = (int)flmr_ceil_div(a.K, rows_per_slice);
+            const size_t ldsq = (size_t)8 * 32 * S0_LDS_STRIDE * sizeof(float) + (size_t)S0Q_NBUF * 8192;
+            FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_qs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
+            hipLaunchKernelGGL(s0_centroid_scores_qs, dim3(ngroups, slices), dim3(512), ldsq, st, a, rows_per_slice);
+        } else if (sparse) {
             FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_f16<false, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((s0_centroid_scores_f16<false, true>), grid, block, lds, st, a);
@@ -604,7 +773,7 @@ int flmr_launch_centroid_scores(flmr_s0_args& a, hipStream_t st) {
     int impl = f16_ok ? S0_F16 : S0_F32;
     if (env && strcmp(env, "valu") == 0) impl = S0_VALU;
     if (env && (strcmp(env, "f32") == 0 || strcmp(env, "mfma") == 0)) impl = S0_F32;
-    if (env && strcmp(env, "f16") == 0 && f16_ok) impl = S0_F16;
+    if (env && (strcmp(env, "f16") == 0 || strcmp(env, "f16rs") == 0) && f16_ok) impl = S0_F16;
     switch (nc_bucket(a.ncells)) {
         case 1: return launch_s0_t<1>(a, st, impl);
         case 2: return launch_s0_t<2>(a, st, impl);

@@ -151,6 +151,42 @@ def test_s0_kernel_variants_agree(hip, scorers):
                 assert np.array_equal(a, b), (name, rec, impl)
 
 
+@pytest.mark.parametrize("K,npass,nq_list,thr", [
+    (2048, 6000, (32, 20, 1), 0.45),     # one table slice per workgroup, ragged query lengths
+    (32768, 20_000, (32, 32, 7), 0.45),  # several slices, several surviving rows per query
+    (4096, 3000, (32, 5, 32), -1.0),     # every centroid survives: the dense epilogue runs for every tile
+    (1024, 2000, (32,), 0.3),            # a single query: 15 of the workgroup's 16 query slots repeat it
+])
+def test_s0_query_stationary_equals_row_stationary(hip, K, npass, nq_list, thr):
+    """Stage 0 on the sparse path, query-stationary kernel (default: queries' hi/lo images in registers, centroid tiles through
+    LDS by DMA with hand-counted waits; s0_centroid_scores_qs) vs the row-stationary kernel (FLMR_S0_IMPL=f16rs): same MFMA
+    sequence per (row, column), so idx bits, cells, candidates and the final ranking must be identical as bits -- also with
+    batches that are not a multiple of 16 queries, ragged query lengths and a threshold every centroid passes."""
+    nat = hip["native"]
+    torch = hip["torch"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    corpus = synth.make_corpus(npass, (8, 60), K, 2, seed=61, device="cuda")
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=64)
+    outs = {}
+    for nb in (1, 21):   # 21: two workgroups of query slots, the second partly filled
+        Q, _ = synth.make_queries(corpus, nb, 32, seed=4)
+        q_lens = torch.tensor([nq_list[j % len(nq_list)] for j in range(nb)], dtype=torch.int32)
+        for impl in ("f16rs", None):
+            with nat.options(**({"FLMR_S0_IMPL": impl} if impl else {})):
+                p, s, c = scorer.search_batch(Q, 16, 2, thr, 64, 32, q_lens=q_lens)
+                torch.cuda.synchronize()
+                scorer.check()
+                taps = [[scorer.tap(t, q) for t in (nat.TAP_IDX_BITS, nat.TAP_CELLS, nat.TAP_CANDIDATES, nat.TAP_STAGE1)]
+                        for q in range(nb)]
+                outs[impl, nb] = (p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), taps)
+        a, b = outs["f16rs", nb], outs[None, nb]
+        for q in range(nb):
+            for x, y in zip(a[3][q], b[3][q]):
+                assert np.array_equal(x, y), (nb, q)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[2], b[2]), nb
+
+
 def test_ops_vs_golden(hip):
     torch, ops = hip["torch"], hip["ops"]
     z = load_golden("ops")
