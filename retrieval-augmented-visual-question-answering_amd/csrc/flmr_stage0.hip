@@ -415,19 +415,20 @@ __global__ __launch_bounds__(64 * S0_WAVES, S0_OCC) void s0_centroid_scores_f16(
 // operand that is REUSED stays in registers instead: a wave holds the fp16 hi/lo images of S0Q_QT = 2 queries (128 VGPRs) for
 // the whole kernel and the centroid tiles stream through LDS, 8 KB per 32-row tile shared by the 8 waves of the workgroup
 // (16 queries): 8 KB of LDS reads per wave for the same 32 MFMAs, a third of the traffic.  The tiles go global -> LDS by DMA
-// (one 1 KB piece per wave and tile, XOR-swizzled like stage 2's), S0Q_AHEAD tiles ahead, one block barrier per tile.
+// (one 1 KB piece per wave and tile, XOR-swizzled like stage 2's), S0Q_AHEAD 64-row blocks ahead.
 // Same MFMA sequence per (row, column) as the row-stationary kernel: every value is bitwise the same.
 //
-// vmcnt: a step's VMEM operations are fixed so that the wait for a tile's piece can leave the younger STORES outstanding
-// (stores retire slowly and share the counter): step t issues the DMA of tile t + AHEAD first, then one idx-word store per
-// query, and after odd tiles one block-maximum store per query -- 3 operations after an even tile, 5 after an odd one.
-// The piece of tile t was the first operation of step t - AHEAD = t - 3: younger are the rest of that step and two full
-// steps: 4 + 3 + 5 = 12 for even t, 2 + 5 + 3 = 10 for odd t.  (The rare dense epilogue's row stores only add to that.)
-// grid = (ceil(nqueries / 16), slices), block = 512; dynamic LDS = 8 x 4.5 KB staging + S0Q_NBUF x 8 KB tiles.
+// A step handles one 64-row block = two tiles (one block barrier per 64 MFMAs of a wave).
+// vmcnt: a step's VMEM operations are fixed so that the wait for a block's pieces can leave the younger STORES outstanding
+// (stores retire slowly and share the counter): step p issues the two DMA pieces of block p + AHEAD first, then per query two
+// idx-word stores and one block-maximum store -- 8 operations.  The pieces of block p were the first two operations of step
+// p - AHEAD = p - 2: younger are the rest of that step (6) and one full step (8): vmcnt(14); in the first two steps (pieces
+// from the prologue) 2 and 8.  (The rare dense epilogue's row stores only add to that.)
+// grid = (ceil(nqueries / 16), slices), block = 512; dynamic LDS = 8 x 4.5 KB staging + S0Q_NBUF x 16 KB blocks.
 // ------------------------------------------------------------------------------------------------
 #define S0Q_QT 2
-#define S0Q_AHEAD 3
-#define S0Q_NBUF 4
+#define S0Q_AHEAD 2   // in 64-row blocks
+#define S0Q_NBUF 3    // block buffers of 2 x 8 KB
 
 template <int N>
 __device__ __forceinline__ void s0q_wait_vm() {
@@ -469,97 +470,95 @@ __global__ __launch_bounds__(512, 1) void s0_centroid_scores_qs(flmr_s0_args a, 
     // position p ^ (r & 15).  Tiles past the end repeat the last tile (the counts above need every step's DMA).
     const int prow = 4 * wave + (lane >> 4);
     const uint32_t poff = (uint32_t)((((lane & 15) ^ (prow & 15)) << 4));
-    auto dma_tile = [&](int t) {
-        const int tt = t < ntiles ? t : ntiles - 1;
-        const uint32_t voff = (uint32_t)(row_begin + 32 * tt + prow) * 256u + poff;  // K * 256 < 4 GB (checked by the launcher)
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(abuf_lds + (t % S0Q_NBUF) * 8192 + wave * 1024);
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(voff), "s"(dst), "s"(a.centroids_f16) : "memory", "m0");
+    const int nblocks = ntiles >> 1;
+    auto dma_block = [&](int p) {
+        const int pp = p < nblocks ? p : nblocks - 1;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t voff = (uint32_t)(row_begin + 64 * pp + 32 * u + prow) * 256u + poff;  // K * 256 < 4 GB (launcher)
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(abuf_lds + ((p % S0Q_NBUF) * 2 + u) * 8192 + wave * 1024);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(voff), "s"(dst), "s"(a.centroids_f16) : "memory", "m0");
+        }
     };
 #pragma unroll
-    for (int t = 0; t < S0Q_AHEAD; t++) dma_tile(t);
+    for (int p = 0; p < S0Q_AHEAD; p++) dma_block(p);
 
-    float cmax[S0Q_QT];
-#pragma unroll
-    for (int q = 0; q < S0Q_QT; q++) cmax[q] = FLMR_NEG_INF;
     const int c4 = (lane & 7) * 4;  // first of the 4 columns this lane stores in the dense epilogue
-
-    auto step = [&](int t, bool odd) {
-        // ---- tile t: this wave's piece has landed, then everybody's ----
-        if (t < S0Q_AHEAD) {  // the prologue's pieces: younger are the later prologue pieces and the steps so far
-            if (t == 0) s0q_wait_vm<S0Q_AHEAD - 1>();
-            else if (t == 1) s0q_wait_vm<S0Q_AHEAD - 2 + 3>();
-            else s0q_wait_vm<S0Q_AHEAD - 3 + 3 + 5>();
-        } else if (odd) {
-            s0q_wait_vm<10>();
-        } else {
-            s0q_wait_vm<12>();
-        }
+    for (int p = 0; p < nblocks; p++) {
+        // ---- block p: this wave's pieces have landed, then everybody's ----
+        if (p == 0) s0q_wait_vm<2>(); else if (p == 1) s0q_wait_vm<8>(); else s0q_wait_vm<14>();
         __syncthreads();
-        dma_tile(t + S0Q_AHEAD);  // (its buffer was read two steps ago at the latest: every wave has passed this barrier since)
-        f16x8 av[8];
-        {
-            const char* pa = abuf + (t % S0Q_NBUF) * 8192 + i * 256;
+        dma_block(p + S0Q_AHEAD);  // (its buffer was read a step ago at the latest: every wave has passed this barrier since)
+        float cmax[S0Q_QT];
 #pragma unroll
-            for (int s = 0; s < 8; s++) av[s] = *reinterpret_cast<const f16x8*>(pa + (((8 * h + s) ^ (i & 15)) << 4));
-        }
-        const int rbase = row_begin + 32 * t;
+        for (int q = 0; q < S0Q_QT; q++) cmax[q] = FLMR_NEG_INF;
 #pragma unroll
-        for (int q = 0; q < S0Q_QT; q++) {
-            f32x16 ah, al;
+        for (int u = 0; u < 2; u++) {
+            f16x8 av[8];
+            {
+                const char* pa = abuf + ((p % S0Q_NBUF) * 2 + u) * 8192 + i * 256;
 #pragma unroll
-            for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
-#pragma unroll
-            for (int s = 0; s < 8; s++) {
-                ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[q][s], ah, 0, 0, 0);
-                al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[q][s], al, 0, 0, 0);
+                for (int s = 0; s < 8; s++) av[s] = *reinterpret_cast<const f16x8*>(pa + (((8 * h + s) ^ (i & 15)) << 4));
             }
-            const int b = bq[q];
-            const bool full_cols = nqc[q] >= 32;
-            const unsigned long long colmask = full_cols ? ~0ull : (((1ull << nqc[q]) - 1ull) * 0x100000001ull);
-            float tmax = FLMR_NEG_INF;
+            const int rbase = row_begin + 64 * p + 32 * u;
 #pragma unroll
-            for (int r = 0; r < 16; r++) tmax = fmaxf(tmax, fmaf(al[r], 1.0f / 2048.0f, ah[r]));
-            cmax[q] = fmaxf(cmax[q], tmax);
-            uint32_t idxw = 0u;
-            if ((__ballot(tmax >= a.thr) & colmask) != 0ull) {  // wave-uniform and rare: some row of this tile survives
-                float* cs_b = a.cs + (size_t)b * a.K * a.ncol;
-                const int nvalid4 = nqc[q] - c4;
+            for (int q = 0; q < S0Q_QT; q++) {
+                f32x16 ah, al;
 #pragma unroll
-                for (int r = 0; r < 16; r++) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * S0_LDS_STRIDE + i] = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
-                __builtin_amdgcn_wave_barrier();
+                for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
 #pragma unroll
-                for (int mrow = 0; mrow < 4; mrow++) {
-                    const int R = (lane >> 3) + 8 * mrow;
-                    const float4 v4 = *reinterpret_cast<const float4*>(stage + R * S0_LDS_STRIDE + c4);
-                    float m4;
-                    if (full_cols) {
-                        m4 = fmaxf(fmaxf(v4.x, v4.y), fmaxf(v4.z, v4.w));
-                    } else {
-                        m4 = nvalid4 > 0 ? v4.x : FLMR_NEG_INF;
-                        m4 = fmaxf(m4, nvalid4 > 1 ? v4.y : FLMR_NEG_INF);
-                        m4 = fmaxf(m4, nvalid4 > 2 ? v4.z : FLMR_NEG_INF);
-                        m4 = fmaxf(m4, nvalid4 > 3 ? v4.w : FLMR_NEG_INF);
-                    }
-                    unsigned long long bal = __ballot(m4 >= a.thr);  // byte j of `bal` = the 8 lanes of row 8*mrow + j
-                    bal |= bal >> 4; bal |= bal >> 2; bal |= bal >> 1;
-                    bal &= 0x0101010101010101ull;
-                    const uint32_t byte = (uint32_t)((bal * 0x0102040810204080ull) >> 56);
-                    idxw |= byte << (8 * mrow);
-                    if ((byte >> (lane >> 3)) & 1u) *reinterpret_cast<float4*>(cs_b + (size_t)(rbase + R) * a.ncol + c4) = v4;
+                for (int s = 0; s < 8; s++) {
+                    ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[q][s], ah, 0, 0, 0);
+                    al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[q][s], al, 0, 0, 0);
                 }
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (lane == 0) a.idx_bits[(size_t)b * a.idx_words + (rbase >> 5)] = idxw;
-            if (odd) {  // end of a 64-row block: its column maxima, for the cell selection
-                const float m = flmr_xhalf_max(cmax[q]);
-                if (lane < 32) a.part_val[((size_t)b * a.nblk + (rbase >> 6)) * a.ncol + i] = (i < nqc[q]) ? m : FLMR_NEG_INF;
-                cmax[q] = FLMR_NEG_INF;
+                const int b = bq[q];
+                const bool full_cols = nqc[q] >= 32;
+                const unsigned long long colmask = full_cols ? ~0ull : (((1ull << nqc[q]) - 1ull) * 0x100000001ull);
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+#pragma unroll
+                for (int r = 0; r < 8; r++) v[r] = fmaxf(v[r], v[r + 8]);
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], v[r + 4]);
+                const float tmax = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                cmax[q] = fmaxf(cmax[q], tmax);
+                uint32_t idxw = 0u;
+                if ((__ballot(tmax >= a.thr) & colmask) != 0ull) {  // wave-uniform and rare: some row of this tile survives
+                    float* cs_b = a.cs + (size_t)b * a.K * a.ncol;
+                    const int nvalid4 = nqc[q] - c4;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * S0_LDS_STRIDE + i] = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int mrow = 0; mrow < 4; mrow++) {
+                        const int R = (lane >> 3) + 8 * mrow;
+                        const float4 v4 = *reinterpret_cast<const float4*>(stage + R * S0_LDS_STRIDE + c4);
+                        float m4;
+                        if (full_cols) {
+                            m4 = fmaxf(fmaxf(v4.x, v4.y), fmaxf(v4.z, v4.w));
+                        } else {
+                            m4 = nvalid4 > 0 ? v4.x : FLMR_NEG_INF;
+                            m4 = fmaxf(m4, nvalid4 > 1 ? v4.y : FLMR_NEG_INF);
+                            m4 = fmaxf(m4, nvalid4 > 2 ? v4.z : FLMR_NEG_INF);
+                            m4 = fmaxf(m4, nvalid4 > 3 ? v4.w : FLMR_NEG_INF);
+                        }
+                        unsigned long long bal = __ballot(m4 >= a.thr);  // byte j of `bal` = the 8 lanes of row 8*mrow + j
+                        bal |= bal >> 4; bal |= bal >> 2; bal |= bal >> 1;
+                        bal &= 0x0101010101010101ull;
+                        const uint32_t byte = (uint32_t)((bal * 0x0102040810204080ull) >> 56);
+                        idxw |= byte << (8 * mrow);
+                        if ((byte >> (lane >> 3)) & 1u) *reinterpret_cast<float4*>(cs_b + (size_t)(rbase + R) * a.ncol + c4) = v4;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (lane == 0) a.idx_bits[(size_t)b * a.idx_words + (rbase >> 5)] = idxw;
+                if (u == 1) {  // end of the 64-row block: its column maxima, for the cell selection
+                    const float m = flmr_xhalf_max(cmax[q]);
+                    if (lane < 32) a.part_val[((size_t)b * a.nblk + (rbase >> 6)) * a.ncol + i] = (i < nqc[q]) ? m : FLMR_NEG_INF;
+                }
             }
         }
-    };
-    for (int t = 0; t < ntiles; t += 2) {
-        step(t, false);
-        step(t + 1, true);  // (ntiles is even: slices are multiples of 64 rows)
     }
     s0q_wait_vm<0>();  // the DMA of the repeated tiles past the end must have landed before the LDS is released
 }
@@ -679,13 +678,13 @@ static int launch_s0_t(flmr_s0_args& a, hipStream_t st, int impl) {
         if (qs) {
             // query-stationary: 16 queries per workgroup, the table cut into as many slices (multiples of 64 rows) as fill the chip
             const int ngroups = (int)flmr_ceil_div(a.nqueries, 8 * S0Q_QT);
-            int slices = (int)flmr_ceil_div(512, ngroups);
+            int slices = (int)flmr_ceil_div(512, ngroups);  // (256 .. 768 workgroups measure the same)
             const int max_slices = a.K / 64;
             if (slices > max_slices) slices = max_slices;
             if (slices < 1) slices = 1;
             const int rows_per_slice = (int)flmr_round_up(flmr_ceil_div(a.K, slices), 64);
             slices = (int)flmr_ceil_div(a.K, rows_per_slice);
-            const size_t ldsq = (size_t)8 * 32 * S0_LDS_STRIDE * sizeof(float) + (size_t)S0Q_NBUF * 8192;
+            const size_t ldsq = (size_t)8 * 32 * S0_LDS_STRIDE * sizeof(float) + (size_t)S0Q_NBUF * 2 * 8192;
             FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_qs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
             hipLaunchKernelGGL(s0_centroid_scores_qs, dim3(ngroups, slices), dim3(512), ldsq, st, a, rows_per_slice);
         } else if (sparse) {
