@@ -534,9 +534,11 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args
         for (int s = 0; s < 8; s++) { bh[s] = ph[s]; bl[s] = pl[s]; }
     }
     const int my_off_lo = (int)(uint32_t)my_off, my_off_hi = (int)(uint32_t)((uint64_t)my_off >> 32);
+    // lane j's value, j wave-uniform: v_readlane into an SGPR -- no LDS-crossbar round trip on the step's critical path
+    auto bcast = [&](int v, int j) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(j)); };
     // flat tile sequence over (document j, tile t); j == ndw: past the end
     auto normalize = [&](int& j, int& t) {
-        while (j < ndw && t >= ((__shfl(my_len, j, 64) + 31) >> 5)) { j++; t = 0; }
+        while (j < ndw && t >= ((bcast(my_len, j) + 31) >> 5)) { j++; t = 0; }
     };
     auto next_of = [&](int j, int t, int& nj, int& nt) {
         nj = j; nt = t + 1;
@@ -544,8 +546,8 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args
     };
     // array position of this lane's token in tile (j, t); padding lanes take the document's last token
     auto tokpos = [&](int j, int t, bool& valid) {
-        const int len = __shfl(my_len, j, 64);
-        const int64_t off = ((int64_t)__shfl(my_off_hi, j, 64) << 32) | (uint32_t)__shfl(my_off_lo, j, 64);
+        const int len = bcast(my_len, j);
+        const int64_t off = ((int64_t)bcast(my_off_hi, j) << 32) | (uint32_t)bcast(my_off_lo, j);
         const int tok = t * 32 + i;
         valid = tok < len;
         return off + (valid ? tok : len - 1);
@@ -558,12 +560,14 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args
         const uint32_t dst = ring_lds + (g & 7) * 256;
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(codes + pos), "s"(dst) : "memory", "m0");
     };
-    // 32 rows of tile g -> rowbuf[g & 1]: piece p of row r at position p ^ (r & 15); codes from the ring
-    auto dma_rows = [&](int g) {
+    // the codes of tile g's rows that this lane's DMA instructions move (from the ring)
+    auto ring_codes = [&](int g, int (&c)[8]) {
         const int* cr = reinterpret_cast<const int*>(ring + (g & 7) * 256) + (lane >> 4);
-        int c[8];
 #pragma unroll
         for (int gq = 0; gq < 8; gq++) c[gq] = cr[4 * gq];
+    };
+    // 32 rows of tile g -> rowbuf[g & 1]: piece p of row r at position p ^ (r & 15)
+    auto dma_rows = [&](int g, const int (&c)[8]) {
 #pragma unroll
         for (int gq = 0; gq < 8; gq++) {
             const uint32_t dst = rowbuf_lds + (g & 1) * 8192 + gq * 1024;
@@ -574,7 +578,6 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args
                          : "memory", "m0");
         }
     };
-
     // tiles g (being consumed), g+1, g+2 of the sequence, and the cursor of the code requests (tile g+6)
     int j0 = 0, t0 = 0, j1, t1, j2, t2, jc, tc;
     normalize(j0, t0);
@@ -592,9 +595,8 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args
     //                    step g    C(g+6), res(g+2) (RL), R(g+2) (8)          past the end the last position is repeated)
     // top of step g: R(g) and res(g) must have landed; younger are the operations of step g-1 (the prologue's second tile
     // for g = 0): 1 + RL + 8, or just the code request when tile g+1 does not exist.
-    // before R(g+2) is issued: C(g+2) -- the first operation of step g-4 -- must have landed; younger than it are the rest of
-    // that step (RL + 8), three full steps (27 + 3 RL), this step's C and res (1 + RL): 36 + 5 RL; from the prologue (g = 0, 1):
-    // 20 + 3 RL, 28 + 4 RL.
+    // R(g+2) needs C(g+2), the first operation of step g-4 (or of the prologue): at least 3 + 2 (RL + 8) operations older
+    // than the youngest, so the wait at the top of the step has already covered it.
     {
 #pragma unroll
         for (int s = 0; s < 8; s++) asm volatile("" : "+v"(bh[s]), "+v"(bl[s])::"memory");
@@ -609,11 +611,11 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args
         asm volatile("" ::: "memory");
         (void)tokpos(j0, t0, vE);
         rE.issue(residuals + (size_t)p0 * PACKED + h * NB);
-        dma_rows(0);
+        { int c0[8]; ring_codes(0, c0); dma_rows(0, c0); }
         if (j1 < ndw) {
             (void)tokpos(j1, t1, vO);
             rO.issue(residuals + (size_t)p1 * PACKED + h * NB);
-            dma_rows(1);
+            { int c1[8]; ring_codes(1, c1); dma_rows(1, c1); }
         }
     }
 
@@ -626,22 +628,25 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args
         else if (g == 0) s3_wait_vm<8 + RL>();
         else s3_wait_vm<9 + RL>();
         r.touch();
+        // ONE LDS round trip: this tile's rows and the codes of tile g+2 (their request, four steps old, is older than anything
+        // the wait above lets through); the decode's table reads only depend on registers and join them
         hf8 c[8];
 #pragma unroll
         for (int s = 0; s < 8; s++)
             c[s] = *reinterpret_cast<const hf8*>(rowbuf + buf * 8192 + i * 256 + (((8 * h + s) ^ (i & 15)) << 4));
+        int cc[8];
+        ring_codes(g + 2, cc);
         // ---- decompress this lane's half row, normalise, split into fp16 hi/lo (the MFMA A operand) ----
         hf8 ah[8], al[8];
         s3_decode_split<NBITS>(wlut, [&](int wi) { return r.word(wi); }, c, v, ah, al);
         const bool last_of_doc = (j1 != j0);
-        const int pid = __shfl(my_pid, j0, 64), dslot = w + j0 * W;
+        const int pid = bcast(my_pid, j0), dslot = w + j0 * W;
         // ---- keep the pipeline full, in this order: codes of tile g+6, residual bytes of tile g+2, rows of tile g+2 ----
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the row buffer has been read: it may be refilled
         issue_codes(next_code_pos(), g + 6);
         if (j2 < ndw) {
             r.issue(residuals + (size_t)tokpos(j2, t2, v) * PACKED + h * NB);
-            if (g == 0) s3_wait_vm<20 + 3 * RL>(); else if (g == 1) s3_wait_vm<28 + 4 * RL>(); else s3_wait_vm<36 + 5 * RL>();
-            dma_rows(g + 2);
+            dma_rows(g + 2, cc);
         }
         // ---- 32 tokens x 32 query tokens ----
         {
