@@ -1,0 +1,59 @@
+// Stand-alone timing harness for the fused decompress + MaxSim kernels (csrc/flmr_maxsim.hip) on synthetic inputs of BASELINE's
+// shape: 1024 queries x 256 finalists x 128 tokens, K = 131072, nbits = 2.  -DS3P_DMA=1 forces the LDS-DMA form; the
+// -DS3P_NO_* switches remove parts of that kernel (results become garbage, timings do not): what does a step consist of?
+// Build (repo root): hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Iretrieval-augmented-visual-question-answering_amd/csrc \
+//                          [-DS3P_NO_MFMA -DS3P_NO_DECODE ...] -o profiles/microbench/s3_probe profiles/microbench/s3_probe.hip
+#include "../../retrieval-augmented-visual-question-answering_amd/csrc/flmr_maxsim.hip"
+
+#include <random>
+#include <vector>
+
+thread_local char flmr_err_buf[512] = {0};
+static flmr_options g_opts;
+const flmr_options& flmr_opts() { return g_opts; }
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+int main(int argc, char** argv) {
+    const int K = 131072, P = 200000, L = 128, NQ = 1024, ND = 256, NBITS = 2;
+    const char* impl = argc > 1 ? argv[1] : "dma";
+    memset(&g_opts, 0, sizeof g_opts);
+    snprintf(g_opts.v[FLMR_OPT_S3_IMPL], sizeof g_opts.v[0], "%s", impl);
+    std::mt19937 rng(1);
+    std::vector<int32_t> codes((size_t)P * L);
+    for (auto& c : codes) c = (int32_t)(rng() % K);
+    std::vector<uint8_t> res((size_t)P * L * 32);
+    for (auto& x : res) x = (uint8_t)rng();
+    std::vector<int64_t> off(P + 1);
+    for (int p = 0; p <= P; p++) off[p] = (int64_t)p * L;
+    std::vector<int32_t> pids((size_t)NQ * ND), counts(NQ, ND);
+    for (auto& x : pids) x = (int32_t)(rng() % P);
+    std::vector<_Float16> cen((size_t)K * 128);
+    for (auto& x : cen) x = (_Float16)((float)(rng() % 2001 - 1000) / 8000.0f);
+    std::vector<float> Q((size_t)NQ * 32 * 128), wl(256 * 4);
+    for (auto& x : Q) x = (float)(rng() % 2001 - 1000) / 8000.0f;
+    for (auto& x : wl) x = (float)(rng() % 2001 - 1000) / 80000.0f;
+    flmr_index ix{};
+    ix.K = K; ix.nbits = NBITS; ix.N = (int64_t)P * L; ix.num_passages = P; ix.centroids_f16_exact = 1; ix.packed_dim = 32;
+    float* dQ; int32_t *d_pids, *d_counts; uint64_t* d_keys; _Float16 *qh, *ql;
+    CK(hipMalloc(&ix.codes, codes.size() * 4)); CK(hipMemcpy(ix.codes, codes.data(), codes.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&ix.residuals, res.size())); CK(hipMemcpy(ix.residuals, res.data(), res.size(), hipMemcpyHostToDevice));
+    CK(hipMalloc(&ix.doc_offsets, off.size() * 8)); CK(hipMemcpy(ix.doc_offsets, off.data(), off.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMalloc(&ix.centroids_f16, cen.size() * 2)); CK(hipMemcpy(ix.centroids_f16, cen.data(), cen.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&ix.wlut, wl.size() * 4)); CK(hipMemcpy(ix.wlut, wl.data(), wl.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&dQ, Q.size() * 4)); CK(hipMemcpy(dQ, Q.data(), Q.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_pids, pids.size() * 4)); CK(hipMemcpy(d_pids, pids.data(), pids.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_counts, counts.size() * 4)); CK(hipMemcpy(d_counts, counts.data(), counts.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_keys, (size_t)NQ * ND * 8)); CK(hipMalloc(&qh, Q.size() * 2)); CK(hipMalloc(&ql, Q.size() * 2));
+    flmr_maxsim_args a{};
+    a.ix = &ix; a.Q = dQ; a.q_lens = nullptr; a.nqueries = NQ; a.nq = 32; a.pids = d_pids; a.pid_stride = ND; a.counts = d_counts;
+    a.max_count = ND; a.keys = d_keys; a.key_stride = ND; a.scores = nullptr; a.q_hi = qh; a.q_lo = ql;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 4; rep++) {
+        CK(hipEventRecord(e0, 0));
+        if (flmr_launch_maxsim(a, 0) != 0) { printf("launch failed: %s\n", flmr_err_buf); return 1; }
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) printf("S3 (%s): %.3f ms per %d queries x %d finalists\n", impl, ms, NQ, ND);
+    }
+    return 0;
+}
