@@ -198,8 +198,10 @@ int flmr_searcher_tap(flmr_searcher_t* searcher, int32_t what, int32_t query, vo
  * FLMR_TAP_CENTROID_SCORES tap will be read (what IndexScorer.retrieve() returns, index_storage.py:67-80). */
 int flmr_searcher_set_full_table(flmr_searcher_t* searcher, int32_t enable);
 
-/* Timing taps: per-stage HIP-event milliseconds of the LAST flmr_search_batch call when the searcher was
- * put in profiling mode (flmr_searcher_set_profiling(s, 1)); ms[FLMR_NUM_STAGES] is HOST memory. */
+/* Timing taps: per-stage HIP-event milliseconds, SUMMED over the flmr_search_batch calls made in profiling mode
+ * (flmr_searcher_set_profiling(s, 1)) since the previous read; reading waits for those calls and clears the sums, so a
+ * caller that splits a batch into sub-batches reads the whole batch's stage times once.  ms[FLMR_NUM_STAGES] is HOST
+ * memory.  (Event sets are kept in a ring of 8 calls; a 9th unread call first waits for the oldest.) */
 #define FLMR_NUM_STAGES 9
 int flmr_searcher_set_profiling(flmr_searcher_t* searcher, int32_t enable);
 int flmr_searcher_stage_ms(flmr_searcher_t* searcher, float* ms_host);

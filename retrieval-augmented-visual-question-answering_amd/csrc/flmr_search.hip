@@ -11,6 +11,8 @@ static const char* kStageNames[FLMR_NUM_STAGES] = {
 
 extern "C" const char* flmr_stage_name(int32_t s) { return (s >= 0 && s < FLMR_NUM_STAGES) ? kStageNames[s] : "?"; }
 
+#define FLMR_PROF_RING 8
+
 struct flmr_searcher {
     const flmr_index* ix;
     int32_t max_queries, max_nq;
@@ -38,7 +40,10 @@ struct flmr_searcher {
     hipStream_t last_stream;
     bool profiling;
     bool full_table;  // keep the whole centroid-score table (needed by the CENTROID_SCORES tap / retrieve())
-    hipEvent_t ev[FLMR_NUM_STAGES + 1];
+    // stage timing: a ring of event sets, one per profiled call, folded into acc_ms when read (or when the ring wraps)
+    hipEvent_t ev[FLMR_PROF_RING][FLMR_NUM_STAGES + 1];
+    int ev_first = 0, ev_pending = 0;   // oldest unread set, number of unread sets
+    float acc_ms[FLMR_NUM_STAGES] = {};
     bool have_ms;
 };
 
@@ -134,7 +139,8 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     FLMR_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->status_host), 2 * sizeof(int32_t), hipHostMallocDefault));
     s->status_host[0] = s->status_host[1] = 0;
     FLMR_HIP(hipEventCreateWithFlags(&s->status_ev, hipEventDisableTiming));
-    for (int i = 0; i <= FLMR_NUM_STAGES; i++) FLMR_HIP(hipEventCreate(&s->ev[i]));
+    for (int r = 0; r < FLMR_PROF_RING; r++)
+        for (int i = 0; i <= FLMR_NUM_STAGES; i++) FLMR_HIP(hipEventCreate(&s->ev[r][i]));
     *out = s;
     return FLMR_OK;
 }
@@ -147,8 +153,9 @@ extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
     for (void* p : ptrs) (void)hipFree(p);
     if (s->status_host) (void)hipHostFree(s->status_host);
     if (s->status_ev) (void)hipEventDestroy(s->status_ev);
-    for (int i = 0; i <= FLMR_NUM_STAGES; i++)
-        if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
+    for (int r = 0; r < FLMR_PROF_RING; r++)
+        for (int i = 0; i <= FLMR_NUM_STAGES; i++)
+            if (s->ev[r][i]) (void)hipEventDestroy(s->ev[r][i]);
     delete s;
     return FLMR_OK;
 }
@@ -159,10 +166,28 @@ extern "C" int flmr_searcher_workspace_bytes(const flmr_searcher_t* s, int64_t* 
     return FLMR_OK;
 }
 
+// waits for the oldest unread event set and adds its stage times to acc_ms
+static int fold_oldest(flmr_searcher* s) {
+    hipEvent_t* e = s->ev[s->ev_first];
+    FLMR_HIP(hipEventSynchronize(e[FLMR_NUM_STAGES]));
+    for (int i = 0; i < FLMR_NUM_STAGES; i++) {
+        float ms = 0.f;
+        FLMR_HIP(hipEventElapsedTime(&ms, e[i], e[i + 1]));
+        s->acc_ms[i] += ms;
+    }
+    s->ev_first = (s->ev_first + 1) % FLMR_PROF_RING;
+    s->ev_pending--;
+    return FLMR_OK;
+}
+
 extern "C" int flmr_searcher_set_profiling(flmr_searcher_t* s, int32_t enable) {
     if (!s) FLMR_FAIL(FLMR_ERR_INVALID, "NULL searcher");
+    if (s->profiling != (enable != 0)) {   // a change of mode starts a fresh accumulation
+        s->ev_pending = 0;
+        s->have_ms = false;
+        for (float& v : s->acc_ms) v = 0.f;
+    }
     s->profiling = enable != 0;
-    s->have_ms = false;
     return FLMR_OK;
 }
 
@@ -174,9 +199,16 @@ extern "C" int flmr_searcher_set_full_table(flmr_searcher_t* s, int32_t enable) 
 
 extern "C" int flmr_searcher_stage_ms(flmr_searcher_t* s, float* ms) {
     if (!s || !ms) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
-    if (!s->have_ms) FLMR_FAIL(FLMR_ERR_INVALID, "no profiled flmr_search_batch call yet");
-    FLMR_HIP(hipEventSynchronize(s->ev[FLMR_NUM_STAGES]));
-    for (int i = 0; i < FLMR_NUM_STAGES; i++) FLMR_HIP(hipEventElapsedTime(&ms[i], s->ev[i], s->ev[i + 1]));
+    if (!s->have_ms) FLMR_FAIL(FLMR_ERR_INVALID, "no profiled flmr_search_batch call since the last read");
+    while (s->ev_pending) {
+        const int rc = fold_oldest(s);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < FLMR_NUM_STAGES; i++) {
+        ms[i] = s->acc_ms[i];
+        s->acc_ms[i] = 0.f;
+    }
+    s->have_ms = false;
     return FLMR_OK;
 }
 
@@ -194,6 +226,7 @@ struct run_ctx {
     flmr_s0_args a0;
     flmr_filter_args f;
     int stage;  // profiling event cursor
+    int ev_set; // event set of this call
 };
 
 #define RUN(x)          \
@@ -203,7 +236,7 @@ struct run_ctx {
     } while (0)
 
 static int mark(run_ctx& c) {
-    if (c.s->profiling && c.stage <= FLMR_NUM_STAGES) FLMR_HIP(hipEventRecord(c.s->ev[c.stage], c.st));
+    if (c.s->profiling && c.stage <= FLMR_NUM_STAGES) FLMR_HIP(hipEventRecord(c.s->ev[c.ev_set][c.stage], c.st));
     c.stage++;
     return FLMR_OK;
 }
@@ -288,6 +321,8 @@ static int prepare_ctx(run_ctx& c, flmr_searcher* s, const float* Q, const int32
     c.s = s; c.Q = Q; c.q_lens = q_lens; c.nqueries = nqueries; c.nq = nq; c.nqc = nqc; c.ncol = ncol; c.p = *p;
     c.st = reinterpret_cast<hipStream_t>(stream);
     c.stage = 0;
+    if (s->profiling && s->ev_pending == FLMR_PROF_RING) RUN(fold_oldest(s));   // the ring is full: make room (waits)
+    c.ev_set = (s->ev_first + s->ev_pending) % FLMR_PROF_RING;
     if (q_lens) {  // kernels only ever see lengths inside [0, nq]; a violation is reported by the next status poll
         hipLaunchKernelGGL(sanitize_q_lens_kernel, dim3((nqueries + 255) / 256), dim3(256), 0, c.st, q_lens, nqueries, nq,
                            s->q_lens_ws, s->overflow + 1);
@@ -436,7 +471,10 @@ extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32
     RUN(flmr_launch_sort_topn(s->keys3, s->maxp.ndocs / 4, s->s2_count, p->ndocs / 4, nqueries, p->k, out_pids,
                               out_scores, p->k, out_counts, s->ix->pid_base, 1, c.st));
     RUN(mark(c));
-    s->have_ms = s->profiling;
+    if (s->profiling) {   // the set is complete: count it
+        s->ev_pending++;
+        s->have_ms = true;
+    }
     return FLMR_OK;
 }
 
@@ -448,7 +486,6 @@ extern "C" int flmr_search_phase1(flmr_searcher_t* s, const float* Q, const int3
     run_ctx c(s);
     RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
     if (s->maxp.ndocs != p->ndocs) FLMR_FAIL(FLMR_ERR_INVALID, "the phased protocol needs ndocs == the searcher's max ndocs (key rows are ndocs wide)");
-    s->have_ms = false;
     return stage_s0_s1(c, out_keys);
 }
 
@@ -471,7 +508,6 @@ extern "C" int flmr_search_probe(flmr_searcher_t* s, const float* Q, const int32
     RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
     if (!c.sparse) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "query-split stage 0 needs the sparse-table path (fp16-exact centroids, K %% 64 == 0, nq_cand <= 32)");
     if (q_begin < 0 || q_count < 0 || q_begin + q_count > nqueries) FLMR_FAIL(FLMR_ERR_INVALID, "query slice [%d, %d) outside the batch of %d", q_begin, q_begin + q_count, nqueries);
-    s->have_ms = false;
     if (q_count == 0) return FLMR_OK;
     flmr_s0_args a0 = c.a0;  // the slice uses workspace slots 0..q_count; its results go straight to the caller's buffers
     a0.Q = Q + (size_t)q_begin * nq * FLMR_DIM;
@@ -491,7 +527,6 @@ extern "C" int flmr_search_phase1_probed(flmr_searcher_t* s, const float* Q, con
     RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
     if (!c.sparse) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "query-split stage 0 needs the sparse-table path (fp16-exact centroids, K %% 64 == 0, nq_cand <= 32)");
     if (s->maxp.ndocs != p->ndocs) FLMR_FAIL(FLMR_ERR_INVALID, "the phased protocol needs ndocs == the searcher's max ndocs (key rows are ndocs wide)");
-    s->have_ms = false;
     FLMR_HIP(hipMemcpyAsync(s->idx_bits, idx_bits, (size_t)nqueries * s->idx_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, c.st));
     FLMR_HIP(hipMemcpyAsync(s->cells, cells, (size_t)nqueries * s->max_cells * sizeof(int32_t), hipMemcpyDeviceToDevice, c.st));
     FLMR_HIP(hipMemcpyAsync(s->ncell, ncell, (size_t)nqueries * sizeof(int32_t), hipMemcpyDeviceToDevice, c.st));

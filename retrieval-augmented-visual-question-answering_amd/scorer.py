@@ -68,7 +68,13 @@ class IndexScorer:
     decompress_residuals = _op("decompress_residuals")
 
     def __init__(self, index_path=None, use_gpu=True, arrays: IndexArrays = None, device_index: DeviceIndex = None,
-                 max_batch=256):
+                 max_batch=256, streams=1):
+        """max_batch: queries per native call (one workspace holds that many); a larger batch is cut into sub-batches.
+        streams: the sub-batches of one search_batch call are dealt round-robin to this many native searchers, each on
+        its own HIP stream, joined with the caller's stream at both ends.  Default 1: with the join a stream-ordered call
+        needs, two streams measured 10.35 ms against 9.60 ms for the same four sub-batches of 256 in sequence (both run the
+        same stage at the same time and compete for it); only free-running streams that drift out of phase gained (9.3 ms,
+        profiles/stream_phase_probe.py), which is a caller-level choice (one IndexScorer per stream)."""
         if arrays is None and device_index is None:
             arrays = load_index_arrays(index_path)
         self.index_path = index_path
@@ -77,9 +83,13 @@ class IndexScorer:
         self.device_index = device_index or DeviceIndex(self.arrays)
         self._lib = _native.load(require_device=True)
         self.max_batch = int(max_batch)
-        self._searcher = None
+        self._searcher = None       # slot 0: the only one single-chunk calls, the phased protocol and taps use
         self._searcher_key = None
         self._searcher_epoch = 0
+        self._side = []             # slots 1..streams-1: (searcher handle, torch stream), same bounds as slot 0
+        self._nstreams = max(1, int(streams))
+        self._tap_from = None       # the searcher that ran the last chunk
+        self._profiled = []         # the searchers of the last profiled search_batch call
         if isinstance(self.arrays, IndexArrays):
             self.codec = _Codec(self.arrays)
             self.embeddings = _Embeddings(self.arrays)
@@ -102,7 +112,20 @@ class IndexScorer:
             self._searcher, self._searcher_key, self._searcher_epoch = h, grown, _native.options_epoch
         return self._searcher
 
+    def _side_slots(self, count):
+        """Searchers for slots 1..count (created on first use with slot 0's bounds; close_searcher drops them)."""
+        g = self._searcher_key
+        while len(self._side) < count:
+            h = C.c_void_p()
+            mp = _params(1, g[2], 0.0, g[3], g[4])
+            _native.check(self._lib.flmr_searcher_create(self.device_index.handle, g[0], g[1], C.byref(mp), C.byref(h)))
+            self._side.append((h, torch.cuda.Stream()))
+        return self._side[:count]
+
     def close_searcher(self):
+        for h, _ in self._side:
+            self._lib.flmr_searcher_destroy(h)
+        self._side, self._tap_from = [], None
         if self._searcher is not None:
             self._lib.flmr_searcher_destroy(self._searcher)
             self._searcher, self._searcher_key = None, None
@@ -110,8 +133,9 @@ class IndexScorer:
     def check(self):
         """Wait for the last batch and raise FlmrNativeError if it overflowed the candidate bound or was handed q_lens
         outside [0, nq] (flmr_searcher_check); without this call the error surfaces on the next batch."""
-        if self._searcher is not None:
-            _native.check(self._lib.flmr_searcher_check(self._searcher))
+        for h in [self._searcher] + [h for h, _ in self._side]:
+            if h is not None:
+                _native.check(self._lib.flmr_searcher_check(h))
 
     def supports_query_split(self, Q, k, ncells, thr, ndocs, nq_cand=32):
         """True iff the query-split stage 0 (probe / phase1_probed) runs for this batch shape; depends only on
@@ -122,9 +146,12 @@ class IndexScorer:
         return bool(ok.value)
 
     def workspace_bytes(self):
-        b = C.c_int64(0)
-        _native.check(self._lib.flmr_searcher_workspace_bytes(self._searcher, C.byref(b)))
-        return b.value
+        total = 0
+        for h in [self._searcher] + [h for h, _ in self._side]:
+            b = C.c_int64(0)
+            _native.check(self._lib.flmr_searcher_workspace_bytes(h, C.byref(b)))
+            total += b.value
+        return total
 
     def __del__(self):
         try:
@@ -145,16 +172,33 @@ class IndexScorer:
         out_p = torch.empty((n, k), dtype=torch.int32, device="cuda")
         out_s = torch.empty((n, k), dtype=torch.float32, device="cuda")
         out_c = torch.empty((n,), dtype=torch.int32, device="cuda")
-        st = _native.stream_ptr()
-        self._lib.flmr_searcher_set_profiling(s, 1 if profile else 0)
-        self._lib.flmr_searcher_set_full_table(s, 1 if full_table else 0)  # needed for the CENTROID_SCORES tap
-        B = self._searcher_key[0]
-        for b0 in range(0, n, B):
+        B = min(self._searcher_key[0], self.max_batch)
+        nchunks = (n + B - 1) // B
+        cur = torch.cuda.current_stream()
+        slots = [(s, cur)]                          # slot 0 stays on the caller's stream
+        if nchunks > 1 and self._nstreams > 1:
+            slots += self._side_slots(min(nchunks, self._nstreams) - 1)
+        for h, _ in slots:
+            self._lib.flmr_searcher_set_profiling(h, 1 if profile else 0)
+            self._lib.flmr_searcher_set_full_table(h, 1 if full_table else 0)  # needed for the CENTROID_SCORES tap
+        if len(slots) > 1:
+            start = cur.record_event()              # inputs / outputs were produced on the caller's stream
+            for _, st in slots[1:]:
+                st.wait_event(start)
+        for i, b0 in enumerate(range(0, n, B)):
             b1 = min(n, b0 + B)
+            h, st = slots[i % len(slots)]
             _native.check(self._lib.flmr_search_batch(
-                s, C.c_void_p(Qd[b0:b1].data_ptr()), C.c_void_p(ql[b0:b1].data_ptr()) if ql is not None else None,
+                h, C.c_void_p(Qd[b0:b1].data_ptr()), C.c_void_p(ql[b0:b1].data_ptr()) if ql is not None else None,
                 b1 - b0, nq, C.byref(p), C.c_void_p(out_p[b0:b1].data_ptr()), C.c_void_p(out_s[b0:b1].data_ptr()),
-                C.c_void_p(out_c[b0:b1].data_ptr()), st))
+                C.c_void_p(out_c[b0:b1].data_ptr()), C.c_void_p(st.cuda_stream)))
+            self._tap_from = h
+        for _, st in slots[1:]:
+            cur.wait_event(st.record_event())
+            for t in (Qd, ql, out_p, out_s, out_c):
+                if t is not None:
+                    t.record_stream(st)             # the caching allocator must not recycle them before the side stream is done
+        self._profiled = [h for h, _ in slots] if profile else []
         return out_p, out_s, out_c
 
     # ---- exact sharded protocol (include/flmr_hip.h: flmr_search_phase1..3) -------------------------------------------
@@ -231,9 +275,14 @@ class IndexScorer:
         return out
 
     def stage_ms(self):
-        ms = (C.c_float * _native.NUM_STAGES)()
-        _native.check(self._lib.flmr_searcher_stage_ms(self._searcher, ms))
-        return {self._lib.flmr_stage_name(i).decode(): float(ms[i]) for i in range(_native.NUM_STAGES)}
+        """Per-stage HIP-event milliseconds of the last profiled search_batch call, summed over its sub-batches (with
+        streams > 1 the sub-batches overlap, so the stages of one call add up to more than its wall time)."""
+        tot = [0.0] * _native.NUM_STAGES
+        for h in (self._profiled or [self._searcher]):
+            ms = (C.c_float * _native.NUM_STAGES)()
+            _native.check(self._lib.flmr_searcher_stage_ms(h, ms))
+            tot = [a + float(b) for a, b in zip(tot, ms)]
+        return {self._lib.flmr_stage_name(i).decode(): tot[i] for i in range(_native.NUM_STAGES)}
 
     def tap(self, what, query=0):
         """Stage output of the last search_batch chunk for `query` (index inside that chunk), as numpy."""
@@ -245,7 +294,7 @@ class IndexScorer:
               _native.TAP_DOC_SCORES: np.float32}.get(what, np.int32)
         buf = np.empty(max(cap, 1), dtype=dt)
         cnt = C.c_int64(0)
-        _native.check(self._lib.flmr_searcher_tap(self._searcher, what, query, buf.ctypes.data, cap, C.byref(cnt)))
+        _native.check(self._lib.flmr_searcher_tap(self._tap_from or self._searcher, what, query, buf.ctypes.data, cap, C.byref(cnt)))
         out = buf[:cnt.value].copy()
         if what == _native.TAP_CENTROID_SCORES:
             out = out.reshape(K, -1)

@@ -3,6 +3,7 @@
 Bars (north_star): integer / index work bit-exact; fp32 scores within 1e-4; ranked ids identical except inside
 runs of reference scores closer than 1e-5 (a different valid fp32 summation order may swap those).
 """
+import contextlib
 import os
 
 import numpy as np
@@ -978,6 +979,50 @@ def test_stage2_xcd_sliced_equals_gather(hip, nbits, doclen, K, npass, policy):
             for q in range(Q.size(0)):
                 assert np.array_equal(a[3][q], b[3][q]), ("stage-2 finalists", other, tag, q)
             assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), (other, tag)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("streams", [1, 2, 3])
+def test_sub_batches_over_streams_equal_one_call(hip, streams):
+    """A batch cut into sub-batches (max_batch) dealt to `streams` searchers / HIP streams returns exactly what one native
+    call over the whole batch returns (ids, score bits, counts), with and without ragged q_lens, from a side stream of
+    the caller's too; the per-stage timing read once covers every sub-batch; taps read the last sub-batch."""
+    nat = hip["native"]
+    torch = hip["torch"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    corpus = synth.make_corpus(30_000, (20, 150), 4096, 2, seed=47, device="cuda")
+    n = 70                                          # 5 sub-batches of 16 (the last one of 6)
+    Q, _ = synth.make_queries(corpus, n, 32, seed=8)
+    q_lens = torch.randint(1, 33, (n,), dtype=torch.int32, generator=torch.Generator().manual_seed(3))
+    di = synth.corpus_device_index(corpus)
+    whole = IndexScorer(device_index=di, max_batch=128, streams=1)
+    cut = IndexScorer(device_index=di, max_batch=16, streams=streams)
+    ncells, thr, ndocs = 2, 0.45, 256
+    for ql in (None, q_lens):
+        ref = whole.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=ql)
+        whole.check()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        for stream in (None, side):
+            with torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext():
+                got = cut.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=ql, profile=True)
+                ms = cut.stage_ms()
+            if stream is not None:
+                torch.cuda.current_stream().wait_stream(stream)
+            cut.check()
+            for a, b in zip(ref, got):
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (streams, ql is not None, stream is not None)
+            assert all(v >= 0 for v in ms.values()) and sum(ms.values()) > 0
+        last = [cut.tap(nat.TAP_STAGE2, q) for q in range(6)]       # queries 64..69
+        want = [whole.tap(nat.TAP_STAGE2, 64 + q) for q in range(6)]
+        for a, b in zip(last, want):
+            assert np.array_equal(a, b)
+    with pytest.raises(nat.FlmrNativeError):
+        cut.stage_ms()                              # read once: nothing profiled since
+    assert cut.workspace_bytes() < whole.workspace_bytes()
+    whole.close_searcher()
+    cut.close_searcher()
 
 
 def test_stage2_xcd_on_golden_fixture(hip, scorers):
