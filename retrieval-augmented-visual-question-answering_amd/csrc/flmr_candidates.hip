@@ -149,8 +149,9 @@ __global__ __launch_bounds__(256) void cand_mark_chunks_kernel(const int32_t* ce
 // integer LDS atomic max is exact); then one thread per candidate sums its columns in ascending k and writes the key.
 // Keys go to keys[b][base + rank] with base from a per-query atomic counter: the top-ndocs selection is order-free.
 // More hits in a chunk than S1S_SLOTS are handled in windows of slots.
-#define S1S_SLOTS 1120   // accumulator slots per window: with the bitmaps this fills the CU's 160 KB of LDS
+#define S1S_SLOTS 1088   // accumulator slots per window: with the bitmaps and the staged rows this fills the CU's 160 KB of LDS
 #define S1S_STRIDE 33
+#define S1S_STAGED 2     // score rows per wave kept in LDS (the first lists of its first group), read back as broadcasts
 #define S1S_WAVES 16     // one 1024-thread workgroup per CU
 
 __device__ __forceinline__ int s1s_enc(float x) { const int i = __float_as_int(x); return i ^ ((i >> 31) & 0x7fffffff); }
@@ -183,6 +184,38 @@ __device__ __forceinline__ int64_t s1s_bcast64(int64_t v, int j) {
     return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 
+// End of a RARE loop body that loads (lists beyond a wave's first four, slices longer than 64 entries): an explicit
+// vmcnt(0) on every path.  The compiler's wait-count bookkeeping is per physical register and merges loop paths
+// conservatively: without this, scratch registers that were load destinations inside such a loop count as pending at the
+// loop exits, and every later write to them in the COMMON path gets a vmcnt(0) -- which would wait for the next chunk's
+// prefetched groups.
+#define S1S_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70)
+
+// barrier that orders LDS only: global loads (the next chunk's prefetch) and stores stay in flight across it
+__device__ __forceinline__ void s1s_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// exclusive scan over the 1024-thread block with ONE barrier: every wave scans the 16 wave totals itself (`lds`: 16 ints,
+// not reused before another barrier)
+__device__ __forceinline__ int s1s_block_scan(int x, int* lds, int lane, int wave, int* total) {
+    const int inc = flmr_wave_inclusive_scan(x, lane);
+    if (lane == 63) lds[wave] = inc;
+    s1s_sync();
+    const int w = lane < S1S_WAVES ? lds[lane] : 0;
+    const int winc = flmr_wave_inclusive_scan(w, lane);
+    *total = __builtin_amdgcn_readlane(winc, S1S_WAVES - 1);
+    return inc - x + __builtin_amdgcn_readlane(winc - w, wave);
+}
+
+#ifdef S1S_PROFILE   // development only: per-phase clocks of wave 0, summed over the grid and printed by the launcher
+__device__ unsigned long long s1s_prof[12];
+#define S1S_STAMP(k) do { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); pt[k] += now_ - plast; plast = now_; } while (0)
+#else
+#define S1S_STAMP(k) do { } while (0)
+#endif
+
 // A workgroup takes S1S_CPB consecutive chunks of one query: the list ids and offsets are fetched once, and only the chunk
 // table entry that ends the NEXT chunk's slice is loaded per chunk (a chunk's slice starts where the previous one ended),
 // requested a whole chunk ahead.
@@ -193,10 +226,12 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     uint32_t* hb = cb + CAND_CHUNK_WORDS;                               // hit-set bitmap
     uint16_t* cbase = reinterpret_cast<uint16_t*>(hb + CAND_CHUNK_WORDS);  // exclusive candidate count before word w
     uint16_t* hbase = cbase + CAND_CHUNK_WORDS;                         // exclusive (candidate & hit) count before word w
-    int* acc = reinterpret_cast<int*>(hbase + CAND_CHUNK_WORDS);        // [S1S_SLOTS][S1S_STRIDE]
-    __shared__ int scan_lds[17];
+    int* acc = reinterpret_cast<int*>(hbase + CAND_CHUNK_WORDS);        // [S1S_SLOTS][S1S_STRIDE] (+ 96 scratch words)
+    int* rows = acc + S1S_SLOTS * S1S_STRIDE + 96;                      // [S1S_WAVES][S1S_STAGED][32] encoded score rows
+    __shared__ int scan_lds[S1S_WAVES];
     __shared__ int s_base;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too: slice bounds stay in SGPRs
     const int k = lane & 31;
     const int ch0 = blockIdx.y * S1S_CPB;
     const int ch_end = ch0 + S1S_CPB < a.nchunks ? ch0 + S1S_CPB : a.nchunks;
@@ -205,6 +240,10 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     const int nq = scatter ? a.nqual[b] : 0;
     s1s_slices mc = s1s_load_slices(a.cells + (size_t)b * a.max_cells, nl, wave, lane, a.ivf_offsets, a.chunk_tab, a.nchunks, ch0);
     s1s_slices mq = s1s_load_slices(a.qual + (size_t)b * a.qmax, nq, wave, lane, a.ivf_offsets, a.chunk_tab, a.nchunks, ch0);
+#ifdef S1S_PROFILE
+    long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long plast = (long long)__builtin_amdgcn_s_memtime();
+#endif
     const int init = s1s_enc(-9999.0f);
     const int qlen = a.q_lens ? a.q_lens[b] : a.nq_cand;
     const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;  // <= 32 on this path
@@ -213,6 +252,52 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     const float* cs_b = a.cs + (size_t)b * a.cs_query_stride;
     uint64_t* keys_b = a.keys + (size_t)b * a.cand_cap;
 
+    // four lists at a time: slice bounds (wave-uniform) + the first 64 entries of each, relative to the chunk's first pid.
+    // `ls` / `le` hold the slice bounds of list j in lane j (this chunk's, or the next chunk's when prefetching).
+    // Every lane of a non-empty slice loads (lanes past the end repeat the last entry) and the values are only
+    // interpreted where they are consumed: a load inside a DIVERGENT branch is waited for before the branch ends, which
+    // would serialise the four round trips of a group.
+    struct grp { int raw[4]; uint32_t sv[4], ev[4]; };
+    struct begs { const int32_t* p[4]; };   // list starts of a group (wave-uniform, the same in every chunk)
+    auto list_begs = [&](const s1s_slices& m, int j0) {
+        begs b;
+#pragma unroll
+        for (int u = 0; u < 4; u++) b.p[u] = a.ivf_pids + s1s_bcast64(m.beg, (j0 + u < m.n) ? j0 + u : (j0 < m.n ? j0 : 0));
+        return b;
+    };
+    auto issue = [&](const s1s_slices& m, const begs& bg, uint32_t ls, uint32_t le, int j0, grp& g) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = (j0 + u < m.n) ? j0 + u : (j0 < m.n ? j0 : 0);
+            g.sv[u] = (uint32_t)__builtin_amdgcn_readlane((int)ls, j);
+            g.ev[u] = (j0 + u < m.n) ? (uint32_t)__builtin_amdgcn_readlane((int)le, j) : g.sv[u];
+            g.raw[u] = 0;
+            if (g.sv[u] < g.ev[u]) {   // wave-uniform; lanes past the end repeat the slice's last entry
+                const uint32_t x = g.sv[u] + lane;
+                g.raw[u] = bg.p[u][x < g.ev[u] ? x : g.ev[u] - 1u];   // uniform base + 32-bit lane offset
+            }
+        }
+    };
+    // entry `lane` of slice u relative to the chunk's first pid, -1 past the slice's end
+    auto pid_of = [&](const grp& g, int u, int pid0) { return (g.sv[u] + lane < g.ev[u]) ? g.raw[u] - pid0 : -1; };
+    // The first group of the probed cells' lists and of the surviving lists of a chunk is requested a chunk ahead (during
+    // the previous chunk's scatter phase), and the surviving group's entries are KEPT for the scatter phase, so in the
+    // common case (<= 4 lists per wave, <= 64 entries per slice) a chunk waits for no global load of its own; the score
+    // rows of the wave's first four surviving centroids do not depend on the chunk and are fetched once.
+    grp gc, gq;
+    const begs bc0 = list_begs(mc, 0), bq0 = list_begs(mq, 0);
+    issue(mc, bc0, mc.s, mc.e, 0, gc);
+    issue(mq, bq0, mq.s, mq.e, 0, gq);
+    int rowq0[4] = {init, init, init, init};
+    if (scatter && mq.n > 0) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) rowq0[u] = s1s_enc(cs_b[(size_t)__builtin_amdgcn_readlane(mq.c, u < mq.n ? u : 0) * 32 + k]);
+#pragma unroll
+        for (int u = 0; u < S1S_STAGED; u++)   // (read after the first chunk's barriers)
+            if (lane < 32) rows[(wave * S1S_STAGED + u) * 32 + lane] = rowq0[u];
+    }
+
+    S1S_STAMP(0);
     for (int ch = ch0; ch < ch_end; ch++) {
     const int pid0 = ch * CAND_CHUNK_PIDS;
     // the end of the NEXT chunk's slices, a chunk ahead of its use
@@ -223,41 +308,42 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     }
     cb[tid] = 0u; hb[tid] = 0u;  // CAND_CHUNK_WORDS == blockDim.x
     if (scatter)  // first window's accumulators, written while the loads above are in flight
-        for (int e = tid; e < S1S_SLOTS * S1S_STRIDE; e += 64 * S1S_WAVES) acc[e] = init;
-    __syncthreads();
-    // lists are taken four at a time: the first 64 entries of each are requested before any is consumed, and the first
-    // group of the surviving lists is requested together with the first group of the probed cells' lists
-    struct grp { int pidv[4]; int64_t begv[4]; uint32_t sv[4], ev[4]; };
-    auto issue = [&](const s1s_slices& m, int j0, grp& g) {
+    {
+        static_assert(S1S_SLOTS * S1S_STRIDE % 4 == 0, "the accumulators are initialised 16 bytes at a time");
+        int4* a4 = reinterpret_cast<int4*>(acc);
+        const int4 i4 = make_int4(init, init, init, init);
+#pragma unroll
+        for (int e = 0; e < (S1S_SLOTS * S1S_STRIDE / 4 + 64 * S1S_WAVES - 1) / (64 * S1S_WAVES); e++)
+            if (e * 64 * S1S_WAVES + tid < S1S_SLOTS * S1S_STRIDE / 4) a4[e * 64 * S1S_WAVES + tid] = i4;
+    }
+    s1s_sync();
+    S1S_STAMP(1);
+    auto consume = [&](const grp& g, const begs& bg, uint32_t* dst) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int j = (j0 + u < m.n) ? j0 + u : (j0 < m.n ? j0 : 0);
-            g.begv[u] = s1s_bcast64(m.beg, j);
-            g.sv[u] = (uint32_t)__builtin_amdgcn_readlane((int)m.s, j);
-            g.ev[u] = (j0 + u < m.n) ? (uint32_t)__builtin_amdgcn_readlane((int)m.e, j) : g.sv[u];
-            g.pidv[u] = (g.sv[u] + lane < g.ev[u]) ? a.ivf_pids[g.begv[u] + g.sv[u] + lane] - pid0 : -1;
-        }
-    };
-    auto consume = [&](const grp& g, uint32_t* dst) {
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (g.pidv[u] >= 0) atomicOr(&dst[g.pidv[u] >> 5], 1u << (g.pidv[u] & 31));
+            const int p0 = pid_of(g, u, pid0);
+            if (p0 >= 0) atomicOr(&dst[p0 >> 5], 1u << (p0 & 31));
             for (uint32_t x = g.sv[u] + 64 + lane; x < g.ev[u]; x += 64) {
-                const int pid = a.ivf_pids[g.begv[u] + x] - pid0;
+                const int pid = bg.p[u][x] - pid0;
                 atomicOr(&dst[pid >> 5], 1u << (pid & 31));
+                S1S_DRAIN();
             }
         }
     };
+    // the only loads in flight here are this chunk's first groups (and, in the first chunk, the score rows): wait for them
+    // in ONE place on every path, so that no later use inside a divergent branch asks for vmcnt(0) again and thereby
+    // waits for the NEXT chunk's groups requested below
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    S1S_STAMP(2);
     {
-        grp gc, gq;
-        issue(mc, 0, gc);
-        issue(mq, 0, gq);
-        consume(gc, cb);
-        for (int j0 = 4; j0 < mc.n; j0 += 4) { issue(mc, j0, gc); consume(gc, cb); }
-        consume(gq, hb);
-        for (int j0 = 4; j0 < mq.n; j0 += 4) { issue(mq, j0, gq); consume(gq, hb); }
+        grp gt;
+        consume(gc, bc0, cb);
+        for (int j0 = 4; j0 < mc.n; j0 += 4) { const begs bg = list_begs(mc, j0); issue(mc, bg, mc.s, mc.e, j0, gt); consume(gt, bg, cb); S1S_DRAIN(); }
+        consume(gq, bq0, hb);
+        for (int j0 = 4; j0 < mq.n; j0 += 4) { const begs bg = list_begs(mq, j0); issue(mq, bg, mq.s, mq.e, j0, gt); consume(gt, bg, hb); S1S_DRAIN(); }
     }
-    __syncthreads();
+    s1s_sync();
+    S1S_STAMP(3);
     // bitmaps out (the ascending candidate list is still produced by cand_emit_kernel) + the two popcount prefixes
     const int64_t gw = (int64_t)ch * CAND_CHUNK_WORDS + tid;
     uint32_t cw = cb[tid];
@@ -271,25 +357,38 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     const uint32_t hcw = cw & hw;
     // one block scan for both ranks: candidates in the low half, candidate-and-hit in the high half (<= 32768 each)
     int tot;
-    const int both = flmr_block_exclusive_scan(__popc(cw) | (__popc(hcw) << 16), scan_lds, &tot);
-    const int cpos = both & 0xffff, hpos = both >> 16;
-    const int cnt = tot & 0xffff, nh = tot >> 16;
+    const int both = s1s_block_scan(__popc(cw) | (__popc(hcw) << 16), scan_lds, lane, wave, &tot);
+    const int cpos = both & 0xffff, hpos = (int)((uint32_t)both >> 16);
+    const int cnt = tot & 0xffff, nh = (int)((uint32_t)tot >> 16);
     cbase[tid] = (uint16_t)cpos;
     hbase[tid] = (uint16_t)hpos;
     // where this chunk's keys go: a global atomic whose ~2 us round trip is only awaited right before the keys are written
     int my_base = 0;
     if (tid == 0) {
         a.chunk_cnt[(size_t)b * a.nchunks + ch] = cnt;
-        if (scatter && cnt) my_base = atomicAdd(&a.key_count[b], cnt);
+        if (scatter && cnt) {
+            // an address the compiler cannot prove uniform: keeps its atomic optimiser (wave reduction + readfirstlane of
+            // the result right behind the atomic, i.e. an immediate wait) away from this single-lane atomic
+            int zero = 0;
+            asm volatile("" : "+v"(zero));
+            my_base = atomicAdd(&a.key_count[b] + zero, cnt);
+        }
     }
-    __syncthreads();
+    s1s_sync();
+    S1S_STAMP(4);
+    grp gcn = gc, gqn = gq;   // the next chunk's first groups: its slices start where this chunk's ended
+    if (ch + 1 < ch_end) {
+        issue(mc, bc0, mc.e, mc_e2, 0, gcn);
+        issue(mq, bq0, mq.e, mq_e2, 0, gqn);
+    }
+    S1S_STAMP(5);
     // (queries without `scatter` leave stage 1 to the scanning kernel; both conditions are block-uniform)
     if (scatter && cnt > 0) {
     for (int win0 = 0; win0 == 0 || win0 < nh; win0 += S1S_SLOTS) {
         const int nslot = (nh - win0) < S1S_SLOTS ? (nh - win0) : S1S_SLOTS;
         if (win0 > 0) {
             for (int e = tid; e < nslot * S1S_STRIDE; e += 64 * S1S_WAVES) acc[e] = init;
-            __syncthreads();
+            s1s_sync();
         }
         // the surviving lists again: (centroid, passage) pairs -> 32-wide max into the passage's slot; four lists at a
         // time (their score rows and first 64 entries are requested up front).  Every lane owns one (centroid, passage)
@@ -302,49 +401,77 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
                 const uint32_t cwd = cb[w];
                 if ((cwd >> bit) & 1u) slot = (int)hbase[w] + __popc(cwd & hb[w] & ((1u << bit) - 1u)) - win0;
             }
+            // lanes without a slot aim at a scratch area behind the accumulators (one word per lane and column, so they
+            // do not collide): 32 x (v_readlane, ds_max) with no exec-mask juggling in between
             const bool on = slot >= 0 && slot < nslot;
-            int* dst = acc + (on ? slot : 0) * S1S_STRIDE;
+            int* dst = on ? acc + slot * S1S_STRIDE : acc + S1S_SLOTS * S1S_STRIDE + lane;
 #pragma unroll
-            for (int q = 0; q < 32; q++) {
-                const int v = __builtin_amdgcn_readlane(rowk, q);
-                if (on) atomicMax(dst + q, v);
+            for (int q = 0; q < 32; q++) atomicMax(dst + q, __builtin_amdgcn_readlane(rowk, q));
+        };
+        // the same with the score row staged in LDS: eight 16-byte broadcast reads replace 32 x (v_readlane, v_mov)
+        auto scatter_pids_staged = [&](int pid, const int* row) {
+            int slot = -1;
+            if (pid >= 0) {
+                const int w = pid >> 5, bit = pid & 31;
+                const uint32_t cwd = cb[w];
+                if ((cwd >> bit) & 1u) slot = (int)hbase[w] + __popc(cwd & hb[w] & ((1u << bit) - 1u)) - win0;
+            }
+            const bool on = slot >= 0 && slot < nslot;
+            int* dst = on ? acc + slot * S1S_STRIDE : acc + S1S_SLOTS * S1S_STRIDE + lane;
+            const int4* r4 = reinterpret_cast<const int4*>(row);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int4 r0 = r4[4 * h], r1 = r4[4 * h + 1], r2 = r4[4 * h + 2], r3 = r4[4 * h + 3];
+                int* d = dst + 16 * h;
+                atomicMax(d + 0, r0.x); atomicMax(d + 1, r0.y); atomicMax(d + 2, r0.z); atomicMax(d + 3, r0.w);
+                atomicMax(d + 4, r1.x); atomicMax(d + 5, r1.y); atomicMax(d + 6, r1.z); atomicMax(d + 7, r1.w);
+                atomicMax(d + 8, r2.x); atomicMax(d + 9, r2.y); atomicMax(d + 10, r2.z); atomicMax(d + 11, r2.w);
+                atomicMax(d + 12, r3.x); atomicMax(d + 13, r3.y); atomicMax(d + 14, r3.z); atomicMax(d + 15, r3.w);
             }
         };
-        for (int j0 = 0; j0 < mq.n; j0 += 4) {
-            int pidv[4], rowv[4];
-            int64_t begv[4];
-            uint32_t sv[4], ev[4];
+        auto scatter_group = [&](const grp& g, const begs& bg, const int* rowv, bool staged) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int j = (j0 + u < mq.n) ? j0 + u : j0;
-                begv[u] = s1s_bcast64(mq.beg, j);
-                sv[u] = (uint32_t)__builtin_amdgcn_readlane((int)mq.s, j);
-                ev[u] = (j0 + u < mq.n) ? (uint32_t)__builtin_amdgcn_readlane((int)mq.e, j) : sv[u];
-                rowv[u] = s1s_enc(cs_b[(size_t)__builtin_amdgcn_readlane(mq.c, j) * 32 + k]);
-                pidv[u] = (sv[u] + lane < ev[u]) ? a.ivf_pids[begv[u] + sv[u] + lane] - pid0 : -1;
+                if (g.sv[u] >= g.ev[u]) continue;  // wave-uniform
+                if (staged && u < S1S_STAGED) scatter_pids_staged(pid_of(g, u, pid0), rows + (wave * S1S_STAGED + u) * 32);
+                else scatter_pids(pid_of(g, u, pid0), rowv[u]);
+                for (uint32_t x0 = g.sv[u] + 64; x0 < g.ev[u]; x0 += 64) {
+                    scatter_pids(x0 + lane < g.ev[u] ? bg.p[u][x0 + lane] - pid0 : -1, rowv[u]);
+                    S1S_DRAIN();
+                }
             }
+        };
+        if (mq.n > 0) scatter_group(gq, bq0, rowq0, true);   // the entries kept from the marking pass
+        for (int j0 = 4; j0 < mq.n; j0 += 4) {
+            grp gt;
+            int rowv[4];
+            const begs bg = list_begs(mq, j0);
+            issue(mq, bg, mq.s, mq.e, j0, gt);
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (sv[u] >= ev[u]) continue;  // wave-uniform
-                scatter_pids(pidv[u], rowv[u]);
-                for (uint32_t x0 = sv[u] + 64; x0 < ev[u]; x0 += 64)
-                    scatter_pids(x0 + lane < ev[u] ? a.ivf_pids[begv[u] + x0 + lane] - pid0 : -1, rowv[u]);
-            }
+            for (int u = 0; u < 4; u++)
+                rowv[u] = s1s_enc(cs_b[(size_t)__builtin_amdgcn_readlane(mq.c, (j0 + u < mq.n) ? j0 + u : j0) * 32 + k]);
+            scatter_group(gt, bg, rowv, false);
+            S1S_DRAIN();
         }
-        __syncthreads();
+        s1s_sync();
+        S1S_STAMP(6);
         // per-slot score = ascending-k sum of the column maxima (filter_pids.cpp:59-63), one thread per slot, kept in the
         // row's padding word
         for (int sl = tid; sl < nslot; sl += 64 * S1S_WAVES) {
-            float v[32];
-#pragma unroll
-            for (int q = 0; q < 32; q++) v[q] = s1s_dec(acc[sl * S1S_STRIDE + q]);
             float sc = 0.0f;
 #pragma unroll
-            for (int q = 0; q < 32; q++) sc += q < nqc ? v[q] : 0.0f;
+            for (int q0 = 0; q0 < 32; q0 += 8) {   // eight LDS reads in flight at a time (registers are scarce here)
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = s1s_dec(acc[sl * S1S_STRIDE + q0 + q]);
+#pragma unroll
+                for (int q = 0; q < 8; q++) sc += q0 + q < nqc ? v[q] : 0.0f;
+            }
             acc[sl * S1S_STRIDE + 32] = __float_as_int(sc);
         }
         if (tid == 0 && win0 == 0) s_base = my_base;
-        __syncthreads();
+        s1s_sync();
+        S1S_STAMP(7);
         // one thread per bitmap word: keys of its candidates (hits of this window; the misses with window 0)
         {
             const int64_t kbase = s_base;
@@ -364,14 +491,24 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
                 }
             }
         }
-        __syncthreads();
+        s1s_sync();
+        S1S_STAMP(8);
     }
     }
-    // next chunk: its slices start where this chunk's ended
+    // next chunk
     mc.s = mc.e; mc.e = mc_e2;
     mq.s = mq.e; mq.e = mq_e2;
-    __syncthreads();  // bitmaps / bases / accumulators are reused
+    gc = gcn; gq = gqn;
+    if (!(scatter && cnt > 0)) s1s_sync();  // bitmaps / bases / accumulators are reused (the window loop ends with a barrier)
+    S1S_STAMP(9);
     }
+#ifdef S1S_PROFILE
+    if (tid == 0) {
+        for (int i = 0; i < 10; i++) atomicAdd(&s1s_prof[i], (unsigned long long)pt[i]);
+        atomicAdd(&s1s_prof[10], (unsigned long long)(ch_end - ch0));
+        atomicAdd(&s1s_prof[11], 1ull);
+    }
+#endif
 }
 
 // ---- kernel B: bitmap chunk -> ascending pids at the chunk's global rank, one hit flag per candidate --------------------------
@@ -417,10 +554,22 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
                        a.ncell, a.max_cells, a.qual, a.nqual, a.qmax, a.hit_valid, a.scatter ? a.key_count : nullptr, a.scatter ? 8 : 2);
     if (a.scatter) {
         const size_t lds = (size_t)CAND_CHUNK_WORDS * (2 * sizeof(uint32_t) + 2 * sizeof(uint16_t)) +
-                           (size_t)S1S_SLOTS * S1S_STRIDE * sizeof(int);
+                           ((size_t)S1S_SLOTS * S1S_STRIDE + 96 + S1S_WAVES * S1S_STAGED * 32) * sizeof(int);   // + scratch words of slot-less lanes, staged rows
         FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cand_mark_score_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(cand_mark_score_kernel, dim3(a.nqueries, (a.nchunks + S1S_CPB - 1) / S1S_CPB), dim3(64 * S1S_WAVES), lds, st, a);
+#ifdef S1S_PROFILE
+        {
+            unsigned long long h[12];
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(s1s_prof), sizeof(h));
+            fprintf(stderr, "[s1s] blocks %llu chunks %llu; 100 MHz ticks per chunk: prologue/blk %.1f init %.1f wait %.1f mark %.1f scan %.1f prefetch %.1f scatter %.1f sum %.1f keys %.1f end %.1f\n",
+                    h[11], h[10], (double)h[0] / h[11], (double)h[1] / h[10], (double)h[2] / h[10], (double)h[3] / h[10], (double)h[4] / h[10],
+                    (double)h[5] / h[10], (double)h[6] / h[10], (double)h[7] / h[10], (double)h[8] / h[10], (double)h[9] / h[10]);
+            unsigned long long z[12] = {};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(s1s_prof), z, sizeof(z));
+        }
+#endif
     } else {
         hipLaunchKernelGGL(cand_mark_chunks_kernel, dim3(a.nqueries, a.nchunks), dim3(256), 0, st, a.cells, a.ncell, a.max_cells,
                            a.qual, a.nqual, a.qmax, a.hit_valid, a.ivf_pids, a.ivf_offsets, a.chunk_tab, a.nchunks, a.cand_bits,
