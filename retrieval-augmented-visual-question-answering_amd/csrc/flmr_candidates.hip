@@ -144,14 +144,21 @@ __global__ __launch_bounds__(256) void cand_mark_chunks_kernel(const int32_t* ce
 // codes never have to be scanned: this replaces the 4*sum(doclen) bytes/candidate code scan -- the largest term of the
 // whole path's compulsory traffic in the reference formulation -- by the (c, pid) pairs of the surviving lists.
 // Per (query, chunk) workgroup, after the bitmaps are marked: every candidate that is also in the hit set gets a slot
-// (popcount rank inside the chunk) with 32 fp32 accumulators in LDS; the surviving lists' slices are walked a second time
-// and each (c, pid) pair does a 32-wide ds_max of c's score row into pid's slot (scores are order-encoded as ints so the
-// integer LDS atomic max is exact); then one thread per candidate sums its columns in ascending k and writes the key.
-// Keys go to keys[b][base + rank] with base from a per-query atomic counter: the top-ndocs selection is order-free.
-// More hits in a chunk than S1S_SLOTS are handled in windows of slots.
-#define S1S_SLOTS 1088   // accumulator slots per window: with the bitmaps and the staged rows this fills the CU's 160 KB of LDS
+// (popcount rank inside the chunk).  The surviving lists' slices are walked a second time (from registers) and every
+// (c, pid) pair adds (1, list id) to its slot's counter with ONE returning LDS atomic.  A passage with a single surviving
+// centroid -- nearly all of them: 1.02 lists per hit passage on the bench corpus -- scores that list's constant
+// sum_k max(-9999, cs[c][k]) (computed once per workgroup); only the pairs of passages with several surviving centroids are
+// queued and fold their 32-column score rows into the slot's accumulator row with ds_max (scores order-encoded as ints, so
+// the integer max is exact), and those slots sum their columns in ascending k.  A window whose queue overflows falls back
+// to the dense form (every pair folds its row).  Keys go to keys[b][base + rank] with base from a per-query atomic
+// counter: the top-ndocs selection is order-free.  More hits in a chunk than S1S_SLOTS are handled in windows of slots.
+// (Measured with the per-phase clock probe -DS1S_PROFILE: the dense form spent 8.4 k of 27 k clocks per chunk in the 32
+// ds_max per pair and 3.3 k initialising accumulators; this form 22 k clocks per chunk, spread over ~8 barrier-separated
+// phases of 2-5 k each -- the workgroup's 16 waves are issue- and barrier-bound, not LDS- or HBM-bound.)
+#define S1S_SLOTS 1088   // slots per window: with the bitmaps, list constants and queue this fills the CU's 160 KB of LDS
 #define S1S_STRIDE 33
-#define S1S_STAGED 2     // score rows per wave kept in LDS (the first lists of its first group), read back as broadcasts
+#define S1S_QCAP 512     // (slot, list) pairs of passages with more than one surviving centroid, per window
+#define S1S_IDBITS 10    // list index inside the query's surviving lists (< qmax = 1024)
 #define S1S_WAVES 16     // one 1024-thread workgroup per CU
 
 __device__ __forceinline__ int s1s_enc(float x) { const int i = __float_as_int(x); return i ^ ((i >> 31) & 0x7fffffff); }
@@ -216,25 +223,25 @@ __device__ unsigned long long s1s_prof[12];
 #define S1S_STAMP(k) do { } while (0)
 #endif
 
-// A workgroup takes S1S_CPB consecutive chunks of one query: the list ids and offsets are fetched once, and only the chunk
+// A workgroup takes `cpb` consecutive chunks of one query: the list ids and offsets are fetched once, and only the chunk
 // table entry that ends the NEXT chunk's slice is loaded per chunk (a chunk's slice starts where the previous one ended),
 // requested a whole chunk ahead.
-#define S1S_CPB 4
-__global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_cand_args a) {
+__global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_cand_args a, int cpb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* cb = reinterpret_cast<uint32_t*>(smem);                   // candidate bitmap of the chunk
     uint32_t* hb = cb + CAND_CHUNK_WORDS;                               // hit-set bitmap
     uint16_t* cbase = reinterpret_cast<uint16_t*>(hb + CAND_CHUNK_WORDS);  // exclusive candidate count before word w
     uint16_t* hbase = cbase + CAND_CHUNK_WORDS;                         // exclusive (candidate & hit) count before word w
     int* acc = reinterpret_cast<int*>(hbase + CAND_CHUNK_WORDS);        // [S1S_SLOTS][S1S_STRIDE] (+ 96 scratch words)
-    int* rows = acc + S1S_SLOTS * S1S_STRIDE + 96;                      // [S1S_WAVES][S1S_STAGED][32] encoded score rows
+    float* rsum = reinterpret_cast<float*>(acc + S1S_SLOTS * S1S_STRIDE + 96);   // [1024] stage-1 score of a passage whose only surviving centroid is list j
+    int* queue = reinterpret_cast<int*>(rsum + 1024);                  // [S1S_QCAP] slot << S1S_IDBITS | list
     __shared__ int scan_lds[S1S_WAVES];
-    __shared__ int s_base;
+    __shared__ int s_base, s_qn;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too: slice bounds stay in SGPRs
     const int k = lane & 31;
-    const int ch0 = blockIdx.y * S1S_CPB;
-    const int ch_end = ch0 + S1S_CPB < a.nchunks ? ch0 + S1S_CPB : a.nchunks;
+    const int ch0 = blockIdx.y * cpb;
+    const int ch_end = ch0 + cpb < a.nchunks ? ch0 + cpb : a.nchunks;
     const int nl = a.ncell[b];
     const bool scatter = a.hit_valid[b] != 0;
     const int nq = scatter ? a.nqual[b] : 0;
@@ -288,13 +295,23 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     const begs bc0 = list_begs(mc, 0), bq0 = list_begs(mq, 0);
     issue(mc, bc0, mc.s, mc.e, 0, gc);
     issue(mq, bq0, mq.s, mq.e, 0, gq);
-    int rowq0[4] = {init, init, init, init};
-    if (scatter && mq.n > 0) {
+    // Stage-1 score of a passage whose ONLY surviving centroid is list j (the usual case: ~1.02 lists per hit passage):
+    // its 32 column maxima are that centroid's score row (floored at the accumulators' start value), so their
+    // ascending-k sum is a per-list constant.  Lane l of wave w owns list w + 16 l.
+    if (scatter && lane < mq.n) {
+        const float4* r4 = reinterpret_cast<const float4*>(cs_b + (size_t)mq.c * 32);
+        float sc = 0.0f;
 #pragma unroll
-        for (int u = 0; u < 4; u++) rowq0[u] = s1s_enc(cs_b[(size_t)__builtin_amdgcn_readlane(mq.c, u < mq.n ? u : 0) * 32 + k]);
+        for (int q4 = 0; q4 < 8; q4++) {
+            const float4 v = r4[q4];
+            const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int u = 0; u < S1S_STAGED; u++)   // (read after the first chunk's barriers)
-            if (lane < 32) rows[(wave * S1S_STAGED + u) * 32 + lane] = rowq0[u];
+            for (int i = 0; i < 4; i++) {
+                const int e = s1s_enc(x[i]);
+                sc += q4 * 4 + i < nqc ? s1s_dec(e > init ? e : init) : 0.0f;
+            }
+        }
+        rsum[wave + S1S_WAVES * lane] = sc;   // (read after the first chunk's barriers)
     }
 
     S1S_STAMP(0);
@@ -307,14 +324,9 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
         if (lane < mq.n) mq_e2 = a.chunk_tab[(size_t)mq.c * (a.nchunks + 1) + ch + 2];
     }
     cb[tid] = 0u; hb[tid] = 0u;  // CAND_CHUNK_WORDS == blockDim.x
-    if (scatter)  // first window's accumulators, written while the loads above are in flight
-    {
-        static_assert(S1S_SLOTS * S1S_STRIDE % 4 == 0, "the accumulators are initialised 16 bytes at a time");
-        int4* a4 = reinterpret_cast<int4*>(acc);
-        const int4 i4 = make_int4(init, init, init, init);
-#pragma unroll
-        for (int e = 0; e < (S1S_SLOTS * S1S_STRIDE / 4 + 64 * S1S_WAVES - 1) / (64 * S1S_WAVES); e++)
-            if (e * 64 * S1S_WAVES + tid < S1S_SLOTS * S1S_STRIDE / 4) a4[e * 64 * S1S_WAVES + tid] = i4;
+    if (scatter) {   // first window's pair counters (the slots' padding words), see (a) below
+        for (int sl = tid; sl < S1S_SLOTS; sl += 64 * S1S_WAVES) acc[sl * S1S_STRIDE + 32] = 0;
+        if (tid == 0) s_qn = 0;
     }
     s1s_sync();
     S1S_STAMP(1);
@@ -377,95 +389,137 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     s1s_sync();
     S1S_STAMP(4);
     grp gcn = gc, gqn = gq;   // the next chunk's first groups: its slices start where this chunk's ended
-    if (ch + 1 < ch_end) {
-        issue(mc, bc0, mc.e, mc_e2, 0, gcn);
-        issue(mq, bq0, mq.e, mq_e2, 0, gqn);
-    }
+    auto prefetch_next = [&]() {
+        if (ch + 1 < ch_end) {
+            issue(mc, bc0, mc.e, mc_e2, 0, gcn);
+            issue(mq, bq0, mq.e, mq_e2, 0, gqn);
+        }
+    };
+    prefetch_next();
     S1S_STAMP(5);
     // (queries without `scatter` leave stage 1 to the scanning kernel; both conditions are block-uniform)
     if (scatter && cnt > 0) {
     for (int win0 = 0; win0 == 0 || win0 < nh; win0 += S1S_SLOTS) {
         const int nslot = (nh - win0) < S1S_SLOTS ? (nh - win0) : S1S_SLOTS;
+        // (a) the slot's padding word counts the (list, passage) pairs that land on it: count << S1S_IDBITS + sum of list
+        // ids (zeroed with the bitmaps for the first window)
         if (win0 > 0) {
-            for (int e = tid; e < nslot * S1S_STRIDE; e += 64 * S1S_WAVES) acc[e] = init;
+            for (int sl = tid; sl < nslot; sl += 64 * S1S_WAVES) acc[sl * S1S_STRIDE + 32] = 0;
+            if (tid == 0) s_qn = 0;
             s1s_sync();
         }
-        // the surviving lists again: (centroid, passage) pairs -> 32-wide max into the passage's slot; four lists at a
-        // time (their score rows and first 64 entries are requested up front).  Every lane owns one (centroid, passage)
-        // pair and walks the 32 columns itself: 32 ds_max per 64 pairs, no cross-lane dependency chain; the row value of
-        // column q is broadcast from lane q of rowk
-        auto scatter_pids = [&](int pid, int rowk) {
+        auto slot_of = [&](int pid) {
             int slot = -1;
             if (pid >= 0) {
                 const int w = pid >> 5, bit = pid & 31;
                 const uint32_t cwd = cb[w];
                 if ((cwd >> bit) & 1u) slot = (int)hbase[w] + __popc(cwd & hb[w] & ((1u << bit) - 1u)) - win0;
             }
-            // lanes without a slot aim at a scratch area behind the accumulators (one word per lane and column, so they
-            // do not collide): 32 x (v_readlane, ds_max) with no exec-mask juggling in between
-            const bool on = slot >= 0 && slot < nslot;
-            int* dst = on ? acc + slot * S1S_STRIDE : acc + S1S_SLOTS * S1S_STRIDE + lane;
-#pragma unroll
-            for (int q = 0; q < 32; q++) atomicMax(dst + q, __builtin_amdgcn_readlane(rowk, q));
+            return (slot >= 0 && slot < nslot) ? slot : -1;
         };
-        // the same with the score row staged in LDS: eight 16-byte broadcast reads replace 32 x (v_readlane, v_mov)
-        auto scatter_pids_staged = [&](int pid, const int* row) {
-            int slot = -1;
-            if (pid >= 0) {
-                const int w = pid >> 5, bit = pid & 31;
-                const uint32_t cwd = cb[w];
-                if ((cwd >> bit) & 1u) slot = (int)hbase[w] + __popc(cwd & hb[w] & ((1u << bit) - 1u)) - win0;
-            }
-            const bool on = slot >= 0 && slot < nslot;
-            int* dst = on ? acc + slot * S1S_STRIDE : acc + S1S_SLOTS * S1S_STRIDE + lane;
-            const int4* r4 = reinterpret_cast<const int4*>(row);
+        // (b) ONE returning LDS atomic per pair.  A pair that finds others before it puts itself on the queue of passages
+        // with several surviving centroids; the second pair also enqueues the first, whose list id it reads off the
+        // count, and starts the slot's row of column maxima (nothing folds into rows before the barrier below)
+        auto count_pid = [&](int pid, int j) {
+            const int slot = slot_of(pid);
+            if (slot >= 0) {
+                const int old = atomicAdd(&acc[slot * S1S_STRIDE + 32], (1 << S1S_IDBITS) | j);
+                const int before = old >> S1S_IDBITS;
+                if (before >= 1) {
+                    const int n = before == 1 ? 2 : 1;
+                    if (before == 1) {
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int4 r0 = r4[4 * h], r1 = r4[4 * h + 1], r2 = r4[4 * h + 2], r3 = r4[4 * h + 3];
-                int* d = dst + 16 * h;
-                atomicMax(d + 0, r0.x); atomicMax(d + 1, r0.y); atomicMax(d + 2, r0.z); atomicMax(d + 3, r0.w);
-                atomicMax(d + 4, r1.x); atomicMax(d + 5, r1.y); atomicMax(d + 6, r1.z); atomicMax(d + 7, r1.w);
-                atomicMax(d + 8, r2.x); atomicMax(d + 9, r2.y); atomicMax(d + 10, r2.z); atomicMax(d + 11, r2.w);
-                atomicMax(d + 12, r3.x); atomicMax(d + 13, r3.y); atomicMax(d + 14, r3.z); atomicMax(d + 15, r3.w);
+                        for (int q = 0; q < 32; q++) acc[slot * S1S_STRIDE + q] = init;
+                    }
+                    const int at = atomicAdd(&s_qn, n);
+                    if (at + n <= S1S_QCAP) {
+                        queue[at] = (slot << S1S_IDBITS) | j;
+                        if (before == 1) queue[at + 1] = (slot << S1S_IDBITS) | (old & ((1 << S1S_IDBITS) - 1));
+                    }
+                }
             }
         };
-        auto scatter_group = [&](const grp& g, const begs& bg, const int* rowv, bool staged) {
+        auto count_group = [&](const grp& g, const begs& bg, int j0) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (g.sv[u] >= g.ev[u]) continue;  // wave-uniform
-                if (staged && u < S1S_STAGED) scatter_pids_staged(pid_of(g, u, pid0), rows + (wave * S1S_STAGED + u) * 32);
-                else scatter_pids(pid_of(g, u, pid0), rowv[u]);
+                const int j = wave + S1S_WAVES * (j0 + u);
+                count_pid(pid_of(g, u, pid0), j);
                 for (uint32_t x0 = g.sv[u] + 64; x0 < g.ev[u]; x0 += 64) {
-                    scatter_pids(x0 + lane < g.ev[u] ? bg.p[u][x0 + lane] - pid0 : -1, rowv[u]);
+                    count_pid(x0 + lane < g.ev[u] ? bg.p[u][x0 + lane] - pid0 : -1, j);
                     S1S_DRAIN();
                 }
             }
         };
-        if (mq.n > 0) scatter_group(gq, bq0, rowq0, true);   // the entries kept from the marking pass
+        if (mq.n > 0) count_group(gq, bq0, 0);   // the entries kept from the marking pass
         for (int j0 = 4; j0 < mq.n; j0 += 4) {
             grp gt;
-            int rowv[4];
             const begs bg = list_begs(mq, j0);
             issue(mq, bg, mq.s, mq.e, j0, gt);
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                rowv[u] = s1s_enc(cs_b[(size_t)__builtin_amdgcn_readlane(mq.c, (j0 + u < mq.n) ? j0 + u : j0) * 32 + k]);
-            scatter_group(gt, bg, rowv, false);
+            count_group(gt, bg, j0);
             S1S_DRAIN();
         }
         s1s_sync();
         S1S_STAMP(6);
-        // per-slot score = ascending-k sum of the column maxima (filter_pids.cpp:59-63), one thread per slot, kept in the
-        // row's padding word
+        const int qn = s_qn;
+        const bool dense = qn > S1S_QCAP;   // block-uniform
+        if (dense) {
+            // More multi-centroid pairs than the queue holds: every pair of the window walks the 32 columns itself --
+            // 32 x (v_readlane, ds_max) per 64 pairs into fully initialised rows; lanes without a slot aim at the scratch
+            // words behind the accumulators (one word per lane and column, so they do not collide).
+            for (int e = tid; e < nslot * S1S_STRIDE; e += 64 * S1S_WAVES) acc[e] = init;
+            s1s_sync();
+            auto scatter_pids = [&](int pid, int rowk) {
+                const int slot = slot_of(pid);
+                int* dst = slot >= 0 ? acc + slot * S1S_STRIDE : acc + S1S_SLOTS * S1S_STRIDE + lane;
+#pragma unroll
+                for (int q = 0; q < 32; q++) atomicMax(dst + q, __builtin_amdgcn_readlane(rowk, q));
+            };
+            for (int j0 = 0; j0 < mq.n; j0 += 4) {
+                grp gt;
+                int rowv[4];
+                const begs bg = list_begs(mq, j0);
+                issue(mq, bg, mq.s, mq.e, j0, gt);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    rowv[u] = s1s_enc(cs_b[(size_t)__builtin_amdgcn_readlane(mq.c, (j0 + u < mq.n) ? j0 + u : j0) * 32 + k]);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (gt.sv[u] >= gt.ev[u]) continue;  // wave-uniform
+                    scatter_pids(pid_of(gt, u, pid0), rowv[u]);
+                    for (uint32_t x0 = gt.sv[u] + 64; x0 < gt.ev[u]; x0 += 64)
+                        scatter_pids(x0 + lane < gt.ev[u] ? bg.p[u][x0 + lane] - pid0 : -1, rowv[u]);
+                }
+                S1S_DRAIN();
+            }
+            s1s_sync();
+        } else if (qn > 0) {
+            // (c) the queued pairs: half a wave per pair, one column per lane -- fold the pair's score row into the slot's
+            // row (ds_max on the order-preserving int encoding, exact)
+            for (int e = tid >> 5; e < qn; e += 2 * S1S_WAVES) {
+                const int ent = queue[e];
+                const int c = a.qual[(size_t)b * a.qmax + (ent & ((1 << S1S_IDBITS) - 1))];
+                atomicMax(&acc[(ent >> S1S_IDBITS) * S1S_STRIDE + k], s1s_enc(cs_b[(size_t)c * 32 + k]));
+            }
+            S1S_DRAIN();
+            s1s_sync();
+        }
+        // (d) per-slot score, one thread per slot, kept in the row's padding word: the list's constant for a passage with
+        // one surviving centroid, else the ascending-k sum of the column maxima (filter_pids.cpp:59-63)
         for (int sl = tid; sl < nslot; sl += 64 * S1S_WAVES) {
+            const int info = acc[sl * S1S_STRIDE + 32];
             float sc = 0.0f;
+            if (!dense && (info >> S1S_IDBITS) == 1) {
+                sc = rsum[info & ((1 << S1S_IDBITS) - 1)];
+            } else {
 #pragma unroll
-            for (int q0 = 0; q0 < 32; q0 += 8) {   // eight LDS reads in flight at a time (registers are scarce here)
-                float v[8];
+                for (int q0 = 0; q0 < 32; q0 += 8) {   // eight LDS reads in flight at a time (registers are scarce here)
+                    float v[8];
 #pragma unroll
-                for (int q = 0; q < 8; q++) v[q] = s1s_dec(acc[sl * S1S_STRIDE + q0 + q]);
+                    for (int q = 0; q < 8; q++) v[q] = s1s_dec(acc[sl * S1S_STRIDE + q0 + q]);
 #pragma unroll
-                for (int q = 0; q < 8; q++) sc += q0 + q < nqc ? v[q] : 0.0f;
+                    for (int q = 0; q < 8; q++) sc += q0 + q < nqc ? v[q] : 0.0f;
+                }
             }
             acc[sl * S1S_STRIDE + 32] = __float_as_int(sc);
         }
@@ -554,10 +608,14 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
                        a.ncell, a.max_cells, a.qual, a.nqual, a.qmax, a.hit_valid, a.scatter ? a.key_count : nullptr, a.scatter ? 8 : 2);
     if (a.scatter) {
         const size_t lds = (size_t)CAND_CHUNK_WORDS * (2 * sizeof(uint32_t) + 2 * sizeof(uint16_t)) +
-                           ((size_t)S1S_SLOTS * S1S_STRIDE + 96 + S1S_WAVES * S1S_STAGED * 32) * sizeof(int);   // + scratch words of slot-less lanes, staged rows
+                           ((size_t)S1S_SLOTS * S1S_STRIDE + 96 + 1024 + S1S_QCAP) * sizeof(int);   // + scratch words of slot-less lanes, list constants, queue
         FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cand_mark_score_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(cand_mark_score_kernel, dim3(a.nqueries, (a.nchunks + S1S_CPB - 1) / S1S_CPB), dim3(64 * S1S_WAVES), lds, st, a);
+        // chunks per workgroup: as many as still leave two workgroups per CU (the per-workgroup set-up -- list ids, offsets,
+        // chunk table, list constants -- costs about a third of a chunk; 8 vs 4 measured -3 % at 256 queries x 31 chunks)
+        int cpb = 8;
+        while (cpb > 1 && (int64_t)a.nqueries * ((a.nchunks + cpb - 1) / cpb) < 512) cpb >>= 1;
+        hipLaunchKernelGGL(cand_mark_score_kernel, dim3(a.nqueries, (a.nchunks + cpb - 1) / cpb), dim3(64 * S1S_WAVES), lds, st, a, cpb);
 #ifdef S1S_PROFILE
         {
             unsigned long long h[12];
