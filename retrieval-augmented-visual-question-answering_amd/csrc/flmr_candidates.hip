@@ -254,8 +254,6 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     const int init = s1s_enc(-9999.0f);
     const int qlen = a.q_lens ? a.q_lens[b] : a.nq_cand;
     const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;  // <= 32 on this path
-    float miss_score = 0.0f;
-    for (int q = 0; q < nqc; q++) miss_score += -9999.0f;
     const float* cs_b = a.cs + (size_t)b * a.cs_query_stride;
     uint64_t* keys_b = a.keys + (size_t)b * a.cand_cap;
 
@@ -372,18 +370,20 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     const int both = s1s_block_scan(__popc(cw) | (__popc(hcw) << 16), scan_lds, lane, wave, &tot);
     const int cpos = both & 0xffff, hpos = (int)((uint32_t)both >> 16);
     const int cnt = tot & 0xffff, nh = (int)((uint32_t)tot >> 16);
-    cbase[tid] = (uint16_t)cpos;
     hbase[tid] = (uint16_t)hpos;
     // where this chunk's keys go: a global atomic whose ~2 us round trip is only awaited right before the keys are written
+    // (only the candidates in the hit set get a key here: the others all score the all-miss constant and are appended by
+    // cand_emit_kernel for the rare query with fewer hits than the selection keeps)
     int my_base = 0;
     if (tid == 0) {
         a.chunk_cnt[(size_t)b * a.nchunks + ch] = cnt;
-        if (scatter && cnt) {
+        a.chunk_hits[(size_t)b * a.nchunks + ch] = scatter ? nh : 0;
+        if (scatter && nh) {
             // an address the compiler cannot prove uniform: keeps its atomic optimiser (wave reduction + readfirstlane of
             // the result right behind the atomic, i.e. an immediate wait) away from this single-lane atomic
             int zero = 0;
             asm volatile("" : "+v"(zero));
-            my_base = atomicAdd(&a.key_count[b] + zero, cnt);
+            my_base = atomicAdd(&a.key_count[b] + zero, nh);
         }
     }
     s1s_sync();
@@ -398,8 +398,8 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     prefetch_next();
     S1S_STAMP(5);
     // (queries without `scatter` leave stage 1 to the scanning kernel; both conditions are block-uniform)
-    if (scatter && cnt > 0) {
-    for (int win0 = 0; win0 == 0 || win0 < nh; win0 += S1S_SLOTS) {
+    if (scatter && nh > 0) {
+    for (int win0 = 0; win0 < nh; win0 += S1S_SLOTS) {
         const int nslot = (nh - win0) < S1S_SLOTS ? (nh - win0) : S1S_SLOTS;
         // (a) the slot's padding word counts the (list, passage) pairs that land on it: count << S1S_IDBITS + sum of list
         // ids (zeroed with the bitmaps for the first window)
@@ -526,23 +526,17 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
         if (tid == 0 && win0 == 0) s_base = my_base;
         s1s_sync();
         S1S_STAMP(7);
-        // one thread per bitmap word: keys of its candidates (hits of this window; the misses with window 0)
+        // one thread per bitmap word: keys of its hit candidates in this window, at the chunk's base + rank among the hits
         {
             const int64_t kbase = s_base;
-            uint32_t bits = cw;
+            uint32_t bits = hcw;
             while (bits) {
                 const int bit = __ffs(bits) - 1;
                 bits &= bits - 1;
-                const uint32_t below = (1u << bit) - 1u;
-                const int64_t pos = kbase + cpos + __popc(cw & below);
-                const int pid = pid0 + tid * 32 + bit;
-                if ((hcw >> bit) & 1u) {
-                    const int slot = hpos + __popc(hcw & below) - win0;
-                    if (slot >= 0 && slot < nslot && pos < a.cand_cap)
-                        keys_b[pos] = flmr_make_key(__int_as_float(acc[slot * S1S_STRIDE + 32]), pid);
-                } else if (win0 == 0 && pos < a.cand_cap) {
-                    keys_b[pos] = flmr_make_key(miss_score, pid);
-                }
+                const int rank = hpos + __popc(hcw & ((1u << bit) - 1u));
+                const int slot = rank - win0;
+                if (slot >= 0 && slot < nslot && kbase + rank < a.cand_cap)
+                    keys_b[kbase + rank] = flmr_make_key(__int_as_float(acc[slot * S1S_STRIDE + 32]), pid0 + tid * 32 + bit);
             }
         }
         s1s_sync();
@@ -553,7 +547,7 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     mc.s = mc.e; mc.e = mc_e2;
     mq.s = mq.e; mq.e = mq_e2;
     gc = gcn; gq = gqn;
-    if (!(scatter && cnt > 0)) s1s_sync();  // bitmaps / bases / accumulators are reused (the window loop ends with a barrier)
+    if (!(scatter && nh > 0)) s1s_sync();  // bitmaps / bases / accumulators are reused (the window loop ends with a barrier)
     S1S_STAMP(9);
     }
 #ifdef S1S_PROFILE
@@ -569,12 +563,48 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
 __global__ __launch_bounds__(1024) void cand_emit_kernel(const uint32_t* cand_bits, const uint32_t* hit_bits, int64_t words,
                                                          const int32_t* chunk_cnt, int nchunks, int32_t* cand, int64_t cand_cap,
                                                          uint8_t* cand_hit, int32_t* cand_count, int32_t* overflow,
-                                                         const int32_t* skip, const int32_t* key_count) {
+                                                         const int32_t* skip, const int32_t* key_count, const int32_t* chunk_hits,
+                                                         uint64_t* keys, const int32_t* q_lens, int nq_cand, int n_select) {
     __shared__ int scan_lds[17];
     __shared__ int base_lds;
     const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
-    if (skip && skip[b]) {  // stage 1 of this query was done by scatter: nobody reads the ascending list (taps rebuild it)
-        if (ch == 0 && tid == 0) cand_count[b] = (int32_t)(key_count[b] < cand_cap ? key_count[b] : cand_cap);
+    if (skip && skip[b]) {
+        // Stage 1 of this query was done by scatter: nobody reads the ascending list (taps rebuild it), and the keys of its
+        // key_count[b] hit candidates are in place.  The other candidates all score the all-miss constant, below every hit:
+        // they only matter when the selection keeps more than there are hits (or the query is empty and everything ties) --
+        // then they are appended here, chunk by chunk at deterministic positions.
+        const int nhit = key_count[b];
+        const int qlen = q_lens ? q_lens[b] : nq_cand;
+        const int nqc = qlen < nq_cand ? qlen : nq_cand;
+        if (nhit >= n_select && nqc > 0) {
+            if (ch == 0 && tid == 0) cand_count[b] = (int32_t)(nhit < cand_cap ? nhit : cand_cap);
+            return;
+        }
+        if (tid == 0) base_lds = 0;
+        __syncthreads();
+        int part = 0;
+        for (int c = tid; c < ch; c += 1024) part += chunk_cnt[(size_t)b * nchunks + c] - chunk_hits[(size_t)b * nchunks + c];
+        if (part) atomicAdd(&base_lds, part);
+        __syncthreads();
+        const int64_t gw = (int64_t)ch * CAND_CHUNK_WORDS + tid;
+        uint32_t bits = 0;
+        if (gw < words) bits = cand_bits[(size_t)b * words + gw] & ~hit_bits[(size_t)b * words + gw];
+        int total;
+        int64_t pos = (int64_t)nhit + base_lds + flmr_block_exclusive_scan(__popc(bits), scan_lds, &total);
+        float miss_score = 0.0f;
+        for (int q = 0; q < nqc; q++) miss_score += -9999.0f;
+        uint64_t* kb = keys + (size_t)b * cand_cap;
+        while (bits) {
+            const int bit = __ffs(bits) - 1;
+            bits &= bits - 1;
+            if (pos < cand_cap) kb[pos] = flmr_make_key(miss_score, (int32_t)(gw * 32 + bit));
+            pos++;
+        }
+        if (ch == nchunks - 1 && tid == 0) {
+            int64_t n = (int64_t)nhit + base_lds + total;
+            if (n > cand_cap) { atomicExch(overflow, 1); n = cand_cap; }
+            cand_count[b] = (int32_t)n;
+        }
         return;
     }
     if (tid == 0) base_lds = 0;
@@ -635,7 +665,7 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
     }
     hipLaunchKernelGGL(cand_emit_kernel, dim3(a.nqueries, a.nchunks), dim3(1024), 0, st, a.cand_bits, a.hit_bits, a.words,
                        a.chunk_cnt, a.nchunks, a.cand, a.cand_cap, a.cand_hit, a.cand_count, a.overflow,
-                       a.scatter ? a.hit_valid : nullptr, a.key_count);
+                       a.scatter ? a.hit_valid : nullptr, a.key_count, a.chunk_hits, a.keys, a.q_lens, a.nq_cand, a.n_select);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }
@@ -643,7 +673,8 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
 // the ascending candidate lists of every query of the last batch (FLMR_TAP_CANDIDATES after a scatter-mode search)
 int flmr_launch_cand_emit_all(const flmr_cand_args& a, hipStream_t st) {
     hipLaunchKernelGGL(cand_emit_kernel, dim3(a.nqueries, a.nchunks), dim3(1024), 0, st, a.cand_bits, a.hit_bits, a.words,
-                       a.chunk_cnt, a.nchunks, a.cand, a.cand_cap, a.cand_hit, a.cand_count, a.overflow, nullptr, nullptr);
+                       a.chunk_cnt, a.nchunks, a.cand, a.cand_cap, a.cand_hit, a.cand_count, a.overflow, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, 0, 0);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }

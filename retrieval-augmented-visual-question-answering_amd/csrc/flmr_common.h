@@ -190,6 +190,8 @@ struct flmr_cand_args {
     int32_t scatter;                 // 0: bitmaps only (stage 1 = filter_stage1_kernel for every query)
     const float* cs; int64_t cs_query_stride; int32_t nq_cand; const int32_t* q_lens;
     uint64_t* keys; int32_t* key_count;   // [nqueries, cand_cap] unordered stage-1 keys, [nqueries] running count
+    int32_t* chunk_hits;                  // [nqueries, nchunks] candidates of the chunk that are in the hit set (scatter mode)
+    int32_t n_select;                     // how many keys the selection after stage 1 keeps (ndocs)
 };
 int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st);
 int flmr_launch_cand_emit_all(const flmr_cand_args& a, hipStream_t st);

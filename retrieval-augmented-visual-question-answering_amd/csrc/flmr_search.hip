@@ -28,7 +28,7 @@ struct flmr_searcher {
     int32_t* q_lens_ws;         // [max_queries] query lengths clamped to [0, nq]: what every kernel reads
     flmr_options opt;           // variant switches, snapshot taken at flmr_searcher_create
     _Float16* q_hi; _Float16* q_lo;
-    uint32_t* hit_bits; int32_t* hit_valid; int32_t* key_count;
+    uint32_t* hit_bits; int32_t* hit_valid; int32_t* key_count; int32_t* chunk_hits;
     int32_t* s1_slot; int32_t* s2_slot;   // sharded protocol: position of each local survivor / finalist in the global list
     float* s2_part;             // XCD-sliced stage 2: per (query, slice, survivor) column maxima (NULL when the index has no split table)
     _Float16* q3_hi; _Float16* q3_lo;
@@ -131,6 +131,7 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     WS(qual, B * (size_t)s->qmax);
     WS(nqual, B);
     WS(chunk_cnt, B * (size_t)ix->nchunks);
+    WS(chunk_hits, B * (size_t)ix->nchunks);
     WS(cand_hit, B * (size_t)s->cand_cap);
     WS(q3_hi, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
     WS(q3_lo, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
@@ -149,7 +150,7 @@ extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
     if (!s) return FLMR_OK;
     void* ptrs[] = {s->cs, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
                     s->keys1, s->s1_pids, s->s1_count, s->keys2, s->s2_pids, s->s2_count, s->keys3, s->doc_scores,
-                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part};
+                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->chunk_hits, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part};
     for (void* p : ptrs) (void)hipFree(p);
     if (s->status_host) (void)hipHostFree(s->status_host);
     if (s->status_ev) (void)hipEventDestroy(s->status_ev);
@@ -386,7 +387,7 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
         scatter = use_hits && c.ncol == 32 && !s->opt.is(FLMR_OPT_S1_IMPL, "scan");
         ca.scatter = scatter ? 1 : 0;
         ca.cs = s->cs; ca.cs_query_stride = c.f.cs_query_stride; ca.nq_cand = c.nqc; ca.q_lens = c.q_lens;
-        ca.keys = s->keys1; ca.key_count = s->key_count;
+        ca.keys = s->keys1; ca.key_count = s->key_count; ca.chunk_hits = s->chunk_hits; ca.n_select = c.p.ndocs;
         RUN(flmr_launch_candidates_chunked(ca, st));
         s->last_ca = ca; s->last_scatter = scatter;
         RUN(mark(c));

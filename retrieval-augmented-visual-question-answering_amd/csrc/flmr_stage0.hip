@@ -916,14 +916,17 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
     }
     __syncthreads();
     // ascending sort of <= 1024 ids (INT_MAX padded) + unique; two elements per thread
+    // (only the first nqc * ncells slots can hold an id: the network is sized for those, not for all 1024)
     constexpr int NT = 64 * SC_WAVES;
-    for (int k = 2; k <= 1024; k <<= 1) {
+    int nsort = 64;
+    while (nsort < nqc * a.ncells) nsort <<= 1;
+    for (int k = 2; k <= nsort; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
 #pragma unroll
             for (int u = 0; u < 1024 / NT; u++) {
                 const int t = tid + u * NT;
                 const int p = t ^ j;
-                if (p > t) {
+                if (p > t && p < nsort) {
                     const int x = raw[t], y = raw[p];
                     const bool asc = ((t & k) == 0);
                     if (asc ? (x > y) : (x < y)) { raw[t] = y; raw[p] = x; }

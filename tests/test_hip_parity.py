@@ -662,7 +662,7 @@ def test_stage1_scatter_equals_code_scan(hip, nbits, doclen, K, npass, policy):
     from ravqa_amd.scorer import IndexScorer
     corpus = synth.make_corpus(npass, doclen, K, nbits, seed=31, device="cuda")
     Q, _ = synth.make_queries(corpus, 9, 32, seed=4)
-    q_lens = torch.tensor([32, 32, 20, 32, 1, 32, 32, 7, 32], dtype=torch.int32)
+    q_lens = torch.tensor([32, 32, 20, 32, 1, 32, 0, 7, 32], dtype=torch.int32)   # incl. an empty query (every stage-1 score ties)
     scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=16)
     ncells, thr, ndocs = policy
     outs = {}
