@@ -265,7 +265,7 @@ def main():
                     pmc[row["kernel"]] = row
         except Exception:
             pass
-        kname = {"s0_centroid_scores": "s0_centroid_scores_f16", "s3_maxsim": "maxsim_f16_kernel",
+        kname = {"s0_centroid_scores": "s0_centroid_scores", "s3_maxsim": "maxsim_f16_kernel",
                  "s2_filter_sort": "filter_stage2", "s0_candidates": "cand_mark_score_kernel"}
 
         def roof_of(stage):
@@ -279,7 +279,9 @@ def main():
                 r["mfma_frac"] = r["TFLOPs"] / F16_MFMA_PEAK_TFLOPS
             for kn, row in pmc.items():
                 if stage in kname and kname[stage] in kn and args.passages == 1_000_000 and world == 1 and args.nbits == 2:
-                    r["traffic"] = (2.0 * float(row["FETCH_SIZE"]) + float(row["WRITE_SIZE"])) * 1024.0
+                    # the summary holds bytes per kernel LAUNCH; a step launches each kernel once per sub-batch
+                    nsub = -(-args.batch // min(args.batch, args.sub_batch))
+                    r["traffic"] = (2.0 * float(row["FETCH_SIZE"]) + float(row["WRITE_SIZE"])) * 1024.0 * nsub
             return r
 
         per_kernel = [roof_of(sname) for sname in sorted(stage_ms, key=stage_ms.get, reverse=True) if stage_ms[sname] > 0.05]
@@ -292,7 +294,7 @@ def main():
                 "peak": F16_MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
                 "frac": dom["mfma_frac"] if mfma_bound else dom["hbm_frac"], "traffic": dom.get("traffic"),
                 "traffic_source": ("static: profiles/r02_pmc_summary.csv (rocprofv3 --pmc of this workload, 2*FETCH_SIZE + "
-                                   "WRITE_SIZE, bytes per launch; not measured in this run)") if dom.get("traffic") else None,
+                                   "WRITE_SIZE, bytes per launch x launches per step; not measured in this run)") if dom.get("traffic") else None,
                 "launch_ms": dom["launch_ms"],
                 "note": ("achieved = the kernel's own compulsory bytes (or split-MFMA flops) per step / its HIP-event time per step "
                          "(summed over the step's sub-batches; events recorded on the launch stream in a second pass of the "
