@@ -784,6 +784,12 @@ int flmr_launch_centroid_scores(flmr_s0_args& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // S0b: merge block partials -> per-token top-ncells -> unique cells.  grid = nqueries, block = 1024.
 // ------------------------------------------------------------------------------------------------
+#ifdef SC_PROFILE   // development only: clocks of wave 0 per phase, summed over the grid, printed by the launcher
+__device__ unsigned long long sc_prof[8];
+#define SC_STAMP(k) do { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); pt[k] += now_ - plast; plast = now_; } while (0)
+#else
+#define SC_STAMP(k) do { } while (0)
+#endif
 #define SC_WAVES 8  // 512 threads: the MFMA recompute needs ~190 VGPRs (B 64 + A 64 + accumulators 32 + lists)
 template <int NC>
 __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a) {
@@ -792,6 +798,10 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qlen = a.q_lens ? a.q_lens[b] : a.nq;
     const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;
+#ifdef SC_PROFILE
+    long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long plast = (long long)__builtin_amdgcn_s_memtime();
+#endif
     raw[tid] = 0x7fffffff; raw[tid + 64 * SC_WAVES] = 0x7fffffff;
     // block-maxima partials with a single column tile: every wave scans a slice of the rows for ALL 32 columns with
     // 128-byte coalesced reads (lane = (row parity, column)) and leaves its per-column top-NC blocks in LDS; the per-column
@@ -800,26 +810,39 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
     __shared__ int pre_i[SC_WAVES][32][NC];
     const bool pre = a.part_rows != 0 && a.ncol == 32;
     if (pre) {
-        flmr_toplist<NC> bt;
-        bt.init();
-        // 8 loads in flight per lane: one workgroup per query means one per CU, so a load -> insert chain per row would
-        // expose the full memory latency 64 times per wave
-        constexpr int RS = 2 * SC_WAVES;  // rows per sweep of the workgroup
-        for (int e0 = wave * 2 + (lane >> 5); e0 < a.nblk; e0 += RS * 8) {
-            float pv[8];
+        // 16-byte loads: lane = (row phase lane >> 3, four columns 4 * (lane & 7)), eight of them in flight per lane -- one
+        // workgroup per query means one per CU, so the scan is a chain of exposed memory round trips: 4 of them for the
+        // 2048 block rows of K = 131072 (it was 16 with 4-byte loads)
+        flmr_toplist<NC> bt[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) bt[c].init();
+        constexpr int RS = 8 * SC_WAVES;  // rows per sweep of the workgroup
+        const int cg = lane & 7;
+        for (int e0 = wave * 8 + (lane >> 3); e0 < a.nblk; e0 += RS * 8) {
+            float4 pv[8];
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                pv[u] = (e0 + RS * u < a.nblk) ? a.part_val[((size_t)b * a.nblk + e0 + RS * u) * 32 + (lane & 31)] : FLMR_NEG_INF;
+                pv[u] = (e0 + RS * u < a.nblk)
+                            ? *reinterpret_cast<const float4*>(a.part_val + ((size_t)b * a.nblk + e0 + RS * u) * 32 + 4 * cg)
+                            : make_float4(FLMR_NEG_INF, FLMR_NEG_INF, FLMR_NEG_INF, FLMR_NEG_INF);
 #pragma unroll
-            for (int u = 0; u < 8; u++) bt.insert(pv[u], (e0 + RS * u < a.nblk) ? e0 + RS * u : 0x7fffffff);
+            for (int u = 0; u < 8; u++) {   // a lane meets its rows in ascending order
+                const int e = (e0 + RS * u < a.nblk) ? e0 + RS * u : 0x7fffffff;
+                bt[0].insert_ascending(pv[u].x, e); bt[1].insert_ascending(pv[u].y, e);
+                bt[2].insert_ascending(pv[u].z, e); bt[3].insert_ascending(pv[u].w, e);
+            }
         }
-        bt.merge_xor(32);
-        if (lane < 32) {
 #pragma unroll
-            for (int t = 0; t < NC; t++) { pre_v[wave][lane][t] = bt.v[t]; pre_i[wave][lane][t] = bt.id[t]; }
+        for (int c = 0; c < 4; c++) {
+            bt[c].merge_xor(8); bt[c].merge_xor(16); bt[c].merge_xor(32);
+            if (lane < 8) {
+#pragma unroll
+                for (int t = 0; t < NC; t++) { pre_v[wave][4 * cg + c][t] = bt[c].v[t]; pre_i[wave][4 * cg + c][t] = bt[c].id[t]; }
+            }
         }
     }
     __syncthreads();
+    SC_STAMP(0);
     for (int col = wave; col < nqc; col += SC_WAVES) {
         flmr_toplist<NC> tl;
         tl.init();
@@ -914,7 +937,9 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
                 if (t < a.ncells && tl.id[t] < a.K) raw[col * a.ncells + t] = tl.id[t];
         }
     }
+    SC_STAMP(1);
     __syncthreads();
+    SC_STAMP(2);
     // ascending sort of <= 1024 ids (INT_MAX padded) + unique; two elements per thread
     // (only the first nqc * ncells slots can hold an id: the network is sized for those, not for all 1024)
     constexpr int NT = 64 * SC_WAVES;
@@ -935,6 +960,7 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
             __syncthreads();
         }
     }
+    SC_STAMP(3);
     int vv[1024 / NT], flag[1024 / NT], cnt = 0;
 #pragma unroll
     for (int u = 0; u < 1024 / NT; u++) {  // thread t owns the consecutive elements t*2, t*2+1 so that ranks stay ordered
@@ -949,6 +975,13 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
     for (int u = 0; u < 1024 / NT; u++)
         if (flag[u]) a.cells[(size_t)b * a.max_cells + pos++] = vv[u];
     if (tid == 0) a.ncell[b] = total;
+    SC_STAMP(4);
+#ifdef SC_PROFILE
+    if (tid == 0) {
+        for (int i = 0; i < 5; i++) atomicAdd(&sc_prof[i], (unsigned long long)pt[i]);
+        atomicAdd(&sc_prof[7], 1ull);
+    }
+#endif
 }
 
 int flmr_launch_select_cells(const flmr_s0_args& a, hipStream_t st) {
@@ -959,6 +992,17 @@ int flmr_launch_select_cells(const flmr_s0_args& a, hipStream_t st) {
         case 4: hipLaunchKernelGGL(s0_select_cells<4>, dim3(a.nqueries), dim3(64 * SC_WAVES), 0, st, a); break;
         default: hipLaunchKernelGGL(s0_select_cells<8>, dim3(a.nqueries), dim3(64 * SC_WAVES), 0, st, a); break;
     }
+#ifdef SC_PROFILE
+    {
+        unsigned long long h[8];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(sc_prof), sizeof(h));
+        fprintf(stderr, "[sc] blocks %llu; clocks per block: scan %.0f columns %.0f barrier %.0f sort %.0f unique+write %.0f\n", h[7],
+                (double)h[0] / h[7], (double)h[1] / h[7], (double)h[2] / h[7], (double)h[3] / h[7], (double)h[4] / h[7]);
+        unsigned long long z[8] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(sc_prof), z, sizeof(z));
+    }
+#endif
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }
