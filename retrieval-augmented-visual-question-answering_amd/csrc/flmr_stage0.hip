@@ -809,24 +809,39 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
     __shared__ float pre_v[SC_WAVES][32][NC];
     __shared__ int pre_i[SC_WAVES][32][NC];
     const bool pre = a.part_rows != 0 && a.ncol == 32;
+    // The pipelined recompute below (sparse table, one column tile, fp16 centroid copy): the queries' hi / lo B fragments of
+    // all 32 columns sit in LDS in fragment order [hi|lo][k-step][lane] (read just in time, 16 bytes per lane, conflict-free),
+    // which leaves the registers for TWO selected blocks' A rows in flight
+    const bool piped = pre && !a.full_table && a.centroids_f16 != nullptr && a.part_rows == 32 * S0_RT;
+    __shared__ f16x8 bfrag[2][8][64];
+    __shared__ int sel[SC_WAVES][4 * NC];   // this wave's (column slot << 24 | block) tasks, valid ones first
+    if (piped) {
+        for (int e = tid; e < 2 * 8 * 64; e += 64 * SC_WAVES) {
+            const int hl = e >> 9, st = (e >> 6) & 7, ln = e & 63;
+            const _Float16* src = (hl ? a.q_lo : a.q_hi) + ((size_t)b * a.ncol + (ln & 31)) * FLMR_DIM + 64 * (ln >> 5) + 8 * st;
+            bfrag[hl][st][ln] = *reinterpret_cast<const f16x8*>(src);
+        }
+    }
     if (pre) {
-        // 16-byte loads: lane = (row phase lane >> 3, four columns 4 * (lane & 7)), eight of them in flight per lane -- one
-        // workgroup per query means one per CU, so the scan is a chain of exposed memory round trips: 4 of them for the
-        // 2048 block rows of K = 131072 (it was 16 with 4-byte loads)
+        if constexpr (NC <= 2) {
+        // 16-byte loads: lane = (row phase lane >> 3, four columns 4 * (lane & 7)), eight in flight per lane.  The scan
+        // moves 256 KB per query and measures ~4 TB/s over the chip at 256 queries whatever the depth (8 or 32 in flight,
+        // 4- or 16-byte loads): it is bandwidth-bound -- fewer block maxima per query would have to come from S0
         flmr_toplist<NC> bt[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) bt[c].init();
         constexpr int RS = 8 * SC_WAVES;  // rows per sweep of the workgroup
+        constexpr int SCAN_U = 8;         // loads in flight per lane
         const int cg = lane & 7;
-        for (int e0 = wave * 8 + (lane >> 3); e0 < a.nblk; e0 += RS * 8) {
-            float4 pv[8];
+        for (int e0 = wave * 8 + (lane >> 3); e0 < a.nblk; e0 += RS * SCAN_U) {
+            float4 pv[SCAN_U];
 #pragma unroll
-            for (int u = 0; u < 8; u++)
+            for (int u = 0; u < SCAN_U; u++)
                 pv[u] = (e0 + RS * u < a.nblk)
                             ? *reinterpret_cast<const float4*>(a.part_val + ((size_t)b * a.nblk + e0 + RS * u) * 32 + 4 * cg)
                             : make_float4(FLMR_NEG_INF, FLMR_NEG_INF, FLMR_NEG_INF, FLMR_NEG_INF);
 #pragma unroll
-            for (int u = 0; u < 8; u++) {   // a lane meets its rows in ascending order
+            for (int u = 0; u < SCAN_U; u++) {   // a lane meets its rows in ascending order
                 const int e = (e0 + RS * u < a.nblk) ? e0 + RS * u : 0x7fffffff;
                 bt[0].insert_ascending(pv[u].x, e); bt[1].insert_ascending(pv[u].y, e);
                 bt[2].insert_ascending(pv[u].z, e); bt[3].insert_ascending(pv[u].w, e);
@@ -840,9 +855,120 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
                 for (int t = 0; t < NC; t++) { pre_v[wave][4 * cg + c][t] = bt[c].v[t]; pre_i[wave][4 * cg + c][t] = bt[c].id[t]; }
             }
         }
+        } else {   // longer lists: one column per lane (four lists of NC entries per lane do not fit the registers)
+        flmr_toplist<NC> bt;
+        bt.init();
+        // 8 loads in flight per lane: one workgroup per query means one per CU, so a load -> insert chain per row would
+        // expose the full memory latency 64 times per wave
+        constexpr int RS = 2 * SC_WAVES;  // rows per sweep of the workgroup
+        for (int e0 = wave * 2 + (lane >> 5); e0 < a.nblk; e0 += RS * 8) {
+            float pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                pv[u] = (e0 + RS * u < a.nblk) ? a.part_val[((size_t)b * a.nblk + e0 + RS * u) * 32 + (lane & 31)] : FLMR_NEG_INF;
+#pragma unroll
+            for (int u = 0; u < 8; u++) bt.insert(pv[u], (e0 + RS * u < a.nblk) ? e0 + RS * u : 0x7fffffff);
+        }
+        bt.merge_xor(32);
+        if (lane < 32) {
+#pragma unroll
+            for (int t = 0; t < NC; t++) { pre_v[wave][lane][t] = bt.v[t]; pre_i[wave][lane][t] = bt.id[t]; }
+        }
+        }
     }
     __syncthreads();
     SC_STAMP(0);
+    if (piped) {
+        // ---- which blocks: the top-NC block maxima of each of this wave's columns (wave-uniform lists), as a task list ----
+        int ntasks = 0;
+        for (int k = 0; wave + SC_WAVES * k < nqc; k++) {
+            const int col = wave + SC_WAVES * k;
+            flmr_toplist<NC> bt;
+            bt.init();
+            for (int e = lane; e < SC_WAVES * NC; e += 64) bt.insert(pre_v[e / NC][col][e % NC], pre_i[e / NC][col][e % NC]);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) bt.merge_xor(m);
+#pragma unroll
+            for (int t = 0; t < NC; t++) {
+                const int id = __builtin_amdgcn_readfirstlane(bt.id[t]);
+                if (t < a.ncells && id < a.nblk) {   // wave-uniform
+                    if (lane == 0) sel[wave][ntasks] = (k << 24) | id;
+                    ntasks++;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- the tasks, software-pipelined: the next block's 64 rows (16 KB, 64 VGPRs per lane) are requested before the
+        // current block is multiplied, so that after the first one no memory round trip (~4 us here: one workgroup per
+        // CU, nothing else to switch to) is exposed.  Same MFMA sequence as s0_centroid_scores_f16 / _qs: bitwise the S0
+        // values (an output element depends only on its A row and B column). ----
+        const int i = lane & 31, h = lane >> 5;
+        auto issue = [&](f16x8 (&av)[S0_RT][8], int m) __attribute__((always_inline)) {
+            const int r0 = (sel[wave][m] & 0xffffff) * a.part_rows;
+#pragma unroll
+            for (int rt = 0; rt < S0_RT; rt++) {
+                const f16x8* p16 = reinterpret_cast<const f16x8*>(a.centroids_f16 + (size_t)(r0 + rt * 32 + i) * FLMR_DIM + 64 * h);
+#pragma unroll
+                for (int st = 0; st < 8; st++) av[rt][st] = p16[st];
+            }
+        };
+        flmr_toplist<NC> tl;
+        tl.init();
+        int cur_k = -1;
+        auto finish = [&]() __attribute__((always_inline)) {   // column done: exact top-NC over the wave, ids to the cell list
+            if (cur_k < 0) return;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) tl.merge_xor(m);
+            const int col = wave + SC_WAVES * cur_k;
+            if (lane == 0) {
+#pragma unroll
+                for (int t = 0; t < NC; t++)
+                    if (t < a.ncells && tl.id[t] < a.K) raw[col * a.ncells + t] = tl.id[t];
+            }
+            tl.init();
+        };
+        auto compute = [&](const f16x8 (&av)[S0_RT][8], int m) __attribute__((always_inline)) {
+            const int ent = sel[wave][m];
+            const int k = __builtin_amdgcn_readfirstlane(ent >> 24);
+            if (k != cur_k) { finish(); cur_k = k; }
+            const int col = wave + SC_WAVES * k;
+            const int r0 = (ent & 0xffffff) * a.part_rows;
+            const bool mine = i == (col & 31);
+#pragma unroll
+            for (int rt = 0; rt < S0_RT; rt++) {
+                f32x16 ah, al;
+#pragma unroll
+                for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
+                // B fragments one k-step ahead of their MFMAs and no further (the fence keeps the scheduler from hoisting all 16
+                // reads -- 64 VGPRs -- above the first MFMA, which would spill the second block's rows)
+                f16x8 nbh = bfrag[0][0][lane], nbl = bfrag[1][0][lane];
+#pragma unroll
+                for (int st = 0; st < 8; st++) {
+                    const f16x8 bh = nbh, bl = nbl;
+                    if (st + 1 < 8) { nbh = bfrag[0][st + 1][lane]; nbl = bfrag[1][st + 1][lane]; }
+                    ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[rt][st], bh, ah, 0, 0, 0);
+                    al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[rt][st], bl, al, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float v = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+                    const int row = r0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    tl.insert(mine ? v : FLMR_NEG_INF, mine ? row : 0x7fffffff);
+                }
+            }
+        };
+        f16x8 avA[S0_RT][8], avB[S0_RT][8];
+        if (ntasks > 0) issue(avA, 0);
+        for (int m = 0; m < ntasks; m += 2) {
+            if (m + 1 < ntasks) issue(avB, m + 1);
+            compute(avA, m);
+            if (m + 2 < ntasks) issue(avA, m + 2);
+            if (m + 1 < ntasks) compute(avB, m + 1);
+        }
+        finish();
+    } else
     for (int col = wave; col < nqc; col += SC_WAVES) {
         flmr_toplist<NC> tl;
         tl.init();
