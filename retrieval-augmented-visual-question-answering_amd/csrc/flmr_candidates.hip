@@ -235,6 +235,7 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     int* acc = reinterpret_cast<int*>(hbase + CAND_CHUNK_WORDS);        // [S1S_SLOTS][S1S_STRIDE] (+ 96 scratch words)
     float* rsum = reinterpret_cast<float*>(acc + S1S_SLOTS * S1S_STRIDE + 96);   // [1024] stage-1 score of a passage whose only surviving centroid is list j
     int* queue = reinterpret_cast<int*>(rsum + 1024);                  // [S1S_QCAP] slot << S1S_IDBITS | list
+    uint16_t* qpid = reinterpret_cast<uint16_t*>(queue + S1S_QCAP);    // [S1S_QCAP] the queued pair's passage (inside the chunk)
     __shared__ int scan_lds[S1S_WAVES];
     __shared__ int s_base, s_qn;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -434,7 +435,11 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
                     const int at = atomicAdd(&s_qn, n);
                     if (at + n <= S1S_QCAP) {
                         queue[at] = (slot << S1S_IDBITS) | j;
-                        if (before == 1) queue[at + 1] = (slot << S1S_IDBITS) | (old & ((1 << S1S_IDBITS) - 1));
+                        qpid[at] = (uint16_t)pid;
+                        if (before == 1) {
+                            queue[at + 1] = (slot << S1S_IDBITS) | (old & ((1 << S1S_IDBITS) - 1));
+                            qpid[at + 1] = (uint16_t)pid;
+                        }
                     }
                 }
             }
@@ -459,6 +464,7 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
             count_group(gt, bg, j0);
             S1S_DRAIN();
         }
+        if (tid == 0 && win0 == 0) s_base = my_base;   // the chunk's key base: the atomic issued before the counting pass
         s1s_sync();
         S1S_STAMP(6);
         const int qn = s_qn;
@@ -504,29 +510,28 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
             S1S_DRAIN();
             s1s_sync();
         }
-        // (d) per-slot score, one thread per slot, kept in the row's padding word: the list's constant for a passage with
-        // one surviving centroid, else the ascending-k sum of the column maxima (filter_pids.cpp:59-63)
-        for (int sl = tid; sl < nslot; sl += 64 * S1S_WAVES) {
-            const int info = acc[sl * S1S_STRIDE + 32];
+        // ascending-k sum of a slot's column maxima (filter_pids.cpp:59-63)
+        auto column_sum = [&](int sl) {
             float sc = 0.0f;
-            if (!dense && (info >> S1S_IDBITS) == 1) {
-                sc = rsum[info & ((1 << S1S_IDBITS) - 1)];
-            } else {
 #pragma unroll
-                for (int q0 = 0; q0 < 32; q0 += 8) {   // eight LDS reads in flight at a time (registers are scarce here)
-                    float v[8];
+            for (int q0 = 0; q0 < 32; q0 += 8) {   // eight LDS reads in flight at a time (registers are scarce here)
+                float v[8];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) v[q] = s1s_dec(acc[sl * S1S_STRIDE + q0 + q]);
+                for (int q = 0; q < 8; q++) v[q] = s1s_dec(acc[sl * S1S_STRIDE + q0 + q]);
 #pragma unroll
-                    for (int q = 0; q < 8; q++) sc += q0 + q < nqc ? v[q] : 0.0f;
-                }
+                for (int q = 0; q < 8; q++) sc += q0 + q < nqc ? v[q] : 0.0f;
             }
-            acc[sl * S1S_STRIDE + 32] = __float_as_int(sc);
+            return sc;
+        };
+        if (dense) {   // every slot holds a row: scores into the padding words, one thread per slot
+            for (int sl = tid; sl < nslot; sl += 64 * S1S_WAVES) acc[sl * S1S_STRIDE + 32] = __float_as_int(column_sum(sl));
+            s1s_sync();
         }
-        if (tid == 0 && win0 == 0) s_base = my_base;
-        s1s_sync();
         S1S_STAMP(7);
-        // one thread per bitmap word: keys of its hit candidates in this window, at the chunk's base + rank among the hits
+        // (d) keys at the chunk's base + rank among the hits.  One thread per bitmap word takes its hit candidates of this
+        // window: a passage with one surviving centroid scores its list's constant (two LDS reads); the multi-centroid ones
+        // are skipped here and written from the queue below, which knows slot and passage of each (a slot queued several
+        // times is written several times with the same key)
         {
             const int64_t kbase = s_base;
             uint32_t bits = hcw;
@@ -535,8 +540,18 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
                 bits &= bits - 1;
                 const int rank = hpos + __popc(hcw & ((1u << bit) - 1u));
                 const int slot = rank - win0;
-                if (slot >= 0 && slot < nslot && kbase + rank < a.cand_cap)
-                    keys_b[kbase + rank] = flmr_make_key(__int_as_float(acc[slot * S1S_STRIDE + 32]), pid0 + tid * 32 + bit);
+                if (slot >= 0 && slot < nslot && kbase + rank < a.cand_cap) {
+                    const int info = acc[slot * S1S_STRIDE + 32];
+                    if (dense) keys_b[kbase + rank] = flmr_make_key(__int_as_float(info), pid0 + tid * 32 + bit);
+                    else if ((info >> S1S_IDBITS) == 1) keys_b[kbase + rank] = flmr_make_key(rsum[info & ((1 << S1S_IDBITS) - 1)], pid0 + tid * 32 + bit);
+                }
+            }
+            if (!dense) {
+                for (int e = tid; e < qn; e += 64 * S1S_WAVES) {
+                    const int slot = queue[e] >> S1S_IDBITS;
+                    const int64_t pos = kbase + win0 + slot;
+                    if (pos < a.cand_cap) keys_b[pos] = flmr_make_key(column_sum(slot), pid0 + (int)qpid[e]);
+                }
             }
         }
         s1s_sync();
@@ -638,7 +653,7 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
                        a.ncell, a.max_cells, a.qual, a.nqual, a.qmax, a.hit_valid, a.scatter ? a.key_count : nullptr, a.scatter ? 8 : 2);
     if (a.scatter) {
         const size_t lds = (size_t)CAND_CHUNK_WORDS * (2 * sizeof(uint32_t) + 2 * sizeof(uint16_t)) +
-                           ((size_t)S1S_SLOTS * S1S_STRIDE + 96 + 1024 + S1S_QCAP) * sizeof(int);   // + scratch words of slot-less lanes, list constants, queue
+                           ((size_t)S1S_SLOTS * S1S_STRIDE + 96 + 1024 + S1S_QCAP) * sizeof(int) + S1S_QCAP * sizeof(uint16_t);   // + scratch words of slot-less lanes, list constants, queue (+ its passages)
         FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cand_mark_score_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // chunks per workgroup: as many as still leave two workgroups per CU (the per-workgroup set-up -- list ids, offsets,
