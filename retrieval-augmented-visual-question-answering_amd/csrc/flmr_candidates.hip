@@ -152,9 +152,12 @@ __global__ __launch_bounds__(256) void cand_mark_chunks_kernel(const int32_t* ce
 // the integer max is exact), and those slots sum their columns in ascending k.  A window whose queue overflows falls back
 // to the dense form (every pair folds its row).  Keys go to keys[b][base + rank] with base from a per-query atomic
 // counter: the top-ndocs selection is order-free.  More hits in a chunk than S1S_SLOTS are handled in windows of slots.
+// Only candidates in the hit set get a key here (rank among the hits); a passage with one surviving centroid is scored
+// inline in the key pass, the multi-centroid ones are written from the queue, which knows slot and passage of each.
 // (Measured with the per-phase clock probe -DS1S_PROFILE: the dense form spent 8.4 k of 27 k clocks per chunk in the 32
-// ds_max per pair and 3.3 k initialising accumulators; this form 22 k clocks per chunk, spread over ~8 barrier-separated
-// phases of 2-5 k each -- the workgroup's 16 waves are issue- and barrier-bound, not LDS- or HBM-bound.)
+// ds_max per pair and 3.3 k initialising accumulators; this form 21 k clocks per chunk, spread over seven
+// barrier-separated phases of 1.5-6 k each -- the workgroup's 16 waves are issue- and barrier-bound, not LDS- or
+// HBM-bound.)
 #define S1S_SLOTS 1088   // slots per window: with the bitmaps, list constants and queue this fills the CU's 160 KB of LDS
 #define S1S_STRIDE 33
 #define S1S_QCAP 512     // (slot, list) pairs of passages with more than one surviving centroid, per window
