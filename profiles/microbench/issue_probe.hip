@@ -23,8 +23,8 @@ __global__ __launch_bounds__(512) void probe(int iters, long long* out, float* s
     extern __shared__ char smem[];
     hf8 a, b;
     for (int k = 0; k < 8; k++) { a[k] = (_Float16)(threadIdx.x * 0.001f + k); b[k] = (_Float16)(k * 0.5f); }
-    f32x16 c0, c1;
-    for (int k = 0; k < 16; k++) { c0[k] = 0.0f; c1[k] = 0.0f; }
+    f32x16 c0, c1, c2;
+    for (int k = 0; k < 16; k++) { c0[k] = 0.0f; c1[k] = 0.0f; c2[k] = 0.0f; }
     float f[8];
     for (int k = 0; k < 8; k++) f[k] = (float)k;
     const float x = 1.0001f, y = 0.5f;
@@ -42,11 +42,16 @@ __global__ __launch_bounds__(512) void probe(int iters, long long* out, float* s
         if (MODE == 5) { for (int g = 0; g < 8; g++) { MFMA(c0); MFMA(c1); } for (int g = 0; g < 16; g++) { VALU8 } }
         if (MODE == 6) { for (int g = 0; g < 16; g++) { VALU8 } }
         if (MODE == 7) { for (int g = 0; g < 8; g++) { MFMA(c0); SALU4 MFMA(c1); SALU4 } }
+        // S3's 24 MFMAs per tile: hi chain + lo chain(s)
+        if (MODE == 9) { for (int g = 0; g < 8; g++) { MFMA(c0); MFMA(c1); MFMA(c1); } }            // as built: the two lo products back to back on ONE accumulator
+        if (MODE == 10) { for (int g = 0; g < 8; g++) { MFMA(c0); MFMA(c1); MFMA(c2); } }          // three accumulators
+        if (MODE == 11) { for (int g = 0; g < 8; g++) { MFMA(c1); MFMA(c0); MFMA(c1); } }           // one accumulator for lo, the hi product between its two
+        if (MODE == 12) { for (int g = 0; g < 24; g++) { MFMA(c0); } }                                 // one chain
         if (MODE == 8) { for (int g = 0; g < 8; g++) { MFMA(c0); VALU(f[0]); VALU(f[1]); MFMA(c1); VALU(f[2]); VALU(f[3]); } }
     }
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();
     if ((threadIdx.x & 63) == 0) out[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6))] = t1 - t0;
-    float s = 0; for (int k = 0; k < 16; k++) s += c0[k] + c1[k]; for (int k = 0; k < 8; k++) s += f[k];
+    float s = 0; for (int k = 0; k < 16; k++) s += c0[k] + c1[k] + c2[k]; for (int k = 0; k < 8; k++) s += f[k];
     if (s == 12345.678f) sink[0] = s + sc;
 }
 
@@ -54,8 +59,9 @@ int main() {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int ncu = prop.multiProcessorCount, iters = 2000;
     long long* out; float* sink; CK(hipMalloc(&out, ncu * 8 * 8)); CK(hipMalloc(&sink, 64));
-    const char* names[9] = {"mfma16", "valu64", "blocked: mfma16 then valu64", "interleaved: (mfma, valu4) x16", "interleaved: (mfma, valu8) x16",
-                            "blocked: mfma16 then valu128", "valu128", "interleaved: (mfma, salu4) x16", "interleaved: (mfma, valu2) x16"};
+    const char* names[13] = {"mfma16", "valu64", "blocked: mfma16 then valu64", "interleaved: (mfma, valu4) x16", "interleaved: (mfma, valu8) x16",
+                            "blocked: mfma16 then valu128", "valu128", "interleaved: (mfma, salu4) x16", "interleaved: (mfma, valu2) x16",
+                            "mfma24: (hi, lo, lo) x8, 2 accumulators", "mfma24: (hi, lo1, lo2) x8, 3 accumulators", "mfma24: (lo, hi, lo) x8, 2 accumulators", "mfma24: one chain"};
     for (int wps = 1; wps <= 2; wps++) {
         const size_t lds = wps == 1 ? 100 * 1024 : 60 * 1024;  // one / two 256-thread blocks per CU
         printf("%d wave(s) per SIMD\n", wps);
@@ -79,7 +85,7 @@ int main() {
             run512(probe<2, 0>, 2, "waves in step"); run512(probe<2, 6>, 2, "waves 4..7 start 384 cycles late");
             run512(probe<5, 0>, 5, "waves in step"); run512(probe<5, 10>, 5, "waves 4..7 start 640 cycles late");
         }
-        run(probe<0>, 0); run(probe<1>, 1); run(probe<2>, 2); run(probe<3>, 3); run(probe<8>, 8); run(probe<4>, 4); run(probe<5>, 5); run(probe<6>, 6); run(probe<7>, 7);
+        run(probe<0>, 0); run(probe<9>, 9); run(probe<10>, 10); run(probe<11>, 11); run(probe<12>, 12); run(probe<1>, 1); run(probe<2>, 2); run(probe<3>, 3); run(probe<8>, 8); run(probe<4>, 4); run(probe<5>, 5); run(probe<6>, 6); run(probe<7>, 7);
     }
     return 0;
 }
