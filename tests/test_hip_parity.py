@@ -652,6 +652,8 @@ def test_exhaustive_search_matches_torch_expression(hip):
     (2, (1, 200), 2048, 6000, (2, 0.45, 256)),
     (2, 64, 512, 70_000, (2, 0.3, 1024)),      # small K on a 3-chunk corpus: > 480 hit candidates per chunk -> several slot windows
     (4, (10, 90), 1024, 40_000, (4, 0.4, 4096)),
+    (2, (20, 120), 4096, 20_000, (1, 0.3, 256)),   # one cell per token, low threshold: surviving centroids that are NOT probed cells
+    (2, 128, 8192, 50_000, (2, 0.45, 8192)),       # more survivors wanted than there are hit candidates: the misses are appended
 ])
 def test_stage1_scatter_equals_code_scan(hip, nbits, doclen, K, npass, policy):
     """Stage 1 computed from the surviving centroids' IVF lists (cand_mark_score_kernel, default) must give exactly the keys
