@@ -316,6 +316,15 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
         rsum[wave + S1S_WAVES * lane] = sc;   // (read after the first chunk's barriers)
     }
 
+    // The chunk bitmaps and the slots' pair counters start at zero and are LEFT at zero by whoever reads them last (the
+    // bitmap words by their owner thread in the chunk's last key pass, a counter by the thread that turns it into a key),
+    // so a chunk has no initialisation phase of its own.
+    cb[tid] = 0u; hb[tid] = 0u;  // CAND_CHUNK_WORDS == blockDim.x
+    if (scatter) {
+        for (int sl = tid; sl < S1S_SLOTS; sl += 64 * S1S_WAVES) acc[sl * S1S_STRIDE + 32] = 0;
+        if (tid == 0) s_qn = 0;
+    }
+    s1s_sync();
     S1S_STAMP(0);
     for (int ch = ch0; ch < ch_end; ch++) {
     const int pid0 = ch * CAND_CHUNK_PIDS;
@@ -325,12 +334,6 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
         if (lane < mc.n) mc_e2 = a.chunk_tab[(size_t)mc.c * (a.nchunks + 1) + ch + 2];
         if (lane < mq.n) mq_e2 = a.chunk_tab[(size_t)mq.c * (a.nchunks + 1) + ch + 2];
     }
-    cb[tid] = 0u; hb[tid] = 0u;  // CAND_CHUNK_WORDS == blockDim.x
-    if (scatter) {   // first window's pair counters (the slots' padding words), see (a) below
-        for (int sl = tid; sl < S1S_SLOTS; sl += 64 * S1S_WAVES) acc[sl * S1S_STRIDE + 32] = 0;
-        if (tid == 0) s_qn = 0;
-    }
-    s1s_sync();
     S1S_STAMP(1);
     auto consume = [&](const grp& g, const begs& bg, uint32_t* dst) {
 #pragma unroll
@@ -406,12 +409,7 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     for (int win0 = 0; win0 < nh; win0 += S1S_SLOTS) {
         const int nslot = (nh - win0) < S1S_SLOTS ? (nh - win0) : S1S_SLOTS;
         // (a) the slot's padding word counts the (list, passage) pairs that land on it: count << S1S_IDBITS + sum of list
-        // ids (zeroed with the bitmaps for the first window)
-        if (win0 > 0) {
-            for (int sl = tid; sl < nslot; sl += 64 * S1S_WAVES) acc[sl * S1S_STRIDE + 32] = 0;
-            if (tid == 0) s_qn = 0;
-            s1s_sync();
-        }
+        // ids (zero on entry: see the note before the chunk loop)
         auto slot_of = [&](int pid) {
             int slot = -1;
             if (pid >= 0) {
@@ -543,12 +541,17 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
                 bits &= bits - 1;
                 const int rank = hpos + __popc(hcw & ((1u << bit) - 1u));
                 const int slot = rank - win0;
-                if (slot >= 0 && slot < nslot && kbase + rank < a.cand_cap) {
+                if (slot >= 0 && slot < nslot) {
                     const int info = acc[slot * S1S_STRIDE + 32];
-                    if (dense) keys_b[kbase + rank] = flmr_make_key(__int_as_float(info), pid0 + tid * 32 + bit);
-                    else if ((info >> S1S_IDBITS) == 1) keys_b[kbase + rank] = flmr_make_key(rsum[info & ((1 << S1S_IDBITS) - 1)], pid0 + tid * 32 + bit);
+                    acc[slot * S1S_STRIDE + 32] = 0;   // the counter's last reader leaves it ready for the next window / chunk
+                    if (kbase + rank < a.cand_cap) {
+                        if (dense) keys_b[kbase + rank] = flmr_make_key(__int_as_float(info), pid0 + tid * 32 + bit);
+                        else if ((info >> S1S_IDBITS) == 1) keys_b[kbase + rank] = flmr_make_key(rsum[info & ((1 << S1S_IDBITS) - 1)], pid0 + tid * 32 + bit);
+                    }
                 }
             }
+            if (tid == 0 && qn > 0) s_qn = 0;   // (qn > 0: a barrier lies between every thread's read of it and this pass)
+            if (win0 + S1S_SLOTS >= nh) { cb[tid] = 0u; hb[tid] = 0u; }   // last window: nobody reads the bitmaps any more
             if (!dense) {
                 for (int e = tid; e < qn; e += 64 * S1S_WAVES) {
                     const int slot = queue[e] >> S1S_IDBITS;
@@ -565,7 +568,10 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     mc.s = mc.e; mc.e = mc_e2;
     mq.s = mq.e; mq.e = mq_e2;
     gc = gcn; gq = gqn;
-    if (!(scatter && nh > 0)) s1s_sync();  // bitmaps / bases / accumulators are reused (the window loop ends with a barrier)
+    if (!(scatter && nh > 0)) {  // (the window loop ends with the bitmaps cleared and a barrier)
+        cb[tid] = 0u; hb[tid] = 0u;
+        s1s_sync();
+    }
     S1S_STAMP(9);
     }
 #ifdef S1S_PROFILE
