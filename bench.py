@@ -110,6 +110,9 @@ def tie_aware_same(ref_p, ref_s, got_p, gap=1e-5):
 
 
 def main():
+    if os.environ.get("BENCH_WATCHDOG"):   # debugging aid: dump every thread's stack after N seconds and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["BENCH_WATCHDOG"]), exit=True)
     args = parse()
     import torch
     import torch.distributed as dist

@@ -120,7 +120,7 @@ def _exact_worker(rank, world, port, out_path, query_split, use_q_lens):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,query_split,use_q_lens", [(2, True, False), (3, True, True), (2, False, True)])
+@pytest.mark.parametrize("world,query_split,use_q_lens", [(2, True, False), (3, True, True), (2, False, True), (4, True, True), (8, True, False)])
 def test_exact_protocol_multirank_equals_unsharded(tmp_path, world, query_split, use_q_lens):
     """ShardedSearcher.search_batch_exact over real gloo collectives (all_gather_into_tensor of the probe state and of the
     stage-1 keys, SUM all-reduce of the slot-aligned stage-2/3 keys): every rank ends with the ranking of the UNSHARDED
