@@ -63,7 +63,33 @@ def parse():
     ap.add_argument("--single-device-smoke", action="store_true",
                     help="debug only: run all ranks on cuda:0 with a gloo group and a host-staged gather (exercises the "
                          "sharding / merge code on a 1-GPU box; timings are meaningless)")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="N = 1 only: run the sharded protocol (one shard) with its collectives issued through RCCL anyway -- "
+                         "checks the torch.distributed / RCCL call path (dtypes, layouts) on a 1-GPU box")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (one per GPU,
+    127.0.0.1 rendezvous on a free port) and exit with their status.  Fewer than N visible devices is an ERROR, never a
+    silent 1-GPU run (only --single-device-smoke puts several ranks on one device)."""
+    import socket
+    import subprocess
+    if not args.single_device_smoke:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} HIP device(s) visible; refusing to run a smaller "
+                             f"job under that name (use --single-device-smoke to exercise the N-rank control flow on one GPU)\n")
+            sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def k_policy(k):
@@ -73,25 +99,6 @@ def k_policy(k):
 def num_centroids(n_tok):
     import math
     return 2 ** int(math.floor(math.log2(16.0 * math.sqrt(n_tok))))       # collection_indexer.py:93
-
-
-def shard_of(corpus, rank, world, synth, torch):
-    """Passage shard `rank` of `world` of a device-resident corpus: contiguous pid range, IVF restricted."""
-    P, K = corpus.doclens.numel(), corpus.K
-    lo, hi = (P * rank) // world, (P * (rank + 1)) // world
-    tlo, thi = int(corpus.doc_offsets[lo]), int(corpus.doc_offsets[hi])
-    keep = (corpus.ivf >= lo) & (corpus.ivf < hi)
-    owner = torch.repeat_interleave(torch.arange(K, device="cuda"), corpus.ivf_lengths)
-    sh = synth.SyntheticCorpus()
-    sh.dim, sh.nbits, sh.K, sh.sigma = corpus.dim, corpus.nbits, K, corpus.sigma
-    sh.centroids, sh.bucket_weights, sh.bucket_cutoffs = corpus.centroids, corpus.bucket_weights, corpus.bucket_cutoffs
-    sh.codes, sh.residuals = corpus.codes[tlo:thi].contiguous(), corpus.residuals[tlo:thi].contiguous()
-    sh.doclens = corpus.doclens[lo:hi].contiguous()
-    sh.doc_offsets = (corpus.doc_offsets[lo:hi + 1] - tlo).contiguous()
-    sh.ivf = (corpus.ivf[keep] - lo).to(torch.int32).contiguous()
-    sh.ivf_lengths = torch.bincount(owner[keep], minlength=K).long()
-    sh.ivf_offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), torch.cumsum(sh.ivf_lengths, 0)])
-    return sh, lo
 
 
 def tie_aware_same(ref_p, ref_s, got_p, gap=1e-5):
@@ -114,6 +121,8 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["BENCH_WATCHDOG"]), exit=True)
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)   # does not return
     import torch
     import torch.distributed as dist
     import ravqa_amd  # noqa: F401
@@ -123,11 +132,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)\n")
+        sys.exit(2)
+    if not args.single_device_smoke and torch.cuda.device_count() < world:
+        sys.stderr.write(f"bench.py: {world} ranks but only {torch.cuda.device_count()} HIP device(s) visible\n")
+        sys.exit(2)
+    if args.force_distributed and world != 1:
+        sys.stderr.write("bench.py: --force-distributed is an N = 1 check\n")
+        sys.exit(2)
     torch.cuda.set_device(0 if args.single_device_smoke else local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_distributed
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.single_device_smoke:
             dist.init_process_group("gloo")
         else:
@@ -139,7 +159,7 @@ def main():
     ncells, thr, ndocs = k_policy(k)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -148,31 +168,50 @@ def main():
         dist.all_gather(parts, t.cpu())
         return torch.stack(parts).cuda()
 
-    # ---- synthetic corpus, generated on the GPU, identical on every rank; then this rank's passage shard -----------
+    # ---- synthetic corpus, generated on the GPU: every rank builds ITS passage shard of the same corpus (the cheap global
+    # state -- centroids, doclens, one code per token -- is identical everywhere; noise, residual bytes and IVF are per shard)
     t0 = time.time()
-    corpus = synth.make_corpus(args.passages, doclen, K, args.nbits, seed=0, device="cuda")
+    lo_pid, hi_pid = synth.shard_range(args.passages, rank, world)
+
+    def build_local():
+        return synth.make_corpus(args.passages, doclen, K, args.nbits, seed=0, device="cuda",
+                                 pid_range=(lo_pid, hi_pid) if world > 1 else None)
+
+    if args.single_device_smoke and world > 1:
+        # all ranks share ONE device here: take turns, or eight processes' device-wide sorts starve each other
+        local = None
+        for r in range(world):
+            if r == rank:
+                local = build_local()
+                torch.cuda.synchronize()
+            dist.barrier()
+    else:
+        local = build_local()
+    corpus = local   # (queries are planted over the whole corpus: make_queries reads the global doclens / codes)
     nb = max(1, args.query_batches)
     Qs, tgts = [], []
     for j in range(nb):
         Qj, tj = synth.make_queries(corpus, args.batch, args.nq, seed=2 + j)
         Qs.append(Qj)
         tgts.append(tj)
-    local, pid_base = shard_of(corpus, rank, world, synth, torch) if world > 1 else (corpus, 0)
-    scorer = IndexScorer(device_index=synth.corpus_device_index(local, pid_base=pid_base), max_batch=min(args.batch, args.sub_batch),
+    scorer = IndexScorer(device_index=synth.corpus_device_index(local), max_batch=min(args.batch, args.sub_batch),
                          streams=args.streams)
     torch.cuda.synchronize()
     t_build = time.time() - t0
 
     from ravqa_amd.distributed import ShardedSearcher
-    sharded = ShardedSearcher(scorer=scorer) if world > 1 else None
-    exact = world > 1 and args.shard_mode == "exact"
+    sharded = ShardedSearcher(scorer=scorer) if use_dist else None
+    if sharded is not None:
+        sharded.force_collectives = args.force_distributed
+    exact = use_dist and args.shard_mode == "exact"
 
     def run_step(sc, Q, kk, pol, profile=False):
         if exact:
+            # check=False: no host sync / flag exchange inside the timed steps; check_all() runs after them
             return sharded.search_batch_exact(Q, kk, nq_cand=32, gather=host_gather if args.single_device_smoke else None,
-                                              split_stage0=not args.replicate_stage0)
+                                              split_stage0=not args.replicate_stage0, check=False)
         p, s, c = sc.search_batch(Q, kk, pol[0], pol[1], pol[2], 32, profile=profile)   # query_maxlen = 32 (index_storage.py:77)
-        if world > 1:
+        if use_dist:
             if args.single_device_smoke:
                 gs, gp = host_gather(s), host_gather(p)
             else:
@@ -196,11 +235,14 @@ def main():
         dt = time.perf_counter() - t0_
         if collect_stages:      # one read after the timed region: the library sums the event sets of all its calls
             stage_sum = sc.stage_ms()
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], device="cpu" if args.single_device_smoke else "cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        sc.check()
+        if exact:
+            sharded.check_all(host_gather if args.single_device_smoke else None)   # a failed shard raises on every rank
+        else:
+            sc.check()
         hits = [float((last[j][0][:, :5] == targets[j].unsqueeze(1).to(torch.int32)).any(dim=1).float().mean()) for j in last]
         return dt, {n: v / steps for n, v in stage_sum.items()}, sum(hits) / len(hits), last
 
@@ -346,7 +388,7 @@ def main():
                                        "un-timed steps): the rest of ms_per_step is per-rank compute")
 
     # ---- CPU baseline (rank 0, N=1 only): the reference's own C++ stages + torch-CPU glue, bounded samples ----------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_queries > 0:
+    if rank == 0 and not use_dist and not args.no_cpu_baseline and args.cpu_queries > 0:
         try:
             from oracle import oracle as orc
             arrays = synth.corpus_to_arrays(corpus)
@@ -405,7 +447,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "queries/sec", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
 
     # ---- sub-results (N = 1): the same path at the other operating points SURVEY 8(d) names -----------------------------
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and not use_dist and not args.no_extras:
         subs = []
 
         def sub(name, sc, batches, targets, kk, note):
@@ -446,7 +488,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

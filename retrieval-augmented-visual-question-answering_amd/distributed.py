@@ -1,11 +1,13 @@
 """Passage-sharded search across the GPUs of one node: one process per GPU, each rank owns a contiguous
-pid range of the index (IndexArrays.shard), runs S0-S4 locally on its shard, and ONE all-gather of the per-shard
-top-k (score f32, global pid i32) lists per query batch crosses xGMI (torch.distributed backend "nccl" = RCCL).
-Every rank then merges nshards*k -> k with the HIP merge kernel, so all ranks hold the global ranking.
+pid range of the index (IndexArrays.shard / synth.make_corpus(pid_range=...)); centroids, codec tables and queries are
+replicated.  The reference has no multi-GPU search at all (src/executors/FLMR_executor.py:778-783 forces the CPU path
+when world_size > 1).  Both modes of SURVEY 8e are implemented; the exchanges go through torch.distributed (backend
+"nccl" = RCCL over xGMI) or, for a caller without torch, through flmr_topk_allgather / flmr_keys_allreduce of the C ABI:
 
-The reference has no multi-GPU search at all (src/executors/FLMR_executor.py:778-783 forces the CPU path when
-world_size > 1).  "Fast mode" of SURVEY 8e is what is implemented: each shard prunes with the same ndocs, so the
-merged list is the exact-score top-k over a superset of the single-index survivors.
+  exact (`search_batch_exact`, the default of bench.py --gpus N)  three phases with one exchange of u64 keys after each
+        (+ an optional phase 0 that splits stage 0 by query): the result is BIT-IDENTICAL to searching the unsharded index;
+  fast  (`search_batch`)  every shard runs S0-S4 with the same ndocs and ONE all-gather of the per-shard top-k
+        (score f32, global pid i32) lists is merged: exact scores over a superset of the single-index survivors.
 """
 import torch
 import torch.distributed as dist
@@ -43,8 +45,9 @@ class ShardedSearcher:
         self._merge = merge
         # key selection / unpacking of the exact protocol: the HIP ops by default (tests on CPU inject numpy restatements)
         self._topn_keys, self._unpack_keys = topn_keys, unpack_keys
-        self._split_ok = {}  # (nq, k, nq_cand) -> query-split stage 0 usable? (capability query, agreed across ranks once)
+        self._split_ok = {}  # (nq, k, nq_cand, options epoch) -> query-split stage 0 usable? (capability query, agreed across ranks once)
         self.timings = None  # set to a dict to collect per-exchange wall times (bench.py --gpus N breakdown)
+        self.force_collectives = False  # True: issue the collectives also when world == 1 (bench.py --force-distributed)
 
     @classmethod
     def from_arrays(cls, arrays, group=None, max_batch=256):
@@ -59,12 +62,17 @@ class ShardedSearcher:
         ncells, thr, ndocs = self.k_policy(k)
         return self.scorer.search_batch(Q, k, ncells, thr, ndocs, nq_cand, q_lens=q_lens)
 
-    def search_batch_exact(self, Q, k, nq_cand=32, q_lens=None, gather=None, split_stage0=True, reduce_sum=None):
+    def search_batch_exact(self, Q, k, nq_cand=32, q_lens=None, gather=None, split_stage0=True, reduce_sum=None, check=True):
         """Exact-parity mode: three phases with one exchange of u64 keys after each; the result is
         bit-identical to searching the unsharded index.  `gather(t)` must return the [world, ...] stack of `t` over the
         ranks (default: torch.distributed.all_gather_into_tensor on the device).  The phase-2/3 outputs are slot-aligned
         with the global survivor list (one non-zero contributor per slot), so they are combined by a SUM all-reduce --
-        2(W-1)/W of the array per rank instead of W-1 copies; `reduce_sum(t)` overrides it (default: dist.all_reduce)."""
+        2(W-1)/W of the array per rank instead of W-1 copies; `reduce_sum(t)` overrides it (default: dist.all_reduce).
+
+        check=True (default): after the batch every rank reads its deferred device status (flmr_searcher_check: candidate
+        overflow, q_lens out of range) and the ranks MAX-reduce one error flag, so that a failure on one shard raises on
+        EVERY rank instead of leaving the others blocked in the next collective.  It costs a host sync and one tiny
+        exchange per batch; a throughput loop passes check=False and calls `check_all()` at its own sync points."""
         if self._topn_keys is None or self._unpack_keys is None:
             from . import ops
             self._topn_keys = self._topn_keys or ops.topn_keys
@@ -88,7 +96,7 @@ class ShardedSearcher:
             return out
 
         def default_gather(t):
-            if self.world == 1:
+            if self.world == 1 and not self.force_collectives:
                 return t.unsqueeze(0)
             # flat in / flat out: the one layout both RCCL and gloo accept for the fused gather
             g = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
@@ -96,7 +104,7 @@ class ShardedSearcher:
             return g.view((self.world,) + tuple(t.shape))
 
         def default_reduce(t):
-            if self.world > 1:
+            if self.world > 1 or self.force_collectives:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             return t
 
@@ -113,7 +121,7 @@ class ShardedSearcher:
             return topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n, ordered=False)
 
         k1 = None
-        if self.world > 1 and split_stage0 and self._use_query_split(Q, k, ncells, thr, ndocs, nq_cand, gather):
+        if (self.world > 1 or self.force_collectives) and split_stage0 and self._use_query_split(Q, k, ncells, thr, ndocs, nq_cand, gather):
             # stage 0 does not depend on the passage shard: each rank probes 1/W of the queries, the ranks exchange the
             # idx bitsets + cells (K/8 bytes + a few ints per query) and rebuild the table rows they need locally.
             # Errors raised in here are real failures (the shape was declared supported): they propagate.
@@ -134,13 +142,42 @@ class ShardedSearcher:
         s1 = exchange(k1, ndocs)
         s2 = topn_keys(timed("reduce_stage2_keys", reduce_sum, self.scorer.phase2(s1)), ndocs // 4, ordered=False)
         fin = topn_keys(timed("reduce_stage3_keys", reduce_sum, self.scorer.phase3(s2)), min(k, max(ndocs // 4, 1)), ordered=True)
-        return unpack_keys(fin, k)
+        out = unpack_keys(fin, k)
+        if check:
+            self.check_all(gather)
+        return out
+
+    def check_all(self, gather=None):
+        """Collective: every rank reads its searcher's deferred status (waits for its last batch) and the ranks exchange one
+        flag; raises on ALL ranks if any shard failed (the failing rank re-raises its own error, the others name the rank)."""
+        err = None
+        try:
+            if hasattr(self.scorer, "check"):
+                self.scorer.check()
+        except Exception as e:  # noqa: BLE001 -- whatever the shard raised must reach the other ranks as a flag
+            err = e
+        dev = self.scorer.probe_device if hasattr(self.scorer, "probe_device") else "cuda"
+        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=dev)
+        if gather is not None:
+            flags = gather(flag).reshape(-1)
+        elif self.world > 1 or self.force_collectives:
+            flags = torch.empty(self.world, dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(flags, flag, group=self.group)
+        else:
+            flags = flag
+        if err is not None:
+            raise err
+        bad = torch.nonzero(flags).reshape(-1).tolist()
+        if bad:
+            raise RuntimeError(f"sharded search failed on rank(s) {bad} (see that rank's error)")
 
     def _use_query_split(self, Q, k, ncells, thr, ndocs, nq_cand, gather):
         """Capability query (flmr_searcher_probe_supported: depends only on replicated data), then -- once per batch shape
         -- the MIN of the answers over the ranks, so that a rank can never take a different branch of the protocol (and
         issue different collectives) than the others."""
-        key = (int(Q.size(1)), int(k), int(nq_cand))
+        from . import _native
+        # the answer also depends on the kernel switches (flmr_set_option) and on whether the scorer keeps the full table
+        key = (int(Q.size(1)), int(k), int(nq_cand), _native.options_epoch, bool(getattr(self.scorer, "full_table_state", False)))
         if key not in self._split_ok:
             ok = bool(self.scorer.supports_query_split(Q, k, ncells, thr, ndocs, nq_cand))
             dev = self.scorer.probe_device if hasattr(self.scorer, "probe_device") else "cuda"

@@ -15,6 +15,17 @@ untouched.  What is rebound:
 
 `install(level="ops")` instead keeps the reference's Python and swaps only the four pybind extensions for the torch
 front-ends of the C ABI (same signatures; INTEGRATION.md level 2).  `uninstall()` restores every binding.
+
+`scoring=True` (default, either level) also rebinds the scoring head:
+
+    colbert.modeling.colbert.colbert_score               -> a dispatcher that runs the HIP padded MaxSim
+    (and the name in every module that imported it)         (`flmr_colbert_score_padded`) for forward-only calls and
+                                                            the reference's own torch expression when autograd needs
+                                                            the result
+
+so `ColBERT.score` (TPC/modeling/colbert.py:217-224) -- what the FLMR model classes inherit and what the exhaustive
+search (`src/executors/FLMR_executor.py:833`) and the RAG re-scoring (`src/models/rag/rag_model_blip.py:435`) call --
+reaches the MI355X kernel in a drop-in run, while training (in-batch negatives under autograd) is untouched.
 """
 import importlib
 import sys
@@ -57,10 +68,60 @@ def _import_reference(package):
             "it does not replace it.") from e
 
 
-def install(level="searcher", package="colbert", require_device=False):
+def make_colbert_score_dispatch(reference_colbert_score):
+    """The function bound over the reference's `colbert_score` (TPC/modeling/colbert.py:268-286).
+
+    HIP path (flmr_colbert_score_padded: fp16-split MFMA, -9999 padding, no clamp, fp32 accumulation) when the call is
+    forward-only -- grad mode off, or no input requires grad -- and the shape is the kernel's ('colbert' interaction,
+    3-D Q / D with Q.size(0) in {1, B}, floating inputs).  Everything else -- autograd (training), 'flipr', odd ranks --
+    goes to the reference's own expression, unchanged.  There is NO host fallback for the forward-only case: without
+    libflmr_hip.so / a HIP device the call raises FlmrNativeError.  The result has D_padded's dtype and lives where the
+    reference would have put it (the inputs' device; cuda when use_gpu)."""
+    import torch
+
+    def colbert_score(Q, D_padded, D_mask, config=None, use_gpu=False):
+        from . import ops
+        interaction = getattr(config, "interaction", "colbert") if config is not None else "colbert"
+        forward_only = not (torch.is_grad_enabled() and (Q.requires_grad or D_padded.requires_grad))
+        shape_ok = (torch.is_tensor(Q) and torch.is_tensor(D_padded) and Q.dim() == 3 and D_padded.dim() == 3
+                    and Q.size(0) in (1, D_padded.size(0)) and Q.size(-1) == D_padded.size(-1)
+                    and Q.is_floating_point() and D_padded.is_floating_point() and D_padded.size(0) > 0 and D_padded.size(1) > 0)
+        if not (forward_only and shape_ok and interaction == "colbert"):
+            if config is None:
+                return reference_colbert_score(Q, D_padded, D_mask, use_gpu=use_gpu)
+            return reference_colbert_score(Q, D_padded, D_mask, config=config, use_gpu=use_gpu)
+        out = ops.colbert_score_padded(Q.detach(), D_padded.detach(), D_mask)      # f32 on the device
+        dev = torch.device("cuda") if use_gpu else D_padded.device
+        return out.to(device=dev, dtype=D_padded.dtype)
+
+    colbert_score.__doc__ = (reference_colbert_score.__doc__ or "") + "\n    [ravqa_amd: forward-only calls run flmr_colbert_score_padded on the MI355X]"
+    colbert_score.__wrapped__ = reference_colbert_score
+    colbert_score.__ravqa_amd__ = True
+    return colbert_score
+
+
+def _install_scoring(package):
+    """Rebind `colbert_score` in colbert.modeling.colbert (ColBERT.score resolves it there at call time) and in every
+    module that imported the name before install() (index_storage.py:12 does)."""
+    mc = _import_reference(package + ".modeling.colbert")
+    reference_fn = getattr(mc, "colbert_score", None)
+    if reference_fn is None or getattr(reference_fn, "__ravqa_amd__", False):
+        return
+    dispatch = make_colbert_score_dispatch(reference_fn)
+    _bind(mc, "colbert_score", dispatch)
+    for mod in list(sys.modules.values()):
+        d = getattr(mod, "__dict__", None)
+        if d is None or mod is mc:
+            continue
+        if d.get("colbert_score") is reference_fn:
+            _bind(mod, "colbert_score", dispatch)
+
+
+def install(level="searcher", package="colbert", require_device=False, scoring=True):
     """Patch the reference's `colbert` package (see module docstring).  Returns the installed Searcher class
     (level "searcher") or the list of patched op names (level "ops").  Idempotent.  `require_device=True` also
-    checks that libflmr_hip.so loads and a HIP device is visible (the search path has no CPU fallback)."""
+    checks that libflmr_hip.so loads and a HIP device is visible (the search path has no CPU fallback).
+    `scoring=True` also routes forward-only `colbert_score` / `ColBERT.score` calls to the HIP padded scorer."""
     global _installed
     if _installed is not None:
         return _installed
@@ -72,6 +133,8 @@ def install(level="searcher", package="colbert", require_device=False):
     ref = _import_reference(package)
     if getattr(ref, "__ravqa_amd__", False):
         raise ImportError(f"`{package}` resolves to a ravqa_amd shim, not to the reference package")
+    if scoring:
+        _install_scoring(package)
 
     if level == "ops":
         from . import ops

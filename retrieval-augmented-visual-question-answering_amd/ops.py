@@ -44,7 +44,7 @@ def filter_pids(pids, centroid_scores, codes, doclens, offsets, idx, nfiltered_d
 
 
 def decompress_residuals(pids, lengths, offsets, bucket_weights, reversed_bit_map, bucket_weight_combinations,
-                         binary_residuals, codes, centroids, dim, nbits):
+                         binary_residuals, codes, centroids, dim, nbits, _on_device=False):
     lib = _native.load()
     pd = _d(pids, torch.int32)
     ln, of = _d(lengths, torch.int64), _d(offsets, torch.int64)
@@ -57,7 +57,7 @@ def decompress_residuals(pids, lengths, offsets, bucket_weights, reversed_bit_ma
         _native.check(lib.flmr_decompress_residuals(
             _p(pd), pd.numel(), _p(ln), _p(of), _p(bw), _p(rbm), _p(lut), _p(res), _p(cod), _p(cen), int(dim), int(nbits),
             _p(out), nrows, None, _native.stream_ptr()))
-    return out.cpu()
+    return out if _on_device else out.cpu()
 
 
 def segmented_lookup(input, pids, lengths, offsets):

@@ -181,6 +181,7 @@ class IndexScorer:
         for h, _ in slots:
             self._lib.flmr_searcher_set_profiling(h, 1 if profile else 0)
             self._lib.flmr_searcher_set_full_table(h, 1 if full_table else 0)  # needed for the CENTROID_SCORES tap
+        self.full_table_state = bool(full_table)
         if len(slots) > 1:
             start = cur.record_event()              # inputs / outputs were produced on the caller's stream
             for _, st in slots[1:]:
@@ -346,9 +347,47 @@ class IndexScorer:
                                                     _native.stream_ptr()))
         return out.cpu(), fin
 
+    # ---- GPU-branch helpers of the reference (index_storage.py:61-65 -> residual_embeddings_strided.py:23-41) ----------
+    def _decompress_rows(self, seg_ids, seg_lengths, seg_offsets):
+        """flmr_decompress_residuals over explicit (id, length, token offset) segments, then the row normalisation of
+        ResidualCodec.decompress (residual.py:268-270: F.normalize(fp32), eps 1e-12) -- fp32 rows on the device."""
+        from . import ops
+        c = self.codec
+        D = ops.decompress_residuals(seg_ids, seg_lengths, seg_offsets, c.bucket_weights, c.reversed_bit_map,
+                                     c.decompression_lookup_table, self._dev("residuals"), self._dev("codes"),
+                                     self._dev("centroids"), c.dim, c.nbits, _on_device=True)
+        return torch.nn.functional.normalize(D, p=2, dim=-1)
+
+    def lookup_pids(self, passage_ids, out_device="cuda", return_mask=False):
+        """-> (embeddings_packed f32 [sum doclens, dim] normalised, doclens i64 [n]) for LOCAL passage ids, in the given
+        order (index_storage.py:64-65; ResidualEmbeddingsStrided.lookup_pids)."""
+        pids = torch.as_tensor(passage_ids).reshape(-1).to(torch.int32)
+        D = self._decompress_rows(pids, self.doclens, self.embeddings_strided.codes_strided.offsets)
+        return D.to(out_device), self.doclens[pids.long().cpu()]
+
+    def lookup_eids(self, embedding_ids, codes=None, out_device="cuda"):
+        """-> normalised embeddings f32 [n, dim] of explicit token ids (index_storage.py:61-62;
+        ResidualEmbeddingsStrided.lookup_eids).  `codes` overrides the tokens' centroid ids like the reference's argument."""
+        eids = torch.as_tensor(embedding_ids).reshape(-1).long().cpu()
+        n = eids.numel()
+        if codes is not None:
+            # the reference adds the residual of token e to centroid codes[i]: decompress with an index view whose code
+            # column is the override (n rows only)
+            from . import ops
+            c = self.codec
+            res = self.embeddings.residuals[eids]
+            D = ops.decompress_residuals(torch.arange(n, dtype=torch.int32), torch.ones(n, dtype=torch.int64),
+                                         torch.arange(n, dtype=torch.int64), c.bucket_weights, c.reversed_bit_map,
+                                         c.decompression_lookup_table, res, torch.as_tensor(codes).reshape(-1).to(torch.int32),
+                                         self._dev("centroids"), c.dim, c.nbits, _on_device=True)
+            return torch.nn.functional.normalize(D, p=2, dim=-1).to(out_device)
+        D = self._decompress_rows(torch.arange(n, dtype=torch.int32), torch.ones(n, dtype=torch.int64), eids)
+        return D.to(out_device)
+
     def _dev(self, name):
         cache = self.__dict__.setdefault("_dev_cache", {})
         if name not in cache:
-            src = {"codes": self.embeddings.codes, "offsets": self.embeddings_strided.codes_strided.offsets}[name]
+            src = {"codes": self.embeddings.codes, "offsets": self.embeddings_strided.codes_strided.offsets,
+                   "residuals": self.embeddings.residuals, "centroids": self.codec.centroids}[name]
             cache[name] = src.to("cuda")
         return cache[name]

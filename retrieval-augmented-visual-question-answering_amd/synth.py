@@ -43,8 +43,8 @@ def bucket_tables(residual_sample, nbits):
     n = 2 ** nbits
     q = torch.arange(0, n, device=residual_sample.device, dtype=torch.float32) / n
     flat = residual_sample.float().flatten()
-    if flat.numel() > 4_000_000:  # torch.quantile input limit
-        flat = flat[torch.randperm(flat.numel(), device=flat.device, generator=None)[:4_000_000]]
+    if flat.numel() > 4_000_000:  # torch.quantile input limit; a FIXED subsample, so every caller derives the same tables
+        flat = flat[:: -(-flat.numel() // 4_000_000)]
     return flat.quantile(q[1:]), flat.quantile(q + 0.5 / n)
 
 
@@ -60,10 +60,23 @@ class SyntheticCorpus:
     pass
 
 
-def make_corpus(n_passages, doclen, K, nbits, seed=0, device="cpu", sigma=0.05, chunk_tokens=1 << 21, dim=128):
+def _chunk_generator(seed, chunk, device):
+    g = torch.Generator(device=device)
+    g.manual_seed((int(seed) * 1_000_003 + 7919 * (int(chunk) + 1)) & 0x7FFFFFFFFFFF)
+    return g
+
+
+def make_corpus(n_passages, doclen, K, nbits, seed=0, device="cpu", sigma=0.05, chunk_tokens=1 << 21, dim=128, pid_range=None):
     """Clustered corpus: protos = normalize(N(0,I)[K,dim]); token = normalize(protos[c] + sigma*N(0,I)), c ~ U{0..K-1};
     the token's code is its generating centroid.  `doclen` is an int (fixed) or (lo, hi) inclusive (ragged).
-    Returns a SyntheticCorpus whose tensors live on `device`."""
+    Returns a SyntheticCorpus whose tensors live on `device`.
+
+    The cheap global state (centroids, doclens, one code per token) comes from ONE generator and is identical for every
+    caller; the expensive part -- the tokens' noise, their residual bytes and the IVF -- is drawn per `chunk_tokens`-token
+    chunk from a generator seeded by (seed, chunk index), so `pid_range=(lo, hi)` builds exactly the passage shard
+    [lo, hi) of the same corpus (same bytes as `shard_corpus(make_corpus(...), ...)`) at 1/N of the cost: each rank of a
+    sharded job generates its own shard.  A shard keeps the GLOBAL doclens / codes as `g_*` for
+    `make_queries` (queries are planted over the whole corpus) and its pid offset as `pid_base`."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     protos = torch.nn.functional.normalize(torch.randn(K, dim, generator=g, device=device), dim=-1)
@@ -75,45 +88,93 @@ def make_corpus(n_passages, doclen, K, nbits, seed=0, device="cpu", sigma=0.05, 
     offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), torch.cumsum(doclens, 0)])
     N = int(offsets[-1])
     codes = torch.randint(0, K, (N,), generator=g, device=device, dtype=torch.int32)
-    residuals = torch.empty((N, dim * nbits // 8), dtype=torch.uint8, device=device)
-    cut = wts = None
-    for t0 in range(0, N, chunk_tokens):
-        t1 = min(N, t0 + chunk_tokens)
+    lo, hi = (0, n_passages) if pid_range is None else (int(pid_range[0]), int(pid_range[1]))
+    assert 0 <= lo <= hi <= n_passages, (lo, hi, n_passages)
+    tlo, thi = int(offsets[lo]), int(offsets[hi])
+    residuals = torch.empty((thi - tlo, dim * nbits // 8), dtype=torch.uint8, device=device)
+
+    def chunk_embeddings(ci):
+        t0, t1 = ci * chunk_tokens, min(N, (ci + 1) * chunk_tokens)
         c = codes[t0:t1].long()
-        emb = torch.nn.functional.normalize(centroids[c] + sigma * torch.randn(t1 - t0, dim, generator=g, device=device), dim=-1)
-        if cut is None:
-            cut, wts = bucket_tables((emb - centroids[c])[: 1 << 15], nbits)
-        _, residuals[t0:t1] = compress(emb, centroids, cut, nbits, codes=c)
-    ivf, ivf_lengths = build_ivf(codes, doclens, K)
+        noise = torch.randn(t1 - t0, dim, generator=_chunk_generator(seed, ci, device), device=device)
+        return t0, t1, c, torch.nn.functional.normalize(centroids[c] + sigma * noise, dim=-1)
+
+    # bucket tables: quantiles of the first 2^15 residuals of chunk 0 (every shard derives the same ones)
+    t0, t1, c, emb = chunk_embeddings(0)
+    cut, wts = bucket_tables((emb - centroids[c])[: 1 << 15], nbits)
+    for ci in range(tlo // chunk_tokens, -(-thi // chunk_tokens) if thi > tlo else 0):
+        if ci > 0:
+            t0, t1, c, emb = chunk_embeddings(ci)
+        a, b = max(t0, tlo), min(t1, thi)
+        _, res = compress(emb[a - t0:b - t0], centroids, cut, nbits, codes=c[a - t0:b - t0])
+        residuals[a - tlo:b - tlo] = res
+    del emb, c
     out = SyntheticCorpus()
     out.dim, out.nbits, out.K, out.sigma = dim, nbits, K, sigma
-    out.centroids, out.doclens, out.doc_offsets = centroids, doclens, offsets
-    out.codes, out.residuals = codes, residuals
-    out.ivf, out.ivf_lengths = ivf, ivf_lengths
-    out.ivf_offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), torch.cumsum(ivf_lengths, 0)])
+    out.centroids = centroids
     out.bucket_cutoffs, out.bucket_weights = cut, wts
+    out.g_doclens, out.g_doc_offsets, out.g_codes = doclens, offsets, codes
+    out.pid_base, out.n_passages_global = lo, n_passages
+    if pid_range is None:
+        out.doclens, out.doc_offsets, out.codes = doclens, offsets, codes
+    else:
+        out.doclens = doclens[lo:hi].contiguous()
+        out.doc_offsets = (offsets[lo:hi + 1] - tlo).contiguous()
+        out.codes = codes[tlo:thi].contiguous()
+    out.residuals = residuals
+    out.ivf, out.ivf_lengths = build_ivf(out.codes, out.doclens, K)
+    out.ivf_offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), torch.cumsum(out.ivf_lengths, 0)])
     return out
 
 
-def make_queries(corpus, n_queries, nq, seed=2, sigma=None):
-    """Planted queries: query i targets passage t_i; its token j sits near the centroid of token (j mod doclen) of t_i.
-    Returns (Q [n, nq, dim] on the corpus device, target pids [n])."""
+def shard_corpus(corpus, rank, world):
+    """Passage shard `rank` of `world` of an UNSHARDED corpus: contiguous pid range, codes / residuals /
+    doclens sliced, IVF restricted to the range and rebased.  Same arrays as make_corpus(..., pid_range=shard_range(...))."""
+    P, K = corpus.doclens.numel(), corpus.K
+    lo, hi = shard_range(P, rank, world)
     dev = corpus.codes.device
+    tlo, thi = int(corpus.doc_offsets[lo]), int(corpus.doc_offsets[hi])
+    keep = (corpus.ivf >= lo) & (corpus.ivf < hi)
+    owner = torch.repeat_interleave(torch.arange(K, device=dev), corpus.ivf_lengths)
+    sh = SyntheticCorpus()
+    sh.dim, sh.nbits, sh.K, sh.sigma = corpus.dim, corpus.nbits, K, corpus.sigma
+    sh.centroids, sh.bucket_weights, sh.bucket_cutoffs = corpus.centroids, corpus.bucket_weights, corpus.bucket_cutoffs
+    sh.g_doclens, sh.g_doc_offsets, sh.g_codes = corpus.doclens, corpus.doc_offsets, corpus.codes
+    sh.pid_base, sh.n_passages_global = lo, P
+    sh.codes, sh.residuals = corpus.codes[tlo:thi].contiguous(), corpus.residuals[tlo:thi].contiguous()
+    sh.doclens = corpus.doclens[lo:hi].contiguous()
+    sh.doc_offsets = (corpus.doc_offsets[lo:hi + 1] - tlo).contiguous()
+    sh.ivf = (corpus.ivf[keep] - lo).to(torch.int32).contiguous()
+    sh.ivf_lengths = torch.bincount(owner[keep], minlength=K).long()
+    sh.ivf_offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(sh.ivf_lengths, 0)])
+    return sh
+
+
+def shard_range(n_passages, rank, world):
+    return (n_passages * rank) // world, (n_passages * (rank + 1)) // world
+
+
+def make_queries(corpus, n_queries, nq, seed=2, sigma=None):
+    """Planted queries: query i targets passage t_i (a GLOBAL pid, also when `corpus` is a shard); its token j sits near the
+    centroid of token (j mod doclen) of t_i.  Returns (Q [n, nq, dim] on the corpus device, target pids [n])."""
+    doclens, doc_offsets, codes = corpus.g_doclens, corpus.g_doc_offsets, corpus.g_codes
+    dev = codes.device
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     sigma = corpus.sigma if sigma is None else sigma
-    n_pass = corpus.doclens.numel()
+    n_pass = doclens.numel()
     targets = torch.randint(0, n_pass, (n_queries,), generator=g, device=dev)
-    lens = corpus.doclens[targets].clamp(min=1)
+    lens = doclens[targets].clamp(min=1)
     j = torch.arange(nq, device=dev).unsqueeze(0) % lens.unsqueeze(1)
-    tok = (corpus.doc_offsets[targets].unsqueeze(1) + j).clamp(max=corpus.codes.numel() - 1)
-    c = corpus.codes[tok].long()
+    tok = (doc_offsets[targets].unsqueeze(1) + j).clamp(max=codes.numel() - 1)
+    c = codes[tok].long()
     Q = torch.nn.functional.normalize(corpus.centroids[c] + sigma * torch.randn(n_queries, nq, corpus.dim, generator=g, device=dev), dim=-1)
     return Q.contiguous(), targets
 
 
-def corpus_to_arrays(corpus, pid_base=0):
+def corpus_to_arrays(corpus, pid_base=None):
     """SyntheticCorpus (any device) -> host IndexArrays."""
+    pid_base = getattr(corpus, "pid_base", 0) if pid_base is None else pid_base
     from .index import IndexArrays
     cpu = lambda t: t.detach().cpu().numpy()
     return IndexArrays(corpus.dim, corpus.nbits, cpu(corpus.codes), cpu(corpus.residuals), cpu(corpus.doclens), cpu(corpus.ivf),
@@ -121,8 +182,9 @@ def corpus_to_arrays(corpus, pid_base=0):
                        bucket_cutoffs=cpu(corpus.bucket_cutoffs), pid_base=pid_base)
 
 
-def corpus_device_index(corpus, pid_base=0):
+def corpus_device_index(corpus, pid_base=None):
     """SyntheticCorpus resident on the GPU -> DeviceIndex borrowing its tensors (no host round trip)."""
+    pid_base = getattr(corpus, "pid_base", 0) if pid_base is None else pid_base
     from types import SimpleNamespace
     from .index import DeviceIndex
     meta = SimpleNamespace(dim=corpus.dim, nbits=corpus.nbits, num_centroids=corpus.K,

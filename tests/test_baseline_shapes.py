@@ -103,3 +103,75 @@ def test_cfg4_1m_passages_headline_shape(hip, nbits, doclen):
     from ravqa_amd import synth
     corpus = synth.make_corpus(1_000_000, doclen, 131072, nbits, seed=0, device="cuda")
     _check(hip, corpus, 32, {100: 32, 500: 4}, ks=(100, 500))
+
+
+def _exact_protocol_on_one_device(torch, ops, shards, Q, k, ncells, thr, ndocs, split_stage0=True):
+    """All ranks' phases of ShardedSearcher.search_batch_exact run in sequence on ONE device: the all-gathers are
+    torch.stack / cat, the SUM all-reduces a sum over the stack (exactly the data movement of distributed.py)."""
+    W, B = len(shards), Q.size(0)
+    if split_stage0:
+        per = -(-B // W)
+        parts = []
+        for r, sh in enumerate(shards):
+            lo = min(B, r * per)
+            parts.append(sh.probe(Q, k, ncells, thr, ndocs, lo, min(B, lo + per) - lo, 32))
+        bits, cells, ncell = (torch.cat([p_[j] for p_ in parts]) for j in range(3))
+        k1 = [sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32) for sh in shards]
+    else:
+        k1 = [sh.phase1(Q, k, ncells, thr, ndocs, 32) for sh in shards]
+    g = torch.stack(k1)                                                     # [W, B, ndocs]
+    s1 = ops.topn_keys(g.permute(1, 0, 2).reshape(B, -1), ndocs, ordered=False)
+    parts2 = torch.stack([sh.phase2(s1) for sh in shards])
+    assert int((parts2 != 0).sum(dim=0).max()) <= 1                         # one contributor per slot: SUM == gather
+    s2 = ops.topn_keys(parts2.sum(dim=0), ndocs // 4, ordered=False)
+    parts3 = torch.stack([sh.phase3(s2) for sh in shards])
+    assert int((parts3 != 0).sum(dim=0).max()) <= 1
+    fin = ops.topn_keys(parts3.sum(dim=0), min(k, ndocs // 4), ordered=True)
+    return ops.unpack_keys(fin, k)
+
+
+def test_cfg4_sharded_into_8_exact_protocol_equals_unsharded(hip):
+    """BASELINE configs[3] at its real shape: the 1 M x 128 corpus (K = 131072) cut into EIGHT passage shards, every rank's
+    probe -> phase1_probed -> phase2 -> phase3 executed on this one device with stack / sum as the exchanges; the result must
+    be BIT-IDENTICAL (ids, scores, counts) to the unsharded search_batch -- 32 queries at the k = 100 policy, 4 at k = 500 --
+    also with the replicated stage 0; and the fast mode (one all-gather of per-shard top-k) must return exact scores over a
+    superset of the unsharded survivors.  (src/executors/FLMR_executor.py:778-783 is what this replaces: the reference drops
+    to its CPU path whenever world_size > 1.)"""
+    torch = hip["torch"]
+    from ravqa_amd import ops, synth
+    from ravqa_amd.scorer import IndexScorer
+    W = 8
+    corpus = synth.make_corpus(1_000_000, 128, 131072, 2, seed=0, device="cuda")
+    single = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=32)
+    shard_corpora = [synth.shard_corpus(corpus, r, W) for r in range(W)]
+    # one shard generated locally (what bench.py --gpus 8 does on each rank) is the same shard
+    own = synth.make_corpus(1_000_000, 128, 131072, 2, seed=0, device="cuda", pid_range=synth.shard_range(1_000_000, 5, W))
+    for n in ("codes", "residuals", "ivf", "ivf_lengths", "doc_offsets"):
+        assert torch.equal(getattr(own, n), getattr(shard_corpora[5], n)), n
+    del own
+    shards = [IndexScorer(device_index=synth.corpus_device_index(sc), max_batch=32) for sc in shard_corpora]
+    Q, targets = synth.make_queries(corpus, 32, 32, seed=2)
+    for k, n in ((100, 32), (500, 4)):
+        ncells, thr, ndocs = POLICY[k]
+        p_ref, s_ref, c_ref = single.search_batch(Q[:n], k, ncells, thr, ndocs, 32)
+        single.check()
+        assert int(c_ref.min()) == k
+        for split in (True, False):
+            p, s, c = _exact_protocol_on_one_device(torch, ops, shards, Q[:n], k, ncells, thr, ndocs, split_stage0=split)
+            for sh in shards:
+                sh.check()
+            assert torch.equal(c, c_ref) and torch.equal(p, p_ref) and torch.equal(s, s_ref), (k, split)
+        # fast mode: every shard prunes with the same ndocs, one gather of the per-shard top-k, merged
+        loc = [sh.search_batch(Q[:n], k, ncells, thr, ndocs, 32) for sh in shards]
+        ms, mp, mc = ops.merge_topk(torch.stack([l[1] for l in loc]), torch.stack([l[0] for l in loc]))
+        assert int(mc.min()) == k
+        assert bool((ms >= s_ref).all())                      # position by position at least the exact mode's score
+        for q in range(n):
+            fast = dict(zip(mp[q].tolist(), ms[q].tolist()))
+            kth = float(ms[q, -1])
+            for pid, sc_ in zip(p_ref[q].tolist(), s_ref[q].tolist()):
+                # an unsharded survivor also survives in its shard (fewer competitors): same exact score, and it is in the
+                # merged list unless k superset documents outrank it
+                assert (pid in fast and fast[pid] == sc_) or sc_ <= kth, (k, q, pid)
+    for sh in shards + [single]:
+        sh.close_searcher()

@@ -189,3 +189,49 @@ def test_ranks_that_disagree_on_the_capability_take_the_same_branch(tmp_path):
     assert torch.equal(res[0]["p"], res[1]["p"])
     for r in res:
         assert "probe" not in r["calls"] and "phase1_probed" not in r["calls"] and "phase1" in r["calls"]
+
+
+def _failing_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ravqa_amd
+    from ravqa_amd.distributed import ShardedSearcher
+    import oracle_shard_scorer as oss
+    z = dict(np.load(os.path.join(ROOT, "tests", "golden", "idx_nb2.npz")))
+    full = ravqa_amd.IndexArrays.from_golden(z)
+    scorer = oss.OracleShardScorer(full.shard(rank, world))
+    if rank == 1:   # this shard's deferred device status reports a failure (flmr_searcher_check's role)
+        def check():
+            raise ravqa_amd._native.FlmrNativeError("libflmr_hip status 5: candidate capacity exceeded (injected)")
+        scorer.check = check
+    ss = ShardedSearcher(scorer=scorer, k_policy=lambda k: (1, 0.5, 64), topn_keys=oss.topn_keys, unpack_keys=oss.unpack_keys)
+    Q = torch.stack([torch.from_numpy(z[f"rank{i}.Q"]) for i in (0, 3)])
+    msg = "no error"
+    try:
+        ss.search_batch_exact(Q, 10)
+    except Exception as e:  # noqa: BLE001
+        msg = f"{type(e).__name__}: {e}"
+    # unchecked batches do not exchange the flag; check_all() at a sync point of the caller's choosing does
+    ss.search_batch_exact(Q, 10, check=False)
+    msg2 = "no error"
+    try:
+        ss.check_all()
+    except Exception as e:  # noqa: BLE001
+        msg2 = f"{type(e).__name__}: {e}"
+    torch.save({"msg": msg, "msg2": msg2}, f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_failure_on_one_shard_raises_on_every_rank(tmp_path):
+    """A shard whose deferred device status reports an error (candidate overflow, bad q_lens) must not leave the other ranks
+    blocked in the next collective: search_batch_exact(check=True) exchanges one flag per batch and EVERY rank raises."""
+    world, port, out = 3, _free_port(), str(tmp_path / "res")
+    mp.spawn(_failing_worker, args=(world, port, out), nprocs=world, join=True)
+    res = [torch.load(f"{out}.{r}") for r in range(world)]
+    for key in ("msg", "msg2"):
+        assert "FlmrNativeError" in res[1][key] and "injected" in res[1][key]
+        for r in (0, 2):
+            assert "RuntimeError" in res[r][key] and "rank(s) [1]" in res[r][key], res[r][key]

@@ -93,8 +93,51 @@ with Run().context(RunConfig(nranks=1, rank=0, root=TMP, experiment="temp_index_
         ns["Searcher"](index="temp_index.nbits=2", config=ColBERTConfig(total_visible_gpus=1))
     assert any("CUDA-path numerics" in str(x.message) for x in w) and calls[-1] == (index_dir, True)
 
+# ---- the scoring head: ColBERT.score -> colbert_score (colbert/modeling/colbert.py:217-224,268-286), what
+# FLMR_executor.py:833 (exhaustive search) and rag_model_blip.py:435 (RAG re-score) call ---------------------------
+import colbert.modeling.colbert as mc
+from oracle import oracle as orc
+assert getattr(mc.colbert_score, "__ravqa_amd__", False) and ixs.colbert_score is mc.colbert_score   # index_storage.py:12 imported the name
+ref_colbert_score = mc.colbert_score.__wrapped__
+zo = dict(np.load(os.path.join(ROOT, "tests", "golden", "ops.npz")))
+Qp, Dp, Mp = torch.from_numpy(zo["padded.Q"]), torch.from_numpy(zo["padded.D"]), torch.from_numpy(zo["padded.mask"])
+hip_calls = []
+def device_stand_in(Q, D, M):          # this container has no GPU: the checker plays the kernel, the DISPATCH is under test
+    hip_calls.append((tuple(Q.shape), tuple(D.shape), tuple(M.shape), Q.requires_grad))
+    return torch.from_numpy(orc.colbert_score_padded(Q.numpy(), D.numpy(), np.asarray(M).reshape(D.shape[0], D.shape[1])))
+import ravqa_amd.ops as rops
+real_op, rops.colbert_score_padded = rops.colbert_score_padded, device_stand_in
+class Model:                           # the attributes ColBERT.score reads (colbert.py:217-224)
+    colbert_config = ColBERTConfig()
+    use_gpu = False
+with torch.no_grad():
+    got = ns["ColBERT"].score(Model(), Qp, Dp, Mp)                              # the executors' call shape
+assert len(hip_calls) == 1 and got.dtype == Dp.dtype and got.device == Dp.device
+assert np.max(np.abs(got.numpy() - zo["padded.output"]) / (1.0 + np.abs(zo["padded.output"]))) <= 2e-6
+Qa = torch.from_numpy(zo["padded_aligned.Q"])
+with torch.inference_mode():
+    got_a = mc.colbert_score(Qa, Dp, Mp.unsqueeze(-1), config=ColBERTConfig())   # [B, Ld, 1] masks, aligned queries
+assert len(hip_calls) == 2 and np.max(np.abs(got_a.numpy() - zo["padded_aligned.output"]) / (1.0 + np.abs(zo["padded_aligned.output"]))) <= 2e-6
+Qg = Qp.clone().requires_grad_(True)
+out_g = ns["ColBERT"].score(Model(), Qg, Dp, Mp)                                   # training: the reference's own expression
+assert len(hip_calls) == 2 and out_g.requires_grad and torch.equal(out_g.detach(), ref_colbert_score(Qp, Dp, Mp))
+out_g.sum().backward()
+assert Qg.grad is not None and float(Qg.grad.abs().sum()) > 0
+with torch.no_grad():
+    mc.colbert_score(Qg, Dp, Mp)                                                   # grad mode off: forward-only again
+assert len(hip_calls) == 3 and hip_calls[-1][3] is False
+rops.colbert_score_padded = real_op
+if not torch.cuda.is_available():      # no silent host fallback for the forward-only case
+    try:
+        with torch.no_grad():
+            mc.colbert_score(Qp, Dp, Mp)
+        raise SystemExit("expected FlmrNativeError")
+    except ravqa_amd.FlmrNativeError:
+        pass
+
 ravqa_amd.uninstall()
 assert colbert.Searcher is ref_searcher and ixs.IndexScorer is ref_scorer and colbert.searcher.IndexScorer is ref_scorer
+assert mc.colbert_score is ref_colbert_score and ixs.colbert_score is ref_colbert_score
 
 # ---- level "ops": the four extension attributes --------------------------------------------------------------
 from colbert.search.strided_tensor import StridedTensor
@@ -135,8 +178,28 @@ def test_install_mechanics_on_stand_in_package(tmp_path):
         assert ixs.IndexScorer is ravqa_amd.IndexScorer and colbert.Indexer.marker == "reference-indexer"
         assert issubclass(Installed, ravqa_amd.Searcher) and Installed.reference_class is ref_searcher
         assert Installed.Queries is colbert.data.Queries and Installed.Run is colbert.infra.Run
+        # the scoring head (scoring=True is the default): module global + the name index_storage imported
+        import colbert.modeling.colbert as mc
+        import torch
+        assert getattr(mc.colbert_score, "__ravqa_amd__", False) and ixs.colbert_score is mc.colbert_score
+        assert mc.colbert_score.__wrapped__.marker == "reference-colbert-score"
+        Q = torch.randn(1, 5, 128, requires_grad=True)
+        D, M = torch.randn(3, 7, 128), torch.ones(3, 7, dtype=torch.bool)
+        out = mc.ColBERT().score(Q, D, M)                     # autograd needs it: the reference expression
+        assert out.requires_grad and out.shape == (3,)
+        seen = []
+        from ravqa_amd import ops
+        real = ops.colbert_score_padded
+        ops.colbert_score_padded = lambda q, d, m: (seen.append((q.requires_grad, tuple(m.shape))), mc.colbert_score.__wrapped__(q, d, m))[1]
+        try:
+            with torch.no_grad():
+                out2 = mc.ColBERT().score(Q, D.half(), M.unsqueeze(-1))
+        finally:
+            ops.colbert_score_padded = real
+        assert seen == [(False, (3, 7, 1))] and out2.dtype == torch.float16 and out2.device == D.device
         ravqa_amd.uninstall()
         assert colbert.Searcher is ref_searcher and late.Searcher is ref_searcher and ixs.IndexScorer.marker == "reference-index-scorer"
+        assert mc.colbert_score.marker == "reference-colbert-score" and ixs.colbert_score is mc.colbert_score
     finally:
         ravqa_amd.uninstall()
         sys.modules.pop("late_importer", None)

@@ -113,6 +113,32 @@ def test_decompress_op_bit_exact(hip, name):
 
 
 @pytest.mark.parametrize("name", INDEX_FIXTURES)
+def test_lookup_pids_and_eids(hip, scorers, name):
+    """IndexScorer.lookup_pids / lookup_eids (index_storage.py:61-65): decompressed + normalised rows of explicit passages /
+    tokens; vs the reference's decompress vector normalised with the CPU oracle (fp32, eps 1e-12), bit-exact up to the
+    normalisation's last ulp."""
+    from oracle import oracle as orc
+    torch = hip["torch"]
+    z, scorer = scorers[name]
+    pids = z["op_decompress.pids"]
+    ref = orc.normalize_rows(z["op_decompress.D"])
+    D, lens = scorer.lookup_pids(torch.from_numpy(pids))
+    assert D.is_cuda and D.dtype == torch.float32 and lens.tolist() == z["index.doclens"][pids].tolist()
+    assert D.shape == ref.shape and np.max(np.abs(D.cpu().numpy() - ref)) <= 2e-7
+    offsets = np.concatenate([[0], np.cumsum(z["index.doclens"])])
+    eids = np.concatenate([np.arange(offsets[p], offsets[p + 1]) for p in pids[:3]])[::-1].copy()
+    E = scorer.lookup_eids(torch.from_numpy(eids), out_device="cpu")
+    rows = {int(e): i for i, e in enumerate(np.concatenate([np.arange(offsets[p], offsets[p + 1]) for p in pids]))}
+    assert np.max(np.abs(E.numpy() - ref[[rows[int(e)] for e in eids]])) <= 2e-7
+    # codes override: residual of token e on another centroid (ResidualEmbeddingsStrided.lookup_eids' `codes` argument)
+    alt = torch.from_numpy(z["index.codes"][eids]).roll(1)
+    E2 = scorer.lookup_eids(torch.from_numpy(eids), codes=alt, out_device="cpu").numpy()
+    cen = z["index.centroids_f16"].astype(np.float32)
+    raw = z["op_decompress.D"][[rows[int(e)] for e in eids]] - cen[z["index.codes"][eids]] + cen[alt.numpy()]
+    assert np.max(np.abs(E2 - orc.normalize_rows(raw.astype(np.float32)))) <= 1e-6
+
+
+@pytest.mark.parametrize("name", INDEX_FIXTURES)
 def test_score_pids_fused_vs_oracle(hip, scorers, name):
     """Fused decompress+normalise+MaxSim (flmr_score_pids) vs the oracle's unfused chain on the same pids."""
     import ctypes as C
@@ -319,6 +345,29 @@ def test_installed_searcher_through_patched_names(hip, tmp_path):
             scorer = IndexScorer(searcher.index, False)
             p0, s0 = scorer.rank(searcher.config, Q[:1])
             assert p0[:100] == [t[0] for t in ranking.todict()[0]]
+            # the scoring head through the patched name: ColBERT.score -> colbert_score -> flmr_colbert_score_padded
+            # (the call shape of FLMR_executor.py:826-833: Q repeated per item, CUDA tensors, grad off) vs the reference's
+            # golden output; with autograd on it must stay with the package's own torch expression
+            import colbert.modeling.colbert as mc
+            zo = load_golden("ops")
+            Qp, Dp, Mp = (torch.from_numpy(zo[f"padded.{n}"]).cuda() for n in ("Q", "D", "mask"))
+            model = mc.ColBERT()
+            with torch.no_grad():
+                got = model.score(Qp, Dp, Mp)
+            assert got.is_cuda and got.dtype == torch.float32
+            ref = zo["padded.output"]
+            assert np.max(np.abs(got.cpu().numpy() - ref) / (1.0 + np.abs(ref))) <= 2e-6
+            with torch.no_grad():
+                got_a = model.score(torch.from_numpy(zo["padded_aligned.Q"]).cuda(), Dp, Mp.unsqueeze(-1))
+            ref_a = zo["padded_aligned.output"]
+            assert np.max(np.abs(got_a.cpu().numpy() - ref_a) / (1.0 + np.abs(ref_a))) <= 2e-6
+            with hip["native"].options(FLMR_SCORE_IMPL="valu"):      # the patched name really runs the library: a switch of the
+                with torch.no_grad():                                 # library changes which kernel answers, not the answer
+                    got_v = model.score(Qp, Dp, Mp)
+            assert np.max(np.abs(got_v.cpu().numpy() - ref) / (1.0 + np.abs(ref))) <= 2e-6
+            Qg = Qp.clone().requires_grad_(True)
+            out_g = model.score(Qg, Dp, Mp)
+            assert out_g.requires_grad and float((out_g.detach() - got).abs().max()) <= 1e-3
     finally:
         pkg.uninstall()
         cleanup()

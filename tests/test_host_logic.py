@@ -338,3 +338,24 @@ def test_metrics_match_the_reference_processors():
         assert abs(got[key] - want) < 1e-12, key
     stripped = [{k: v for k, v in r.items() if k not in ("answers", "gold_answer")} for r in g["records"]]
     assert evaluation.recall_pseudo_relevance(stripped, g["Ks"]) == g["pseudo_relevance_without_answers"] == {}
+
+
+@pytest.mark.parametrize("doclen", [16, (3, 40)])
+def test_synth_shard_local_generation_equals_sliced_corpus(doclen):
+    """bench.py --gpus N: every rank generates only ITS passage shard (make_corpus(pid_range=...)); the shards must be the
+    slices of the one unsharded corpus (same codes, residual bytes, restricted + rebased IVF), and the planted queries --
+    drawn over the whole corpus -- identical on every rank."""
+    import torch
+    from ravqa_amd import synth
+    full = synth.make_corpus(1000, doclen, 64, 2, seed=3, chunk_tokens=4096)
+    Qf, tf = synth.make_queries(full, 5, 32)
+    for world in (1, 3, 8):
+        for r in range(world):
+            lo, hi = synth.shard_range(1000, r, world)
+            a = synth.make_corpus(1000, doclen, 64, 2, seed=3, chunk_tokens=4096, pid_range=(lo, hi))
+            b = synth.shard_corpus(full, r, world)
+            for n in ("codes", "residuals", "doclens", "doc_offsets", "ivf", "ivf_lengths", "ivf_offsets", "bucket_weights", "centroids"):
+                assert torch.equal(getattr(a, n), getattr(b, n)), (doclen, world, r, n)
+            assert a.pid_base == b.pid_base == lo
+            Qa, ta = synth.make_queries(a, 5, 32)
+            assert torch.equal(Qa, Qf) and torch.equal(ta, tf)
