@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FLMR_ABI_VERSION 2
+#define FLMR_ABI_VERSION 3
 
 typedef enum flmr_status {
     FLMR_OK = 0,
@@ -87,6 +87,20 @@ typedef struct flmr_index_desc {
 
 int flmr_index_open(const flmr_index_desc_t* desc, flmr_index_t** out_index);
 int flmr_index_close(flmr_index_t* index);
+
+/* What flmr_index_open derived for this index on this device (the reference has no counterpart: its loader keeps the files'
+ * arrays only).  derived_bytes = HBM held by structures built at open on top of the caller's arrays. */
+typedef struct flmr_index_info {
+    int64_t derived_bytes;
+    int64_t max_doclen;
+    int32_t centroids_f16_exact;  /* 1: every centroid is fp16-representable -> fp16-split MFMA kernels (always true for reference-format indexes) */
+    int32_t stage2_slices;        /* slices the fp16 centroid table is cut into for the XCD-sliced stage 2 (8/16/24/32) */
+    int32_t xcd_round_robin;      /* 1: probe at open saw 8 XCDs and workgroup L of a 1-D grid on XCD (L % 8) */
+    int32_t stage2_sliced;        /* 1: whole-batch stage 2 takes the XCD-sliced kernel on this index */
+    int32_t passage_chunks;       /* 32768-passage chunks of the candidate stage */
+    int32_t reserved;
+} flmr_index_info_t;
+int flmr_index_info(const flmr_index_t* index, flmr_index_info_t* out_info);
 
 /* ------------------------------------------------------------------------------------------------
  * Batched search.  Replaces the per-query loop Searcher._search_all_Q -> dense_search ->

@@ -18,7 +18,7 @@ HEADERS = ["flmr_common.h", "flmr_device.h"]
 FLMR_MEM_HOST, FLMR_MEM_DEVICE = 0, 1
 (TAP_CENTROID_SCORES, TAP_IDX_BITS, TAP_CELLS, TAP_CANDIDATES, TAP_STAGE1, TAP_STAGE2, TAP_DOC_SCORES) = range(7)
 NUM_STAGES = 9
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class FlmrNativeError(RuntimeError):
@@ -33,6 +33,12 @@ class IndexDesc(C.Structure):
                 ("bucket_weights", C.c_void_p)]
 
 
+class IndexInfo(C.Structure):
+    _fields_ = [("derived_bytes", C.c_int64), ("max_doclen", C.c_int64), ("centroids_f16_exact", C.c_int32),
+                ("stage2_slices", C.c_int32), ("xcd_round_robin", C.c_int32), ("stage2_sliced", C.c_int32),
+                ("passage_chunks", C.c_int32), ("reserved", C.c_int32)]
+
+
 class SearchParams(C.Structure):
     _fields_ = [("k", C.c_int32), ("ncells", C.c_int32), ("centroid_score_threshold", C.c_float),
                 ("ndocs", C.c_int32), ("nq_cand", C.c_int32)]
@@ -45,19 +51,37 @@ def hipcc_path():
     return "hipcc"
 
 
-def build_native(force=False, verbose=False):
-    """Compile csrc/*.hip for gfx950 into lib/libflmr_hip.so (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(REPO_ROOT, "include", "flmr_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
-    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(REPO_ROOT, "include"), "-I" + CSRC] + srcs + ["-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB_PATH
+def build_native(force=False, verbose=False, extra_flags=(), lib_path=None, obj_dir=None):
+    """Compile csrc/*.hip for gfx950 into lib/libflmr_hip.so (cross-compiles without a GPU).  One object per source,
+    compiled in parallel and only when the source or a header is newer; `extra_flags` (e.g. -DFLMR_EXPERIMENTAL_VARIANTS,
+    -DX2_PROFILE) build a variant library into `lib_path` with its own object directory."""
+    from concurrent.futures import ThreadPoolExecutor
+    lib_path = lib_path or LIB_PATH
+    obj_dir = obj_dir or os.path.join(os.path.dirname(lib_path), "obj" if not extra_flags else "obj_" + str(abs(hash(tuple(extra_flags))) % 10 ** 8))
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(REPO_ROOT, "include", "flmr_hip.h")]
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
+    os.makedirs(obj_dir, exist_ok=True)
+    base = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-inline-asm",
+            "-I" + os.path.join(REPO_ROOT, "include"), "-I" + CSRC] + list(extra_flags)
+    jobs, objs = [], []
+    for name in SOURCES:
+        src, obj = os.path.join(CSRC, name), os.path.join(obj_dir, name[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append(base + ["-c", src, "-o", obj])
+    if not jobs and os.path.exists(lib_path) and all(os.path.getmtime(lib_path) >= os.path.getmtime(o) for o in objs):
+        return lib_path
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    os.makedirs(os.path.dirname(lib_path), exist_ok=True)
+    run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib_path])
+    return lib_path
 
 
 _lib = None
@@ -71,6 +95,7 @@ _SIGS = {
     "flmr_searcher_probe_supported": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(SearchParams), C.POINTER(C.c_int32)]),
     "flmr_index_open": (C.c_int, [C.POINTER(IndexDesc), C.POINTER(C.c_void_p)]),
     "flmr_index_close": (C.c_int, [C.c_void_p]),
+    "flmr_index_info": (C.c_int, [C.c_void_p, C.POINTER(IndexInfo)]),
     "flmr_searcher_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SearchParams), C.POINTER(C.c_void_p)]),
     "flmr_searcher_destroy": (C.c_int, [C.c_void_p]),
     "flmr_searcher_workspace_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),

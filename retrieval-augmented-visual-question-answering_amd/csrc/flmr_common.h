@@ -112,8 +112,10 @@ struct flmr_index {
     int32_t nchunks;
     int32_t* codes_sorted;        // [N] per-passage ascending copy of `codes` (stage-2 walk); NULL when a passage is too long
     _Float16* centroids_f16_tiled;  // centroids_f16 in MFMA A-operand order, one contiguous 1 KB run per (tile, k-step) (stage-2 walk)
-    uint16_t* doc_splits;         // [num_passages][8]: codes_sorted position of the first code >= s * slice_rows (XCD-sliced stage 2)
-    int32_t slice_rows;           // ceil(K / 8)
+    uint16_t* doc_splits;         // [num_passages][nslices]: codes_sorted position of the first code >= s * slice_rows (XCD-sliced stage 2)
+    int32_t nslices;              // 8, 16, 24 or 32: the fp16 centroid table cut so that a slice fits an XCD's L2
+    int32_t slice_rows;           // ceil(K / nslices)
+    int32_t xcd_round_robin;      // probed at open: workgroup L of a 1-D grid runs on XCD (L % 8) of 8
 };
 int flmr_build_sorted_codes(flmr_index* ix);
 int flmr_build_tiled_centroids(flmr_index* ix);
@@ -220,7 +222,7 @@ int flmr_launch_filter_stage2_xcd(const flmr_filter_args& f, const int32_t* pids
                                   int32_t max_count, uint64_t* keys, int64_t key_stride, const flmr_index* ix,
                                   const _Float16* q_hi, const _Float16* q_lo, float* part, int64_t part_stride, hipStream_t st);
 bool flmr_stage2_xcd_pays(const flmr_index* ix);
-size_t flmr_stage2_xcd_part_floats(int64_t nqueries, int64_t ndocs);
+size_t flmr_stage2_xcd_part_floats(const flmr_index* ix, int64_t nqueries, int64_t ndocs);
 // top-n of count[q] keys, unordered output (radix select); n_out[q] = min(n, count[q])
 int flmr_launch_select_topn(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t nqueries,
                             int32_t n, int32_t* out_pids, int64_t out_stride, int32_t* n_out, hipStream_t st,

@@ -187,6 +187,26 @@ extern "C" int flmr_index_open(const flmr_index_desc_t* d, flmr_index_t** out) {
     return FLMR_OK;
 }
 
+extern "C" int flmr_index_info(const flmr_index_t* ix, flmr_index_info_t* out) {
+    if (!ix || !out) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    memset(out, 0, sizeof(*out));
+    const size_t K = (size_t)ix->K;
+    size_t b = 256 * (8 / ix->nbits) * sizeof(float);
+    if (ix->centroids_f16) b += K * FLMR_DIM * sizeof(_Float16);
+    if (ix->centroids_f16_tiled) b += K * FLMR_DIM * sizeof(_Float16);
+    if (ix->codes_sorted) b += ((size_t)ix->N + 8) * sizeof(int32_t);
+    if (ix->doc_splits) b += (size_t)ix->num_passages * ix->nslices * sizeof(uint16_t);
+    if (ix->ivf_chunk_tab) b += K * ((size_t)ix->nchunks + 1) * sizeof(uint32_t);
+    out->derived_bytes = (int64_t)b;
+    out->max_doclen = ix->max_doclen;
+    out->centroids_f16_exact = ix->centroids_f16_exact;
+    out->stage2_slices = ix->nslices;
+    out->xcd_round_robin = ix->xcd_round_robin;
+    out->stage2_sliced = flmr_stage2_xcd_pays(ix) ? 1 : 0;
+    out->passage_chunks = ix->nchunks;
+    return FLMR_OK;
+}
+
 extern "C" int flmr_index_close(flmr_index_t* ix) {
     if (!ix) return FLMR_OK;
     if (ix->owns) {

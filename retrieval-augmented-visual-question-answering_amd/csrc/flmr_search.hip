@@ -123,7 +123,7 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     WS(s2_slot, B * (size_t)nd4);
     if (ix->doc_splits && s->ncol_max == 32 && (flmr_stage2_xcd_pays(ix) || s->opt.is(FLMR_OPT_S2_IMPL, "xcd"))) {
         // optional: without it (1 KB per query and survivor; e.g. out of memory) stage 2 runs in its gather form
-        const size_t bytes = flmr_stage2_xcd_part_floats((int64_t)B, nd) * sizeof(float);
+        const size_t bytes = flmr_stage2_xcd_part_floats(ix, (int64_t)B, nd) * sizeof(float);
         if (hipMalloc(reinterpret_cast<void**>(&s->s2_part), bytes) == hipSuccess) s->bytes += (int64_t)bytes;
         else { s->s2_part = nullptr; (void)hipGetLastError(); }
     }

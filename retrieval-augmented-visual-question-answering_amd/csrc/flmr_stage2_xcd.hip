@@ -28,7 +28,8 @@
 #include "flmr_common.h"
 #include "flmr_device.h"
 
-#define X2_SLICES 8
+#define X2_XCDS 8        // L2 domains a launch's workgroups are dealt to round-robin (SPX mode: checked at index open)
+#define X2_MAX_SLICES 32 // slices of the centroid table (a multiple of 8, chosen at index open so that a slice fits an L2)
 #define X2_WAVES 4
 #define X2_DOCS 64  // survivors per wave (one per lane)
 #define X2_AHEAD 6  // the codes of a tile are requested six tiles before its rows are consumed (four before they are requested)
@@ -40,13 +41,13 @@ typedef _Float16 x2h8 __attribute__((ext_vector_type(8)));
 typedef float x2f16 __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------------------------------------
-// doc_splits[p * 8 + s] = number of codes of passage p below s * slice_rows (position in the sorted copy), s = 0..7
+// doc_splits[p * nsl + s] = number of codes of passage p below s * slice_rows (position in the sorted copy), s = 0..nsl-1
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void doc_splits_kernel(const int32_t* __restrict__ codes_sorted, const int64_t* __restrict__ offsets,
-                                                         int64_t npass, int slice_rows, uint16_t* __restrict__ splits) {
+                                                         int64_t npass, int slice_rows, int nsl, uint16_t* __restrict__ splits) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t p = t >> 3;
-    const int s = (int)(t & 7);
+    const int64_t p = t / nsl;
+    const int s = (int)(t % nsl);
     if (p >= npass) return;
     const int64_t off = offsets[p];
     const int len = (int)(offsets[p + 1] - off);
@@ -56,17 +57,72 @@ __global__ __launch_bounds__(256) void doc_splits_kernel(const int32_t* __restri
         const int mid = (lo + hi) >> 1;
         if (codes_sorted[off + mid] < bound) lo = mid + 1; else hi = mid;
     }
-    splits[p * 8 + s] = (uint16_t)lo;
+    splits[p * nsl + s] = (uint16_t)lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Which L2 does workgroup L of a 1-D grid run on?  The sliced kernel confines the workgroups with L % 8 == x to table
+// slices x, x + 8, ...: that only helps if those workgroups share an L2, i.e. if the dispatcher deals consecutive
+// workgroups to the eight XCDs round-robin (SPX partition mode).  Checked ONCE at index open instead of assumed: every
+// workgroup of a probe grid reads its XCC_ID hardware register; the sliced form is enabled only if the device shows
+// all 8 XCDs and L % 8 determines the XCD.
+// ------------------------------------------------------------------------------------------------
+__global__ void xcc_probe_kernel(int32_t* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        uint32_t v;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+        out[blockIdx.x] = (int32_t)(v & 0xf);
+    }
+}
+
+static int x2_xcd_mapping_ok(bool* ok) {
+    *ok = false;
+    const int n = 4096;
+    int32_t* dev = nullptr;
+    FLMR_HIP(hipMalloc(reinterpret_cast<void**>(&dev), n * sizeof(int32_t)));
+    int32_t host[4096];
+    bool good = true;
+    for (int rep = 0; rep < 2 && good; rep++) {   // twice: the mapping must not depend on where the previous launch stopped
+        hipLaunchKernelGGL(xcc_probe_kernel, dim3(n), dim3(64), 0, 0, dev);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(host, dev, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) { good = false; break; }
+        int of_residue[X2_XCDS];
+        bool seen[16] = {};
+        for (int r = 0; r < X2_XCDS; r++) { of_residue[r] = host[r]; seen[host[r] & 15] = true; }
+        int distinct = 0;
+        for (int x = 0; x < 16; x++) distinct += seen[x] ? 1 : 0;
+        if (distinct != X2_XCDS) good = false;
+        for (int L = 0; L < n && good; L++) good = host[L] == of_residue[L % X2_XCDS];
+    }
+    (void)hipFree(dev);
+    (void)hipGetLastError();
+    *ok = good;
+    return FLMR_OK;
+}
+
+// slices: the smallest multiple of 8 whose slices fit an XCD's L2 next to the streams passing through it (4 MB L2; 4.2 MB
+// slices -- K = 131072 in 8 -- still measured at the resident rate, 8 MB slices at a third of it: DESIGN.md section 4)
+static int x2_slices_for(int64_t K) {
+    const size_t table = (size_t)K * FLMR_DIM * sizeof(_Float16);
+    const size_t per_slice = ((size_t)4 << 20) + ((size_t)1 << 18);
+    int n = X2_XCDS;
+    while (n < X2_MAX_SLICES && table > per_slice * (size_t)n) n += X2_XCDS;
+    return n;
 }
 
 int flmr_build_doc_splits(flmr_index* ix) {
     ix->doc_splits = nullptr;
-    ix->slice_rows = (int32_t)flmr_ceil_div(ix->K, X2_SLICES);
+    ix->nslices = x2_slices_for(ix->K);
+    ix->slice_rows = (int32_t)flmr_ceil_div(ix->K, ix->nslices);
+    ix->xcd_round_robin = 0;
     if (!ix->codes_sorted || ix->max_doclen > 65535) return FLMR_OK;
-    FLMR_HIP(hipMalloc(reinterpret_cast<void**>(&ix->doc_splits), (size_t)ix->num_passages * 8 * sizeof(uint16_t)));
-    const int64_t threads = ix->num_passages * 8;
+    bool ok = false;
+    const int rc = x2_xcd_mapping_ok(&ok);
+    if (rc) return rc;
+    ix->xcd_round_robin = ok ? 1 : 0;
+    FLMR_HIP(hipMalloc(reinterpret_cast<void**>(&ix->doc_splits), (size_t)ix->num_passages * ix->nslices * sizeof(uint16_t)));
+    const int64_t threads = ix->num_passages * ix->nslices;
     hipLaunchKernelGGL(doc_splits_kernel, dim3((unsigned)flmr_ceil_div(threads, 256)), dim3(256), 0, 0, ix->codes_sorted,
-                       ix->doc_offsets, ix->num_passages, ix->slice_rows, ix->doc_splits);
+                       ix->doc_offsets, ix->num_passages, ix->slice_rows, ix->nslices, ix->doc_splits);
     FLMR_LAUNCH_CHECK();
     FLMR_HIP(hipDeviceSynchronize());
     return FLMR_OK;
@@ -88,14 +144,16 @@ __device__ __forceinline__ float x2_max3(float a, float b, float c) {
     return r;
 }
 
-// grid = 8 * nqueries * G (1-D; block L: slice L & 7, query (L >> 3) % nqueries, survivor group (L >> 3) / nqueries),
-// block = 256 (4 waves x 64 survivors); dynamic LDS = 4 x (16 KB row buffers + 2 KB code ring + 1.5 KB octet table).
+// grid = nsl * nqueries * G (1-D; block L: XCD x = L & 7, query (L >> 3) % nqueries, survivor group ((L >> 3) / nqueries) % G,
+// pass hf = (L >> 3) / (nqueries * G), slice 8 * hf + x: with more than 8 slices the grid works through them eight at a time,
+// so that an L2 holds one slice at any moment), block = 256 (4 waves x 64 survivors);
+// dynamic LDS = 4 x (16 KB row buffers + 2 KB code ring + 1.5 KB octet table).
 __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_args f, const int32_t* __restrict__ pids, int64_t pid_stride,
                                                                     const int32_t* __restrict__ counts, float* __restrict__ part,
                                                                     int64_t part_stride, const _Float16* __restrict__ cen16,
                                                                     const _Float16* __restrict__ q_hi, const _Float16* __restrict__ q_lo,
                                                                     const int32_t* __restrict__ codes_sorted,
-                                                                    const uint16_t* __restrict__ splits
+                                                                    const uint16_t* __restrict__ splits, int nsl, int G
 #ifdef X2_PROFILE
                                                                     , long long* prof
 #endif
@@ -110,9 +168,10 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
 #define X2_STAMP(k) do { } while (0)
 #endif
     const int L = blockIdx.x;
-    const int sl = L & (X2_SLICES - 1);
     const int rest = L >> 3;
-    const int b = rest % f.nqueries, g = rest / f.nqueries;
+    const int b = rest % f.nqueries, gg = rest / f.nqueries;
+    const int g = gg % G;
+    const int sl = (gg / G) * X2_XCDS + (L & (X2_XCDS - 1));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int cnt = counts[b];
@@ -137,8 +196,8 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
         const int pid = pids[(size_t)b * pid_stride + slot0 + lane];
         const int64_t off = f.offsets[pid];
         const int len = (int)(f.doclens ? f.doclens[pid] : (f.offsets[pid + 1] - off));
-        const int start = splits[(size_t)pid * 8 + sl];
-        const int end = sl < X2_SLICES - 1 ? (int)splits[(size_t)pid * 8 + sl + 1] : len;
+        const int start = splits[(size_t)pid * nsl + sl];
+        const int end = sl < nsl - 1 ? (int)splits[(size_t)pid * nsl + sl + 1] : len;
         run_len = end - start;
         run_base = (uint32_t)(off + start);
     }
@@ -162,7 +221,8 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
 #pragma unroll
     for (int s = 0; s < 8; s++) asm volatile("" : "+v"(bh[s]), "+v"(bl[s])::"memory");
     // part[query][survivor slot][slice][32]: the eight partial rows of a survivor are one contiguous KB for the combine kernel
-    float* const prow = part + (((size_t)b * part_stride + slot0) * X2_SLICES + sl) * 32;
+    float* const prow = part + (((size_t)b * part_stride + slot0) * nsl + sl) * 32;
+    const size_t pstep = (size_t)nsl * 32;
     uint32_t piece_off[8];  // byte offset, inside its row, of the 16-byte piece this lane moves in DMA instruction gq
 #pragma unroll
     for (int gq = 0; gq < 8; gq++) piece_off[gq] = (uint32_t)(((lane & 15) ^ ((4 * gq + (lane >> 4)) & 15)) << 4);
@@ -238,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
             float cm = -9999.0f;
             auto flush = [&](int j) {
                 const float v = flmr_xhalf_max(cm);
-                if (h == 0) prow[(size_t)j * (X2_SLICES * 32) + i] = v;
+                if (h == 0) prow[(size_t)j * pstep + i] = v;
             };
             for (int t = 0; t < ntiles; t++) {
                 // ---- tile t's rows ----
@@ -339,6 +399,7 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
 
 // one half-wave per survivor: maximum over the slices that hold tokens, k-ascending sum of the first nqc columns, key.
 // grid = (nqueries, ceil(max_count / 8)), block = 256
+template <int NSL>
 __global__ __launch_bounds__(256) void s2_combine_kernel(flmr_filter_args f, const int32_t* __restrict__ pids, int64_t pid_stride,
                                                          const int32_t* __restrict__ counts, const float* __restrict__ part,
                                                          int64_t part_stride, const uint16_t* __restrict__ splits,
@@ -356,16 +417,20 @@ __global__ __launch_bounds__(256) void s2_combine_kernel(flmr_filter_args f, con
         pid = pids[(size_t)b * pid_stride + d];
         const int64_t off = f.offsets[pid];
         const int len = (int)(f.doclens ? f.doclens[pid] : (f.offsets[pid + 1] - off));
-        const uint4 sp = *reinterpret_cast<const uint4*>(splits + (size_t)pid * 8);
-        const uint32_t w[4] = {sp.x, sp.y, sp.z, sp.w};
-        // all eight rows are requested before the first is used (a slice without tokens was never written: its row is read and dropped)
-        float v[X2_SLICES];
+        uint32_t w[NSL / 2];
 #pragma unroll
-        for (int s = 0; s < X2_SLICES; s++) v[s] = __builtin_nontemporal_load(part + (((size_t)b * part_stride + d) * X2_SLICES + s) * 32 + i);
+        for (int q4 = 0; q4 < NSL / 8; q4++) {
+            const uint4 sp = *reinterpret_cast<const uint4*>(splits + (size_t)pid * NSL + 8 * q4);
+            w[4 * q4] = sp.x; w[4 * q4 + 1] = sp.y; w[4 * q4 + 2] = sp.z; w[4 * q4 + 3] = sp.w;
+        }
+        // all rows are requested before the first is used (a slice without tokens was never written: its row is read and dropped)
+        float v[NSL];
 #pragma unroll
-        for (int s = 0; s < X2_SLICES; s++) {
+        for (int s = 0; s < NSL; s++) v[s] = __builtin_nontemporal_load(part + (((size_t)b * part_stride + d) * NSL + s) * 32 + i);
+#pragma unroll
+        for (int s = 0; s < NSL; s++) {
             const int start = (int)((w[s >> 1] >> (16 * (s & 1))) & 0xffffu);
-            const int end = s < 7 ? (int)((w[(s + 1) >> 1] >> (16 * ((s + 1) & 1))) & 0xffffu) : len;
+            const int end = s < NSL - 1 ? (int)((w[(s + 1) >> 1] >> (16 * ((s + 1) & 1))) & 0xffffu) : len;
             m = end > start ? fmaxf(m, v[s]) : m;
         }
     }
@@ -379,13 +444,17 @@ __global__ __launch_bounds__(256) void s2_combine_kernel(flmr_filter_args f, con
 long long* x2_prof_buffer = nullptr;  // set by the stand-alone harness (profiles/microbench/s2_xcd_probe.hip)
 #endif
 
-// the sliced form pays when the centroid table does not fit an XCD's L2 anyway (the gather kernel then reads it from the fabric)
+// the sliced form pays when the centroid table does not fit an XCD's L2 anyway (the gather kernel then reads it from the
+// fabric) AND consecutive workgroups really land on the eight XCDs in turn (probed at index open)
 bool flmr_stage2_xcd_pays(const flmr_index* ix) {
     const size_t table = (size_t)ix->K * FLMR_DIM * sizeof(_Float16);
-    return ix->doc_splits && ix->codes_sorted && table > ((size_t)6 << 20) && table < ((size_t)1 << 32);  // 32-bit row offsets
+    return ix->doc_splits && ix->codes_sorted && ix->xcd_round_robin && table > ((size_t)6 << 20) &&
+           table < ((size_t)1 << 32);  // 32-bit row offsets
 }
 
-size_t flmr_stage2_xcd_part_floats(int64_t nqueries, int64_t ndocs) { return (size_t)nqueries * X2_SLICES * ndocs * 32; }
+size_t flmr_stage2_xcd_part_floats(const flmr_index* ix, int64_t nqueries, int64_t ndocs) {
+    return (size_t)nqueries * (size_t)ix->nslices * ndocs * 32;
+}
 
 int flmr_launch_filter_stage2_xcd(const flmr_filter_args& f, const int32_t* pids, int64_t pid_stride, const int32_t* counts,
                                   int32_t max_count, uint64_t* keys, int64_t key_stride, const flmr_index* ix,
@@ -395,18 +464,26 @@ int flmr_launch_filter_stage2_xcd(const flmr_filter_args& f, const int32_t* pids
     if (!ix->doc_splits || !ix->codes_sorted || !part) FLMR_FAIL(FLMR_ERR_INVALID, "stage-2 sliced kernel needs the sorted codes and their split table");
     if ((size_t)ix->K * FLMR_DIM * sizeof(_Float16) >= ((size_t)1 << 32)) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "stage-2 sliced kernel: centroid table >= 4 GB");
     const int G = (int)flmr_ceil_div(max_count, X2_WAVES * X2_DOCS);
-    const int64_t grid = (int64_t)X2_SLICES * f.nqueries * G;
+    const int nsl = ix->nslices;
+    const int64_t grid = (int64_t)nsl * f.nqueries * G;
     if (grid > 0x7fffffffLL) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "stage-2 grid too large");
     const size_t lds = (size_t)X2_WAVES * X2_WAVE_LDS;
     FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_stage2_xcd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(filter_stage2_xcd_kernel, dim3((unsigned)grid), dim3(256), lds, st, f, pids, pid_stride, counts, part, part_stride,
-                       ix->centroids_f16, q_hi, q_lo, ix->codes_sorted, ix->doc_splits
+                       ix->centroids_f16, q_hi, q_lo, ix->codes_sorted, ix->doc_splits, nsl, G
 #ifdef X2_PROFILE
                        , x2_prof_buffer
 #endif
     );
-    hipLaunchKernelGGL(s2_combine_kernel, dim3(f.nqueries, (unsigned)flmr_ceil_div(max_count, 8)), dim3(256), 0, st, f, pids, pid_stride,
-                       counts, part, part_stride, ix->doc_splits, keys, key_stride);
+    const dim3 cgrid(f.nqueries, (unsigned)flmr_ceil_div(max_count, 8));
+    if (nsl == 8)
+        hipLaunchKernelGGL(s2_combine_kernel<8>, cgrid, dim3(256), 0, st, f, pids, pid_stride, counts, part, part_stride, ix->doc_splits, keys, key_stride);
+    else if (nsl == 16)
+        hipLaunchKernelGGL(s2_combine_kernel<16>, cgrid, dim3(256), 0, st, f, pids, pid_stride, counts, part, part_stride, ix->doc_splits, keys, key_stride);
+    else if (nsl == 24)
+        hipLaunchKernelGGL(s2_combine_kernel<24>, cgrid, dim3(256), 0, st, f, pids, pid_stride, counts, part, part_stride, ix->doc_splits, keys, key_stride);
+    else
+        hipLaunchKernelGGL(s2_combine_kernel<32>, cgrid, dim3(256), 0, st, f, pids, pid_stride, counts, part, part_stride, ix->doc_splits, keys, key_stride);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }

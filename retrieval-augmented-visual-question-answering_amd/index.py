@@ -215,6 +215,13 @@ class DeviceIndex:
         self.handle = h
         self._lib = lib
 
+    def info(self):
+        """dict of what flmr_index_open derived on this device (flmr_index_info): stage-2 slice count, the XCD dispatch
+        probe, derived HBM bytes, ..."""
+        out = _native.IndexInfo()
+        _native.check(self._lib.flmr_index_info(self.handle, C.byref(out)))
+        return {name: getattr(out, name) for name, _ in out._fields_ if name != "reserved"}
+
     def close(self):
         if getattr(self, "handle", None):
             self._lib.flmr_index_close(self.handle)

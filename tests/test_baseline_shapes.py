@@ -3,7 +3,10 @@
 
   cfg2  10 k passages x 128 tokens, K = 16384                    (BASELINE.json configs[1])
   cfg3  160 k passages, K = 65536, nbits = 8, Nq in {320, 832}  (configs[2]: PreFLMR's long queries + PQ decompress)
-  cfg4  1 M passages x 128 tokens, K = 131072, nbits 2 and 8, fixed and ragged doclens   (configs[3], one GPU's view)
+  cfg4  1 M passages x 128 tokens, K = 131072, nbits 2 and 8, fixed and ragged doclens   (configs[3], one GPU's view);
+        the same corpus cut into 8 passage shards through the exact three-exchange protocol (bit-identical to unsharded)
+  cfg5  6 M passages x 128 tokens (768 M tokens), K = 262144 (collection_indexer.py:93), nbits = 2 on one device, and one
+        GPU's shard of it (750 k passages, K = 262144, nbits = 8)                         (configs[4])
 
 Policies follow searcher.py:92-118: k <= 100 -> (ncells 2, thr 0.45, ndocs 1024); k = 500 -> (4, 0.4, 4096).
 Bars: ranked ids identical position by position except inside runs of reference scores closer than `gap` (another valid
@@ -45,13 +48,28 @@ def _reference_ranker(arrays):
     return lambda Q, ncells, thr, ndocs: oi.rank(Q, ncells, thr, ndocs, 32), "port"
 
 
-def _check(hip, corpus, nq, n_queries, ks, seed=2, max_batch=32):
+def _check(hip, corpus, nq, n_queries, ks, seed=2, max_batch=32, local_queries=False):
+    """local_queries: `corpus` is one passage shard (pid_base > 0) searched on its own -- plant the queries inside it and
+    compare LOCAL pids with the reference run on the shard's arrays (flmr_search_batch returns global pids)."""
     torch = hip["torch"]
     from ravqa_amd import synth
     from ravqa_amd.scorer import IndexScorer
     scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=max_batch)
+    info = scorer.device_index.info()
+    # the sliced stage 2 is the default at these table sizes when the dispatch probe confirms the XCD mapping; a slice must
+    # fit an L2 (4 MB + slack) whatever K is
+    if corpus.K * 256 > (6 << 20):
+        assert info["stage2_sliced"] == info["xcd_round_robin"] and corpus.K * 256 <= info["stage2_slices"] * ((4 << 20) + (1 << 18)), info
     rank, kind = _reference_ranker(synth.corpus_to_arrays(corpus))
-    Q, targets = synth.make_queries(corpus, max(n_queries.values()), nq, seed=seed)
+    base = 0
+    if local_queries:
+        import copy
+        view = copy.copy(corpus)
+        view.g_doclens, view.g_doc_offsets, view.g_codes = corpus.doclens, corpus.doc_offsets, corpus.codes
+        base = corpus.pid_base
+        Q, targets = synth.make_queries(view, max(n_queries.values()), nq, seed=seed)
+    else:
+        Q, targets = synth.make_queries(corpus, max(n_queries.values()), nq, seed=seed)
     Qh = Q.cpu().numpy()
     checked = 0
     for k in ks:
@@ -59,7 +77,7 @@ def _check(hip, corpus, nq, n_queries, ks, seed=2, max_batch=32):
         n = n_queries[k]
         p, s, c = scorer.search_batch(Q[:n], ndocs // 4, ncells, thr, ndocs, 32)
         scorer.check()
-        p, s, c = p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy()
+        p, s, c = p.cpu().numpy() - base, s.cpu().numpy(), c.cpu().numpy()
         for i in range(n):
             rp, rs, ncand = rank(Qh[i], ncells, thr, ndocs)
             if ncand < ndocs:       # the reference's undefined case (filter_pids.cpp:119-123): defined here, tested elsewhere
@@ -103,6 +121,27 @@ def test_cfg4_1m_passages_headline_shape(hip, nbits, doclen):
     from ravqa_amd import synth
     corpus = synth.make_corpus(1_000_000, doclen, 131072, nbits, seed=0, device="cuda")
     _check(hip, corpus, 32, {100: 32, 500: 4}, ks=(100, 500))
+
+
+def test_cfg5_6m_passages_768m_tokens_one_device(hip):
+    """BASELINE configs[4] at its size, on ONE device (the 8-GPU job holds an eighth of it per rank): 6 M passages x 128
+    tokens = 768 M tokens, K = 2^18 (collection_indexer.py:93), nbits = 2 -- 3 GB of codes, 24.6 GB of residual bytes.
+    Exercises what the smaller shapes cannot: token positions past 2^29 (byte offsets past 2^31 in every code / residual
+    access), 184 passage chunks per query in candidate generation, a 64 MB fp16 centroid table (16 stage-2 slices so that
+    each still fits an XCD's L2), 190 k candidates per query.  Every ranked list is compared with the reference's CPU stages."""
+    from ravqa_amd import synth
+    corpus = synth.make_corpus(6_000_000, 128, 262144, 2, seed=0, device="cuda")
+    assert corpus.codes.numel() == 768_000_000
+    _check(hip, corpus, 32, {100: 8, 500: 2}, ks=(100, 500), max_batch=8)
+
+
+def test_cfg5_one_shard_view_nbits8(hip):
+    """What ONE rank of the 8-GPU configs[4] job holds: passages [2.25 M, 3 M) of the 6 M corpus (generated shard-locally),
+    K = 2^18 replicated, nbits = 8 (the FLMR configs' setting: 128 residual bytes per token, 12.3 GB)."""
+    from ravqa_amd import synth
+    corpus = synth.make_corpus(6_000_000, 128, 262144, 8, seed=0, device="cuda", pid_range=synth.shard_range(6_000_000, 3, 8))
+    assert corpus.pid_base == 2_250_000 and corpus.doclens.numel() == 750_000
+    _check(hip, corpus, 32, {100: 8, 500: 2}, ks=(100, 500), max_batch=8, local_queries=True)
 
 
 def _exact_protocol_on_one_device(torch, ops, shards, Q, k, ncells, thr, ndocs, split_stage0=True):

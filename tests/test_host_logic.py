@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/flmr_hip.h but not exported"
     assert declared == set(_native.EXPORTED_SYMBOLS)
-    assert lib.flmr_abi_version() == _native.ABI_VERSION == 2
+    assert lib.flmr_abi_version() == _native.ABI_VERSION == int(re.search(r"#define FLMR_ABI_VERSION (\d+)", header).group(1))
 
 
 def test_product_path_fails_loudly_without_device():
