@@ -272,6 +272,20 @@ int flmr_colbert_score_padded(const float* Q, int32_t q_batch, int32_t nq, const
 int flmr_merge_topk(const float* scores, const int32_t* pids, int32_t nshards, int32_t nqueries, int32_t k,
                     float* out_scores, int32_t* out_pids, int32_t* out_counts, flmr_stream_t stream);
 
+/* Exchange steps over RCCL for a caller without torch.  `comm` is an ncclComm_t the CALLER created
+ * (one rank per GPU); the collectives are enqueued on `stream`.  libflmr_hip.so does not link librccl: the symbols are
+ * resolved on first use from the RCCL instance already loaded in the process (FLMR_ERR_UNSUPPORTED when there is none).
+ *   flmr_topk_allgather     fast mode: all-gather of every rank's flmr_search_batch output (scores f32 / GLOBAL pids i32
+ *                           [nqueries, k]) into the caller's [nranks, nqueries, k] workspaces, then flmr_merge_topk.
+ *   flmr_keys_allgather     exact mode after phase 1: keys [count] per rank -> out [nranks, count] (then flmr_select_keys on
+ *                           the [nqueries, nranks * ndocs] view; the permutation of ranks inside a row does not matter).
+ *   flmr_keys_allreduce_sum exact mode after phases 2 / 3: slot-aligned keys, one non-zero contributor per slot, summed in place. */
+int flmr_topk_allgather(void* comm, int32_t nranks, const float* scores, const int32_t* pids, int32_t nqueries, int32_t k,
+                        float* gathered_scores, int32_t* gathered_pids, float* out_scores, int32_t* out_pids,
+                        int32_t* out_counts, flmr_stream_t stream);
+int flmr_keys_allgather(void* comm, int32_t nranks, const uint64_t* keys, int64_t count, uint64_t* out, flmr_stream_t stream);
+int flmr_keys_allreduce_sum(void* comm, uint64_t* keys, int64_t count, flmr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Index build ops: ResidualCodec.compress (colbert/indexing/codecs/residual.py:169-222).  All pointers are
  * DEVICE pointers, dim == 128.

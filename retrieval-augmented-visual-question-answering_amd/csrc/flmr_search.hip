@@ -504,12 +504,12 @@ extern "C" int flmr_searcher_probe_dims(const flmr_searcher_t* s, int32_t* idx_w
 extern "C" int flmr_search_probe(flmr_searcher_t* s, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
                                  const flmr_search_params_t* p, int32_t q_begin, int32_t q_count, uint32_t* out_idx_bits,
                                  int32_t* out_cells, int32_t* out_ncell, flmr_stream_t stream) {
+    if (q_count == 0 && s && q_begin >= 0 && q_begin <= nqueries) return FLMR_OK;  // an empty slice (more ranks than queries) has no outputs
     if (!out_idx_bits || !out_cells || !out_ncell) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
     run_ctx c(s);
     RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
     if (!c.sparse) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "query-split stage 0 needs the sparse-table path (fp16-exact centroids, K %% 64 == 0, nq_cand <= 32)");
     if (q_begin < 0 || q_count < 0 || q_begin + q_count > nqueries) FLMR_FAIL(FLMR_ERR_INVALID, "query slice [%d, %d) outside the batch of %d", q_begin, q_begin + q_count, nqueries);
-    if (q_count == 0) return FLMR_OK;
     flmr_s0_args a0 = c.a0;  // the slice uses workspace slots 0..q_count; its results go straight to the caller's buffers
     a0.Q = Q + (size_t)q_begin * nq * FLMR_DIM;
     a0.q_lens = c.q_lens ? c.q_lens + q_begin : nullptr;

@@ -56,6 +56,7 @@ def _check(hip, corpus, nq, n_queries, ks, seed=2, max_batch=32, local_queries=F
     from ravqa_amd.scorer import IndexScorer
     scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=max_batch)
     info = scorer.device_index.info()
+    print("index info:", info)
     # the sliced stage 2 is the default at these table sizes when the dispatch probe confirms the XCD mapping; a slice must
     # fit an L2 (4 MB + slack) whatever K is
     if corpus.K * 256 > (6 << 20):
@@ -151,9 +152,12 @@ def _exact_protocol_on_one_device(torch, ops, shards, Q, k, ncells, thr, ndocs, 
     if split_stage0:
         per = -(-B // W)
         parts = []
-        for r, sh in enumerate(shards):
+        for r, sh in enumerate(shards):                                     # (k = 500: 4 queries over 8 ranks -> empty slices)
             lo = min(B, r * per)
-            parts.append(sh.probe(Q, k, ncells, thr, ndocs, lo, min(B, lo + per) - lo, 32))
+            iw, mc = sh.probe_dims(Q, k, ncells, thr, ndocs, 32)
+            bufs = (torch.zeros((per, iw), dtype=torch.int32, device="cuda"), torch.zeros((per, mc), dtype=torch.int32, device="cuda"),
+                    torch.zeros((per,), dtype=torch.int32, device="cuda"))  # what distributed.py gathers: `per` rows per rank
+            parts.append(sh.probe(Q, k, ncells, thr, ndocs, lo, min(B, lo + per) - lo, 32, out=bufs))
         bits, cells, ncell = (torch.cat([p_[j] for p_ in parts]) for j in range(3))
         k1 = [sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32) for sh in shards]
     else:

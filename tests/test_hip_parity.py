@@ -1142,3 +1142,57 @@ def test_flmr_model_surface_score_and_forward(hip):
     Qg = Q.clone().requires_grad_(True)
     with pytest.raises(RuntimeError, match="forward-only"):
         model.score(Qg.repeat_interleave(nway, dim=0), D, mask)
+
+
+def test_rccl_exchange_entry_points_single_rank_communicator(hip):
+    """flmr_topk_allgather / flmr_keys_allgather / flmr_keys_allreduce_sum (the exchange steps of SURVEY 8e for a caller
+    without torch) over a REAL RCCL communicator -- one rank, the most this box has -- created here through ctypes the way a
+    C caller would (ncclGetUniqueId + ncclCommInitRank): checks the symbol resolution from the loaded RCCL, dtypes, the
+    grouped gather and the merge that follows, against ops.merge_topk on the same lists."""
+    import ctypes as C
+    torch, ops, nat = hip["torch"], hip["ops"], hip["native"]
+    lib = nat.load()
+    rccl = None
+    for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1",
+                 os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")):
+        try:
+            rccl = C.CDLL(name, mode=C.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    assert rccl is not None, "no RCCL on this box"
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        g = torch.Generator().manual_seed(3)
+        n, k = 37, 100
+        scores = torch.randn(n, k, generator=g).sort(dim=1, descending=True).values.cuda()
+        pids = torch.randint(0, 1 << 20, (n, k), generator=g, dtype=torch.int32).cuda()
+        pids[5, 60:] = -1                                        # a short list
+        gs, gp = torch.empty(1, n, k, device="cuda"), torch.empty(1, n, k, dtype=torch.int32, device="cuda")
+        os_, op, oc = torch.empty(n, k, device="cuda"), torch.empty(n, k, dtype=torch.int32, device="cuda"), torch.empty(n, dtype=torch.int32, device="cuda")
+        P = lambda t: C.c_void_p(t.data_ptr())
+        nat.check(lib.flmr_topk_allgather(comm, 1, P(scores), P(pids), n, k, P(gs), P(gp), P(os_), P(op), P(oc), nat.stream_ptr()))
+        rs, rp, rc = ops.merge_topk(scores.unsqueeze(0), pids.unsqueeze(0))
+        torch.cuda.synchronize()
+        assert torch.equal(gs[0], scores) and torch.equal(gp[0], pids)
+        assert torch.equal(os_, rs) and torch.equal(op, rp) and torch.equal(oc, rc) and int(oc[5]) == 60
+        keys = torch.randint(0, 1 << 62, (n * 64,), generator=g, dtype=torch.int64).cuda()
+        out = torch.zeros_like(keys)
+        nat.check(lib.flmr_keys_allgather(comm, 1, P(keys), keys.numel(), P(out), nat.stream_ptr()))
+        red = keys.clone()
+        nat.check(lib.flmr_keys_allreduce_sum(comm, P(red), red.numel(), nat.stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(out, keys) and torch.equal(red, keys)
+        # a communicator of another size is refused before anything is enqueued
+        assert lib.flmr_keys_allgather(comm, 2, P(keys), keys.numel(), P(out), nat.stream_ptr()) != 0
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
