@@ -212,6 +212,28 @@ int flmr_searcher_tap(flmr_searcher_t* searcher, int32_t what, int32_t query, vo
  * FLMR_TAP_CENTROID_SCORES tap will be read (what IndexScorer.retrieve() returns, index_storage.py:67-80). */
 int flmr_searcher_set_full_table(flmr_searcher_t* searcher, int32_t enable);
 
+/* Numerics mode.  FLMR_NUMERICS_CPU (default) = the reference's CPU path, the one the golden vectors pin.
+ * FLMR_NUMERICS_GPU_FP16 = the reference's CUDA path (use_gpu=True: TPC/search/index_storage.py:113-149,157-158,
+ * TPC/search/candidate_generation.py:50-52, TPC/indexing/codecs/residual.py:242-278 + decompress_residuals.cu,
+ * TPC/modeling/colbert.py:235-263,289-311), what the reference runs when config.total_visible_gpus > 0
+ * (src/executors/FLMR_executor.py:784):
+ *   - Q rounded to fp16; centroid scores = fp16 x fp16 products accumulated in fp32, rounded to fp16;
+ *   - idx = half(score) >= half(thr);
+ *   - stage 1 / 2: per-column maxima of the fp16 scores, padding -9999 stored in fp16 (-10000), the column sum accumulated
+ *     in fp32 and rounded to fp16 (a passage without a qualifying code scores -inf); top-ndocs, then top-ndocs/4;
+ *   - stage 3: embeddings = half(centroid + half(bucket weight)), L2-normalised with an fp16 norm into fp16, scores =
+ *     fp16 x fp16 products accumulated in fp32 and rounded to fp16, max over the passage's REAL tokens only (no zero clamp),
+ *     summed in fp32 and rounded to fp16.
+ * Where torch leaves an order open (topk / sort among equal fp16 scores, GEMM summation order) this build breaks ties by
+ * (score, pid) descending and accumulates k-ascending inside the MFMA's blocks.  Parity of this mode is checked against the
+ * reference's torch expressions evaluated on CPU half tensors (tests/golden/make_golden_gpu_numerics.py); the reference's
+ * CUDA kernels themselves cannot run in the build environment, so where they decide (decompress_residuals.cu, the CUDA
+ * GEMMs) parity is UNPINNED.  FLMR_ERR_UNSUPPORTED unless the centroids are fp16-representable and K % 64 == 0.  The mode
+ * applies to flmr_search_batch and the phased protocol alike; the walk variant of stage 2 is not used in it. */
+#define FLMR_NUMERICS_CPU 0
+#define FLMR_NUMERICS_GPU_FP16 1
+int flmr_searcher_set_numerics(flmr_searcher_t* searcher, int32_t mode);
+
 /* Timing taps: per-stage HIP-event milliseconds, SUMMED over the flmr_search_batch calls made in profiling mode
  * (flmr_searcher_set_profiling(s, 1)) since the previous read; reading waits for those calls and clears the sums, so a
  * caller that splits a batch into sub-batches reads the whole batch's stage times once.  ms[FLMR_NUM_STAGES] is HOST

@@ -290,3 +290,107 @@ class RefCpuScorer:
             sc = self.maxsim(D @ Q.T, self.doclens[fin.long()])
             srt = sc.sort(descending=True)
             return fin[srt.indices].tolist(), srt.values.tolist(), int(pids.numel())
+
+
+# ---- the reference's CUDA-branch arithmetic (FLMR_NUMERICS_GPU_FP16), restated with numpy float16 ---------------
+def f16(x):
+    """fp32 -> nearest fp16 (ties to even, overflow -> +-inf) -> fp32: the value a half tensor holds."""
+    with np.errstate(over="ignore"):
+        return np.asarray(x, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
+class GpuNumericsOracle:
+    """CPU restatement of IndexScorer.rank with use_gpu=True (TPC/search/index_storage.py:86-98,113-158,176-177,
+    candidate_generation.py:12-64, indexing/codecs/residual.py:242-278 + decompress_residuals.cu, modeling/colbert.py:235-263,
+    289-311): fp16 tensors where that branch holds fp16, fp32 accumulation where the CUDA GEMM / sum accumulates in fp32.
+    Where torch leaves the order open (topk / sort among equal scores) ties go to the larger pid, as in the HIP build.
+    TEST INFRASTRUCTURE: pinned to the reference's own expressions evaluated on CPU half tensors by
+    tests/test_oracle_golden.py::test_gpu_numerics_oracle_vs_reference_expressions (tests/golden/gpu_numerics.npz); parity
+    with the reference's CUDA kernels themselves is UNPINNED (no CUDA device in the build environment)."""
+
+    PAD = np.float32(-10000.0)   # half(-9999)
+
+    def __init__(self, oi: OracleIndex):
+        self.oi = oi
+        self.bw16 = f16(oi.bucket_weights)
+
+    def centroid_scores_raw(self, Q, nq_cand=32):
+        return self.oi.centroids @ f16(Q[:nq_cand]).T            # fp32 accumulation of fp16 x fp16 products, [K, nqc]
+
+    def cells(self, raw, ncells):
+        """per column the ncells best centroids by (value desc, index asc) of the UNROUNDED products (a valid choice among
+        the fp16 ties torch.topk resolves arbitrarily), ascending unique."""
+        out = set()
+        for k in range(raw.shape[1]):
+            order = np.lexsort((np.arange(raw.shape[0]), -raw[:, k]))
+            out.update(order[:ncells].tolist())
+        return np.array(sorted(out), dtype=np.int32)
+
+    def idx(self, cs16, thr):
+        return cs16.max(-1) >= f16(np.float32(thr))
+
+    def approx_scores(self, cs16, pids, idx=None):
+        """per passage: sum over columns (fp32 accumulation, fp16 result) of the per-column maximum over its codes
+        (restricted to idx when given), -9999 -> half -10000 where no code qualifies."""
+        oi, nqc = self.oi, cs16.shape[1]
+        out = np.empty(len(pids), dtype=np.float32)
+        for j, p in enumerate(np.asarray(pids).tolist()):
+            c = oi.codes[oi.offsets[p]:oi.offsets[p + 1]]
+            if idx is not None:
+                c = c[idx[c]]
+            col = cs16[c].max(0) if len(c) else np.full(nqc, self.PAD, dtype=np.float32)
+            col = np.maximum(col, self.PAD)
+            s = np.float32(0.0)
+            for k in range(nqc):
+                s = np.float32(s + col[k])
+            out[j] = f16(s)
+        return out
+
+    @staticmethod
+    def top(scores, pids, n):
+        """the n best by (score, pid) descending, in that order"""
+        pids = np.asarray(pids)
+        order = np.lexsort((-pids.astype(np.int64), -scores.astype(np.float64)))
+        return pids[order[:n]], scores[order[:n]]
+
+    def embeddings(self, pids):
+        oi = self.oi
+        vpb = 8 // oi.nbits
+        rows = np.concatenate([np.arange(oi.offsets[p], oi.offsets[p + 1]) for p in np.asarray(pids).tolist()] or [np.zeros(0, np.int64)]).astype(np.int64)
+        lut = oi.lut.reshape(256, vpb)
+        w = self.bw16[lut[oi.reversed_bit_map[oi.residuals[rows]]].reshape(len(rows), -1)]
+        D = f16(w + oi.centroids[oi.codes[rows]])                            # half(weight) + half(centroid) in half
+        nrm = f16(np.sqrt((D.astype(np.float32) ** 2).sum(-1, dtype=np.float32)))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            Dn = np.where(nrm[:, None] > 0, f16(D / nrm[:, None]), np.float32(0.0))
+        return Dn.astype(np.float32)
+
+    def doc_scores(self, Q, pids):
+        oi = self.oi
+        Dn = self.embeddings(pids)
+        sc = f16(Dn @ f16(Q).T)                                               # [tokens, Nq] half
+        out = np.empty(len(pids), dtype=np.float32)
+        t = 0
+        for j, p in enumerate(np.asarray(pids).tolist()):
+            n = int(oi.doclens[p])
+            col = sc[t:t + n].max(0) if n else np.full(Q.shape[0], self.PAD, dtype=np.float32)
+            t += n
+            s = np.float32(0.0)
+            for k in range(Q.shape[0]):
+                s = np.float32(s + col[k])
+            out[j] = f16(s)
+        return out
+
+    def rank(self, Q, ncells, thr, ndocs, nq_cand=32):
+        Q = np.asarray(Q, dtype=np.float32)
+        raw = self.centroid_scores_raw(Q, nq_cand)
+        cs16 = f16(raw)
+        cand = self.oi.candidates(self.cells(raw, ncells))
+        idx = self.idx(cs16, thr)
+        s1 = self.approx_scores(cs16, cand, idx)
+        p1, _ = self.top(s1, cand, ndocs) if ndocs < len(cand) else (cand, s1)
+        s2 = self.approx_scores(cs16, p1)
+        p2, _ = self.top(s2, p1, ndocs // 4) if ndocs // 4 < len(p1) else (p1, s2)
+        sc = self.doc_scores(Q, p2)
+        fp, fs = self.top(sc, p2, len(p2))
+        return fp, fs, len(cand)

@@ -120,6 +120,7 @@ _SIGS = {
     "flmr_searcher_tap": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "flmr_searcher_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "flmr_searcher_set_full_table": (C.c_int, [C.c_void_p, C.c_int32]),
+    "flmr_searcher_set_numerics": (C.c_int, [C.c_void_p, C.c_int32]),
     "flmr_searcher_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "flmr_stage_name": (C.c_char_p, [C.c_int32]),
     "flmr_filter_pids": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

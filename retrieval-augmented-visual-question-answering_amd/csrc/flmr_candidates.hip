@@ -310,10 +310,11 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int e = s1s_enc(x[i]);
-                sc += q4 * 4 + i < nqc ? s1s_dec(e > init ? e : init) : 0.0f;
+                const float m = s1s_dec(e > init ? e : init);
+                sc += q4 * 4 + i < nqc ? (a.f16_round ? flmr_round_f16(m) : m) : 0.0f;
             }
         }
-        rsum[wave + S1S_WAVES * lane] = sc;   // (read after the first chunk's barriers)
+        rsum[wave + S1S_WAVES * lane] = a.f16_round ? flmr_round_f16(sc) : sc;   // (read after the first chunk's barriers)
     }
 
     // The chunk bitmaps and the slots' pair counters start at zero and are LEFT at zero by whoever reads them last (the
@@ -520,9 +521,9 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
 #pragma unroll
                 for (int q = 0; q < 8; q++) v[q] = s1s_dec(acc[sl * S1S_STRIDE + q0 + q]);
 #pragma unroll
-                for (int q = 0; q < 8; q++) sc += q0 + q < nqc ? v[q] : 0.0f;
+                for (int q = 0; q < 8; q++) sc += q0 + q < nqc ? (a.f16_round ? flmr_round_f16(v[q]) : v[q]) : 0.0f;
             }
-            return sc;
+            return a.f16_round ? flmr_round_f16(sc) : sc;
         };
         if (dense) {   // every slot holds a row: scores into the padding words, one thread per slot
             for (int sl = tid; sl < nslot; sl += 64 * S1S_WAVES) acc[sl * S1S_STRIDE + 32] = __float_as_int(column_sum(sl));
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(1024) void cand_emit_kernel(const uint32_t* cand_bi
                                                          const int32_t* chunk_cnt, int nchunks, int32_t* cand, int64_t cand_cap,
                                                          uint8_t* cand_hit, int32_t* cand_count, int32_t* overflow,
                                                          const int32_t* skip, const int32_t* key_count, const int32_t* chunk_hits,
-                                                         uint64_t* keys, const int32_t* q_lens, int nq_cand, int n_select) {
+                                                         uint64_t* keys, const int32_t* q_lens, int nq_cand, int n_select, int f16_round) {
     __shared__ int scan_lds[17];
     __shared__ int base_lds;
     const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
@@ -615,8 +616,7 @@ __global__ __launch_bounds__(1024) void cand_emit_kernel(const uint32_t* cand_bi
         if (gw < words) bits = cand_bits[(size_t)b * words + gw] & ~hit_bits[(size_t)b * words + gw];
         int total;
         int64_t pos = (int64_t)nhit + base_lds + flmr_block_exclusive_scan(__popc(bits), scan_lds, &total);
-        float miss_score = 0.0f;
-        for (int q = 0; q < nqc; q++) miss_score += -9999.0f;
+        const float miss_score = flmr_miss_score(nqc, f16_round);
         uint64_t* kb = keys + (size_t)b * cand_cap;
         while (bits) {
             const int bit = __ffs(bits) - 1;
@@ -689,7 +689,7 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
     }
     hipLaunchKernelGGL(cand_emit_kernel, dim3(a.nqueries, a.nchunks), dim3(1024), 0, st, a.cand_bits, a.hit_bits, a.words,
                        a.chunk_cnt, a.nchunks, a.cand, a.cand_cap, a.cand_hit, a.cand_count, a.overflow,
-                       a.scatter ? a.hit_valid : nullptr, a.key_count, a.chunk_hits, a.keys, a.q_lens, a.nq_cand, a.n_select);
+                       a.scatter ? a.hit_valid : nullptr, a.key_count, a.chunk_hits, a.keys, a.q_lens, a.nq_cand, a.n_select, a.f16_round);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }
@@ -698,7 +698,7 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
 int flmr_launch_cand_emit_all(const flmr_cand_args& a, hipStream_t st) {
     hipLaunchKernelGGL(cand_emit_kernel, dim3(a.nqueries, a.nchunks), dim3(1024), 0, st, a.cand_bits, a.hit_bits, a.words,
                        a.chunk_cnt, a.nchunks, a.cand, a.cand_cap, a.cand_hit, a.cand_count, a.overflow, nullptr, nullptr, nullptr, nullptr,
-                       nullptr, 0, 0);
+                       nullptr, 0, 0, 0);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }

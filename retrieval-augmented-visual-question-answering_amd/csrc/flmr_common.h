@@ -149,6 +149,7 @@ struct flmr_s0_args {
     _Float16* q_hi;          // [nqueries, ncol, 128] fp16 split of Q (fp16 MFMA path)
     _Float16* q_lo;          //   Q ~= q_hi + q_lo * 2^-11
     int32_t centroids_f16_exact;
+    int32_t q_hi_only;       // FLMR_NUMERICS_GPU_FP16: Q is ROUNDED to fp16 (q_lo = 0), as the reference's `Q.cuda().half()`
 };
 int flmr_launch_centroid_scores(flmr_s0_args& a, hipStream_t st);
 int flmr_launch_select_cells(const flmr_s0_args& a, hipStream_t st);
@@ -173,6 +174,7 @@ struct flmr_filter_args {
     const int32_t* codes;
     const int64_t* doclens;    // nullable -> offsets[p+1]-offsets[p]
     const int64_t* offsets;
+    int32_t f16_round;         // FLMR_NUMERICS_GPU_FP16: column maxima rounded to fp16, fp32 sum rounded to fp16 (flmr_device.h)
 };
 // stage 1: candidates (cand[q*cand_stride + i], i < cand_count[q]) restricted to idx_bits -> keys
 int flmr_launch_filter_stage1(const flmr_filter_args& f, const uint32_t* idx_bits, int32_t idx_words,
@@ -194,6 +196,7 @@ struct flmr_cand_args {
     uint64_t* keys; int32_t* key_count;   // [nqueries, cand_cap] unordered stage-1 keys, [nqueries] running count
     int32_t* chunk_hits;                  // [nqueries, nchunks] candidates of the chunk that are in the hit set (scatter mode)
     int32_t n_select;                     // how many keys the selection after stage 1 keeps (ndocs)
+    int32_t f16_round;                    // see flmr_filter_args
 };
 int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st);
 int flmr_launch_cand_emit_all(const flmr_cand_args& a, hipStream_t st);
@@ -260,6 +263,7 @@ struct flmr_maxsim_args {
     float* scores;            // out [nqueries, key_stride] fp32 scores        (nullable)
     _Float16* q_hi;           // scratch [nqueries, round_up(nq,32), 128]: fp16 split of Q (nullable -> fp32 MFMA kernel)
     _Float16* q_lo;
+    int32_t gpu_fp16;         // FLMR_NUMERICS_GPU_FP16: the reference's CUDA-path scoring (fp16 embeddings, -9999 padding, no clamp)
 };
 int flmr_launch_maxsim(const flmr_maxsim_args& a, hipStream_t st);
 

@@ -121,10 +121,27 @@ __device__ __forceinline__ float flmr_xhalf_max(float v) {
 }
 __device__ __forceinline__ float flmr_xhalf_sum(float v) { float a, b; flmr_both_halves(v, a, b); return a + b; }  // = v + other half's v
 
+// ---- the reference's CUDA-path numerics (FLMR_NUMERICS_GPU_FP16; index_storage.py:113-149, colbert.py:235-263) ------------
+// There the centroid scores are an fp16 tensor, padding is -9999 stored in fp16 (= -10000) and `.sum(-1)` of an fp16 tensor
+// accumulates in fp32 and rounds the result to fp16 (overflow -> -inf).  Rounding is monotone, so max over a column of
+// rounded values = the rounded maximum: the kernels keep their fp32 column maxima and round ONCE per (passage, column) where
+// the maxima are summed.  `f16` is a kernel argument (wave-uniform).
+__device__ __forceinline__ float flmr_round_f16(float x) { return (float)(_Float16)x; }   // RNE; |x| > 65504 -> +-inf
+__device__ __forceinline__ float flmr_pad_score(int f16) { return f16 ? -10000.0f : -9999.0f; }
+__device__ __forceinline__ float flmr_miss_score(int nqc, int f16) {   // a passage with no qualifying code: nqc x the padding value
+    float s = 0.0f;
+    for (int q = 0; q < nqc; q++) s += flmr_pad_score(f16);
+    return f16 ? flmr_round_f16(s) : s;
+}
+
 // sequential fp32 sum of per-column maxima, the reference's `score += per_doc_approx_scores[k]` order
 // (filter_pids.cpp:59-63): kept strictly k-ascending so pruning decisions are bit-identical to the CPU path.
-__device__ __forceinline__ float flmr_seq_sum(const float* v, int n) {
+__device__ __forceinline__ float flmr_seq_sum(const float* v, int n, int f16 = 0) {
     float s = 0.0f;
+    if (f16) {   // fp16 column maxima, fp32 accumulation, fp16 result
+        for (int k = 0; k < n; k++) s += flmr_round_f16(v[k]);
+        return flmr_round_f16(s);
+    }
     if (n <= 32) {
         // the common case (one column tile): all loads are issued before the first add -- a loop of dependent LDS reads costs
         // one LDS round trip per column (~3000 cycles per passage, as much as a token tile), the adds alone ~250.  Columns

@@ -40,11 +40,11 @@ __device__ __forceinline__ int64_t shfl_i64(int64_t v, int src) {
 // docs that provably contain no surviving centroid take the precomputed all-miss score (-9999 summed nqc times)
 __device__ __forceinline__ void emit_group(const float* tr /* [S1_GROUP][ncolp] */, int ncolp, int nqc, int nslots,
                                            int lane, int my_pid, bool scanned, float miss_score,
-                                           uint64_t* keys_out /* &keys[group base] */) {
+                                           uint64_t* keys_out /* &keys[group base] */, int f16 = 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane < nslots) {
-        const float s = scanned ? flmr_seq_sum(tr + lane * ncolp, nqc) : miss_score;
+        const float s = scanned ? flmr_seq_sum(tr + lane * ncolp, nqc, f16) : miss_score;
         keys_out[lane] = flmr_make_key(s, my_pid);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -170,8 +170,7 @@ __global__ __launch_bounds__(512) void filter_stage1_kernel(flmr_filter_args f, 
     const bool hits_on = hit_valid && hit_valid[b];
     const uint32_t* hb = (hit_bits && hits_on && !hit_flags) ? hit_bits + (size_t)b * hit_words : nullptr;
     const uint8_t* hf = (hit_flags && hits_on) ? hit_flags + (size_t)b * cand_stride : nullptr;  // aligned with cand
-    float miss_score = 0.0f;
-    for (int q = 0; q < nqc; q++) miss_score += -9999.0f;
+    const float miss_score = flmr_miss_score(nqc, f.f16_round);
 
     int my_pid = 0;
     bool my_scan = false;
@@ -231,7 +230,7 @@ __global__ __launch_bounds__(512) void filter_stage1_kernel(flmr_filter_args f, 
                 }
             }
         }
-        emit_group(tr, ncolp, nqc, ndoc, lane, my_pid, my_scan, miss_score, keys_b + g0);
+        emit_group(tr, ncolp, nqc, ndoc, lane, my_pid, my_scan, miss_score, keys_b + g0, f.f16_round);
         my_pid = nx_pid; my_scan = nx_scan;
     }
 }
@@ -375,7 +374,7 @@ __global__ __launch_bounds__(256) void filter_stage2_kernel(flmr_filter_args f, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
-        const float s = flmr_seq_sum(tr, nqc);
+        const float s = flmr_seq_sum(tr, nqc, f.f16_round);
         keys[(size_t)b * key_stride + d] = flmr_make_key(s, pid);
     }
 }
@@ -490,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_mfma_kernel(flmr_filter_
         if (h == 0) tr[i] = cmax;
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
-            const float sc = flmr_seq_sum(tr, nqc);
+            const float sc = flmr_seq_sum(tr, nqc, f.f16_round);
             keys[(size_t)b * key_stride + w + j * W] = flmr_make_key(sc, pid);
         }
         __builtin_amdgcn_wave_barrier();
@@ -636,7 +635,7 @@ __global__ __launch_bounds__(64 * WAVES, B_LDS ? 1 : 2) void filter_stage2_lds_k
         if (h == 0) tr[i] = cmax;
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
-            const float sc = flmr_seq_sum(tr, nqc);
+            const float sc = flmr_seq_sum(tr, nqc, f.f16_round);
             keys[(size_t)b * key_stride + w + j * W] = flmr_make_key(sc, pid);
         }
         __builtin_amdgcn_wave_barrier();

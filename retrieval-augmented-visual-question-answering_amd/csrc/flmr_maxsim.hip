@@ -131,6 +131,111 @@ __global__ __launch_bounds__(256) void maxsim_kernel(flmr_maxsim_args m, const i
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stage 3 in the reference's CUDA-path numerics (FLMR_NUMERICS_GPU_FP16, include/flmr_hip.h): what IndexScorer.score_pids
+// computes when use_gpu is set (TPC/search/index_storage.py:157-158,176-177):
+//   lookup_pids -> ResidualCodec.decompress (residual.py:242-278): decompress_residuals.cu writes half(weight) then adds the
+//     half centroid value in half arithmetic -> D = half(c + half(w)); F.normalize on the half tensor: the norm is
+//     accumulated in fp32 and stored as half, the quotient is rounded to half;
+//   colbert_score_packed (colbert.py:289-311, use_gpu branch): scores = D_half @ Q_half^T (fp32 accumulation, half result),
+//     padded per passage with -9999 (half: -10000), max over the passage's tokens -- NO zero clamp on this path --, then
+//     `.sum(-1)` of the half maxima: fp32 accumulation, half result.
+// Same structure as maxsim_kernel (one workgroup per (query, finalist), the fp32 MFMA on operands that are exactly fp16, so
+// every product is exact and the accumulation is fp32 like the GEMM's); it is an optional compatibility mode, not the tuned
+// path.  A row of norm 0 (never produced by a real index) scores 0 instead of the reference's NaN.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int s3g_enc(float x) { const int i = __float_as_int(x); return i ^ ((i >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float s3g_dec(int e) { return __int_as_float(e ^ ((e >> 31) & 0x7fffffff)); }
+
+template <int NBITS>
+__global__ __launch_bounds__(256) void maxsim_gpu_fp16_kernel(flmr_maxsim_args m, const int32_t* __restrict__ codes,
+                                                              const uint8_t* __restrict__ residuals,
+                                                              const int64_t* __restrict__ doc_offsets,
+                                                              const float* __restrict__ centroids,
+                                                              const float* __restrict__ wlut_g, int y_base) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int VPB = 8 / NBITS;
+    constexpr int PACKED = FLMR_DIM / VPB;
+    float* wlut = reinterpret_cast<float*>(smem);                            // [256 * VPB], rounded to fp16 (bucket_weights.half())
+    int* colmax = reinterpret_cast<int*>(smem + 256 * VPB * sizeof(float));  // [nq] order-preserving images
+    const int b = blockIdx.x, d = y_base + blockIdx.y;
+    if (d >= m.counts[b]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int qlen = m.q_lens ? m.q_lens[b] : m.nq;
+    const int pid = m.pids[(size_t)b * m.pid_stride + d];
+    const int64_t off = doc_offsets[pid];
+    const int len = (int)(doc_offsets[pid + 1] - off);
+    const float pad = -10000.0f;   // half(-9999)
+    for (int t = tid; t < 256 * VPB; t += 256) wlut[t] = flmr_round_f16(wlut_g[t]);
+    for (int t = tid; t < qlen; t += 256) colmax[t] = s3g_enc(pad);
+    __syncthreads();
+    const float* Qb = m.Q + (size_t)b * m.nq * FLMR_DIM;
+
+    for (int t0 = wave * 32; t0 < len; t0 += 128) {
+        const int tok = t0 + i;
+        const bool valid = tok < len;
+        float a[64];
+        if (valid) {
+            const int code = codes[off + tok];
+            decompress_half_row<NBITS>(residuals + (size_t)(off + tok) * PACKED + h * (PACKED / 2),
+                                       centroids + (size_t)code * FLMR_DIM + 64 * h, wlut, a);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 64; t++) a[t] = 0.0f;
+        }
+        float ss = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 64; t++) {
+            a[t] = flmr_round_f16(a[t]);          // half(c + half(w)): the fp32 sum of two halves rounds like the half add
+            ss = fmaf(a[t], a[t], ss);
+        }
+        ss += __shfl_xor(ss, 32, 64);
+        const float nrm = flmr_round_f16(sqrtf(ss));
+        const float inv_ok = nrm > 0.0f ? 1.0f : 0.0f;
+#pragma unroll
+        for (int t = 0; t < 64; t++) a[t] = inv_ok != 0.0f ? flmr_round_f16(a[t] / nrm) : 0.0f;
+
+        for (int q0 = 0; q0 < qlen; q0 += 32) {
+            const int col = q0 + i;
+            float bv[64];
+            if (col < qlen) {
+                const float4* p = reinterpret_cast<const float4*>(Qb + (size_t)col * FLMR_DIM + 64 * h);
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const float4 v = p[t];
+                    bv[4 * t + 0] = flmr_round_f16(v.x); bv[4 * t + 1] = flmr_round_f16(v.y);
+                    bv[4 * t + 2] = flmr_round_f16(v.z); bv[4 * t + 3] = flmr_round_f16(v.w);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 64; t++) bv[t] = 0.0f;
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 64; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bv[s], acc, 0, 0, 0);
+            float mx = pad;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;  // token row of this accumulator register
+                mx = fmaxf(mx, t0 + row < len ? flmr_round_f16(acc[r]) : pad);
+            }
+            mx = flmr_xhalf_max(mx);
+            if (h == 0 && col < qlen) atomicMax(&colmax[col], s3g_enc(mx));
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.0f;
+        for (int k = 0; k < qlen; k++) s += s3g_dec(colmax[k]);
+        s = flmr_round_f16(s);
+        if (m.keys) m.keys[(size_t)b * m.key_stride + d] = flmr_make_key(s, pid);
+        if (m.scores) m.scores[(size_t)b * m.key_stride + d] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // S3, fp16-split variant (default when the centroids are fp16-exact): one WAVE per finalist document.
 //   * a wave owns a strided list of documents of one query; lanes fetch all their (pid, offset, length) triples in
 //     parallel up front, the NEXT document's codes are loaded while the current one is scored, and the NEXT token
@@ -877,9 +982,32 @@ static int launch_maxsim_t(const flmr_maxsim_args& a, hipStream_t st) {
     return FLMR_OK;
 }
 
+template <int NBITS>
+static int launch_maxsim_gpu_fp16_t(const flmr_maxsim_args& a, hipStream_t st) {
+    const flmr_index* ix = a.ix;
+    const size_t lds = (size_t)256 * (8 / NBITS) * sizeof(float) + (size_t)a.nq * sizeof(int);
+    if (lds > 64 * 1024) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nq=%d too large for the MaxSim kernel's LDS column maxima", a.nq);
+    for (int y0 = 0; y0 < a.max_count; y0 += 32768) {
+        const int ny = (a.max_count - y0) < 32768 ? (a.max_count - y0) : 32768;
+        hipLaunchKernelGGL(maxsim_gpu_fp16_kernel<NBITS>, dim3(a.nqueries, ny), dim3(256), lds, st, a, ix->codes, ix->residuals,
+                           ix->doc_offsets, ix->centroids, ix->wlut, y0);
+    }
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
 // FLMR_S3_IMPL = f16 (default when the centroids are fp16-exact and split buffers are supplied) | f32
 int flmr_launch_maxsim(const flmr_maxsim_args& a, hipStream_t st) {
     if (a.max_count <= 0) return FLMR_OK;
+    if (a.gpu_fp16) {
+        switch (a.ix->nbits) {
+            case 1: return launch_maxsim_gpu_fp16_t<1>(a, st);
+            case 2: return launch_maxsim_gpu_fp16_t<2>(a, st);
+            case 4: return launch_maxsim_gpu_fp16_t<4>(a, st);
+            case 8: return launch_maxsim_gpu_fp16_t<8>(a, st);
+        }
+        FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nbits=%d", a.ix->nbits);
+    }
     const bool f16 = a.ix->centroids_f16_exact && a.ix->centroids_f16 && a.q_hi && a.q_lo && !flmr_opts().is(FLMR_OPT_S3_IMPL, "f32");
     if (f16) {
         switch (a.ix->nbits) {

@@ -61,7 +61,7 @@ extern "C" int flmr_filter_pids(const int32_t* pids, int64_t npids, const float*
     RUN(sc.alloc(&n1, 1));
     hipLaunchKernelGGL(pack_idx_bits_kernel, dim3((unsigned)flmr_ceil_div(words, 256)), dim3(256), 0, st, idx, K, bits, words);
     hipLaunchKernelGGL(set_i32_kernel, dim3(1), dim3(1), 0, st, cnt, (int32_t)npids);
-    flmr_filter_args f;
+    flmr_filter_args f{};
     f.cs = cs; f.cs_query_stride = 0; f.K = K; f.ncol = nq; f.nq_cand = nq; f.nqueries = 1; f.q_lens = nullptr;
     f.codes = codes; f.doclens = doclens; f.offsets = offsets;
     const int64_t stride = npids > 0 ? npids : 1;
@@ -205,7 +205,7 @@ extern "C" int flmr_score_pids(const flmr_index_t* ix, const float* Q, int32_t n
     int32_t* cnt;
     RUN(sc.alloc(&cnt, 1));
     hipLaunchKernelGGL(set_i32_kernel, dim3(1), dim3(1), 0, st, cnt, npids);
-    flmr_maxsim_args m;
+    flmr_maxsim_args m{};
     m.ix = ix; m.Q = Q; m.q_lens = nullptr; m.nqueries = 1; m.nq = nq; m.pids = pids; m.pid_stride = npids;
     m.counts = cnt; m.max_count = npids; m.keys = nullptr; m.key_stride = npids; m.scores = out;
     m.q_hi = nullptr; m.q_lo = nullptr;

@@ -40,6 +40,7 @@ struct flmr_searcher {
     hipStream_t last_stream;
     bool profiling;
     bool full_table;  // keep the whole centroid-score table (needed by the CENTROID_SCORES tap / retrieve())
+    int32_t numerics; // FLMR_NUMERICS_CPU (default) | FLMR_NUMERICS_GPU_FP16
     // stage timing: a ring of event sets, one per profiled call, folded into acc_ms when read (or when the ring wraps)
     hipEvent_t ev[FLMR_PROF_RING][FLMR_NUM_STAGES + 1];
     int ev_first = 0, ev_pending = 0;   // oldest unread set, number of unread sets
@@ -198,6 +199,40 @@ extern "C" int flmr_searcher_set_full_table(flmr_searcher_t* s, int32_t enable) 
     return FLMR_OK;
 }
 
+// The smallest fp32 x with half(x) >= half(thr): the reference's CUDA path compares an fp16 tensor with the Python scalar
+// (index_storage.py:116 on `centroid_scores.cuda()` half values: the scalar is taken in the tensor's dtype), so the
+// predicate on the fp32-accumulated score s is  half(s) >= half(thr)  <=>  s >= that x (rounding is monotone).
+static float f16_threshold(float thr) {
+    const _Float16 h = (_Float16)thr;
+    if (!(h == h)) return thr;
+    uint16_t hb;
+    memcpy(&hb, &h, 2);
+    if ((hb & 0x7fffu) == 0) {   // +-0: anything that rounds to (+-)0 or above
+        hb = 0x8001u;            // largest negative subnormal half = predecessor of zero
+    } else if (hb & 0x8000u) {
+        hb++;                    // negative: predecessor = larger magnitude
+    } else {
+        hb--;                    // positive: predecessor = smaller magnitude
+    }
+    _Float16 pred;
+    memcpy(&pred, &hb, 2);
+    const float mid = 0.5f * ((float)pred + (float)h);   // exact in fp32 (two adjacent halves)
+    // the midpoint rounds to the neighbour with the even mantissa
+    uint16_t hbits;
+    memcpy(&hbits, &h, 2);
+    const bool h_even = (hbits & 1u) == 0;
+    return h_even ? mid : nextafterf(mid, INFINITY);
+}
+
+extern "C" int flmr_searcher_set_numerics(flmr_searcher_t* s, int32_t mode) {
+    if (!s) FLMR_FAIL(FLMR_ERR_INVALID, "NULL searcher");
+    if (mode != FLMR_NUMERICS_CPU && mode != FLMR_NUMERICS_GPU_FP16) FLMR_FAIL(FLMR_ERR_INVALID, "unknown numerics mode %d", mode);
+    if (mode == FLMR_NUMERICS_GPU_FP16 && !(s->ix->centroids_f16_exact && s->ix->centroids_f16 && s->ix->K % 64 == 0))
+        FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "the fp16 numerics mode needs fp16-representable centroids (every reference-format index) and K %% 64 == 0");
+    s->numerics = mode;
+    return FLMR_OK;
+}
+
 extern "C" int flmr_searcher_stage_ms(flmr_searcher_t* s, float* ms) {
     if (!s || !ms) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
     if (!s->have_ms) FLMR_FAIL(FLMR_ERR_INVALID, "no profiled flmr_search_batch call since the last read");
@@ -224,8 +259,8 @@ struct run_ctx {
     flmr_search_params_t p;
     bool sparse;
     hipStream_t st;
-    flmr_s0_args a0;
-    flmr_filter_args f;
+    flmr_s0_args a0{};
+    flmr_filter_args f{};
     int stage;  // profiling event cursor
     int ev_set; // event set of this call
 };
@@ -333,7 +368,9 @@ static int prepare_ctx(run_ctx& c, flmr_searcher* s, const float* Q, const int32
     flmr_s0_args& a0 = c.a0;
     a0.centroids = ix->centroids; a0.Q = Q; a0.q_lens = q_lens;
     a0.K = ix->K; a0.nqueries = nqueries; a0.nq = nq; a0.nq_cand = nqc; a0.ncol = ncol; a0.ncells = p->ncells;
-    a0.thr = p->centroid_score_threshold;
+    const bool f16num = s->numerics == FLMR_NUMERICS_GPU_FP16;
+    a0.thr = f16num ? f16_threshold(p->centroid_score_threshold) : p->centroid_score_threshold;
+    a0.q_hi_only = f16num ? 1 : 0;
     a0.cs = s->cs; a0.idx_bits = s->idx_bits; a0.idx_words = s->idx_words;
     a0.part_val = s->part_val; a0.part_idx = s->part_idx; a0.nblk = s->nblk;
     a0.cells = s->cells; a0.ncell = s->ncell; a0.max_cells = s->max_cells;
@@ -345,6 +382,7 @@ static int prepare_ctx(run_ctx& c, flmr_searcher* s, const float* Q, const int32
     flmr_filter_args& f = c.f;
     f.cs = s->cs; f.cs_query_stride = (int64_t)ix->K * ncol; f.K = ix->K; f.ncol = ncol; f.nq_cand = nqc;
     f.nqueries = nqueries; f.q_lens = q_lens; f.codes = ix->codes; f.doclens = nullptr; f.offsets = ix->doc_offsets;
+    f.f16_round = f16num ? 1 : 0;
     s->last_nqueries = nqueries; s->last_ncol = ncol; s->last_ndocs = p->ndocs; s->last_stream = c.st;
     s->last_full_table = a0.full_table;
     return FLMR_OK;
@@ -374,7 +412,7 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
     bool scatter = false;
     s->last_scatter = false;
     if (chunked) {
-        flmr_cand_args ca;
+        flmr_cand_args ca{};
         ca.nqueries = c.nqueries; ca.idx_words = s->idx_words; ca.max_cells = s->max_cells; ca.qmax = s->qmax;
         ca.nchunks = ix->nchunks; ca.words = s->bitmap_words; ca.cand_cap = s->cand_cap;
         ca.idx_bits = s->idx_bits; ca.cells = s->cells; ca.ncell = s->ncell;
@@ -388,6 +426,7 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
         ca.scatter = scatter ? 1 : 0;
         ca.cs = s->cs; ca.cs_query_stride = c.f.cs_query_stride; ca.nq_cand = c.nqc; ca.q_lens = c.q_lens;
         ca.keys = s->keys1; ca.key_count = s->key_count; ca.chunk_hits = s->chunk_hits; ca.n_select = c.p.ndocs;
+        ca.f16_round = c.f.f16_round;
         RUN(flmr_launch_candidates_chunked(ca, st));
         s->last_ca = ca; s->last_scatter = scatter;
         RUN(mark(c));
@@ -423,7 +462,7 @@ static int stage_s2(run_ctx& c, bool whole_batch) {
     flmr_searcher* s = c.s;
     const flmr_index* ix = s->ix;
     const flmr_options& o = s->opt;
-    const bool walk = c.sparse && ix->codes_sorted && ix->centroids_f16_tiled &&
+    const bool walk = c.sparse && !c.f.f16_round && ix->codes_sorted && ix->centroids_f16_tiled &&
                       (o.is(FLMR_OPT_S2_IMPL, "walk") ||
                        (!o.has(FLMR_OPT_S2_IMPL) && whole_batch && flmr_stage2_walk_pays(ix, c.nqueries, c.p.ndocs)));
     const bool xcd = !walk && c.sparse && s->s2_part && c.f.ncol == 32 &&
@@ -445,11 +484,12 @@ static int stage_s2(run_ctx& c, bool whole_batch) {
 // S3 over s->s2_pids / s2_count -> s->keys3 / doc_scores (slot-aligned with s2_pids)
 static int stage_s3(run_ctx& c) {
     flmr_searcher* s = c.s;
-    flmr_maxsim_args m;
+    flmr_maxsim_args m{};
     m.ix = s->ix; m.Q = c.Q; m.q_lens = c.q_lens; m.nqueries = c.nqueries; m.nq = c.nq;
     m.pids = s->s2_pids; m.pid_stride = s->maxp.ndocs / 4; m.counts = s->s2_count; m.max_count = c.p.ndocs / 4;
     m.keys = s->keys3; m.key_stride = s->maxp.ndocs / 4; m.scores = s->doc_scores;
     m.q_hi = s->q3_hi; m.q_lo = s->q3_lo;
+    m.gpu_fp16 = c.f.f16_round;
     return flmr_launch_maxsim(m, c.st);
 }
 

@@ -150,8 +150,10 @@ __global__ __launch_bounds__(256) void s0_centroid_scores_mfma(flmr_s0_args a) {
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// hi_only (FLMR_NUMERICS_GPU_FP16): the query is ROUNDED to fp16 like the reference's `Q.cuda().half()`
+// (candidate_generation.py:50-52): q_lo = 0 and every split kernel then computes the fp32-accumulated fp16 product.
 __global__ __launch_bounds__(256) void s0_split_q(const float* Q, const int32_t* q_lens, int nq, int nq_cand, int ncol,
-                                                  _Float16* q_hi, _Float16* q_lo) {
+                                                  _Float16* q_hi, _Float16* q_lo, int hi_only) {
     const int b = blockIdx.y;
     const int qlen = q_lens ? q_lens[b] : nq;
     const int nqc = qlen < nq_cand ? qlen : nq_cand;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void s0_split_q(const float* Q, const int32_t*
         float v = 0.0f;
         if (col < nqc) v = Q[((size_t)b * nq + col) * FLMR_DIM + (e % FLMR_DIM)];
         const _Float16 hi = (_Float16)v;
-        const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+        const _Float16 lo = hi_only ? (_Float16)0.0f : (_Float16)((v - (float)hi) * 2048.0f);
         q_hi[(size_t)b * ncol * FLMR_DIM + e] = hi;
         q_lo[(size_t)b * ncol * FLMR_DIM + e] = lo;
     }
@@ -670,7 +672,7 @@ static int launch_s0_t(flmr_s0_args& a, hipStream_t st, int impl) {
     a.part_rows = impl == S0_F16 ? 32 * S0_RT : 0;
     if (impl == S0_F16) {
         hipLaunchKernelGGL(s0_split_q, dim3((a.ncol * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens,
-                           a.nq, a.nq_cand, a.ncol, a.q_hi, a.q_lo);
+                           a.nq, a.nq_cand, a.ncol, a.q_hi, a.q_lo, a.q_hi_only);
         const size_t lds = (size_t)S0_WAVES * 32 * S0_LDS_STRIDE * sizeof(float) + (S0_DMA_B ? (size_t)2 * S0_DCH * 2 * 8192 : (size_t)S0_CH * 2 * 32 * S0_BROW * sizeof(_Float16));
         const bool sparse = !a.full_table && a.ncol == 32 && !flmr_opts().has(FLMR_OPT_S0_STAGED);
         const dim3 grid((a.nblk + S0_WAVES - 1) / S0_WAVES, qsplit), block(64 * S0_WAVES);
@@ -745,7 +747,7 @@ int flmr_launch_centroid_argmax(flmr_s0_args& a, int32_t* out_codes, hipStream_t
     a.thr = __builtin_inff();  // nothing qualifies: no table rows are stored
     const int qsplit = a.nqueries < 8 ? a.nqueries : 8;
     hipLaunchKernelGGL(s0_split_q, dim3((a.ncol * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens, a.nq,
-                       a.nq_cand, a.ncol, a.q_hi, a.q_lo);
+                       a.nq_cand, a.ncol, a.q_hi, a.q_lo, a.q_hi_only);
     const size_t lds = (size_t)S0_WAVES * 32 * S0_LDS_STRIDE * sizeof(float) + (S0_DMA_B ? (size_t)2 * S0_DCH * 2 * 8192 : (size_t)S0_CH * 2 * 32 * S0_BROW * sizeof(_Float16));
     FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_f16<true, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -757,7 +759,7 @@ int flmr_launch_centroid_argmax(flmr_s0_args& a, int32_t* out_codes, hipStream_t
 
 int flmr_launch_split_q(const flmr_s0_args& a, hipStream_t st) {
     hipLaunchKernelGGL(s0_split_q, dim3((a.ncol * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens, a.nq,
-                       a.nq_cand, a.ncol, a.q_hi, a.q_lo);
+                       a.nq_cand, a.ncol, a.q_hi, a.q_lo, a.q_hi_only);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void s2_combine_kernel(flmr_filter_args f, con
     tr[grp][i] = m;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (live && i == 0) keys[(size_t)b * key_stride + d] = flmr_make_key(flmr_seq_sum(tr[grp], nqc), pid);
+    if (live && i == 0) keys[(size_t)b * key_stride + d] = flmr_make_key(flmr_seq_sum(tr[grp], nqc, f.f16_round), pid);
 }
 
 #ifdef X2_PROFILE

@@ -67,9 +67,15 @@ class IndexScorer:
     filter_pids = _op("filter_pids")
     decompress_residuals = _op("decompress_residuals")
 
+    NUMERICS = {"cpu": 0, "gpu-fp16": 1}   # FLMR_NUMERICS_CPU / FLMR_NUMERICS_GPU_FP16 (include/flmr_hip.h)
+
     def __init__(self, index_path=None, use_gpu=True, arrays: IndexArrays = None, device_index: DeviceIndex = None,
-                 max_batch=256, streams=1):
-        """max_batch: queries per native call (one workspace holds that many); a larger batch is cut into sub-batches.
+                 max_batch=256, streams=1, numerics=None):
+        """numerics: "cpu" (default; FLMR_NUMERICS env overrides the default) = the reference's CPU-path arithmetic, the
+        pinned claim; "gpu-fp16" = the reference's CUDA-path arithmetic (fp16 scores / embeddings, -9999 padding, no
+        clamp: index_storage.py:113-158) -- what `Searcher` selects when the caller's config assigns
+        total_visible_gpus > 0, as FLMR_executor.py:784 does on a single GPU.  Either way everything runs on the MI355X.
+        max_batch: queries per native call (one workspace holds that many); a larger batch is cut into sub-batches.
         streams: the sub-batches of one search_batch call are dealt round-robin to this many native searchers, each on
         its own HIP stream, joined with the caller's stream at both ends.  Default 1: with the join a stream-ordered call
         needs, two streams measured 10.35 ms against 9.60 ms for the same four sub-batches of 256 in sequence (both run the
@@ -77,6 +83,10 @@ class IndexScorer:
         profiles/stream_phase_probe.py), which is a caller-level choice (one IndexScorer per stream)."""
         if arrays is None and device_index is None:
             arrays = load_index_arrays(index_path)
+        import os
+        self.numerics = numerics or os.environ.get("FLMR_NUMERICS") or "cpu"
+        if self.numerics not in self.NUMERICS:
+            raise ValueError(f"numerics must be one of {sorted(self.NUMERICS)}, got {self.numerics!r}")
         self.index_path = index_path
         self.use_gpu = True  # see module docstring
         self.arrays = arrays if arrays is not None else device_index.arrays
@@ -110,6 +120,7 @@ class IndexScorer:
             mp = _params(1, grown[2], 0.0, grown[3], grown[4])
             _native.check(self._lib.flmr_searcher_create(self.device_index.handle, grown[0], grown[1], C.byref(mp), C.byref(h)))
             self._searcher, self._searcher_key, self._searcher_epoch = h, grown, _native.options_epoch
+            _native.check(self._lib.flmr_searcher_set_numerics(h, self.NUMERICS[self.numerics]))
         return self._searcher
 
     def _side_slots(self, count):
@@ -119,6 +130,7 @@ class IndexScorer:
             h = C.c_void_p()
             mp = _params(1, g[2], 0.0, g[3], g[4])
             _native.check(self._lib.flmr_searcher_create(self.device_index.handle, g[0], g[1], C.byref(mp), C.byref(h)))
+            _native.check(self._lib.flmr_searcher_set_numerics(h, self.NUMERICS[self.numerics]))
             self._side.append((h, torch.cuda.Stream()))
         return self._side[:count]
 

@@ -67,8 +67,9 @@ index_dir = os.path.join(TMP, "temp_index_0", "indexes", "temp_index.nbits=2")
 ravqa_amd.IndexArrays.from_golden(z).save(index_dir)
 calls = []
 class RecordingScorer:
-    def __init__(self, index_path, use_gpu=True, max_batch=256):
+    def __init__(self, index_path, use_gpu=True, max_batch=256, numerics=None):
         calls.append((index_path, use_gpu))
+        self.numerics = numerics
     def search_batch(self, Q, k, ncells, thr, ndocs, nq_cand=32, q_lens=None):
         calls.append(("search_batch", tuple(Q.shape), k, ncells, thr, ndocs, nq_cand))
         n = Q.size(0)
@@ -87,11 +88,10 @@ with Run().context(RunConfig(nranks=1, rank=0, root=TMP, experiment="temp_index_
     assert list(d) == [7, 9] and d[9][0] == (5, 1, 1.0) and len(d[7]) == 5
     assert calls[1] == ("search_batch", (2, 32, 128), 5, 2, 0.45, 1024, 32), calls
     assert searcher.config.ndocs == 1024                                 # the policy is sticky on the config (searcher.py:92-118)
-    import warnings
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        ns["Searcher"](index="temp_index.nbits=2", config=ColBERTConfig(total_visible_gpus=1))
-    assert any("CUDA-path numerics" in str(x.message) for x in w) and calls[-1] == (index_dir, True)
+    assert searcher.ranker.numerics == "cpu"                             # total_visible_gpus=0: the CPU-path arithmetic
+    # FLMR_executor.py:784 on a single GPU: total_visible_gpus=1 -> the reference's CUDA-branch arithmetic
+    s1 = ns["Searcher"](index="temp_index.nbits=2", config=ColBERTConfig(total_visible_gpus=1))
+    assert calls[-1] == (index_dir, True) and s1.ranker.numerics == "gpu-fp16" and s1.numerics == "gpu-fp16"
 
 # ---- the scoring head: ColBERT.score -> colbert_score (colbert/modeling/colbert.py:217-224,268-286), what
 # FLMR_executor.py:833 (exhaustive search) and rag_model_blip.py:435 (RAG re-score) call ---------------------------

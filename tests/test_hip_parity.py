@@ -1196,3 +1196,127 @@ def test_rccl_exchange_entry_points_single_rank_communicator(hip):
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def _f16r(x):
+    with np.errstate(over="ignore"):
+        return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+def _f16_ulps(a, b):
+    a16, b16 = np.asarray(a, np.float32).astype(np.float16), np.asarray(b, np.float32).astype(np.float16)
+    ia, ib = a16.view(np.int16).astype(np.int32), b16.view(np.int16).astype(np.int32)
+    ia = np.where(ia < 0, -(ia & 0x7fff), ia)
+    ib = np.where(ib < 0, -(ib & 0x7fff), ib)
+    return np.abs(ia - ib)
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_gpu_fp16_numerics_mode_vs_reference_expressions(hip, case):
+    """FLMR_NUMERICS_GPU_FP16 (what a config with total_visible_gpus > 0 selects) against
+    tests/golden/gpu_numerics.npz -- the reference's CUDA-branch torch expressions evaluated on CPU half tensors.  Stage by
+    stage through the phase entry points on the FIXTURE's own intermediate lists (the branch keeps an arbitrary subset of the
+    candidates tied at -inf, so only per-passage scores and above-the-cut sets are comparable across implementations), then
+    end to end against the numpy restatement with this build's tie rule.  fp16 values may differ by an ulp where the fp32
+    accumulation order differs; parity with the reference's CUDA kernels themselves is unpinned (see the fixture's meta)."""
+    from oracle import oracle as orc
+    import oracle_shard_scorer as oss
+    torch, pkg, nat = hip["torch"], hip["pkg"], hip["native"]
+    z = load_golden("gpu_numerics")
+    zi = load_golden(str(z[f"case{case}.index"]))
+    r = str(z[f"case{case}.record"])
+    ncells, thr, ndocs, nqc = int(zi[f"{r}.ncells"]), float(zi[f"{r}.thr"]), int(zi[f"{r}.ndocs"]), int(zi[f"{r}.nq_cand"])
+    scorer = hip["IndexScorer"](arrays=pkg.IndexArrays.from_golden(zi), numerics="gpu-fp16")
+    Qn = zi[f"{r}.Q"]
+    Q = torch.from_numpy(Qn).unsqueeze(0)
+    k = max(ndocs // 4, 1)
+    pre = f"case{case}."
+    # ---- stage 0: the table holds the fp32-accumulated fp16 products; rounded they are the reference's half scores
+    p, s, c = scorer.search_batch(Q, k, ncells, thr, ndocs, nqc, full_table=True)
+    nq_c = min(nqc, Qn.shape[0])
+    cs16 = _f16r(scorer.tap(nat.TAP_CENTROID_SCORES)[:, :nq_c])
+    ref_cs = z[pre + "centroid_scores_f16"].astype(np.float32)
+    assert _f16_ulps(cs16, ref_cs).max() <= 1 and (cs16 != ref_cs).mean() < 0.01
+    K = cs16.shape[0]
+    bits = scorer.tap(nat.TAP_IDX_BITS)
+    idx = ((bits[np.arange(K) >> 5] >> (np.arange(K) & 31)) & 1).astype(bool)
+    assert np.array_equal(idx, cs16.max(-1) >= _f16r(np.float32(thr)))          # half(score) >= half(thr) on its own table
+    same_rows = (cs16.max(-1) == ref_cs.max(-1))
+    assert np.array_equal(idx[same_rows], z[pre + "idx"][same_rows])
+    cand = scorer.tap(nat.TAP_CANDIDATES)
+    ref_cand = z[pre + "cand_pids"]
+    if not np.array_equal(cand, ref_cand):    # only through a tie at a column's top-ncells cut
+        cells, ref_cells = set(scorer.tap(nat.TAP_CELLS).tolist()), set(z[pre + "cells"].tolist())
+        for cc in cells ^ ref_cells:
+            assert any(np.sum(ref_cs[:, q] > ref_cs[cc, q]) < ncells and np.sum(ref_cs[:, q] >= ref_cs[cc, q]) > ncells for q in range(ref_cs.shape[1])), cc
+    # ---- stage 1 (phase 1 exports this index's top-ndocs keys): per-passage scores, above-the-cut set
+    unpack = lambda keys: (lambda u: ((u & np.uint64(0xFFFFFFFF)).astype(np.int64), oss.ord2f((u >> np.uint64(32)).astype(np.uint32)), u != 0))(keys.cpu().numpy().view(np.uint64))
+    k1p, k1s, k1v = unpack(scorer.phase1(Q, k, ncells, thr, ndocs, nqc)[0])
+    ref_s1 = dict(zip(ref_cand.tolist(), z[pre + "s1_scores"].tolist()))
+    if np.array_equal(cand, ref_cand):
+        mine = {int(a): float(b) for a, b, v in zip(k1p, k1s, k1v) if v}
+        for pid, sc_ in mine.items():
+            assert _f16_ulps(sc_, ref_s1[pid]).max() <= 1, (pid, sc_, ref_s1[pid])
+        if ndocs < len(ref_cand):
+            cut = np.sort(z[pre + "s1_scores"])[::-1][ndocs - 1]
+            above = {pid for pid, v in ref_s1.items() if v > cut and _f16_ulps(v, cut).max() > 1}
+            assert above <= set(mine), len(above - set(mine))
+    # ---- stage 2 on the fixture's survivor list (phase 2 scores the members of an explicit list, slot-aligned)
+    mk = lambda pids: torch.from_numpy(((np.uint64(0x80000000) << np.uint64(32)) | np.asarray(pids).astype(np.uint64)).view(np.int64)).unsqueeze(0)
+    s2_in = z[pre + "s2_in_pids"]
+    pad = lambda a, n: np.concatenate([a, np.zeros(n - len(a), dtype=a.dtype)])
+    o2p, o2s, o2v = unpack(scorer.phase2(mk(s2_in))[0])
+    assert o2v[: len(s2_in)].all() and np.array_equal(o2p[: len(s2_in)], s2_in)
+    assert _f16_ulps(o2s[: len(s2_in)], z[pre + "s2_scores_f16"]).max() <= 1
+    # ---- stage 3 on the fixture's finalists
+    docs = z[pre + "doc_pids"]
+    o3p, o3s, o3v = unpack(scorer.phase3(mk(docs))[0])
+    assert o3v[: len(docs)].all() and np.array_equal(o3p[: len(docs)], docs)
+    assert _f16_ulps(o3s[: len(docs)], z[pre + "doc_scores_f16"]).max() <= 2
+    # ---- end to end vs the numpy restatement with the same tie rule: same finalists up to one-ulp effects
+    oi = orc.OracleIndex.from_golden(zi)
+    fp, fs, ncand = orc.GpuNumericsOracle(oi).rank(Qn, ncells, thr, ndocs, nqc)
+    n = int(c[0])
+    got_p, got_s = p[0, :n].cpu().numpy(), s[0, :n].cpu().numpy()
+    assert n == len(fp) and np.array_equal(got_s, _f16r(got_s))                  # scores are fp16 values
+    common = set(got_p.tolist()) & set(fp.tolist())
+    assert len(common) >= 0.95 * n, (len(common), n)
+    ref = dict(zip(fp.tolist(), fs.tolist()))
+    for pid, sc_ in zip(got_p.tolist(), got_s.tolist()):
+        if pid in ref:
+            assert _f16_ulps(sc_, ref[pid]).max() <= 2, (pid, sc_, ref[pid])
+    if all(_f16_ulps(fs[j], fs[j + 1]).max() > 4 for j in range(min(5, n - 1))):
+        assert got_p[:5].tolist() == fp[:5].tolist()
+    # the sparse-table path (scatter stage 1, recomputing stage 2) must give the same bits as the full-table path above
+    p2, s2_, c2 = scorer.search_batch(Q, k, ncells, thr, ndocs, nqc)
+    assert torch.equal(p2, p) and torch.equal(s2_, s) and torch.equal(c2, c)
+    for impl in ("lds", "xcd"):
+        with nat.options(FLMR_S2_IMPL=impl):
+            p3, s3, c3 = scorer.search_batch(Q, k, ncells, thr, ndocs, nqc)
+        assert torch.equal(p3, p) and torch.equal(s3, s) and torch.equal(c3, c), impl
+
+
+def test_gpu_fp16_numerics_mode_through_the_searcher(hip, tmp_path):
+    """Searcher(config=ColBERTConfig(total_visible_gpus=1)) -- the executor's single-GPU call (FLMR_executor.py:784) -- selects
+    the CUDA-branch arithmetic; total_visible_gpus=0 keeps the pinned CPU-branch arithmetic.  Both find the planted passages;
+    the fp16 mode returns fp16-valued scores, also for a batch cut into sub-batches and for long queries."""
+    torch, pkg = hip["torch"], hip["pkg"]
+    z = load_golden("idx_nb2")
+    root = str(tmp_path / "ckpt")
+    pkg.IndexArrays.from_golden(z).save(os.path.join(root, "e", "indexes", "ix"))
+    recs = ["rank0", "rank3", "rank9"]
+    Q = torch.zeros(len(recs), 96, 128)
+    for i, r in enumerate(recs):
+        q = torch.from_numpy(z[f"{r}.Q"])
+        Q[i, : q.size(0)] = q
+    with pkg.Run().context(pkg.RunConfig(nranks=1, rank=0, root=root, experiment="e")):
+        s_gpu = pkg.Searcher(index="ix", config=pkg.ColBERTConfig(total_visible_gpus=1), max_batch=2)
+        s_cpu = pkg.Searcher(index="ix", config=pkg.ColBERTConfig(total_visible_gpus=0), max_batch=2)
+        assert s_gpu.ranker.numerics == "gpu-fp16" and s_cpu.ranker.numerics == "cpu"
+        qs = pkg.Queries(data={i: f"q{i}" for i in range(len(recs))})
+        r_gpu = s_gpu._search_all_Q(qs, Q, k=10, remove_zero_tensors=True).todict()
+        r_cpu = s_cpu._search_all_Q(qs, Q, k=10, remove_zero_tensors=True).todict()
+    for i, r in enumerate(recs):
+        assert r_gpu[i][0][0] == r_cpu[i][0][0] == int(z[f"{r}.final_pids"][0])
+        sc = np.array([t[2] for t in r_gpu[i]], dtype=np.float32)
+        assert np.array_equal(sc, _f16r(sc)) and not np.array_equal(sc, np.array([t[2] for t in r_cpu[i]], dtype=np.float32))
