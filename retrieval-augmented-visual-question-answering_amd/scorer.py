@@ -261,7 +261,7 @@ class IndexScorer:
         """phase1 continuing from the gathered probe state of ALL queries (flmr_search_phase1_probed)."""
         Qd, ql, n, nq, p, s = self._phase_args(Q, k, ncells, thr, ndocs, nq_cand, q_lens)
         self._phase_state = (Qd, ql, n, nq, p)
-        bits, cells, ncell = idx_bits.contiguous(), cells.contiguous(), ncell.contiguous()
+        bits, cells, ncell = (t.to(device="cuda", dtype=torch.int32).contiguous() for t in (idx_bits, cells, ncell))
         assert bits.size(0) >= n and cells.size(0) >= n and ncell.numel() >= n
         out = torch.empty((n, ndocs), dtype=torch.int64, device="cuda")
         _native.check(self._lib.flmr_search_phase1_probed(s, C.c_void_p(Qd.data_ptr()), C.c_void_p(ql.data_ptr()) if ql is not None else None,
@@ -271,7 +271,7 @@ class IndexScorer:
 
     def phase2(self, global_s1):
         Qd, ql, n, nq, p = self._phase_state
-        g = global_s1.contiguous()
+        g = global_s1.to(device="cuda", dtype=torch.int64).contiguous()
         out = torch.empty((n, p.ndocs), dtype=torch.int64, device="cuda")
         _native.check(self._lib.flmr_search_phase2(self._searcher, C.c_void_p(Qd.data_ptr()), C.c_void_p(ql.data_ptr()) if ql is not None else None,
                                                    n, nq, C.byref(p), C.c_void_p(g.data_ptr()), g.size(1), C.c_void_p(out.data_ptr()),
@@ -280,7 +280,7 @@ class IndexScorer:
 
     def phase3(self, global_s2):
         Qd, ql, n, nq, p = self._phase_state
-        g = global_s2.contiguous()
+        g = global_s2.to(device="cuda", dtype=torch.int64).contiguous()
         out = torch.empty((n, p.ndocs // 4), dtype=torch.int64, device="cuda")
         _native.check(self._lib.flmr_search_phase3(self._searcher, C.c_void_p(Qd.data_ptr()), C.c_void_p(ql.data_ptr()) if ql is not None else None,
                                                    n, nq, C.byref(p), C.c_void_p(g.data_ptr()), g.size(1), C.c_void_p(out.data_ptr()),
