@@ -57,7 +57,7 @@ def build_native(force=False, verbose=False, extra_flags=(), lib_path=None, obj_
     -DX2_PROFILE) build a variant library into `lib_path` with its own object directory."""
     from concurrent.futures import ThreadPoolExecutor
     lib_path = lib_path or LIB_PATH
-    obj_dir = obj_dir or os.path.join(os.path.dirname(lib_path), "obj" if not extra_flags else "obj_" + str(abs(hash(tuple(extra_flags))) % 10 ** 8))
+    obj_dir = obj_dir or os.path.join(os.path.dirname(lib_path), "obj" if not extra_flags else "obj_%08x" % __import__("zlib").crc32(" ".join(extra_flags).encode()))
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(REPO_ROOT, "include", "flmr_hip.h")]
     hdr_time = max(os.path.getmtime(h) for h in hdrs)
     os.makedirs(obj_dir, exist_ok=True)

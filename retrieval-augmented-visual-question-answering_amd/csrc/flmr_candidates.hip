@@ -229,6 +229,9 @@ __device__ unsigned long long s1s_prof[12];
 // A workgroup takes `cpb` consecutive chunks of one query: the list ids and offsets are fetched once, and only the chunk
 // table entry that ends the NEXT chunk's slice is loaded per chunk (a chunk's slice starts where the previous one ended),
 // requested a whole chunk ahead.
+// F16: FLMR_NUMERICS_GPU_FP16 (column maxima and sums rounded to fp16, flmr_device.h); a template parameter so that the
+// default instantiation carries none of it (as a kernel argument the selects cost this register-bound kernel 0.8 ms per step)
+template <bool F16>
 __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_cand_args a, int cpb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* cb = reinterpret_cast<uint32_t*>(smem);                   // candidate bitmap of the chunk
@@ -311,10 +314,10 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
             for (int i = 0; i < 4; i++) {
                 const int e = s1s_enc(x[i]);
                 const float m = s1s_dec(e > init ? e : init);
-                sc += q4 * 4 + i < nqc ? (a.f16_round ? flmr_round_f16(m) : m) : 0.0f;
+                sc += q4 * 4 + i < nqc ? (F16 ? flmr_round_f16(m) : m) : 0.0f;
             }
         }
-        rsum[wave + S1S_WAVES * lane] = a.f16_round ? flmr_round_f16(sc) : sc;   // (read after the first chunk's barriers)
+        rsum[wave + S1S_WAVES * lane] = F16 ? flmr_round_f16(sc) : sc;   // (read after the first chunk's barriers)
     }
 
     // The chunk bitmaps and the slots' pair counters start at zero and are LEFT at zero by whoever reads them last (the
@@ -521,9 +524,9 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
 #pragma unroll
                 for (int q = 0; q < 8; q++) v[q] = s1s_dec(acc[sl * S1S_STRIDE + q0 + q]);
 #pragma unroll
-                for (int q = 0; q < 8; q++) sc += q0 + q < nqc ? (a.f16_round ? flmr_round_f16(v[q]) : v[q]) : 0.0f;
+                for (int q = 0; q < 8; q++) sc += q0 + q < nqc ? (F16 ? flmr_round_f16(v[q]) : v[q]) : 0.0f;
             }
-            return a.f16_round ? flmr_round_f16(sc) : sc;
+            return F16 ? flmr_round_f16(sc) : sc;
         };
         if (dense) {   // every slot holds a row: scores into the padding words, one thread per slot
             for (int sl = tid; sl < nslot; sl += 64 * S1S_WAVES) acc[sl * S1S_STRIDE + 32] = __float_as_int(column_sum(sl));
@@ -663,13 +666,17 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
     if (a.scatter) {
         const size_t lds = (size_t)CAND_CHUNK_WORDS * (2 * sizeof(uint32_t) + 2 * sizeof(uint16_t)) +
                            ((size_t)S1S_SLOTS * S1S_STRIDE + 96 + 1024 + S1S_QCAP) * sizeof(int) + S1S_QCAP * sizeof(uint16_t);   // + scratch words of slot-less lanes, list constants, queue (+ its passages)
-        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cand_mark_score_kernel),
+        const void* kfn = a.f16_round ? reinterpret_cast<const void*>(cand_mark_score_kernel<true>) : reinterpret_cast<const void*>(cand_mark_score_kernel<false>);
+        FLMR_HIP(hipFuncSetAttribute(kfn,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // chunks per workgroup: as many as still leave two workgroups per CU (the per-workgroup set-up -- list ids, offsets,
         // chunk table, list constants -- costs about a third of a chunk; 8 vs 4 measured -3 % at 256 queries x 31 chunks)
         int cpb = 8;
         while (cpb > 1 && (int64_t)a.nqueries * ((a.nchunks + cpb - 1) / cpb) < 512) cpb >>= 1;
-        hipLaunchKernelGGL(cand_mark_score_kernel, dim3(a.nqueries, (a.nchunks + cpb - 1) / cpb), dim3(64 * S1S_WAVES), lds, st, a, cpb);
+        if (a.f16_round)
+            hipLaunchKernelGGL(cand_mark_score_kernel<true>, dim3(a.nqueries, (a.nchunks + cpb - 1) / cpb), dim3(64 * S1S_WAVES), lds, st, a, cpb);
+        else
+            hipLaunchKernelGGL(cand_mark_score_kernel<false>, dim3(a.nqueries, (a.nchunks + cpb - 1) / cpb), dim3(64 * S1S_WAVES), lds, st, a, cpb);
 #ifdef S1S_PROFILE
         {
             unsigned long long h[12];

@@ -47,7 +47,7 @@ enum flmr_opt_id {
     FLMR_OPT_S2_IMPL,        // xcd | walk | lds | ldsb | regs: force the XCD-sliced gather / the dense walk / the LDS-DMA gather (4-wave blocks; 16-wave blocks with the query operand in LDS) / the register gather (default: cost model)
     FLMR_OPT_S0_STAGED,      // set: staged epilogue for every tile
     FLMR_OPT_S3_NO_MULTIQ,   // set: single-tile MaxSim kernel for long queries too
-    FLMR_OPT_S3_IMPL,        // f32: fp32-MFMA MaxSim kernel; dma / regs: fp16-split kernel with LDS-DMA row gathers two tiles ahead / register gathers (default: dma for nbits = 8, else regs)
+    FLMR_OPT_S3_IMPL,        // cw (default for Nq <= 32): (c.q + w.q) * 1/norm with table-decoded weights; regs / dma: decompress-normalise-split kernel with register / LDS-DMA row gathers; f32: fp32-MFMA kernel
     FLMR_OPT_SCORE_IMPL,     // valu: plain-FMA padded scorer
     FLMR_OPT_COUNT
 };
@@ -103,6 +103,8 @@ struct flmr_index {
     float* centroids;
     float* wlut;  // [256][8/nbits] fused decode table: bucket_weights[lut[rev[byte]][l]]
     _Float16* centroids_f16;  // [K,128] fp16 image of the centroids (only when centroids_f16_exact)
+    uint32_t* wtab16;   // fp16 hi / lo images of wlut as MFMA A-operand fragments per residual byte (S3 "cw" form; flmr_maxsim.hip)
+    float* inv_norm;    // [N + 64] 1 / max(||centroid + weights||, 1e-12) per token (S3 "cw" form); NULL when unavailable
     float bucket_weights[256];
     // host copy of the IVF list lengths sorted descending, prefix-summed: bound on #candidates for c cells
     int64_t* ivf_len_prefix;  // [K+1] host
@@ -120,6 +122,7 @@ struct flmr_index {
 int flmr_build_sorted_codes(flmr_index* ix);
 int flmr_build_tiled_centroids(flmr_index* ix);
 int flmr_build_doc_splits(flmr_index* ix);
+int flmr_build_s3_tables(flmr_index* ix);   // wtab16 + inv_norm (optional: left NULL when they cannot be built)
 
 // build the fused byte -> (8/nbits) fp32 decode table from the codec tables (host)
 void flmr_build_wlut(int nbits, const float* bucket_weights, const uint8_t* reversed_bit_map,

@@ -182,6 +182,7 @@ extern "C" int flmr_index_open(const flmr_index_desc_t* d, flmr_index_t** out) {
         if (rc) { flmr_index_close(ix); return rc; }
         ix->wlut = dw;
     }
+    FLMR_TRY(flmr_build_s3_tables(ix));
 #undef FLMR_TRY
     *out = ix;
     return FLMR_OK;
@@ -197,6 +198,7 @@ extern "C" int flmr_index_info(const flmr_index_t* ix, flmr_index_info_t* out) {
     if (ix->codes_sorted) b += ((size_t)ix->N + 8) * sizeof(int32_t);
     if (ix->doc_splits) b += (size_t)ix->num_passages * ix->nslices * sizeof(uint16_t);
     if (ix->ivf_chunk_tab) b += K * ((size_t)ix->nchunks + 1) * sizeof(uint32_t);
+    if (ix->inv_norm) b += ((size_t)ix->N + 64) * sizeof(float);
     out->derived_bytes = (int64_t)b;
     out->max_doclen = ix->max_doclen;
     out->centroids_f16_exact = ix->centroids_f16_exact;
@@ -214,6 +216,8 @@ extern "C" int flmr_index_close(flmr_index_t* ix) {
         (void)hipFree(ix->ivf_pids); (void)hipFree(ix->ivf_offsets); (void)hipFree(ix->centroids);
     }
     (void)hipFree(ix->wlut);
+    (void)hipFree(ix->wtab16);
+    (void)hipFree(ix->inv_norm);
     (void)hipFree(ix->centroids_f16);
     (void)hipFree(ix->ivf_chunk_tab);
     (void)hipFree(ix->codes_sorted);

@@ -533,6 +533,227 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// S3, "centroid + weight" form (default for Nq <= 32 when the centroids are fp16-exact; FLMR_S3_IMPL=cw):
+//     d_t . q_k  =  (c_t . q_k  +  w_t . q_k) * inv_t ,     inv_t = 1 / max(||c_t + w_t||, 1e-12)
+// The decompressed row d = c + w is never formed.  The centroid row c is fp16-exact, so its fp16 image IS an MFMA A
+// operand (c . q = c . q_hi + 2^-11 c . q_lo: two products, the very sequence of stage 0 / stage 2); the bucket weights w take
+// only 2^nbits values, so a 256-entry table indexed by the residual BYTE returns the fp16 hi / lo halves of the byte's
+// 8 / nbits weights already packed as A-operand fragments (w = w_hi + 2^-11 w_lo; w . q = w_hi . q_hi + 2^-11 (w_hi . q_lo +
+// w_lo . q_hi): three products); inv_t is computed once per token when the index is opened (flmr_index.inv_norm, 4 bytes per
+// token) and applied to the 32 x 32 score tile.  maxsim_f16_kernel spent 340 VALU operations per tile and lane on
+// add / square / scale / convert / split and 24 MFMAs; this form spends ~80 (byte extraction, the hi + lo / 2048 combine, the
+// row scaling, the maxima) and 40 MFMAs: the kernel moves from VALU issue to the matrix pipe.
+// Rounding differs from the (c + w) / ||c + w|| . q order of the other S3 kernels by fp32-roundoff-class terms (products
+// exact, fp32 accumulation; tests/test_split_arithmetic.py bounds it against fp64 like the others); it is NOT bit-identical
+// to them.  Document iteration, code preload and the one-tile-ahead row prefetch are maxsim_f16_kernel's.
+// LDS: hi table | lo table (256 x 2 * (8 / NBITS) bytes each; NBITS = 8: one table of (hi | lo << 16) words), then per wave
+// the column maxima [32] and the tile's 32 row scales.
+// ------------------------------------------------------------------------------------------------
+template <int NBITS>
+struct s3cw_raw {        // one lane's share of one token: half a centroid row (fp16), its residual bytes, the token's 1 / norm
+    hf8 c[8];
+    uint2 r[NBITS];
+    float inv;
+    bool valid;
+};
+
+template <int NBITS>
+__device__ __forceinline__ void s3cw_issue_rows(s3cw_raw<NBITS>& raw, const int* cdreg, int t, int64_t off, int len, int i, int h,
+                                                const int32_t* __restrict__ codes, const uint8_t* __restrict__ residuals,
+                                                const _Float16* __restrict__ cen16, const float* __restrict__ inv_norm) {
+    constexpr int PACKED = FLMR_DIM * NBITS / 8, NB = 8 * NBITS;
+    const int tok = t * 32 + i;
+    raw.valid = tok < len;
+    const int tokc = raw.valid ? tok : len - 1;   // lanes past the end repeat the last token; their row scale is set to zero
+    int code = 0;
+    if (t < 8) {
+        const int sel = t >> 1;
+        const int reg = sel == 0 ? cdreg[0] : sel == 1 ? cdreg[1] : sel == 2 ? cdreg[2] : cdreg[3];
+        code = __shfl(reg, (t & 1) * 32 + i, 64);
+    } else {
+        code = codes[off + tokc];
+    }
+    const hf8* pc = reinterpret_cast<const hf8*>(cen16 + (size_t)code * FLMR_DIM + 64 * h);
+#pragma unroll
+    for (int s = 0; s < 8; s++) raw.c[s] = pc[s];
+    const uint2* pr = reinterpret_cast<const uint2*>(residuals + (size_t)(off + tokc) * PACKED + h * NB);
+#pragma unroll
+    for (int w = 0; w < NBITS; w++) raw.r[w] = pr[w];
+    raw.inv = inv_norm[off + tokc];
+}
+
+// residual bytes -> the w_hi / w_lo A-operand fragments of the lane's half row, by table look-up only
+template <int NBITS>
+__device__ __forceinline__ void s3cw_decode(const char* tab, const uint2 (&r)[NBITS], hf8 (&wh)[8], hf8 (&wl)[8]) {
+    constexpr int VPB = 8 / NBITS;
+    auto byte_at = [&](int kb) -> uint32_t {   // kb-th of the lane's 8 * NBITS residual bytes
+        const uint32_t word = ((kb >> 2) & 1) ? r[kb >> 3].y : r[kb >> 3].x;
+        return (word >> (8 * (kb & 3))) & 255u;
+    };
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        s3u4 hpk, lpk;
+        if constexpr (VPB == 8) {            // one byte per k-step: 16-byte entries
+            const uint32_t b0 = byte_at(s);
+            hpk = reinterpret_cast<const s3u4*>(tab)[b0];
+            lpk = reinterpret_cast<const s3u4*>(tab + 4096)[b0];
+        } else if constexpr (VPB == 4) {     // two bytes per k-step: 8-byte entries
+            const uint32_t b0 = byte_at(2 * s), b1 = byte_at(2 * s + 1);
+            const uint2 h0 = reinterpret_cast<const uint2*>(tab)[b0], h1 = reinterpret_cast<const uint2*>(tab)[b1];
+            const uint2 l0 = reinterpret_cast<const uint2*>(tab + 2048)[b0], l1 = reinterpret_cast<const uint2*>(tab + 2048)[b1];
+            hpk = s3u4{h0.x, h0.y, h1.x, h1.y};
+            lpk = s3u4{l0.x, l0.y, l1.x, l1.y};
+        } else if constexpr (VPB == 2) {     // four bytes per k-step: 4-byte entries
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t bj = byte_at(4 * s + j);
+                hpk[j] = reinterpret_cast<const uint32_t*>(tab)[bj];
+                lpk[j] = reinterpret_cast<const uint32_t*>(tab + 1024)[bj];
+            }
+        } else {                             // eight bytes per k-step: one (hi | lo << 16) word per byte
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t e0 = reinterpret_cast<const uint32_t*>(tab)[byte_at(8 * s + 2 * j)];
+                const uint32_t e1 = reinterpret_cast<const uint32_t*>(tab)[byte_at(8 * s + 2 * j + 1)];
+                hpk[j] = __builtin_amdgcn_perm(e1, e0, 0x05040100u);   // {e0.lo16, e1.lo16}
+                lpk[j] = __builtin_amdgcn_perm(e1, e0, 0x07060302u);   // {e0.hi16, e1.hi16}
+            }
+        }
+        wh[s] = __builtin_bit_cast(hf8, hpk);
+        wl[s] = __builtin_bit_cast(hf8, lpk);
+    }
+}
+
+template <int NBITS>
+__global__ __launch_bounds__(256, 2) void maxsim_cw_kernel(flmr_maxsim_args m, const int32_t* __restrict__ codes,
+                                                           const uint8_t* __restrict__ residuals,
+                                                           const int64_t* __restrict__ doc_offsets,
+                                                           const _Float16* __restrict__ cen16,
+                                                           const uint32_t* __restrict__ wtab_g, const float* __restrict__ inv_norm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int VPB = 8 / NBITS;
+    constexpr int TAB_BYTES = NBITS == 8 ? 1024 : 2 * 512 * VPB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    float* colmax = reinterpret_cast<float*>(smem + TAB_BYTES) + (size_t)wave * 64;   // this wave's column maxima [32]
+    float* invs = colmax + 32;                                                           // the current tile's row scales [32]
+    const int b = blockIdx.x;
+    const int cnt = m.counts[b];
+    const int qlen = m.q_lens ? m.q_lens[b] : m.nq;
+    for (int t = tid; t < TAB_BYTES / 4; t += 256) reinterpret_cast<uint32_t*>(smem)[t] = wtab_g[t];
+    if (lane < 32) colmax[lane] = 0.0f;
+    __syncthreads();
+
+    const int W = gridDim.y * 4, w = blockIdx.y * 4 + wave;
+    const int ndw = cnt > w ? (cnt - w + W - 1) / W : 0;  // documents of this wave (<= 64, guaranteed by the launcher)
+    if (ndw == 0) return;
+    int my_pid = 0, my_len = 0;
+    int64_t my_off = 0;
+    if (lane < ndw) {
+        my_pid = m.pids[(size_t)b * m.pid_stride + w + lane * W];
+        my_off = doc_offsets[my_pid];
+        my_len = (int)(doc_offsets[my_pid + 1] - my_off);
+    }
+    hf8 bh[8], bl[8];
+    {
+        const hf8* ph = reinterpret_cast<const hf8*>(m.q_hi + ((size_t)b * 32 + i) * FLMR_DIM + 64 * h);
+        const hf8* pl = reinterpret_cast<const hf8*>(m.q_lo + ((size_t)b * 32 + i) * FLMR_DIM + 64 * h);
+#pragma unroll
+        for (int s = 0; s < 8; s++) { bh[s] = ph[s]; bl[s] = pl[s]; }
+    }
+    auto load_codes = [&](int64_t off, int len, int* cd) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) cd[r] = (lane + 64 * r < len) ? codes[off + lane + 64 * r] : 0;
+    };
+    auto bcast64 = [&](int64_t v, int src) -> int64_t {
+        return ((int64_t)__shfl((int)(uint32_t)((uint64_t)v >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src, 64);
+    };
+    int cd[4], ncd[4];
+    load_codes(bcast64(my_off, 0), __shfl(my_len, 0, 64), cd);
+    s3cw_raw<NBITS> raw;
+    bool have_raw = false;
+    float cmx = 0.0f;  // this lane's column maximum over its own half's rows of the current document
+    for (int j = 0; j < ndw; j++) {
+        const int pid = __shfl(my_pid, j, 64);
+        const int len = __shfl(my_len, j, 64);
+        const int64_t off = bcast64(my_off, j);
+        int nlen = 0;
+        int64_t noff = 0;
+        if (j + 1 < ndw) {
+            nlen = __shfl(my_len, j + 1, 64);
+            noff = bcast64(my_off, j + 1);
+            load_codes(noff, nlen, ncd);
+        }
+        const int ntiles = (len + 31) >> 5;
+        if (ntiles > 0 && !have_raw) s3cw_issue_rows<NBITS>(raw, cd, 0, off, len, i, h, codes, residuals, cen16, inv_norm);
+        have_raw = false;
+        for (int t = 0; t < ntiles; t++) {
+            // ---- the weights' fragments by table look-up; the row scales to LDS (0 for rows past the document's end) ----
+            hf8 wh[8], wl[8];
+            s3cw_decode<NBITS>(smem, raw.r, wh, wl);
+            if (h == 0) invs[i] = raw.valid ? raw.inv : 0.0f;
+            // ---- centroid part: c . q_hi, c . q_lo (the registers of c are free for the next tile afterwards) ----
+            f32x16 acch, accl;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { acch[r] = 0.0f; accl[r] = 0.0f; }
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(raw.c[s], bh[s], acch, 0, 0, 0);
+                accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(raw.c[s], bl[s], accl, 0, 0, 0);
+            }
+            // ---- prefetch the next tile's rows (this document's next tile, or the next document's first tile) ----
+            if (t + 1 < ntiles) {
+                s3cw_issue_rows<NBITS>(raw, cd, t + 1, off, len, i, h, codes, residuals, cen16, inv_norm);
+            } else if (j + 1 < ndw && nlen > 0) {
+                s3cw_issue_rows<NBITS>(raw, ncd, 0, noff, nlen, i, h, codes, residuals, cen16, inv_norm);
+                have_raw = true;
+            }
+            // ---- weight part: w_hi . q_hi, w_hi . q_lo, w_lo . q_hi ----
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], bh[s], acch, 0, 0, 0);
+                accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], bl[s], accl, 0, 0, 0);
+                accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s], bh[s], accl, 0, 0, 0);
+            }
+            // ---- (hi + lo / 2048) * inv_row, maximum over this lane's 16 rows, zero floor (segmented_maxsim.cpp:58-59) ----
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float v[16];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {   // accumulator registers 4g..4g+3 hold rows 8g + 4h + {0..3}
+                const f32x4 iv = *reinterpret_cast<const f32x4*>(invs + 8 * g + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[4 * g + e] = fmaf(accl[4 * g + e], 1.0f / 2048.0f, acch[4 * g + e]) * iv[e];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) v[r] = fmaxf(v[r], v[r + 8]);
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], v[r + 4]);
+            cmx = fmaxf(cmx, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+            __builtin_amdgcn_wave_barrier();   // (the scales are read before the next tile overwrites them)
+        }
+        // ---- document done: k-ascending sum of the column maxima, reset for the next document ----
+        {
+            const float vx = flmr_xhalf_max(cmx);  // the two half-waves hold the maxima over their own rows
+            if (h == 0) colmax[i] = vx;
+            cmx = 0.0f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            const float sc = flmr_seq_sum(colmax, qlen);
+            const int dslot = w + j * W;
+            if (m.keys) m.keys[(size_t)b * m.key_stride + dslot] = flmr_make_key(sc, pid);
+            if (m.scores) m.scores[(size_t)b * m.key_stride + dslot] = sc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; r++) cd[r] = ncd[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // S3, fp16-split, centroid rows by LDS-DMA with TWO token tiles in flight (Nq <= 32; default for nbits = 8, FLMR_S3_IMPL=dma).
 // maxsim_f16_kernel above keeps one tile's rows in flight in registers (32 VGPRs per lane, requested after the current
 // tile has been decompressed): a row gather from the Infinity Cache takes ~2 us, the MFMA phase it overlaps with ~0.3 us,
@@ -953,7 +1174,12 @@ static int launch_maxsim_f16_t(const flmr_maxsim_args& a, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(maxsim_f16_multiq_kernel<NBITS>, dim3(a.nqueries, G2), dim3(64 * S3_MQW), lds2, st, a, ix->codes,
                            ix->residuals, ix->doc_offsets, ix->centroids_f16, ix->wlut, nqp);
-    } else if (nqp == 32 && (flmr_opts().is(FLMR_OPT_S3_IMPL, "dma") || (NBITS == 8 && !flmr_opts().has(FLMR_OPT_S3_IMPL)))) {
+    } else if (nqp == 32 && ix->inv_norm && ix->wtab16 && (flmr_opts().is(FLMR_OPT_S3_IMPL, "cw") || !flmr_opts().has(FLMR_OPT_S3_IMPL))) {
+        // centroid + weight form (the default for one query tile): tables + per-wave maxima / row scales
+        const size_t lds4 = (size_t)(NBITS == 8 ? 1024 : 2 * 512 * (8 / NBITS)) + (size_t)4 * 64 * sizeof(float);
+        hipLaunchKernelGGL(maxsim_cw_kernel<NBITS>, dim3(a.nqueries, G), dim3(256), lds4, st, a, ix->codes, ix->residuals,
+                           ix->doc_offsets, ix->centroids_f16, ix->wtab16, ix->inv_norm);
+    } else if (nqp == 32 && flmr_opts().is(FLMR_OPT_S3_IMPL, "dma")) {
         // (measured, 1 M passages: nbits = 2  2.03 vs 2.04 ms for the register form; nbits = 8  2.31 vs 2.43 ms)
         const size_t lds3 = ((size_t)256 * (8 / NBITS) * sizeof(float) + (size_t)4 * nqp * sizeof(float) + 15) / 16 * 16 + 4 * 16384 + 4 * 2048;
         FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_f16_dma_kernel<NBITS>),
@@ -993,6 +1219,88 @@ static int launch_maxsim_gpu_fp16_t(const flmr_maxsim_args& a, hipStream_t st) {
                            ix->doc_offsets, ix->centroids, ix->wlut, y0);
     }
     FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Index-side tables of the "cw" form, built once at flmr_index_open (optional: a failure leaves them NULL and S3 takes the
+// decompress-normalise-split kernel).
+//   inv_norm[t] = 1 / max(|| weight + centroid ||_2, 1e-12): the decompressed row exactly as decompress_residuals.cpp:69-71
+//                 forms it (fp32 `weight + centroid`), squared and summed k-ascending per 64-dim half, the halves added.
+//   wtab16      = per residual byte the fp16 hi / lo halves (w = hi + 2^-11 lo) of its 8 / nbits weights, packed in the
+//                 order maxsim_cw_kernel's look-ups expect.
+// ------------------------------------------------------------------------------------------------
+template <int NBITS>
+__global__ __launch_bounds__(256) void s3_inv_norm_kernel(const int32_t* __restrict__ codes, const uint8_t* __restrict__ residuals,
+                                                          const float* __restrict__ centroids, const float* __restrict__ wlut_g,
+                                                          int64_t N, float* __restrict__ out) {
+    constexpr int VPB = 8 / NBITS;
+    constexpr int PACKED = FLMR_DIM / VPB;
+    __shared__ float wlut[256 * VPB];
+    for (int t = threadIdx.x; t < 256 * VPB; t += 256) wlut[t] = wlut_g[t];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); wv * 32 < N; wv += nwaves) {
+        const int64_t tok = wv * 32 + i;
+        const int64_t tc = tok < N ? tok : N - 1;
+        float a[64];
+        decompress_half_row<NBITS>(residuals + (size_t)tc * PACKED + h * (PACKED / 2), centroids + (size_t)codes[tc] * FLMR_DIM + 64 * h, wlut, a);
+        float ss = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 64; t++) ss = fmaf(a[t], a[t], ss);
+        ss += __shfl_xor(ss, 32, 64);
+        float nrm = sqrtf(ss);
+        nrm = nrm < 1e-12f ? 1e-12f : nrm;
+        if (h == 0 && tok < N) out[tok] = 1.0f / nrm;
+    }
+}
+
+int flmr_build_s3_tables(flmr_index* ix) {
+    ix->wtab16 = nullptr;
+    ix->inv_norm = nullptr;
+    if (!ix->centroids_f16_exact || !ix->centroids_f16 || ix->N <= 0) return FLMR_OK;
+    const int vpb = 8 / ix->nbits;
+    float wl[256 * 8];
+    if (hipMemcpy(wl, ix->wlut, sizeof(float) * 256 * vpb, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return FLMR_OK; }
+    uint32_t tab[2 * 512 * 8 / 4];
+    const size_t tab_bytes = ix->nbits == 8 ? 1024 : (size_t)2 * 512 * vpb;
+    auto split = [](float w, uint16_t& hi, uint16_t& lo) {
+        const _Float16 h = (_Float16)w;
+        const _Float16 l = (_Float16)((w - (float)h) * 2048.0f);
+        memcpy(&hi, &h, 2);
+        memcpy(&lo, &l, 2);
+    };
+    uint16_t* t16 = reinterpret_cast<uint16_t*>(tab);
+    for (int byte = 0; byte < 256; byte++)
+        for (int l = 0; l < vpb; l++) {
+            uint16_t hi, lo;
+            split(wl[byte * vpb + l], hi, lo);
+            if (ix->nbits == 8) { t16[2 * byte] = hi; t16[2 * byte + 1] = lo; }            // one (hi | lo << 16) word per byte
+            else { t16[byte * vpb + l] = hi; t16[256 * vpb + byte * vpb + l] = lo; }      // hi table, then lo table
+        }
+    if (hipMalloc(reinterpret_cast<void**>(&ix->wtab16), tab_bytes) != hipSuccess ||
+        hipMemcpy(ix->wtab16, tab, tab_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&ix->inv_norm), ((size_t)ix->N + 64) * sizeof(float)) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(ix->wtab16); (void)hipFree(ix->inv_norm);
+        ix->wtab16 = nullptr; ix->inv_norm = nullptr;
+        return FLMR_OK;   // feature unavailable, not an error
+    }
+    (void)hipMemset(ix->inv_norm + ix->N, 0, 64 * sizeof(float));
+    const int64_t want = flmr_ceil_div(ix->N, 128);
+    const dim3 grid((unsigned)(want < 65536 ? want : 65536)), block(256);
+    switch (ix->nbits) {
+        case 1: hipLaunchKernelGGL(s3_inv_norm_kernel<1>, grid, block, 0, 0, ix->codes, ix->residuals, ix->centroids, ix->wlut, ix->N, ix->inv_norm); break;
+        case 2: hipLaunchKernelGGL(s3_inv_norm_kernel<2>, grid, block, 0, 0, ix->codes, ix->residuals, ix->centroids, ix->wlut, ix->N, ix->inv_norm); break;
+        case 4: hipLaunchKernelGGL(s3_inv_norm_kernel<4>, grid, block, 0, 0, ix->codes, ix->residuals, ix->centroids, ix->wlut, ix->N, ix->inv_norm); break;
+        default: hipLaunchKernelGGL(s3_inv_norm_kernel<8>, grid, block, 0, 0, ix->codes, ix->residuals, ix->centroids, ix->wlut, ix->N, ix->inv_norm); break;
+    }
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(ix->wtab16); (void)hipFree(ix->inv_norm);
+        ix->wtab16 = nullptr; ix->inv_norm = nullptr;
+    }
     return FLMR_OK;
 }
 

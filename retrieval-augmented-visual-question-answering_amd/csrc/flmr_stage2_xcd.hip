@@ -349,7 +349,9 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
 #pragma unroll
                 for (int s = 0; s < 8; s++) {
                     ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[s], ah, 0, 0, 0);
+#ifndef X2_NO_LO   // (timing experiment only: the hi product alone)
                     al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[s], al, 0, 0, 0);
+#endif
                 }
                 // rows 8k .. 8k+7 (octet k) live in registers 4k .. 4k+3 of the two half-waves: each lane keeps the maximum over
                 // ITS four rows; the two halves are only combined when a passage is flushed (one LDS-crossbar op per passage
@@ -357,8 +359,12 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
                 float mq[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
+#ifdef X2_NO_LO
+                    const float v0 = ah[4 * k], v1 = ah[4 * k + 1], v2 = ah[4 * k + 2], v3 = ah[4 * k + 3];
+#else
                     const float v0 = fmaf(al[4 * k], 1.0f / 2048.0f, ah[4 * k]), v1 = fmaf(al[4 * k + 1], 1.0f / 2048.0f, ah[4 * k + 1]);
                     const float v2 = fmaf(al[4 * k + 2], 1.0f / 2048.0f, ah[4 * k + 2]), v3 = fmaf(al[4 * k + 3], 1.0f / 2048.0f, ah[4 * k + 3]);
+#endif
                     mq[k] = x2_max(x2_max3(v0, v1, v2), v3);
                 }
 #ifdef X2_PROFILE
