@@ -583,12 +583,12 @@ __device__ __forceinline__ void s3cw_issue_rows(s3cw_raw<NBITS>& raw, const int*
 }
 
 // residual bytes -> the w_hi / w_lo A-operand fragments of the lane's half row, by table look-up only
-template <int NBITS>
-__device__ __forceinline__ void s3cw_decode(const char* tab, const uint2 (&r)[NBITS], hf8 (&wh)[8], hf8 (&wl)[8]) {
+// `word(wi)`: wi-th 32-bit word of the lane's 8 * NBITS residual bytes
+template <int NBITS, typename WordFn>
+__device__ __forceinline__ void s3cw_decode(const char* tab, WordFn word, hf8 (&wh)[8], hf8 (&wl)[8]) {
     constexpr int VPB = 8 / NBITS;
     auto byte_at = [&](int kb) -> uint32_t {   // kb-th of the lane's 8 * NBITS residual bytes
-        const uint32_t word = ((kb >> 2) & 1) ? r[kb >> 3].y : r[kb >> 3].x;
-        return (word >> (8 * (kb & 3))) & 255u;
+        return (word(kb >> 2) >> (8 * (kb & 3))) & 255u;
     };
 #pragma unroll
     for (int s = 0; s < 8; s++) {
@@ -622,6 +622,23 @@ __device__ __forceinline__ void s3cw_decode(const char* tab, const uint2 (&r)[NB
         wh[s] = __builtin_bit_cast(hf8, hpk);
         wl[s] = __builtin_bit_cast(hf8, lpk);
     }
+}
+
+// (hi + lo / 2048) * inv_row, maximum over this lane's 16 rows, zero floor (segmented_maxsim.cpp:58-59); `invs`: the tile's 32
+// row scales in LDS (0 for rows past the document's end)
+__device__ __forceinline__ float s3cw_tile_max(const f32x16& acch, const f32x16& accl, const float* invs, int h) {
+    float v[16];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {   // accumulator registers 4g..4g+3 hold rows 8g + 4h + {0..3}
+        const f32x4 iv = *reinterpret_cast<const f32x4*>(invs + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[4 * g + e] = fmaf(accl[4 * g + e], 1.0f / 2048.0f, acch[4 * g + e]) * iv[e];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = fmaxf(v[r], v[r + 8]);
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], v[r + 4]);
+    return fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), 0.0f);
 }
 
 template <int NBITS>
@@ -690,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_cw_kernel(flmr_maxsim_args m, c
         for (int t = 0; t < ntiles; t++) {
             // ---- the weights' fragments by table look-up; the row scales to LDS (0 for rows past the document's end) ----
             hf8 wh[8], wl[8];
-            s3cw_decode<NBITS>(smem, raw.r, wh, wl);
+            s3cw_decode<NBITS>(smem, [&](int wi) { return (wi & 1) ? raw.r[wi >> 1].y : raw.r[wi >> 1].x; }, wh, wl);
             if (h == 0) invs[i] = raw.valid ? raw.inv : 0.0f;
             // ---- centroid part: c . q_hi, c . q_lo (the registers of c are free for the next tile afterwards) ----
             f32x16 acch, accl;
@@ -718,18 +735,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_cw_kernel(flmr_maxsim_args m, c
             // ---- (hi + lo / 2048) * inv_row, maximum over this lane's 16 rows, zero floor (segmented_maxsim.cpp:58-59) ----
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            float v[16];
-#pragma unroll
-            for (int g = 0; g < 4; g++) {   // accumulator registers 4g..4g+3 hold rows 8g + 4h + {0..3}
-                const f32x4 iv = *reinterpret_cast<const f32x4*>(invs + 8 * g + 4 * h);
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[4 * g + e] = fmaf(accl[4 * g + e], 1.0f / 2048.0f, acch[4 * g + e]) * iv[e];
-            }
-#pragma unroll
-            for (int r = 0; r < 8; r++) v[r] = fmaxf(v[r], v[r + 8]);
-#pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], v[r + 4]);
-            cmx = fmaxf(cmx, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+            cmx = fmaxf(cmx, s3cw_tile_max(acch, accl, invs, h));
             __builtin_amdgcn_wave_barrier();   // (the scales are read before the next tile overwrites them)
         }
         // ---- document done: k-ascending sum of the column maxima, reset for the next document ----
@@ -792,6 +798,10 @@ __device__ __forceinline__ void s3_wait_vm() {
 template <int NBITS>
 struct s3_res {
     u32x4 q[(NBITS + 1) / 2];  // NBITS == 1: only .xy of q[0]
+    float inv;                 // "cw" form: the token's 1 / norm (one more load of the tile's residual group)
+    __device__ __forceinline__ void issue_inv(const float* p) {
+        asm volatile("global_load_dword %0, %1, off" : "=v"(inv) : "v"(p) : "memory");
+    }
     __device__ __forceinline__ void issue(const uint8_t* p) {  // asynchronous: wait, then touch(), before any use
         if constexpr (NBITS == 1) {
             u32x2 t;
@@ -809,32 +819,40 @@ struct s3_res {
     __device__ __forceinline__ void touch() {
 #pragma unroll
         for (int k = 0; k < (NBITS + 1) / 2; k++) asm volatile("" : "+v"(q[k])::"memory");
+        asm volatile("" : "+v"(inv)::"memory");
     }
     __device__ __forceinline__ uint32_t word(int wi) const { return q[wi >> 2][wi & 3]; }
 };
 
-template <int NBITS>
+// CW = true: the same pipeline with the "centroid + weight" arithmetic of maxsim_cw_kernel (table = wtab16, one more load per
+// tile for the token's 1 / norm, 40 MFMAs and no decode arithmetic) -- the default S3 kernel: with the VALU work gone the
+// kernel is bound by how many row tiles it keeps in flight, and this pipeline keeps two per wave where the register form
+// keeps one.
+template <int NBITS, bool CW>
 __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args m, const int32_t* __restrict__ codes,
                                                                 const uint8_t* __restrict__ residuals,
                                                                 const int64_t* __restrict__ doc_offsets,
                                                                 const _Float16* __restrict__ cen16,
-                                                                const float* __restrict__ wlut_g, int nqp) {
+                                                                const float* __restrict__ wlut_g, int nqp,
+                                                                const float* __restrict__ inv_norm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int VPB = 8 / NBITS, PACKED = FLMR_DIM * NBITS / 8, NB = 8 * NBITS;
-    constexpr int RL = NBITS == 1 ? 1 : NBITS / 2;  // residual load instructions per tile
-    float* wlut = reinterpret_cast<float*>(smem);  // [256 * VPB]
+    constexpr int RL = (NBITS == 1 ? 1 : NBITS / 2) + (CW ? 1 : 0);  // residual (+ 1 / norm) load instructions per tile
+    constexpr int TABF = CW ? (NBITS == 8 ? 256 : 256 * VPB) : 256 * VPB;   // table size in 32-bit words
+    float* wlut = reinterpret_cast<float*>(smem);  // [TABF]: wlut, or (CW) the fp16 hi / lo fragment tables
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    float* colmax = wlut + 256 * VPB + (size_t)wave * nqp;  // this wave's running maxima [nqp] (nqp == 32 here)
-    char* const rowbuf = smem + ((256 * VPB + 4 * (size_t)nqp) * sizeof(float) + 15) / 16 * 16 + (size_t)wave * 16384;
+    float* colmax = wlut + TABF + (size_t)wave * (nqp + 32);  // this wave's running maxima [nqp] (nqp == 32 here) + row scales [32]
+    float* invs = colmax + nqp;
+    char* const rowbuf = smem + ((TABF + 4 * (size_t)(nqp + 32)) * sizeof(float) + 15) / 16 * 16 + (size_t)wave * 16384;
     const uint32_t rowbuf_lds =
         __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)rowbuf);
-    char* const ring = smem + ((256 * VPB + 4 * (size_t)nqp) * sizeof(float) + 15) / 16 * 16 + 4 * 16384 + (size_t)wave * 2048;
+    char* const ring = smem + ((TABF + 4 * (size_t)(nqp + 32)) * sizeof(float) + 15) / 16 * 16 + 4 * 16384 + (size_t)wave * 2048;
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring);
     const int b = blockIdx.x;
     const int cnt = m.counts[b];
     const int qlen = m.q_lens ? m.q_lens[b] : m.nq;
-    for (int t = tid; t < 256 * VPB; t += 256) wlut[t] = wlut_g[t];
+    for (int t = tid; t < TABF; t += 256) wlut[t] = wlut_g[t];
     for (int t = lane; t < nqp; t += 64) colmax[t] = 0.0f;
     __syncthreads();
 
@@ -937,10 +955,12 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args
         asm volatile("" ::: "memory");
         (void)tokpos(j0, t0, vE);
         rE.issue(residuals + (size_t)p0 * PACKED + h * NB);
+        if constexpr (CW) rE.issue_inv(inv_norm + p0);
         { int c0[8]; ring_codes(0, c0); dma_rows(0, c0); }
         if (j1 < ndw) {
             (void)tokpos(j1, t1, vO);
             rO.issue(residuals + (size_t)p1 * PACKED + h * NB);
+            if constexpr (CW) rO.issue_inv(inv_norm + p1);
             { int c1[8]; ring_codes(1, c1); dma_rows(1, c1); }
         }
     }
@@ -962,16 +982,23 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args
             c[s] = *reinterpret_cast<const hf8*>(rowbuf + buf * 8192 + i * 256 + (((8 * h + s) ^ (i & 15)) << 4));
         int cc[8];
         ring_codes(g + 2, cc);
-        // ---- decompress this lane's half row, normalise, split into fp16 hi/lo (the MFMA A operand) ----
+        // ---- the A operands: decompress + normalise + split, or (CW) the weights' fragments by table look-up ----
         hf8 ah[8], al[8];
-        s3_decode_split<NBITS>(wlut, [&](int wi) { return r.word(wi); }, c, v, ah, al);
+        if constexpr (CW) {
+            s3cw_decode<NBITS>(reinterpret_cast<const char*>(wlut), [&](int wi) { return r.word(wi); }, ah, al);
+            if (h == 0) invs[i] = v ? r.inv : 0.0f;   // the tile's row scales (0 past the document's end), read in the epilogue
+        } else {
+            s3_decode_split<NBITS>(wlut, [&](int wi) { return r.word(wi); }, c, v, ah, al);
+        }
         const bool last_of_doc = (j1 != j0);
         const int pid = bcast(my_pid, j0), dslot = w + j0 * W;
         // ---- keep the pipeline full, in this order: codes of tile g+6, residual bytes of tile g+2, rows of tile g+2 ----
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the row buffer has been read: it may be refilled
         issue_codes(next_code_pos(), g + 6);
         if (j2 < ndw) {
-            r.issue(residuals + (size_t)tokpos(j2, t2, v) * PACKED + h * NB);
+            const int64_t p2 = tokpos(j2, t2, v);
+            r.issue(residuals + (size_t)p2 * PACKED + h * NB);
+            if constexpr (CW) r.issue_inv(inv_norm + p2);
             dma_rows(g + 2, cc);
         }
         // ---- 32 tokens x 32 query tokens ----
@@ -979,13 +1006,31 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_dma_kernel(flmr_maxsim_args
             f32x16 acch, accl;
 #pragma unroll
             for (int q = 0; q < 16; q++) { acch[q] = 0.0f; accl[q] = 0.0f; }
+            if constexpr (CW) {
 #pragma unroll
-            for (int s = 0; s < 8; s++) {
-                acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[s], acch, 0, 0, 0);
-                accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[s], accl, 0, 0, 0);
-                accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s], accl, 0, 0, 0);
+                for (int s = 0; s < 8; s++) {   // centroid part, then weight part (hi . hi | hi . lo + lo . hi)
+                    acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[s], bh[s], acch, 0, 0, 0);
+                    accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[s], bl[s], accl, 0, 0, 0);
+                }
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[s], acch, 0, 0, 0);
+                    accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[s], accl, 0, 0, 0);
+                    accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s], accl, 0, 0, 0);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                cmx = fmaxf(cmx, s3cw_tile_max(acch, accl, invs, h));
+                __builtin_amdgcn_wave_barrier();   // (the scales are read before the next step overwrites them)
+            } else {
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[s], acch, 0, 0, 0);
+                    accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[s], accl, 0, 0, 0);
+                    accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s], accl, 0, 0, 0);
+                }
+                cmx = fmaxf(cmx, s3_tile_max(acch, accl));  // this lane's column, over its own half's rows, kept in a register
             }
-            cmx = fmaxf(cmx, s3_tile_max(acch, accl));  // this lane's column, over its own half's rows, kept in a register
         }
         if (last_of_doc) {  // k-ascending sum of the column maxima, reset for the next document
             {
@@ -1174,18 +1219,27 @@ static int launch_maxsim_f16_t(const flmr_maxsim_args& a, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(maxsim_f16_multiq_kernel<NBITS>, dim3(a.nqueries, G2), dim3(64 * S3_MQW), lds2, st, a, ix->codes,
                            ix->residuals, ix->doc_offsets, ix->centroids_f16, ix->wlut, nqp);
-    } else if (nqp == 32 && ix->inv_norm && ix->wtab16 && (flmr_opts().is(FLMR_OPT_S3_IMPL, "cw") || !flmr_opts().has(FLMR_OPT_S3_IMPL))) {
-        // centroid + weight form (the default for one query tile): tables + per-wave maxima / row scales
+    } else if (nqp == 32 && ix->inv_norm && ix->wtab16 && ((size_t)ix->K * 256 < ((size_t)1 << 32)) &&
+               (flmr_opts().is(FLMR_OPT_S3_IMPL, "cw") || !flmr_opts().has(FLMR_OPT_S3_IMPL))) {
+        // centroid + weight form on the LDS-DMA pipeline (the default for one query tile; 32-bit row offsets: table < 4 GB)
+        const size_t tabw = NBITS == 8 ? 256 : 256 * (8 / NBITS);
+        const size_t lds4 = ((tabw + (size_t)4 * (nqp + 32)) * sizeof(float) + 15) / 16 * 16 + 4 * 16384 + 4 * 2048;
+        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_f16_dma_kernel<NBITS, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+        hipLaunchKernelGGL((maxsim_f16_dma_kernel<NBITS, true>), dim3(a.nqueries, G), dim3(256), lds4, st, a, ix->codes, ix->residuals,
+                           ix->doc_offsets, ix->centroids_f16, reinterpret_cast<const float*>(ix->wtab16), nqp, ix->inv_norm);
+    } else if (nqp == 32 && ix->inv_norm && ix->wtab16 && flmr_opts().is(FLMR_OPT_S3_IMPL, "cwregs")) {
+        // the same arithmetic with register row gathers, one tile in flight (A/B runs; bit-identical to the default)
         const size_t lds4 = (size_t)(NBITS == 8 ? 1024 : 2 * 512 * (8 / NBITS)) + (size_t)4 * 64 * sizeof(float);
         hipLaunchKernelGGL(maxsim_cw_kernel<NBITS>, dim3(a.nqueries, G), dim3(256), lds4, st, a, ix->codes, ix->residuals,
                            ix->doc_offsets, ix->centroids_f16, ix->wtab16, ix->inv_norm);
-    } else if (nqp == 32 && flmr_opts().is(FLMR_OPT_S3_IMPL, "dma")) {
+    } else if (nqp == 32 && ((size_t)ix->K * 256 < ((size_t)1 << 32)) && flmr_opts().is(FLMR_OPT_S3_IMPL, "dma")) {
         // (measured, 1 M passages: nbits = 2  2.03 vs 2.04 ms for the register form; nbits = 8  2.31 vs 2.43 ms)
-        const size_t lds3 = ((size_t)256 * (8 / NBITS) * sizeof(float) + (size_t)4 * nqp * sizeof(float) + 15) / 16 * 16 + 4 * 16384 + 4 * 2048;
-        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_f16_dma_kernel<NBITS>),
+        const size_t lds3 = (((size_t)256 * (8 / NBITS) + (size_t)4 * (nqp + 32)) * sizeof(float) + 15) / 16 * 16 + 4 * 16384 + 4 * 2048;
+        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_f16_dma_kernel<NBITS, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-        hipLaunchKernelGGL(maxsim_f16_dma_kernel<NBITS>, dim3(a.nqueries, G), dim3(256), lds3, st, a, ix->codes, ix->residuals,
-                           ix->doc_offsets, ix->centroids_f16, ix->wlut, nqp);
+        hipLaunchKernelGGL((maxsim_f16_dma_kernel<NBITS, false>), dim3(a.nqueries, G), dim3(256), lds3, st, a, ix->codes, ix->residuals,
+                           ix->doc_offsets, ix->centroids_f16, ix->wlut, nqp, nullptr);
     } else {
         hipLaunchKernelGGL(maxsim_f16_kernel<NBITS>, dim3(a.nqueries, G), dim3(256), lds, st, a, ix->codes, ix->residuals,
                            ix->doc_offsets, ix->centroids_f16, ix->wlut, nqp);

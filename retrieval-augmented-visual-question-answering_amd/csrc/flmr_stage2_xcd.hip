@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
     for (int s = 0; s < 8; s++) asm volatile("" : "+v"(bh[s]), "+v"(bl[s])::"memory");
     // part[query][survivor slot][slice][32]: the eight partial rows of a survivor are one contiguous KB for the combine kernel
     float* const prow = part + (((size_t)b * part_stride + slot0) * nsl + sl) * 32;
-    const size_t pstep = (size_t)nsl * 32;
+    const int pstep = nsl * 32;   // (<= 64 x 1024 floats: 32-bit arithmetic in the flush)
     uint32_t piece_off[8];  // byte offset, inside its row, of the 16-byte piece this lane moves in DMA instruction gq
 #pragma unroll
     for (int gq = 0; gq < 8; gq++) piece_off[gq] = (uint32_t)(((lane & 15) ^ ((4 * gq + (lane >> 4)) & 15)) << 4);
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
             float cm = -9999.0f;
             auto flush = [&](int j) {
                 const float v = flmr_xhalf_max(cm);
-                if (h == 0) prow[(size_t)j * pstep + i] = v;
+                if (h == 0) prow[(unsigned)(j * pstep) + i] = v;
             };
             for (int t = 0; t < ntiles; t++) {
                 // ---- tile t's rows ----
@@ -349,9 +349,7 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
 #pragma unroll
                 for (int s = 0; s < 8; s++) {
                     ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[s], ah, 0, 0, 0);
-#ifndef X2_NO_LO   // (timing experiment only: the hi product alone)
                     al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[s], al, 0, 0, 0);
-#endif
                 }
                 // rows 8k .. 8k+7 (octet k) live in registers 4k .. 4k+3 of the two half-waves: each lane keeps the maximum over
                 // ITS four rows; the two halves are only combined when a passage is flushed (one LDS-crossbar op per passage
@@ -359,12 +357,8 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
                 float mq[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-#ifdef X2_NO_LO
-                    const float v0 = ah[4 * k], v1 = ah[4 * k + 1], v2 = ah[4 * k + 2], v3 = ah[4 * k + 3];
-#else
                     const float v0 = fmaf(al[4 * k], 1.0f / 2048.0f, ah[4 * k]), v1 = fmaf(al[4 * k + 1], 1.0f / 2048.0f, ah[4 * k + 1]);
                     const float v2 = fmaf(al[4 * k + 2], 1.0f / 2048.0f, ah[4 * k + 2]), v3 = fmaf(al[4 * k + 3], 1.0f / 2048.0f, ah[4 * k + 3]);
-#endif
                     mq[k] = x2_max(x2_max3(v0, v1, v2), v3);
                 }
 #ifdef X2_PROFILE
