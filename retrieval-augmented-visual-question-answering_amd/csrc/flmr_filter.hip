@@ -654,7 +654,10 @@ int flmr_launch_filter_stage2_mfma(const flmr_filter_args& f, const int32_t* pid
     if (G < gmin) G = gmin;
     if (G > (int)flmr_ceil_div(max_count, 4)) G = (int)flmr_ceil_div(max_count, 4);
     if (G < 1) G = 1;
-    // FLMR_S2_IMPL=regs: the first form of the kernel (per-lane half-row gathers into registers), kept for A/B runs
+#ifdef FLMR_EXPERIMENTAL_VARIANTS
+    // Measured losers, compiled only into a -DFLMR_EXPERIMENTAL_VARIANTS library (profiles/build_variant.py):
+    // FLMR_S2_IMPL=regs: the first form of the kernel (per-lane half-row gathers into registers);
+    // FLMR_S2_IMPL=ldsb: 16-wave blocks with the query operand in LDS (5.6 ms against 4.1 ms)
     if (flmr_opts().is(FLMR_OPT_S2_IMPL, "regs"))
         hipLaunchKernelGGL(filter_stage2_mfma_kernel, dim3(f.nqueries, G), dim3(256), 4 * 33 * sizeof(float), st, f, pids, pid_stride,
                            counts, keys, key_stride, cen16, q_hi, q_lo);
@@ -671,6 +674,7 @@ int flmr_launch_filter_stage2_mfma(const flmr_filter_args& f, const int32_t* pid
         hipLaunchKernelGGL((filter_stage2_lds_kernel<16, true>), dim3(f.nqueries, G16), dim3(1024), lds16, st, f, pids, pid_stride,
                            counts, keys, key_stride, cen16, q_hi, q_lo);
     } else
+#endif
         hipLaunchKernelGGL((filter_stage2_lds_kernel<4, false>), dim3(f.nqueries, G), dim3(256), (4 * 33 * sizeof(float) + 15) / 16 * 16 + 4 * 32 * 256, st,
                            f, pids, pid_stride, counts, keys, key_stride, cen16, q_hi, q_lo);
     FLMR_LAUNCH_CHECK();

@@ -120,7 +120,10 @@ extern "C" int flmr_index_open(const flmr_index_desc_t* d, flmr_index_t** out) {
     ix->N = d->num_embeddings; ix->num_passages = d->num_passages; ix->pid_base = d->pid_base;
     ix->packed_dim = d->dim * d->nbits / 8;
     ix->owns = (d->memory == FLMR_MEM_HOST);
-    FLMR_HIP(hipGetDevice(&ix->device));
+    if (hipGetDevice(&ix->device) != hipSuccess) {
+        delete ix;
+        FLMR_FAIL(FLMR_ERR_HIP, "hipGetDevice failed");
+    }
     const int K = ix->K;
 
     // host-side metadata: IVF offsets (for the candidate-capacity bound) and the longest document

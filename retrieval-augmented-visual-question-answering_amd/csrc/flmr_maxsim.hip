@@ -804,9 +804,9 @@ struct s3_res {
     }
     __device__ __forceinline__ void issue(const uint8_t* p) {  // asynchronous: wait, then touch(), before any use
         if constexpr (NBITS == 1) {
-            u32x2 t;
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(t) : "v"(p) : "memory");
-            q[0].x = t.x; q[0].y = t.y;
+            // straight into the member's low half (a temporary + copy would read the destination while the load is in flight
+            // unless the register allocator happened to coalesce them)
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(*reinterpret_cast<u32x2*>(&q[0])) : "v"(p) : "memory");
         } else {
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q[0]) : "v"(p) : "memory");
             if constexpr (NBITS >= 4) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(q[1]) : "v"(p) : "memory");

@@ -292,7 +292,9 @@ static int poll_status(flmr_searcher* s, bool wait) {
     const int32_t ovf = s->status_host[0], bad = s->status_host[1];
     if (ovf || bad) {
         s->status_host[0] = s->status_host[1] = 0;
-        FLMR_HIP(hipMemset(s->overflow, 0, 2 * sizeof(int32_t)));
+        // cleared IN ORDER on the searcher's stream: a synchronous memset on the null stream is not ordered against a later
+        // batch already running on a non-blocking stream and could wipe that batch's flag
+        FLMR_HIP(hipMemsetAsync(s->overflow, 0, 2 * sizeof(int32_t), s->last_stream));
         if (ovf)
             FLMR_FAIL(FLMR_ERR_CAPACITY, "an earlier batch produced more candidates than the workspace bound (cand_cap=%lld): its "
                       "candidate lists were truncated and its results are not reliable (is the IVF consistent with the codes?)",

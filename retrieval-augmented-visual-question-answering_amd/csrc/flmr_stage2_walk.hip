@@ -123,10 +123,21 @@ __global__ __launch_bounds__(256) void tile_centroids_kernel(const _Float16* __r
     }
 }
 
+// Built only where the walk can be chosen at all: the cost model below (K * ceil(ndocs / 1024) <= 0.6 x survivor tokens) bounds
+// K by ~0.6 * 1024 * mean passage length whatever ndocs is -- BASELINE's 1 M / 6 M-passage indexes (K = 2^17, 2^18) never take
+// the walk and do not pay for the copy -- or where FLMR_S2_IMPL=walk forces it.  A failed allocation only makes the walk
+// unavailable.
 int flmr_build_tiled_centroids(flmr_index* ix) {
     ix->centroids_f16_tiled = nullptr;
-    if (!ix->centroids_f16 || ix->K % 32 != 0) return FLMR_OK;
-    FLMR_HIP(hipMalloc(reinterpret_cast<void**>(&ix->centroids_f16_tiled), (size_t)ix->K * FLMR_DIM * sizeof(_Float16)));
+    if (!ix->centroids_f16 || ix->K % 32 != 0 || !ix->codes_sorted) return FLMR_OK;
+    const double mean_len = (double)ix->N / (double)(ix->num_passages > 0 ? ix->num_passages : 1);
+    const bool can_pay = (double)ix->K <= 0.6 * W2_DOCS * mean_len;
+    if (!can_pay && !flmr_process_options().is(FLMR_OPT_S2_IMPL, "walk")) return FLMR_OK;
+    if (hipMalloc(reinterpret_cast<void**>(&ix->centroids_f16_tiled), (size_t)ix->K * FLMR_DIM * sizeof(_Float16)) != hipSuccess) {
+        (void)hipGetLastError();
+        ix->centroids_f16_tiled = nullptr;
+        return FLMR_OK;
+    }
     hipLaunchKernelGGL(tile_centroids_kernel, dim3(2048), dim3(256), 0, 0, ix->centroids_f16, ix->K,
                        reinterpret_cast<uint4*>(ix->centroids_f16_tiled));
     FLMR_LAUNCH_CHECK();
@@ -137,7 +148,18 @@ int flmr_build_tiled_centroids(flmr_index* ix) {
 int flmr_build_sorted_codes(flmr_index* ix) {
     ix->codes_sorted = nullptr;
     if (ix->max_doclen > W2_MAX_DOCLEN || ix->N >= 0x7fffffffLL || ix->num_passages <= 0 || ix->N <= 0) return FLMR_OK;
-    FLMR_HIP(hipMalloc(reinterpret_cast<void**>(&ix->codes_sorted), ((size_t)ix->N + 8) * sizeof(int32_t)));  // + window padding
+    // needed by the sliced / walking stage-2 forms only: where neither can be chosen (small K: the table fits an L2 and no walk
+    // was asked for) the gather form runs from `codes` and the copy (4 bytes per token) is not built; a failed allocation
+    // likewise only makes those forms unavailable
+    const double mean_len = (double)ix->N / (double)ix->num_passages;
+    const bool sliced = (size_t)ix->K * FLMR_DIM * sizeof(_Float16) > ((size_t)6 << 20);
+    const bool walk = ix->centroids_f16 && ix->K % 32 == 0 && ((double)ix->K <= 0.6 * W2_DOCS * mean_len);
+    if (!sliced && !walk && !flmr_process_options().has(FLMR_OPT_S2_IMPL)) return FLMR_OK;
+    if (hipMalloc(reinterpret_cast<void**>(&ix->codes_sorted), ((size_t)ix->N + 8) * sizeof(int32_t)) != hipSuccess) {  // + window padding
+        (void)hipGetLastError();
+        ix->codes_sorted = nullptr;
+        return FLMR_OK;
+    }
     FLMR_HIP(hipMemset(ix->codes_sorted + ix->N, 0x7f, 8 * sizeof(int32_t)));
     const int64_t grid = ix->num_passages < 262144 ? ix->num_passages : 262144;
     hipLaunchKernelGGL(sort_doc_codes_kernel, dim3((unsigned)grid), dim3(64), 0, 0, ix->codes, ix->doc_offsets, ix->num_passages,

@@ -119,7 +119,11 @@ int flmr_build_doc_splits(flmr_index* ix) {
     const int rc = x2_xcd_mapping_ok(&ok);
     if (rc) return rc;
     ix->xcd_round_robin = ok ? 1 : 0;
-    FLMR_HIP(hipMalloc(reinterpret_cast<void**>(&ix->doc_splits), (size_t)ix->num_passages * ix->nslices * sizeof(uint16_t)));
+    if (hipMalloc(reinterpret_cast<void**>(&ix->doc_splits), (size_t)ix->num_passages * ix->nslices * sizeof(uint16_t)) != hipSuccess) {
+        (void)hipGetLastError();   // the sliced form is then unavailable: stage 2 takes the gather form
+        ix->doc_splits = nullptr;
+        return FLMR_OK;
+    }
     const int64_t threads = ix->num_passages * ix->nslices;
     hipLaunchKernelGGL(doc_splits_kernel, dim3((unsigned)flmr_ceil_div(threads, 256)), dim3(256), 0, 0, ix->codes_sorted,
                        ix->doc_offsets, ix->num_passages, ix->slice_rows, ix->nslices, ix->doc_splits);

@@ -137,7 +137,7 @@ class IndexScorer:
     def close_searcher(self):
         for h, _ in self._side:
             self._lib.flmr_searcher_destroy(h)
-        self._side, self._tap_from = [], None
+        self._side, self._tap_from, self._profiled = [], None, []
         if self._searcher is not None:
             self._lib.flmr_searcher_destroy(self._searcher)
             self._searcher, self._searcher_key = None, None
@@ -160,6 +160,8 @@ class IndexScorer:
     def workspace_bytes(self):
         total = 0
         for h in [self._searcher] + [h for h, _ in self._side]:
+            if h is None:
+                continue
             b = C.c_int64(0)
             _native.check(self._lib.flmr_searcher_workspace_bytes(h, C.byref(b)))
             total += b.value
@@ -211,7 +213,8 @@ class IndexScorer:
             for t in (Qd, ql, out_p, out_s, out_c):
                 if t is not None:
                     t.record_stream(st)             # the caching allocator must not recycle them before the side stream is done
-        self._profiled = [h for h, _ in slots] if profile else []
+        if profile:   # every searcher profiled since the last stage_ms() read (the library sums per searcher until it is read)
+            self._profiled = list({id(h): h for h in self._profiled + [h for h, _ in slots]}.values())
         return out_p, out_s, out_c
 
     # ---- exact sharded protocol (include/flmr_hip.h: flmr_search_phase1..3) -------------------------------------------
@@ -288,13 +291,15 @@ class IndexScorer:
         return out
 
     def stage_ms(self):
-        """Per-stage HIP-event milliseconds of the last profiled search_batch call, summed over its sub-batches (with
-        streams > 1 the sub-batches overlap, so the stages of one call add up to more than its wall time)."""
+        """Per-stage HIP-event milliseconds ACCUMULATED over every search_batch(profile=True) call since the previous read
+        (flmr_searcher_stage_ms sums per searcher and clears on read), over all sub-batches and all the searchers those
+        calls used (with streams > 1 the sub-batches overlap, so the stages add up to more than the wall time)."""
         tot = [0.0] * _native.NUM_STAGES
         for h in (self._profiled or [self._searcher]):
             ms = (C.c_float * _native.NUM_STAGES)()
             _native.check(self._lib.flmr_searcher_stage_ms(h, ms))
             tot = [a + float(b) for a, b in zip(tot, ms)]
+        self._profiled = []
         return {self._lib.flmr_stage_name(i).decode(): tot[i] for i in range(_native.NUM_STAGES)}
 
     def tap(self, what, query=0):
