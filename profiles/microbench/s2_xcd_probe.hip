@@ -40,8 +40,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_qh, qh.size() * 2)); CK(hipMemcpy(d_qh, qh.data(), qh.size() * 2, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_ql, ql.size() * 2)); CK(hipMemcpy(d_ql, ql.data(), ql.size() * 2, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_keys, (size_t)NQ * ND * 8));
-    CK(hipMalloc(&d_part, flmr_stage2_xcd_part_floats(NQ, ND) * sizeof(float)));
     if (flmr_build_doc_splits(&ix) != 0 || !ix.doc_splits) { printf("split table failed: %s\n", flmr_err_buf); return 1; }
+    printf("slices %d, XCD round-robin dispatch confirmed: %d\n", ix.nslices, ix.xcd_round_robin);
+    CK(hipMalloc(&d_part, flmr_stage2_xcd_part_floats(&ix, NQ, ND) * sizeof(float)));
 #ifdef X2_PROFILE
     CK(hipMalloc(&x2_prof_buffer, 128));
 #endif

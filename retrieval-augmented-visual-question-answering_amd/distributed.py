@@ -27,6 +27,33 @@ def all_gather_topk(scores, pids, group=None):
     return gs, gp
 
 
+_SIGN = -(1 << 63)   # keys are u64 bit patterns held in int64 tensors: x ^ _SIGN maps unsigned order to signed order (0 -> smallest)
+
+
+def phase1_width(ndocs, world, slack=64):
+    """Keys per shard in the truncated phase-1 exchange: twice the shard's expected share of the global top-ndocs plus slack
+    (a multiple of 64), never more than ndocs.  A passage-sharded index holds ~ndocs / world of the global survivors per
+    shard (binomial: sd < sqrt(ndocs / world)), so the certificate below fails only on adversarially skewed shards."""
+    m = 2 * (-(-ndocs // world)) + slack
+    m = -(-m // 64) * 64
+    return min(ndocs, m)
+
+
+def merge_truncated(g, n, topn_keys):
+    """g [W, B, m]: every shard's m best stage-1 keys (unordered, 0 = empty).  -> (the n best of their union [B, n], unordered;
+    violated: 0-d bool tensor).  The union's top-n equals the top-n over ALL the shards' keys iff no shard omitted a key that
+    belongs to it.  A shard that sent fewer than m keys omitted nothing; one that sent m omitted only keys BELOW its smallest
+    sent key, so it is enough that this smallest key did not itself make the top-n (it is below the n-th kept key).  Every
+    rank evaluates this on the same gathered bytes, so all ranks see the same verdict."""
+    W, B, m = g.shape
+    out = topn_keys(g.permute(1, 0, 2).reshape(B, W * m), n, ordered=False)
+    kept_min = (out ^ _SIGN).min(dim=1).values                    # n-th kept key in signed order (smallest if fewer than n exist)
+    shard_min = (g ^ _SIGN).min(dim=2).values                     # [W, B]; a shard with an empty slot maps to the smallest value
+    full = (g != 0).all(dim=2)
+    violated = (full & (shard_min >= kept_min.unsqueeze(0))).any()
+    return out, violated
+
+
 class ShardedSearcher:
     """local_search(Q, k) -> (pids [n,k] GLOBAL ids, -1 padded; scores [n,k]; counts [n]);  merge(scores, pids) ->
     (scores, pids, counts).  Defaults: the HIP IndexScorer on this rank's shard and the HIP merge kernel."""
@@ -48,6 +75,7 @@ class ShardedSearcher:
         self._split_ok = {}  # (nq, k, nq_cand, options epoch) -> query-split stage 0 usable? (capability query, agreed across ranks once)
         self.timings = None  # set to a dict to collect per-exchange wall times (bench.py --gpus N breakdown)
         self.force_collectives = False  # True: issue the collectives also when world == 1 (bench.py --force-distributed)
+        self._cert = []                 # device flags of unchecked batches: truncated phase-1 exchange certificate violated?
 
     @classmethod
     def from_arrays(cls, arrays, group=None, max_batch=256):
@@ -62,7 +90,8 @@ class ShardedSearcher:
         ncells, thr, ndocs = self.k_policy(k)
         return self.scorer.search_batch(Q, k, ncells, thr, ndocs, nq_cand, q_lens=q_lens)
 
-    def search_batch_exact(self, Q, k, nq_cand=32, q_lens=None, gather=None, split_stage0=True, reduce_sum=None, check=True):
+    def search_batch_exact(self, Q, k, nq_cand=32, q_lens=None, gather=None, split_stage0=True, reduce_sum=None, check=True,
+                           truncate_phase1=True):
         """Exact-parity mode: three phases with one exchange of u64 keys after each; the result is
         bit-identical to searching the unsharded index.  `gather(t)` must return the [world, ...] stack of `t` over the
         ranks (default: torch.distributed.all_gather_into_tensor on the device).  The phase-2/3 outputs are slot-aligned
@@ -72,7 +101,13 @@ class ShardedSearcher:
         check=True (default): after the batch every rank reads its deferred device status (flmr_searcher_check: candidate
         overflow, q_lens out of range) and the ranks MAX-reduce one error flag, so that a failure on one shard raises on
         EVERY rank instead of leaving the others blocked in the next collective.  It costs a host sync and one tiny
-        exchange per batch; a throughput loop passes check=False and calls `check_all()` at its own sync points."""
+        exchange per batch; a throughput loop passes check=False and calls `check_all()` at its own sync points.
+
+        truncate_phase1=True: after phase 1 a shard ships only its `phase1_width(ndocs, world)` best keys instead of all ndocs
+        (8 MB -> 2.5 MB per rank and 1024 queries at 8 shards) together with a certificate evaluated on the gathered data
+        (`merge_truncated`).  The certificate's verdict stays on the device: with check=True it is read at the batch's sync
+        point and a violated batch is redone with the full exchange (the result is exact either way); with check=False it is
+        read by `check_all()`, which raises."""
         if self._topn_keys is None or self._unpack_keys is None:
             from . import ops
             self._topn_keys = self._topn_keys or ops.topn_keys
@@ -116,8 +151,17 @@ class ShardedSearcher:
         # Every rank derives the global lists from the same gathered data, and the phase-2/3 outputs are slot-aligned with
         # them: the lists must come out in the SAME ORDER on every rank.  The radix select places its output by a block scan
         # (no atomics), so its order is a function of the input alone and no sort is needed.
-        def exchange(keys, n):  # [B, m] per rank -> global top-n per query (reproducible order)
-            g = timed("gather_stage1_keys", gather, keys)                 # [W, B, m]
+        cert = []
+
+        def exchange(keys, n):  # [B, ndocs] per rank -> global top-n per query (reproducible order)
+            m = phase1_width(n, self.world) if truncate_phase1 else n
+            if m < n and keys.size(1) > m:
+                local = topn_keys(keys, m, ordered=False)                  # this shard's m best
+                g = timed("gather_stage1_keys", gather, local)            # [W, B, m]
+                out, violated = merge_truncated(g, n, topn_keys)
+                cert.append(violated)
+                return out
+            g = timed("gather_stage1_keys", gather, keys)                 # [W, B, ndocs]
             return topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n, ordered=False)
 
         k1 = None
@@ -145,6 +189,11 @@ class ShardedSearcher:
         out = unpack_keys(fin, k)
         if check:
             self.check_all(gather)
+            if cert and bool(cert[0]):   # (never on evenly sharded data) redo this batch with the full phase-1 exchange
+                return self.search_batch_exact(Q, k, nq_cand=nq_cand, q_lens=q_lens, gather=gather, split_stage0=split_stage0,
+                                               reduce_sum=reduce_sum, check=True, truncate_phase1=False)
+        else:
+            self._cert += cert
         return out
 
     def check_all(self, gather=None):
@@ -165,11 +214,16 @@ class ShardedSearcher:
             dist.all_gather_into_tensor(flags, flag, group=self.group)
         else:
             flags = flag
+        pending, self._cert = self._cert, []
         if err is not None:
             raise err
         bad = torch.nonzero(flags).reshape(-1).tolist()
         if bad:
             raise RuntimeError(f"sharded search failed on rank(s) {bad} (see that rank's error)")
+        if pending and bool(torch.stack([c.reshape(()) for c in pending]).any()):   # identical on every rank (same gathered data)
+            raise RuntimeError("truncated phase-1 exchange: a shard held more of the global stage-1 survivors than it shipped "
+                               "(skewed sharding); the unchecked batches since the last check_all() are not exact -- rerun them "
+                               "with truncate_phase1=False or check=True")
 
     def _use_query_split(self, Q, k, ncells, thr, ndocs, nq_cand, gather):
         """Capability query (flmr_searcher_probe_supported: depends only on replicated data), then -- once per batch shape

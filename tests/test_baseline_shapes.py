@@ -145,7 +145,7 @@ def test_cfg5_one_shard_view_nbits8(hip):
     _check(hip, corpus, 32, {100: 8, 500: 2}, ks=(100, 500), max_batch=8, local_queries=True)
 
 
-def _exact_protocol_on_one_device(torch, ops, shards, Q, k, ncells, thr, ndocs, split_stage0=True):
+def _exact_protocol_on_one_device(torch, ops, shards, Q, k, ncells, thr, ndocs, split_stage0=True, truncate=True):
     """All ranks' phases of ShardedSearcher.search_batch_exact run in sequence on ONE device: the all-gathers are
     torch.stack / cat, the SUM all-reduces a sum over the stack (exactly the data movement of distributed.py)."""
     W, B = len(shards), Q.size(0)
@@ -162,8 +162,15 @@ def _exact_protocol_on_one_device(torch, ops, shards, Q, k, ncells, thr, ndocs, 
         k1 = [sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32) for sh in shards]
     else:
         k1 = [sh.phase1(Q, k, ncells, thr, ndocs, 32) for sh in shards]
-    g = torch.stack(k1)                                                     # [W, B, ndocs]
-    s1 = ops.topn_keys(g.permute(1, 0, 2).reshape(B, -1), ndocs, ordered=False)
+    from ravqa_amd.distributed import merge_truncated, phase1_width
+    m = phase1_width(ndocs, W) if truncate else ndocs
+    if m < ndocs:   # each shard ships its m best keys + the certificate (distributed.py: the default exchange)
+        g = torch.stack([ops.topn_keys(k_, m, ordered=False) for k_ in k1])                     # [W, B, m]
+        s1, violated = merge_truncated(g, ndocs, ops.topn_keys)
+        assert not bool(violated)
+    else:
+        g = torch.stack(k1)                                                 # [W, B, ndocs]
+        s1 = ops.topn_keys(g.permute(1, 0, 2).reshape(B, -1), ndocs, ordered=False)
     parts2 = torch.stack([sh.phase2(s1) for sh in shards])
     assert int((parts2 != 0).sum(dim=0).max()) <= 1                         # one contributor per slot: SUM == gather
     s2 = ops.topn_keys(parts2.sum(dim=0), ndocs // 4, ordered=False)
@@ -199,11 +206,11 @@ def test_cfg4_sharded_into_8_exact_protocol_equals_unsharded(hip):
         p_ref, s_ref, c_ref = single.search_batch(Q[:n], k, ncells, thr, ndocs, 32)
         single.check()
         assert int(c_ref.min()) == k
-        for split in (True, False):
-            p, s, c = _exact_protocol_on_one_device(torch, ops, shards, Q[:n], k, ncells, thr, ndocs, split_stage0=split)
+        for split, trunc in ((True, True), (False, True), (True, False)):
+            p, s, c = _exact_protocol_on_one_device(torch, ops, shards, Q[:n], k, ncells, thr, ndocs, split_stage0=split, truncate=trunc)
             for sh in shards:
                 sh.check()
-            assert torch.equal(c, c_ref) and torch.equal(p, p_ref) and torch.equal(s, s_ref), (k, split)
+            assert torch.equal(c, c_ref) and torch.equal(p, p_ref) and torch.equal(s, s_ref), (k, split, trunc)
         # fast mode: every shard prunes with the same ndocs, one gather of the per-shard top-k, merged
         loc = [sh.search_batch(Q[:n], k, ncells, thr, ndocs, 32) for sh in shards]
         ms, mp, mc = ops.merge_topk(torch.stack([l[1] for l in loc]), torch.stack([l[0] for l in loc]))

@@ -235,3 +235,35 @@ def test_failure_on_one_shard_raises_on_every_rank(tmp_path):
         assert "FlmrNativeError" in res[1][key] and "injected" in res[1][key]
         for r in (0, 2):
             assert "RuntimeError" in res[r][key] and "rank(s) [1]" in res[r][key], res[r][key]
+
+
+def test_truncated_phase1_exchange_certificate():
+    """merge_truncated (the phase-1 exchange that ships each shard's 2 * ndocs / W + slack best keys): on evenly spread keys
+    the union's top-n equals the top-n of all keys and the certificate holds; when one shard holds more of the global top-n
+    than it shipped the certificate FAILS (so the caller redoes the batch with the full exchange) -- it must never pass a
+    wrong result."""
+    import oracle_shard_scorer as oss
+    from ravqa_amd.distributed import merge_truncated, phase1_width
+    rng = np.random.default_rng(0)
+    W, B, n = 8, 5, 1024
+    m = phase1_width(n, W)
+    assert m == 320 and phase1_width(n, 2) == n and phase1_width(64, 3) == 64
+    u = lambda a: torch.from_numpy(a.astype(np.uint64).view(np.int64))
+    sel = lambda keys, k: np.sort(np.ascontiguousarray(keys).view(np.uint64), axis=-1)[..., ::-1][..., :k]
+    for skew in (False, True):
+        # per shard 600 keys (high word = score order incl. "negative" scores below 2^63, low word = pid)
+        allk = rng.integers(1, 1 << 62, size=(W, B, 600), dtype=np.int64).astype(np.uint64) * np.uint64(3)
+        if skew:
+            allk[0] |= np.uint64(1) << np.uint64(63)        # shard 0 holds every large key of every query
+        g = np.zeros((W, B, m), dtype=np.uint64)
+        for w in range(W):
+            g[w] = sel(allk[w], m)
+        out, violated = merge_truncated(u(g), n, oss.topn_keys)
+        truth = sel(allk.transpose(1, 0, 2).reshape(B, -1), n)
+        same = np.array_equal(np.sort(out.numpy().view(np.uint64), axis=1)[:, ::-1], truth)
+        assert bool(violated) == skew and same == (not skew)
+    # a shard with fewer keys than the width omitted nothing: no violation although all its keys are kept
+    g = np.zeros((W, B, m), dtype=np.uint64)
+    g[:, :, :100] = rng.integers(1, 1 << 62, size=(W, B, 100), dtype=np.int64).astype(np.uint64)
+    out, violated = merge_truncated(u(g), n, oss.topn_keys)
+    assert not bool(violated) and int((out != 0).sum()) == B * W * 100
