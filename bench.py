@@ -310,7 +310,8 @@ def main():
         per_kernel_flops = {
             "s0_centroid_scores": 2.0 * 2 * K * d * nq_s0,                # hi + lo products
             "s2_filter_sort": 2.0 * 2 * ns_tok * d * nq_s0,
-            "s3_maxsim": 3.0 * 2 * nfin_tok * d * args.nq,                # hi.hi + hi.lo + lo.hi
+            # centroid + weight form: c.q_hi, c.q_lo, w_hi.q_hi, w_hi.q_lo, w_lo.q_hi (five executed products per useful one)
+            "s3_maxsim": 5.0 * 2 * nfin_tok * d * args.nq,
         }
         alg_build = sum(per_kernel_bytes.values()) + 4 * d * args.nq + 8 * k + 8 * P_mean
         if not stage_ms:  # phased multi-GPU run: per-stage events are a single-GPU measurement (see the N=1 line)
@@ -323,7 +324,7 @@ def main():
                     pmc[row["kernel"]] = row
         except Exception:
             pass
-        kname = {"s0_centroid_scores": "s0_centroid_scores", "s3_maxsim": "maxsim_f16_kernel",
+        kname = {"s0_centroid_scores": "s0_centroid_scores", "s3_maxsim": "maxsim_f16_dma_kernel",
                  "s2_filter_sort": "filter_stage2", "s0_candidates": "cand_mark_score_kernel"}
 
         def roof_of(stage):

@@ -21,22 +21,6 @@ corpus = synth.make_corpus(P, DOCLEN, K, NB, seed=0, device="cuda")
 Q, _ = synth.make_queries(corpus, B, NQ, seed=2)
 
 
-def shard_of(corpus, lo, hi):
-    tlo, thi = int(corpus.doc_offsets[lo]), int(corpus.doc_offsets[hi])
-    keep = (corpus.ivf >= lo) & (corpus.ivf < hi)
-    owner = torch.repeat_interleave(torch.arange(K, device="cuda"), corpus.ivf_lengths)
-    sh = synth.SyntheticCorpus()
-    sh.dim, sh.nbits, sh.K, sh.sigma = corpus.dim, corpus.nbits, K, corpus.sigma
-    sh.centroids, sh.bucket_weights, sh.bucket_cutoffs = corpus.centroids, corpus.bucket_weights, corpus.bucket_cutoffs
-    sh.codes, sh.residuals = corpus.codes[tlo:thi].contiguous(), corpus.residuals[tlo:thi].contiguous()
-    sh.doclens = corpus.doclens[lo:hi].contiguous()
-    sh.doc_offsets = (corpus.doc_offsets[lo:hi + 1] - tlo).contiguous()
-    sh.ivf = (corpus.ivf[keep] - lo).to(torch.int32).contiguous()
-    sh.ivf_lengths = torch.bincount(owner[keep], minlength=K).long()
-    sh.ivf_offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), torch.cumsum(sh.ivf_lengths, 0)])
-    return sh
-
-
 def timed(fn, reps=20, warm=3):
     for _ in range(warm):
         fn()
@@ -51,13 +35,18 @@ def timed(fn, reps=20, warm=3):
 out = {}
 WORLDS = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (1, 2, 4, 8)
 for W in WORLDS:
-    sh = corpus if W == 1 else shard_of(corpus, 0, P // W)
+    sh = corpus if W == 1 else synth.shard_corpus(corpus, 0, W)
     sc = IndexScorer(device_index=synth.corpus_device_index(sh, pid_base=0), max_batch=B)
     per = -(-B // W)
 
     def exchange(keys, n, ordered=False):
         # the other ranks' rows: the same keys with their pids moved into that rank's pid range (same scores, disjoint pids),
-        # so that about 1/W of each global survivor set belongs to this shard -- as in a real run
+        # so that about 1/W of each global survivor set belongs to this shard -- as in a real run; each shard ships its
+        # phase1_width(ndocs, W) best keys like distributed.py's default exchange
+        from ravqa_amd.distributed import phase1_width
+        m = phase1_width(n, W)
+        if m < keys.size(1):
+            keys = ops.topn_keys(keys, m, ordered=False)
         shift = (torch.arange(W, device="cuda", dtype=torch.int64) * (P // W)).view(W, 1, 1)
         g = torch.where(keys.unsqueeze(0) != 0, keys.unsqueeze(0) + shift, torch.zeros_like(keys).unsqueeze(0))
         return ops.topn_keys(g.permute(1, 0, 2).reshape(g.size(1), -1), n, ordered=ordered)
