@@ -51,8 +51,8 @@ int main(int argc, char** argv) {
     {
         int nb = 0;
         const size_t lds = (size_t)X2_WAVES * X2_WAVE_LDS;
-        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_stage2_xcd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, filter_stage2_xcd_kernel, 64 * X2_WAVES, lds));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_stage2_xcd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, filter_stage2_xcd_kernel<false>, 64 * X2_WAVES, lds));
         hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
         printf("dynamic LDS per block %zu B, resident blocks per CU %d (LDS per CU %zu B, per block max %zu B)\n", lds, nb,
                (size_t)prop.maxSharedMemoryPerMultiProcessor, (size_t)prop.sharedMemPerBlockOptin);

@@ -360,6 +360,50 @@ __device__ __forceinline__ void s3_decode_split(const float* wlut, WordFn word, 
     }
 }
 
+// FLMR_NUMERICS_GPU_FP16 (maxsim_gpu_fp16_kernel's arithmetic on this kernel's pipeline): the lane's half row is
+// half(c + half(w)) (`wlut` holds the weights already rounded to fp16), the norm is accumulated in fp32 and rounded to fp16, the
+// quotient is rounded to fp16 -- the A operand is that fp16 row, there is no lo part.  x / norm is evaluated as x * (1 / norm):
+// before the fp16 rounding the two differ by an fp32 ulp, so an element can differ from the true quotient's rounding only when
+// it sits within 2^-13 relative of a rounding boundary.
+template <int NBITS, typename WordFn>
+__device__ __forceinline__ void s3_decode_f16(const float* wlut, WordFn word, const hf8 (&c)[8], hf8 (&ah)[8]) {
+    constexpr int VPB = 8 / NBITS;
+    float d[64];
+    float ss = 0.0f;
+#pragma unroll
+    for (int wq = 0; wq < NBITS; wq++) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t byte = (word(wq * 2 + (e >> 2)) >> (8 * (e & 3))) & 255u;
+            const int kb = wq * 8 + e;
+            float wv[VPB];
+            s3_lut<VPB>(wlut, byte, wv);
+#pragma unroll
+            for (int l = 0; l < VPB; l++) {
+                const int dd = kb * VPB + l;
+                const uint32_t cpk = __builtin_bit_cast(s3u4, c[dd >> 3])[(dd & 7) >> 1];
+                const float x = flmr_round_f16((dd & 1) ? s3_add_f16<1>(cpk, wv[l]) : s3_add_f16<0>(cpk, wv[l]));
+                d[dd] = x;
+                ss = fmaf(x, x, ss);
+            }
+        }
+    }
+    ss += __shfl_xor(ss, 32, 64);
+    const float nrm = flmr_round_f16(sqrtf(ss));
+    const float inv = nrm > 0.0f ? 1.0f / nrm : 0.0f;
+#pragma unroll
+    for (int s8 = 0; s8 < 8; s8++) {
+        s3u4 hpk;
+#pragma unroll
+        for (int pr = 0; pr < 4; pr++) {
+            const int dd = s8 * 8 + 2 * pr;
+            const s3v2 v = {d[dd] * inv, d[dd + 1] * inv};
+            hpk[pr] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, s3h2));
+        }
+        ah[s8] = __builtin_bit_cast(hf8, hpk);
+    }
+}
+
 // maximum over a lane's 16 accumulator rows of hi + lo / 2048, zero floor (segmented_maxsim.cpp:58-59), as a tree
 __device__ __forceinline__ float s3_tile_max(const f32x16& acch, const f32x16& accl) {
     float v[16];
@@ -407,7 +451,10 @@ __device__ __forceinline__ void s3_issue_rows(s3_raw<NBITS>& raw, const int* cdr
     }
 }
 
-template <int NBITS>
+// GPUF16 = true: the reference's CUDA-branch arithmetic (maxsim_gpu_fp16_kernel's, see there) on this kernel's wave-per-
+// document pipeline: fp16 embeddings by s3_decode_f16, ONE product per k-step against the fp16-rounded query, scores rounded
+// to fp16, rows past the passage's end excluded (-10000, no zero clamp), fp32 column sum rounded to fp16.  Nq <= 32.
+template <int NBITS, bool GPUF16 = false>
 __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, const int32_t* __restrict__ codes,
                                                             const uint8_t* __restrict__ residuals,
                                                             const int64_t* __restrict__ doc_offsets,
@@ -422,8 +469,9 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
     const int b = blockIdx.x;
     const int cnt = m.counts[b];
     const int qlen = m.q_lens ? m.q_lens[b] : m.nq;
-    for (int t = tid; t < 256 * VPB; t += 256) wlut[t] = wlut_g[t];
-    for (int t = lane; t < nqp; t += 64) colmax[t] = 0.0f;
+    constexpr float kFloor = GPUF16 ? -10000.0f : 0.0f;   // a column's running maximum starts at half(-9999) / at zero
+    for (int t = tid; t < 256 * VPB; t += 256) wlut[t] = GPUF16 ? flmr_round_f16(wlut_g[t]) : wlut_g[t];
+    for (int t = lane; t < nqp; t += 64) colmax[t] = kFloor;
     __syncthreads();
 
     const int W = gridDim.y * 4, w = blockIdx.y * 4 + wave;
@@ -460,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
     }
     s3_raw<NBITS> raw;
     bool have_raw = false;
-    float cmx = 0.0f;  // single q-tile: this lane's column maximum over its own half's rows of the current document
+    float cmx = kFloor;  // single q-tile: this lane's column maximum over its own half's rows of the current document
     for (int j = 0; j < ndw; j++) {
         const int pid = __shfl(my_pid, j, 64);
         const int len = __shfl(my_len, j, 64);
@@ -480,7 +528,9 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
         for (int t = 0; t < ntiles; t++) {
             // ---- decompress this lane's half row, normalise, split into fp16 hi/lo (the MFMA A operand) ----
             hf8 ah[8], al[8];
-            s3_decode_split<NBITS>(wlut, [&](int wi) { return (wi & 1) ? raw.r[wi >> 1].y : raw.r[wi >> 1].x; }, raw.c, raw.valid, ah, al);
+            if constexpr (GPUF16) s3_decode_f16<NBITS>(wlut, [&](int wi) { return (wi & 1) ? raw.r[wi >> 1].y : raw.r[wi >> 1].x; }, raw.c, ah);
+            else s3_decode_split<NBITS>(wlut, [&](int wi) { return (wi & 1) ? raw.r[wi >> 1].y : raw.r[wi >> 1].x; }, raw.c, raw.valid, ah, al);
+            const int rem = len - t * 32;   // rows of this tile that belong to the passage (GPUF16: the others are excluded)
             // ---- prefetch the next tile's rows (this document's next tile, or the next document's first tile) ----
             if (t + 1 < ntiles) {
                 s3_issue_rows<NBITS>(raw, cd, t + 1, off, len, i, h, codes, residuals, cen16);
@@ -494,13 +544,31 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
                 f32x16 acch, accl;
 #pragma unroll
                 for (int r = 0; r < 16; r++) { acch[r] = 0.0f; accl[r] = 0.0f; }
+                float mx;
+                if constexpr (GPUF16) {
 #pragma unroll
-                for (int s = 0; s < 8; s++) {
-                    acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[s], acch, 0, 0, 0);
-                    accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[s], accl, 0, 0, 0);
-                    accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s], accl, 0, 0, 0);
+                    for (int s = 0; s < 8; s++) acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[s], acch, 0, 0, 0);
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) v[r] = flmr_round_f16(acch[r]);   // the half score tensor
+                    if (rem < 32) {   // wave-uniform, last tile of a passage: rows past its end are padding (-9999 -> half -10000)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) v[r] = ((r & 3) + 8 * (r >> 2) + 4 * h) < rem ? v[r] : kFloor;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; r++) v[r] = fmaxf(v[r], v[r + 8]);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], v[r + 4]);
+                    mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 8; s++) {
+                        acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[s], acch, 0, 0, 0);
+                        accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[s], accl, 0, 0, 0);
+                        accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s], accl, 0, 0, 0);
+                    }
+                    mx = s3_tile_max(acch, accl);  // over this lane's 16 rows
                 }
-                const float mx = s3_tile_max(acch, accl);  // over this lane's 16 rows
                 if (single_qt) {
                     cmx = fmaxf(cmx, mx);  // one column per lane pair: kept in a register until the document ends
                 } else {
@@ -514,19 +582,19 @@ __global__ __launch_bounds__(256, 2) void maxsim_f16_kernel(flmr_maxsim_args m, 
         if (single_qt) {
             const float v = flmr_xhalf_max(cmx);  // the two half-waves hold the maxima over their own rows
             if (h == 0) colmax[i] = v;
-            cmx = 0.0f;  // segmented_maxsim.cpp:58-59: the running max starts at zero
+            cmx = kFloor;  // segmented_maxsim.cpp:58-59: the running max starts at zero (GPUF16: at the padding value)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
-            const float sc = flmr_seq_sum(colmax, qlen);
+            const float sc = flmr_seq_sum(colmax, qlen, GPUF16 ? 1 : 0);
             const int dslot = w + j * W;
             if (m.keys) m.keys[(size_t)b * m.key_stride + dslot] = flmr_make_key(sc, pid);
             if (m.scores) m.scores[(size_t)b * m.key_stride + dslot] = sc;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int t = lane; t < nqp; t += 64) colmax[t] = 0.0f;
+        for (int t = lane; t < nqp; t += 64) colmax[t] = kFloor;
 #pragma unroll
         for (int r = 0; r < 4; r++) cd[r] = ncd[r];
     }
@@ -1263,6 +1331,24 @@ static int launch_maxsim_t(const flmr_maxsim_args& a, hipStream_t st) {
 }
 
 template <int NBITS>
+static int launch_maxsim_f16_gpunum_t(const flmr_maxsim_args& a, hipStream_t st) {
+    const flmr_index* ix = a.ix;
+    const int nqp = 32;
+    const size_t lds = (size_t)256 * (8 / NBITS) * sizeof(float) + (size_t)4 * nqp * sizeof(float);
+    hipLaunchKernelGGL(s3_split_q, dim3((nqp * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens, a.nq, nqp,
+                       a.q_hi, a.q_lo);   // q_hi = half(Q): the only image this mode reads
+    int G = (int)flmr_ceil_div(4096, 4 * (int64_t)a.nqueries);
+    const int gmin = (int)flmr_ceil_div(a.max_count, 4 * 64);
+    if (G < gmin) G = gmin;
+    if (G > (int)flmr_ceil_div(a.max_count, 4)) G = (int)flmr_ceil_div(a.max_count, 4);
+    if (G < 1) G = 1;
+    hipLaunchKernelGGL((maxsim_f16_kernel<NBITS, true>), dim3(a.nqueries, G), dim3(256), lds, st, a, ix->codes, ix->residuals,
+                       ix->doc_offsets, ix->centroids_f16, ix->wlut, nqp);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
+template <int NBITS>
 static int launch_maxsim_gpu_fp16_t(const flmr_maxsim_args& a, hipStream_t st) {
     const flmr_index* ix = a.ix;
     const size_t lds = (size_t)256 * (8 / NBITS) * sizeof(float) + (size_t)a.nq * sizeof(int);
@@ -1362,11 +1448,14 @@ int flmr_build_s3_tables(flmr_index* ix) {
 int flmr_launch_maxsim(const flmr_maxsim_args& a, hipStream_t st) {
     if (a.max_count <= 0) return FLMR_OK;
     if (a.gpu_fp16) {
+        // one query tile, fp16 centroid copy and split buffers at hand: the wave-per-document pipeline; else (long queries,
+        // FLMR_S3_IMPL=f32) the plain one-workgroup-per-passage kernel with the same arithmetic
+        const bool tuned = a.nq <= 32 && a.ix->centroids_f16 && a.q_hi && a.q_lo && !flmr_opts().is(FLMR_OPT_S3_IMPL, "f32");
         switch (a.ix->nbits) {
-            case 1: return launch_maxsim_gpu_fp16_t<1>(a, st);
-            case 2: return launch_maxsim_gpu_fp16_t<2>(a, st);
-            case 4: return launch_maxsim_gpu_fp16_t<4>(a, st);
-            case 8: return launch_maxsim_gpu_fp16_t<8>(a, st);
+            case 1: return tuned ? launch_maxsim_f16_gpunum_t<1>(a, st) : launch_maxsim_gpu_fp16_t<1>(a, st);
+            case 2: return tuned ? launch_maxsim_f16_gpunum_t<2>(a, st) : launch_maxsim_gpu_fp16_t<2>(a, st);
+            case 4: return tuned ? launch_maxsim_f16_gpunum_t<4>(a, st) : launch_maxsim_gpu_fp16_t<4>(a, st);
+            case 8: return tuned ? launch_maxsim_f16_gpunum_t<8>(a, st) : launch_maxsim_gpu_fp16_t<8>(a, st);
         }
         FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nbits=%d", a.ix->nbits);
     }

@@ -437,6 +437,9 @@ __device__ __forceinline__ void s0q_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// HI_ONLY (FLMR_NUMERICS_GPU_FP16: Q is rounded to fp16, q_lo = 0): the lo products would multiply by zero -- they and the
+// hi / lo combine are left out, the values are the same (fma(0, 2^-11, x) = x)
+template <bool HI_ONLY>
 __global__ __launch_bounds__(512, 1) void s0_centroid_scores_qs(flmr_s0_args a, int rows_per_slice) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -460,13 +463,19 @@ __global__ __launch_bounds__(512, 1) void s0_centroid_scores_qs(flmr_s0_args a, 
         const f16x8* ph = reinterpret_cast<const f16x8*>(a.q_hi + ((size_t)bq[q] * a.ncol + i) * FLMR_DIM + 64 * h);
         const f16x8* pl = reinterpret_cast<const f16x8*>(a.q_lo + ((size_t)bq[q] * a.ncol + i) * FLMR_DIM + 64 * h);
 #pragma unroll
-        for (int s = 0; s < 8; s++) { bh[q][s] = ph[s]; bl[q][s] = pl[s]; }
+        for (int s = 0; s < 8; s++) {
+            bh[q][s] = ph[s];
+            if constexpr (!HI_ONLY) bl[q][s] = pl[s];
+        }
     }
     // every compiler-visible load lands here, before the first hand-counted operation
 #pragma unroll
     for (int q = 0; q < S0Q_QT; q++)
 #pragma unroll
-        for (int s = 0; s < 8; s++) asm volatile("" : "+v"(bh[q][s]), "+v"(bl[q][s])::"memory");
+        for (int s = 0; s < 8; s++) {
+            asm volatile("" : "+v"(bh[q][s])::"memory");
+            if constexpr (!HI_ONLY) asm volatile("" : "+v"(bl[q][s])::"memory");
+        }
 
     // tile t (rows row_begin + 32 t ...) -> buffer t % NBUF; this wave moves rows 4*wave .. 4*wave+3: piece p of row r at
     // position p ^ (r & 15).  Tiles past the end repeat the last tile (the counts above need every step's DMA).
@@ -511,14 +520,14 @@ __global__ __launch_bounds__(512, 1) void s0_centroid_scores_qs(flmr_s0_args a, 
 #pragma unroll
                 for (int s = 0; s < 8; s++) {
                     ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[q][s], ah, 0, 0, 0);
-                    al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[q][s], al, 0, 0, 0);
+                    if constexpr (!HI_ONLY) al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[q][s], al, 0, 0, 0);
                 }
                 const int b = bq[q];
                 const bool full_cols = nqc[q] >= 32;
                 const unsigned long long colmask = full_cols ? ~0ull : (((1ull << nqc[q]) - 1ull) * 0x100000001ull);
                 float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; r++) v[r] = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+                for (int r = 0; r < 16; r++) v[r] = HI_ONLY ? ah[r] : fmaf(al[r], 1.0f / 2048.0f, ah[r]);
 #pragma unroll
                 for (int r = 0; r < 8; r++) v[r] = fmaxf(v[r], v[r + 8]);
 #pragma unroll
@@ -530,7 +539,7 @@ __global__ __launch_bounds__(512, 1) void s0_centroid_scores_qs(flmr_s0_args a, 
                     float* cs_b = a.cs + (size_t)b * a.K * a.ncol;
                     const int nvalid4 = nqc[q] - c4;
 #pragma unroll
-                    for (int r = 0; r < 16; r++) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * S0_LDS_STRIDE + i] = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+                    for (int r = 0; r < 16; r++) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * S0_LDS_STRIDE + i] = HI_ONLY ? ah[r] : fmaf(al[r], 1.0f / 2048.0f, ah[r]);
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int mrow = 0; mrow < 4; mrow++) {
@@ -687,8 +696,13 @@ static int launch_s0_t(flmr_s0_args& a, hipStream_t st, int impl) {
             const int rows_per_slice = (int)flmr_round_up(flmr_ceil_div(a.K, slices), 64);
             slices = (int)flmr_ceil_div(a.K, rows_per_slice);
             const size_t ldsq = (size_t)8 * 32 * S0_LDS_STRIDE * sizeof(float) + (size_t)S0Q_NBUF * 2 * 8192;
-            FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_qs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
-            hipLaunchKernelGGL(s0_centroid_scores_qs, dim3(ngroups, slices), dim3(512), ldsq, st, a, rows_per_slice);
+            if (a.q_hi_only) {
+                FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_qs<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
+                hipLaunchKernelGGL(s0_centroid_scores_qs<true>, dim3(ngroups, slices), dim3(512), ldsq, st, a, rows_per_slice);
+            } else {
+                FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_qs<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
+                hipLaunchKernelGGL(s0_centroid_scores_qs<false>, dim3(ngroups, slices), dim3(512), ldsq, st, a, rows_per_slice);
+            }
         } else if (sparse) {
             FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_f16<false, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -152,6 +152,8 @@ __device__ __forceinline__ float x2_max3(float a, float b, float c) {
 // pass hf = (L >> 3) / (nqueries * G), slice 8 * hf + x: with more than 8 slices the grid works through them eight at a time,
 // so that an L2 holds one slice at any moment), block = 256 (4 waves x 64 survivors);
 // dynamic LDS = 4 x (16 KB row buffers + 2 KB code ring + 1.5 KB octet table).
+// HI_ONLY (FLMR_NUMERICS_GPU_FP16: q_lo = 0): the lo products and the hi / lo combine are left out, same values
+template <bool HI_ONLY>
 __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_args f, const int32_t* __restrict__ pids, int64_t pid_stride,
                                                                     const int32_t* __restrict__ counts, float* __restrict__ part,
                                                                     int64_t part_stride, const _Float16* __restrict__ cen16,
@@ -219,11 +221,17 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
         const x2h8* ph = reinterpret_cast<const x2h8*>(q_hi + ((size_t)b * f.ncol + i) * FLMR_DIM + 64 * h);
         const x2h8* pl = reinterpret_cast<const x2h8*>(q_lo + ((size_t)b * f.ncol + i) * FLMR_DIM + 64 * h);
 #pragma unroll
-        for (int s = 0; s < 8; s++) { bh[s] = ph[s]; bl[s] = pl[s]; }
+        for (int s = 0; s < 8; s++) {
+            bh[s] = ph[s];
+            if constexpr (!HI_ONLY) bl[s] = pl[s];
+        }
     }
     // every compiler-visible load lands here, before the first hand-counted one is issued
 #pragma unroll
-    for (int s = 0; s < 8; s++) asm volatile("" : "+v"(bh[s]), "+v"(bl[s])::"memory");
+    for (int s = 0; s < 8; s++) {
+        asm volatile("" : "+v"(bh[s])::"memory");
+        if constexpr (!HI_ONLY) asm volatile("" : "+v"(bl[s])::"memory");
+    }
     // part[query][survivor slot][slice][32]: the eight partial rows of a survivor are one contiguous KB for the combine kernel
     float* const prow = part + (((size_t)b * part_stride + slot0) * nsl + sl) * 32;
     const int pstep = nsl * 32;   // (<= 64 x 1024 floats: 32-bit arithmetic in the flush)
@@ -353,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
 #pragma unroll
                 for (int s = 0; s < 8; s++) {
                     ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[s], ah, 0, 0, 0);
-                    al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[s], al, 0, 0, 0);
+                    if constexpr (!HI_ONLY) al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[s], al, 0, 0, 0);
                 }
                 // rows 8k .. 8k+7 (octet k) live in registers 4k .. 4k+3 of the two half-waves: each lane keeps the maximum over
                 // ITS four rows; the two halves are only combined when a passage is flushed (one LDS-crossbar op per passage
@@ -361,9 +369,13 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
                 float mq[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const float v0 = fmaf(al[4 * k], 1.0f / 2048.0f, ah[4 * k]), v1 = fmaf(al[4 * k + 1], 1.0f / 2048.0f, ah[4 * k + 1]);
-                    const float v2 = fmaf(al[4 * k + 2], 1.0f / 2048.0f, ah[4 * k + 2]), v3 = fmaf(al[4 * k + 3], 1.0f / 2048.0f, ah[4 * k + 3]);
-                    mq[k] = x2_max(x2_max3(v0, v1, v2), v3);
+                    if constexpr (HI_ONLY) {
+                        mq[k] = x2_max(x2_max3(ah[4 * k], ah[4 * k + 1], ah[4 * k + 2]), ah[4 * k + 3]);
+                    } else {
+                        const float v0 = fmaf(al[4 * k], 1.0f / 2048.0f, ah[4 * k]), v1 = fmaf(al[4 * k + 1], 1.0f / 2048.0f, ah[4 * k + 1]);
+                        const float v2 = fmaf(al[4 * k + 2], 1.0f / 2048.0f, ah[4 * k + 2]), v3 = fmaf(al[4 * k + 3], 1.0f / 2048.0f, ah[4 * k + 3]);
+                        mq[k] = x2_max(x2_max3(v0, v1, v2), v3);
+                    }
                 }
 #ifdef X2_PROFILE
                 asm volatile("" : "+v"(mq[0]), "+v"(mq[1]), "+v"(mq[2]), "+v"(mq[3]));
@@ -472,13 +484,23 @@ int flmr_launch_filter_stage2_xcd(const flmr_filter_args& f, const int32_t* pids
     const int64_t grid = (int64_t)nsl * f.nqueries * G;
     if (grid > 0x7fffffffLL) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "stage-2 grid too large");
     const size_t lds = (size_t)X2_WAVES * X2_WAVE_LDS;
-    FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_stage2_xcd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(filter_stage2_xcd_kernel, dim3((unsigned)grid), dim3(256), lds, st, f, pids, pid_stride, counts, part, part_stride,
-                       ix->centroids_f16, q_hi, q_lo, ix->codes_sorted, ix->doc_splits, nsl, G
+    if (f.f16_round) {
+        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_stage2_xcd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(filter_stage2_xcd_kernel<true>, dim3((unsigned)grid), dim3(256), lds, st, f, pids, pid_stride, counts, part, part_stride,
+                           ix->centroids_f16, q_hi, q_lo, ix->codes_sorted, ix->doc_splits, nsl, G
 #ifdef X2_PROFILE
-                       , x2_prof_buffer
+                           , x2_prof_buffer
 #endif
-    );
+        );
+    } else {
+        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_stage2_xcd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(filter_stage2_xcd_kernel<false>, dim3((unsigned)grid), dim3(256), lds, st, f, pids, pid_stride, counts, part, part_stride,
+                           ix->centroids_f16, q_hi, q_lo, ix->codes_sorted, ix->doc_splits, nsl, G
+#ifdef X2_PROFILE
+                           , x2_prof_buffer
+#endif
+        );
+    }
     const dim3 cgrid(f.nqueries, (unsigned)flmr_ceil_div(max_count, 8));
     if (nsl == 8)
         hipLaunchKernelGGL(s2_combine_kernel<8>, cgrid, dim3(256), 0, st, f, pids, pid_stride, counts, part, part_stride, ix->doc_splits, keys, key_stride);

@@ -1310,6 +1310,15 @@ def test_gpu_fp16_numerics_mode_vs_reference_expressions(hip, case):
         with nat.options(FLMR_S2_IMPL=impl):
             p3, s3, c3 = scorer.search_batch(Q, k, ncells, thr, ndocs, nqc)
         assert torch.equal(p3, p) and torch.equal(s3, s) and torch.equal(c3, c), impl
+    # stage 3 of this mode has two kernels with the same arithmetic: the wave-per-document pipeline (default for one query
+    # tile; x / norm evaluated as x * (1 / norm)) and the plain one-workgroup-per-passage kernel (FLMR_S3_IMPL=f32, true
+    # division): same finalists, scores equal up to an fp16 ulp
+    with nat.options(FLMR_S3_IMPL="f32"):
+        p4, s4, c4 = scorer.search_batch(Q, k, ncells, thr, ndocs, nqc)
+    assert torch.equal(c4, c) and sorted(p4[0, :n].tolist()) == sorted(got_p.tolist())
+    plain = dict(zip(p4[0, :n].tolist(), s4[0, :n].tolist()))
+    d = np.array([_f16_ulps(plain[pid], sc_).max() for pid, sc_ in zip(got_p.tolist(), got_s.tolist())])
+    assert d.max() <= 1 and (d == 0).mean() >= 0.9, (d.max(), (d == 0).mean())
 
 
 def test_gpu_fp16_numerics_mode_through_the_searcher(hip, tmp_path):
