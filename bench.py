@@ -547,6 +547,16 @@ def main():
                                                      "inputs resident on the device, 200 calls after 20 warm-up calls"}
         sub("k5", scorer, Qs, tgts, 5, "same index, k=5 (same pruning policy as k=100, searcher.py:92-107; 5 results returned)")
         sub("k500", scorer, Qs, tgts, 500, "same index, k=500 policy (ncells=4, thr=0.4, ndocs=4096)")
+        try:   # what a config with total_visible_gpus = 1 (FLMR_executor.py:784) selects: the reference's CUDA-branch arithmetic
+            scf = IndexScorer(device_index=scorer.device_index, max_batch=min(args.batch, args.sub_batch), streams=args.streams,
+                              numerics="gpu-fp16")
+            sub("gpu_fp16_numerics", scf, Qs, tgts, k, "same index and queries in the reference's CUDA-branch arithmetic (FLMR_NUMERICS_GPU_FP16: "
+                "fp16 centroid scores / embeddings, -9999 padding, fp16 sums; Q rounded to fp16, so the split kernels run their hi "
+                "products only) -- parity of this mode: reference expressions on CPU half tensors, tests/golden/gpu_numerics.npz")
+            scf.close_searcher()
+            del scf
+        except Exception as e:
+            subs.append({"name": "gpu_fp16_numerics", "value": None, "note": f"failed: {e!r}"})
         try:
             Q8, t8 = zip(*[synth.make_queries(corpus, args.batch, 832, seed=40 + j) for j in range(2)])
             sc8 = IndexScorer(device_index=scorer.device_index, max_batch=min(256, args.sub_batch), streams=args.streams)

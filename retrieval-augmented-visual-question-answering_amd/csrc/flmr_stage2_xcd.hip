@@ -370,7 +370,9 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     if constexpr (HI_ONLY) {
-                        mq[k] = x2_max(x2_max3(ah[4 * k], ah[4 * k + 1], ah[4 * k + 2]), ah[4 * k + 3]);
+                        // (compiler-visible maxima: an inline-asm instruction reading the accumulators right after the MFMAs would
+                        // have to carry the MFMA -> VALU wait states itself; in the other branch the fmas are what the compiler sees)
+                        mq[k] = fmaxf(fmaxf(ah[4 * k], ah[4 * k + 1]), fmaxf(ah[4 * k + 2], ah[4 * k + 3]));
                     } else {
                         const float v0 = fmaf(al[4 * k], 1.0f / 2048.0f, ah[4 * k]), v1 = fmaf(al[4 * k + 1], 1.0f / 2048.0f, ah[4 * k + 1]);
                         const float v2 = fmaf(al[4 * k + 2], 1.0f / 2048.0f, ah[4 * k + 2]), v3 = fmaf(al[4 * k + 3], 1.0f / 2048.0f, ah[4 * k + 3]);
