@@ -39,7 +39,7 @@ extern thread_local char flmr_err_buf[512];
 // snapshot (flmr_opt_scope): nothing on the per-batch launch path calls getenv, and the environment cannot flip a running
 // searcher to another kernel path.
 enum flmr_opt_id {
-    FLMR_OPT_S0_IMPL = 0,    // f16 (default when the centroids are fp16-exact; query-stationary on the sparse path) | f16rs (row-stationary fp16 kernel) | f32 | mfma | valu
+    FLMR_OPT_S0_IMPL = 0,    // (unset: fp16-split, query-stationary + "hi first" on the sparse path) | f16 (the same kernel with both products everywhere) | f16rs (row-stationary fp16 kernel) | f32 | mfma | valu
     FLMR_OPT_FULL_TABLE,     // set: keep the whole centroid-score table
     FLMR_OPT_CAND_IMPL,      // atomic: first candidate-generation implementation
     FLMR_OPT_S1_NO_HITMAP,   // set: no hit prefilter
@@ -115,6 +115,7 @@ struct flmr_index {
     int32_t* codes_sorted;        // [N] per-passage ascending copy of `codes` (stage-2 walk); NULL when a passage is too long
     _Float16* centroids_f16_tiled;  // centroids_f16 in MFMA A-operand order, one contiguous 1 KB run per (tile, k-step) (stage-2 walk)
     uint16_t* doc_splits;         // [num_passages][nslices]: codes_sorted position of the first code >= s * slice_rows (XCD-sliced stage 2)
+    float cen_norm_max;           // >= the largest centroid 2-norm (bound of the "hi first" stage 0)
     int32_t nslices;              // 8, 16, 24 or 32: the fp16 centroid table cut so that a slice fits an XCD's L2
     int32_t slice_rows;           // ceil(K / nslices)
     int32_t xcd_round_robin;      // probed at open: workgroup L of a 1-D grid runs on XCD (L % 8) of 8
@@ -153,6 +154,11 @@ struct flmr_s0_args {
     _Float16* q_lo;          //   Q ~= q_hi + q_lo * 2^-11
     int32_t centroids_f16_exact;
     int32_t q_hi_only;       // FLMR_NUMERICS_GPU_FP16: Q is ROUNDED to fp16 (q_lo = 0), as the reference's `Q.cuda().half()`
+    // "hi first" stage 0 (sparse query-stationary path): the hi products alone give every score to within q_err[query][column];
+    // the lo products are computed only for the tiles that can hold a surviving row, the block maxima stay hi-only and
+    // s0_select_cells verifies its choice against that bound (flmr_stage0.hip).  q_err == NULL: both products everywhere.
+    float* q_err;            // [nqueries, ncol] rigorous bound on |c . q_lo| / 2048 (+ the combine's rounding), written by s0_q_err_kernel
+    float cen_norm_max;      // >= max_c ||c||_2
 };
 int flmr_launch_centroid_scores(flmr_s0_args& a, hipStream_t st);
 int flmr_launch_select_cells(const flmr_s0_args& a, hipStream_t st);
@@ -162,6 +168,7 @@ int flmr_launch_qual_rows(const uint32_t* idx_bits, int idx_words, int nqueries,
                           const _Float16* cen16, const _Float16* q_hi, const _Float16* q_lo, hipStream_t st);
 int flmr_check_f16_exact(const float* dev, size_t n, int32_t* host_result);
 int flmr_convert_f16(const float* dev, size_t n, _Float16* out);
+int flmr_max_row_norm(const float* dev, int64_t rows, float* host_result);   // >= max_r ||row_r||_2 over [rows, 128] (rounded up)
 
 int flmr_launch_ivf_mark(const int32_t* cells, const int32_t* ncell, int32_t max_cells, int32_t nqueries,
                          const int32_t* ivf_pids, const int64_t* ivf_offsets, uint32_t* bitmap, int64_t bitmap_words,

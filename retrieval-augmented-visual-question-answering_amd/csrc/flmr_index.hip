@@ -163,6 +163,7 @@ extern "C" int flmr_index_open(const flmr_index_desc_t* d, flmr_index_t** out) {
     FLMR_TRY(to_device(d->ivf_offsets, (size_t)K + 1, d->memory, &ix->ivf_offsets));
     FLMR_TRY(to_device(d->centroids, (size_t)K * FLMR_DIM, d->memory, &ix->centroids));
     FLMR_TRY(flmr_check_f16_exact(ix->centroids, (size_t)K * FLMR_DIM, &ix->centroids_f16_exact));
+    FLMR_TRY(flmr_max_row_norm(ix->centroids, K, &ix->cen_norm_max));
     if (ix->centroids_f16_exact) {
         rc = hipMalloc(reinterpret_cast<void**>(&ix->centroids_f16), (size_t)K * FLMR_DIM * sizeof(_Float16)) == hipSuccess ? FLMR_OK : FLMR_ERR_NOMEM;
         if (rc) { snprintf(flmr_err_buf, sizeof(flmr_err_buf), "hipMalloc centroids_f16"); flmr_index_close(ix); return rc; }

@@ -28,6 +28,7 @@ struct flmr_searcher {
     int32_t* q_lens_ws;         // [max_queries] query lengths clamped to [0, nq]: what every kernel reads
     flmr_options opt;           // variant switches, snapshot taken at flmr_searcher_create
     _Float16* q_hi; _Float16* q_lo;
+    float* q_err;               // [max_queries, ncol_max] per-column error bound of the hi-only stage-0 scores
     uint32_t* hit_bits; int32_t* hit_valid; int32_t* key_count; int32_t* chunk_hits;
     int32_t* s1_slot; int32_t* s2_slot;   // sharded protocol: position of each local survivor / finalist in the global list
     float* s2_part;             // XCD-sliced stage 2: per (query, slice, survivor) column maxima (NULL when the index has no split table)
@@ -117,6 +118,7 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     WS(q_lens_ws, B);
     WS(q_hi, B * (size_t)s->ncol_max * FLMR_DIM);
     WS(q_lo, B * (size_t)s->ncol_max * FLMR_DIM);
+    WS(q_err, B * (size_t)s->ncol_max);
     WS(hit_bits, B * (size_t)s->bitmap_words);
     WS(hit_valid, B);
     WS(key_count, B);
@@ -151,7 +153,7 @@ extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
     if (!s) return FLMR_OK;
     void* ptrs[] = {s->cs, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
                     s->keys1, s->s1_pids, s->s1_count, s->keys2, s->s2_pids, s->s2_count, s->keys3, s->doc_scores,
-                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->chunk_hits, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part};
+                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->q_err, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->chunk_hits, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part};
     for (void* p : ptrs) (void)hipFree(p);
     if (s->status_host) (void)hipHostFree(s->status_host);
     if (s->status_ev) (void)hipEventDestroy(s->status_ev);
@@ -344,6 +346,8 @@ extern "C" int flmr_searcher_probe_supported(const flmr_searcher_t* s, int32_t n
     return FLMR_OK;
 }
 
+static inline bool f16num_early(const flmr_searcher* s) { return s->numerics == FLMR_NUMERICS_GPU_FP16; }
+
 static int prepare_ctx(run_ctx& c, flmr_searcher* s, const float* Q, const int32_t* q_lens, int32_t nqueries, int32_t nq,
                        const flmr_search_params_t* p, flmr_stream_t stream) {
     if (!s || !Q) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
@@ -377,6 +381,9 @@ static int prepare_ctx(run_ctx& c, flmr_searcher* s, const float* Q, const int32
     a0.part_val = s->part_val; a0.part_idx = s->part_idx; a0.nblk = s->nblk;
     a0.cells = s->cells; a0.ncell = s->ncell; a0.max_cells = s->max_cells;
     a0.q_hi = s->q_hi; a0.q_lo = s->q_lo; a0.centroids_f16_exact = ix->centroids_f16_exact;
+    // "hi first" stage 0: on unless the fp16 numerics mode makes it moot (q_lo = 0) or FLMR_S0_IMPL asks for another kernel
+    a0.q_err = (!f16num_early(s) && !s->opt.has(FLMR_OPT_S0_IMPL)) ? s->q_err : nullptr;
+    a0.cen_norm_max = ix->cen_norm_max;
     a0.centroids_f16 = ix->centroids_f16;
     a0.part_rows = 0;
     c.sparse = sparse_path(s, ncol);

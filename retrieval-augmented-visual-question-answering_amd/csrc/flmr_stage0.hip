@@ -439,7 +439,11 @@ __device__ __forceinline__ void s0q_wait_vm() {
 
 // HI_ONLY (FLMR_NUMERICS_GPU_FP16: Q is rounded to fp16, q_lo = 0): the lo products would multiply by zero -- they and the
 // hi / lo combine are left out, the values are the same (fma(0, 2^-11, x) = x)
-template <bool HI_ONLY>
+// APPROX ("hi first", the default of the CPU-path numerics): the hi products of a tile come first; their column maxima go to
+// the block maxima as they are (s0_select_cells knows they are within q_err of the full values and verifies its choice), and
+// the lo products are computed only for a tile in which  ah + q_err >= thr  somewhere -- a tile that can hold a surviving row,
+// a few dozen of a query's 4096 -- after which the dense epilogue tests and stores the FULL values exactly as before.
+template <bool HI_ONLY, bool APPROX = false>
 __global__ __launch_bounds__(512, 1) void s0_centroid_scores_qs(flmr_s0_args a, int rows_per_slice) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -453,6 +457,7 @@ __global__ __launch_bounds__(512, 1) void s0_centroid_scores_qs(flmr_s0_args a, 
     if (ntiles <= 0) return;
     // this wave's queries (a query past the end repeats the last one: same values to the same addresses)
     int bq[S0Q_QT], nqc[S0Q_QT];
+    float qe[S0Q_QT];   // APPROX: the bound of this lane's column
     f16x8 bh[S0Q_QT][8], bl[S0Q_QT][8];
 #pragma unroll
     for (int q = 0; q < S0Q_QT; q++) {
@@ -460,6 +465,7 @@ __global__ __launch_bounds__(512, 1) void s0_centroid_scores_qs(flmr_s0_args a, 
         bq[q] = b < a.nqueries ? b : a.nqueries - 1;
         const int qlen = a.q_lens ? a.q_lens[bq[q]] : a.nq;
         nqc[q] = qlen < a.nq_cand ? qlen : a.nq_cand;
+        qe[q] = APPROX ? a.q_err[(size_t)bq[q] * a.ncol + i] : 0.0f;
         const f16x8* ph = reinterpret_cast<const f16x8*>(a.q_hi + ((size_t)bq[q] * a.ncol + i) * FLMR_DIM + 64 * h);
         const f16x8* pl = reinterpret_cast<const f16x8*>(a.q_lo + ((size_t)bq[q] * a.ncol + i) * FLMR_DIM + 64 * h);
 #pragma unroll
@@ -520,14 +526,14 @@ __global__ __launch_bounds__(512, 1) void s0_centroid_scores_qs(flmr_s0_args a, 
 #pragma unroll
                 for (int s = 0; s < 8; s++) {
                     ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[q][s], ah, 0, 0, 0);
-                    if constexpr (!HI_ONLY) al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[q][s], al, 0, 0, 0);
+                    if constexpr (!HI_ONLY && !APPROX) al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[q][s], al, 0, 0, 0);
                 }
                 const int b = bq[q];
                 const bool full_cols = nqc[q] >= 32;
                 const unsigned long long colmask = full_cols ? ~0ull : (((1ull << nqc[q]) - 1ull) * 0x100000001ull);
                 float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; r++) v[r] = HI_ONLY ? ah[r] : fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+                for (int r = 0; r < 16; r++) v[r] = (HI_ONLY || APPROX) ? ah[r] : fmaf(al[r], 1.0f / 2048.0f, ah[r]);
 #pragma unroll
                 for (int r = 0; r < 8; r++) v[r] = fmaxf(v[r], v[r + 8]);
 #pragma unroll
@@ -535,7 +541,11 @@ __global__ __launch_bounds__(512, 1) void s0_centroid_scores_qs(flmr_s0_args a, 
                 const float tmax = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
                 cmax[q] = fmaxf(cmax[q], tmax);
                 uint32_t idxw = 0u;
-                if ((__ballot(tmax >= a.thr) & colmask) != 0ull) {  // wave-uniform and rare: some row of this tile survives
+                if ((__ballot(tmax + qe[q] >= a.thr) & colmask) != 0ull) {  // wave-uniform and rare: some row of this tile survives (APPROX: may survive)
+                    if constexpr (APPROX) {   // now the lo products of this tile (the A fragments are still in registers)
+#pragma unroll
+                        for (int s = 0; s < 8; s++) al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[q][s], al, 0, 0, 0);
+                    }
                     float* cs_b = a.cs + (size_t)b * a.K * a.ncol;
                     const int nvalid4 = nqc[q] - c4;
 #pragma unroll
@@ -583,6 +593,63 @@ __global__ void check_f16_exact_kernel(const float* x, size_t n, int* flag) {
 
 __global__ void convert_f16_kernel(const float* x, size_t n, _Float16* out) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) out[e] = (_Float16)x[e];
+}
+
+// max over the rows of ||row||_2 (fp32, non-negative: the float's bit pattern orders like an int), rounded up
+__global__ __launch_bounds__(256) void max_row_norm_kernel(const float* __restrict__ x, int64_t rows, int* out_bits) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float n = 0.0f;
+    if (r < rows) {
+        float ss = 0.0f;
+        const float4* p = reinterpret_cast<const float4*>(x + (size_t)r * FLMR_DIM);
+#pragma unroll 8
+        for (int j = 0; j < FLMR_DIM / 4; j++) {
+            const float4 v = p[j];
+            ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+        }
+        n = sqrtf(ss);
+    }
+    if (n == n) atomicMax(out_bits, __float_as_int(n));
+}
+
+int flmr_max_row_norm(const float* dev, int64_t rows, float* host_result) {
+    int* bits = nullptr;
+    FLMR_HIP(hipMalloc(reinterpret_cast<void**>(&bits), sizeof(int)));
+    FLMR_HIP(hipMemset(bits, 0, sizeof(int)));
+    hipLaunchKernelGGL(max_row_norm_kernel, dim3((unsigned)flmr_ceil_div(rows > 0 ? rows : 1, 256)), dim3(256), 0, 0, dev, rows, bits);
+    int b = 0;
+    FLMR_HIP(hipMemcpy(&b, bits, sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(bits);
+    float f;
+    memcpy(&f, &b, 4);
+    *host_result = f * 1.0001f + 1e-30f;   // (the fp32 sum of squares is within 128 * 2^-24 of the true one)
+    return FLMR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// "hi first" stage 0: per (query, column) a RIGOROUS bound on how far the hi-only score  ah = sum_j c_j qh_j  (what the MFMA
+// accumulates in fp32) can be from the value the full sequence stores,  s = fl(ah + al * 2^-11),  al = fl(sum_j c_j ql_j):
+//     |s - ah| <= |al| / 2048 + ulp/2(s),   |al| <= (1 + 128 * 2^-24) * ||c|| ||ql||   (Cauchy-Schwarz on the exact products),
+//     ulp/2(s) <= 2^-24 |s| <= 2^-24 ||c|| ||q||.
+// err = cen_norm_max * (||ql|| / 2048 * 1.001 + ||q|| * 2.5e-7), norms accumulated in fp32 and rounded up by the 1.001.
+// With it the kernels decide where the lo products are needed at all (a tile can hold a surviving row only if ah + err >= thr)
+// and s0_select_cells verifies its block choice; every stored value and every decision is still the full sequence's.
+// grid = nqueries, block = 64 (lane = column, two columns per lane for ncol = 64 .. 128)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void s0_q_err_kernel(const _Float16* __restrict__ q_hi, const _Float16* __restrict__ q_lo, int ncol,
+                                                      float cen_norm_max, float* __restrict__ q_err) {
+    const int b = blockIdx.x;
+    for (int col = threadIdx.x; col < ncol; col += 64) {
+        const _Float16* ph = q_hi + ((size_t)b * ncol + col) * FLMR_DIM;
+        const _Float16* pl = q_lo + ((size_t)b * ncol + col) * FLMR_DIM;
+        float sl = 0.0f, sq = 0.0f;
+        for (int j = 0; j < FLMR_DIM; j++) {
+            const float l = (float)pl[j], x = fmaf(l, 1.0f / 2048.0f, (float)ph[j]);
+            sl = fmaf(l, l, sl);
+            sq = fmaf(x, x, sq);
+        }
+        q_err[(size_t)b * ncol + col] = cen_norm_max * (sqrtf(sl) * (1.001f / 2048.0f) + sqrtf(sq) * 2.5e-7f);
+    }
 }
 
 int flmr_convert_f16(const float* dev, size_t n, _Float16* out) {
@@ -686,6 +753,7 @@ static int launch_s0_t(flmr_s0_args& a, hipStream_t st, int impl) {
         const bool sparse = !a.full_table && a.ncol == 32 && !flmr_opts().has(FLMR_OPT_S0_STAGED);
         const dim3 grid((a.nblk + S0_WAVES - 1) / S0_WAVES, qsplit), block(64 * S0_WAVES);
         const bool qs = sparse && a.centroids_f16 && (int64_t)a.K * 256 < (1ll << 32) && !flmr_opts().is(FLMR_OPT_S0_IMPL, "f16rs");
+        if (!qs) a.q_err = nullptr;   // the block maxima of the other kernels are the full values: s0_select_cells must not assume otherwise
         if (qs) {
             // query-stationary: 16 queries per workgroup, the table cut into as many slices (multiples of 64 rows) as fill the chip
             const int ngroups = (int)flmr_ceil_div(a.nqueries, 8 * S0Q_QT);
@@ -699,6 +767,10 @@ static int launch_s0_t(flmr_s0_args& a, hipStream_t st, int impl) {
             if (a.q_hi_only) {
                 FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_qs<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
                 hipLaunchKernelGGL(s0_centroid_scores_qs<true>, dim3(ngroups, slices), dim3(512), ldsq, st, a, rows_per_slice);
+            } else if (a.q_err) {
+                hipLaunchKernelGGL(s0_q_err_kernel, dim3(a.nqueries), dim3(64), 0, st, a.q_hi, a.q_lo, a.ncol, a.cen_norm_max, a.q_err);
+                FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_qs<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
+                hipLaunchKernelGGL((s0_centroid_scores_qs<false, true>), dim3(ngroups, slices), dim3(512), ldsq, st, a, rows_per_slice);
             } else {
                 FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_qs<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
                 hipLaunchKernelGGL(s0_centroid_scores_qs<false>, dim3(ngroups, slices), dim3(512), ldsq, st, a, rows_per_slice);
@@ -822,15 +894,17 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
     // block-maxima partials with a single column tile: every wave scans a slice of the rows for ALL 32 columns with
     // 128-byte coalesced reads (lane = (row parity, column)) and leaves its per-column top-NC blocks in LDS; the per-column
     // loop below then merges 16 short lists instead of walking 2048 rows with a 128-byte stride per column.
-    __shared__ float pre_v[SC_WAVES][32][NC];
-    __shared__ int pre_i[SC_WAVES][32][NC];
+    // lists hold NC + 1 entries: the extra one is the best block NOT chosen, the guard of the "hi first" verification below
+    constexpr int NL = NC + 1;
+    __shared__ float pre_v[SC_WAVES][32][NL];
+    __shared__ int pre_i[SC_WAVES][32][NL];
     const bool pre = a.part_rows != 0 && a.ncol == 32;
     // The pipelined recompute below (sparse table, one column tile, fp16 centroid copy): the queries' hi / lo B fragments of
     // all 32 columns sit in LDS in fragment order [hi|lo][k-step][lane] (read just in time, 16 bytes per lane, conflict-free),
     // which leaves the registers for TWO selected blocks' A rows in flight
     const bool piped = pre && !a.full_table && a.centroids_f16 != nullptr && a.part_rows == 32 * S0_RT;
     __shared__ f16x8 bfrag[2][8][64];
-    __shared__ int sel[SC_WAVES][4 * NC];   // this wave's (column slot << 24 | block) tasks, valid ones first
+    __shared__ int sel[SC_WAVES][4 * NC + 1];   // this wave's (column slot << 24 | block) tasks, valid ones first (+ one scratch slot)
     if (piped) {
         for (int e = tid; e < 2 * 8 * 64; e += 64 * SC_WAVES) {
             const int hl = e >> 9, st = (e >> 6) & 7, ln = e & 63;
@@ -843,7 +917,7 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
         // 16-byte loads: lane = (row phase lane >> 3, four columns 4 * (lane & 7)), eight in flight per lane.  The scan
         // moves 256 KB per query and measures ~4 TB/s over the chip at 256 queries whatever the depth (8 or 32 in flight,
         // 4- or 16-byte loads): it is bandwidth-bound -- fewer block maxima per query would have to come from S0
-        flmr_toplist<NC> bt[4];
+        flmr_toplist<NL> bt[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) bt[c].init();
         constexpr int RS = 8 * SC_WAVES;  // rows per sweep of the workgroup
@@ -868,11 +942,11 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
             bt[c].merge_xor(8); bt[c].merge_xor(16); bt[c].merge_xor(32);
             if (lane < 8) {
 #pragma unroll
-                for (int t = 0; t < NC; t++) { pre_v[wave][4 * cg + c][t] = bt[c].v[t]; pre_i[wave][4 * cg + c][t] = bt[c].id[t]; }
+                for (int t = 0; t < NL; t++) { pre_v[wave][4 * cg + c][t] = bt[c].v[t]; pre_i[wave][4 * cg + c][t] = bt[c].id[t]; }
             }
         }
         } else {   // longer lists: one column per lane (four lists of NC entries per lane do not fit the registers)
-        flmr_toplist<NC> bt;
+        flmr_toplist<NL> bt;
         bt.init();
         // 8 loads in flight per lane: one workgroup per query means one per CU, so a load -> insert chain per row would
         // expose the full memory latency 64 times per wave
@@ -888,7 +962,7 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
         bt.merge_xor(32);
         if (lane < 32) {
 #pragma unroll
-            for (int t = 0; t < NC; t++) { pre_v[wave][lane][t] = bt.v[t]; pre_i[wave][lane][t] = bt.id[t]; }
+            for (int t = 0; t < NL; t++) { pre_v[wave][lane][t] = bt.v[t]; pre_i[wave][lane][t] = bt.id[t]; }
         }
         }
     }
@@ -896,22 +970,38 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
     SC_STAMP(0);
     if (piped) {
         // ---- which blocks: the top-NC block maxima of each of this wave's columns (wave-uniform lists), as a task list ----
+        // "hi first" stage 0 (a.q_err != NULL): the block maxima are hi-only values, each within err = q_err[b][col] of the
+        // full one.  The blocks holding the true top-ncells rows are then still the chosen ones PROVIDED every other block's
+        // full maximum is below the ncells-th best row found:  guard + err < v_ncells,  guard = the best maximum not chosen (any
+        // unchosen block's rows are <= its hi maximum + err <= guard + err).  A column failing that test (a near-tie, ~3 % of
+        // them) is redone below against ALL the blocks.
+        const bool approx = a.q_err != nullptr;
+        __shared__ float guard[SC_WAVES][4];
+        __shared__ int redo_n[SC_WAVES];
+        __shared__ int redo_k[SC_WAVES][4];
+        __shared__ float redo_v[SC_WAVES][4][NC];
+        __shared__ int redo_i[SC_WAVES][4][NC];
+        if (lane == 0) redo_n[wave] = 0;
         int ntasks = 0;
         for (int k = 0; wave + SC_WAVES * k < nqc; k++) {
             const int col = wave + SC_WAVES * k;
-            flmr_toplist<NC> bt;
+            flmr_toplist<NL> bt;
             bt.init();
-            for (int e = lane; e < SC_WAVES * NC; e += 64) bt.insert(pre_v[e / NC][col][e % NC], pre_i[e / NC][col][e % NC]);
+            for (int e = lane; e < SC_WAVES * NL; e += 64) bt.insert(pre_v[e / NL][col][e % NL], pre_i[e / NL][col][e % NL]);
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) bt.merge_xor(m);
+            float gv = FLMR_NEG_INF;
 #pragma unroll
-            for (int t = 0; t < NC; t++) {
+            for (int t = 0; t < NL; t++) {
                 const int id = __builtin_amdgcn_readfirstlane(bt.id[t]);
                 if (t < a.ncells && id < a.nblk) {   // wave-uniform
                     if (lane == 0) sel[wave][ntasks] = (k << 24) | id;
                     ntasks++;
+                } else if (t == a.ncells && id < a.nblk) {
+                    gv = bt.v[t];
                 }
             }
+            if (lane == 0) guard[wave][k] = gv;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -932,15 +1022,33 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
         flmr_toplist<NC> tl;
         tl.init();
         int cur_k = -1;
+        auto write_cells = [&](int col) __attribute__((always_inline)) {
+            if (lane == 0) {
+#pragma unroll
+                for (int t = 0; t < NC; t++)
+                    if (t < a.ncells && tl.id[t] < a.K) raw[col * a.ncells + t] = tl.id[t];
+            }
+        };
         auto finish = [&]() __attribute__((always_inline)) {   // column done: exact top-NC over the wave, ids to the cell list
             if (cur_k < 0) return;
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) tl.merge_xor(m);
             const int col = wave + SC_WAVES * cur_k;
-            if (lane == 0) {
+            bool safe = true;
+            if (approx) {   // (wave-uniform: the merged list is the same in every lane)
+                float vn = FLMR_NEG_INF;
 #pragma unroll
-                for (int t = 0; t < NC; t++)
-                    if (t < a.ncells && tl.id[t] < a.K) raw[col * a.ncells + t] = tl.id[t];
+                for (int t = 0; t < NC; t++) vn = (t == a.ncells - 1) ? tl.v[t] : vn;
+                safe = guard[wave][cur_k] + a.q_err[(size_t)b * a.ncol + col] < vn;
+            }
+            if (safe) {
+                write_cells(col);
+            } else if (lane == 0) {   // park the column: its list so far, to be completed after the pipelined loop
+                const int n = redo_n[wave];
+                redo_k[wave][n] = cur_k;
+#pragma unroll
+                for (int t = 0; t < NC; t++) { redo_v[wave][n][t] = tl.v[t]; redo_i[wave][n][t] = tl.id[t]; }
+                redo_n[wave] = n + 1;
             }
             tl.init();
         };
@@ -984,6 +1092,57 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
             if (m + 1 < ntasks) compute(avB, m + 1);
         }
         finish();
+        // ---- parked columns: every block whose hi maximum + err reaches the current ncells-th best row is recomputed too (the
+        // list can only improve, which only tightens the test: a block skipped earlier stays skippable) ----
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nredo = approx ? redo_n[wave] : 0;
+        for (int rd = 0; rd < nredo; rd++) {
+            const int k = redo_k[wave][rd];
+            const int col = wave + SC_WAVES * k;
+            const float err = a.q_err[(size_t)b * a.ncol + col];
+            // the list so far lives in lane 0 only while rows are inserted (every lane holding it would duplicate its entries in
+            // the merge); merged, it is the same in all lanes for the wave-uniform tests
+            tl.init();
+            if (lane == 0) {
+#pragma unroll
+                for (int t = 0; t < NC; t++) { tl.v[t] = redo_v[wave][rd][t]; tl.id[t] = redo_i[wave][rd][t]; }
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) tl.merge_xor(m);
+            cur_k = -1;
+            for (int j0 = 0; j0 < a.nblk; j0 += 64) {
+                const int j = j0 + lane;
+                const float A = j < a.nblk ? a.part_val[((size_t)b * a.nblk + j) * a.ncol + col] : FLMR_NEG_INF;
+                bool chosen = false;
+                for (int m = 0; m < ntasks; m++) chosen |= (sel[wave][m] >> 24) == k && (sel[wave][m] & 0xffffff) == j;
+                float vn = FLMR_NEG_INF;
+#pragma unroll
+                for (int t = 0; t < NC; t++) vn = (t == a.ncells - 1) ? tl.v[t] : vn;
+                unsigned long long need = __ballot(j < a.nblk && !chosen && !(A + err < vn));
+                while (need) {
+                    const int src = __ffsll((long long)need) - 1;
+                    need &= need - 1;
+                    // (the list may have improved since the ballot: re-test this block against it)
+                    const float Aj = __shfl(A, src, 64);
+                    vn = FLMR_NEG_INF;
+#pragma unroll
+                    for (int t = 0; t < NC; t++) vn = (t == a.ncells - 1) ? tl.v[t] : vn;
+                    if (Aj + err < vn) continue;
+                    if (lane == 0) sel[wave][4 * NC] = (k << 24) | (j0 + src);   // the scratch task slot
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane != 0) tl.init();
+                    issue(avA, 4 * NC);
+                    cur_k = k;              // compute() must not take this for a column change
+                    compute(avA, 4 * NC);
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1) tl.merge_xor(m);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            write_cells(col);
+        }
     } else
     for (int col = wave; col < nqc; col += SC_WAVES) {
         flmr_toplist<NC> tl;

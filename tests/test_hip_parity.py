@@ -1345,3 +1345,55 @@ def test_gpu_fp16_numerics_mode_through_the_searcher(hip, tmp_path):
         assert r_gpu[i][0][0] == r_cpu[i][0][0] == int(z[f"{r}.final_pids"][0])
         sc = np.array([t[2] for t in r_gpu[i]], dtype=np.float32)
         assert np.array_equal(sc, _f16r(sc)) and not np.array_equal(sc, np.array([t[2] for t in r_cpu[i]], dtype=np.float32))
+
+
+@pytest.mark.parametrize("ties", [False, True])
+def test_s0_hi_first_equals_full_products(hip, ties):
+    """Stage 0 "hi first" (default: hi products everywhere, lo products only for tiles that can hold a surviving row, hi-only
+    block maxima verified in the cell selection against a rigorous bound) vs the same kernels with both products everywhere
+    (FLMR_S0_IMPL=f16): idx bits, cells, candidates and the final ranking must be IDENTICAL -- the shortcut changes where
+    arithmetic is spent, never a stored value or a decision.  `ties`: a centroid table made of one 64-row block repeated with
+    one-ulp perturbations, so that the best block maxima of every column lie within the bound of each other and the selection
+    has to take its verification's slow path (all near-tying blocks recomputed; exact ties broken by the lower row index);
+    cells are also checked against the oracle's selection on the full table."""
+    from oracle import oracle as orc
+    torch, nat = hip["torch"], hip["native"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    K = 2048
+    corpus = synth.make_corpus(5000, (4, 60), K, 2, seed=23, device="cuda")
+    if ties:
+        g = torch.Generator(device="cuda").manual_seed(7)
+        base = corpus.centroids[:64].clone()
+        cen = base.repeat(K // 64, 1)
+        bump = (torch.rand(cen.shape, generator=g, device="cuda") < 0.02).float() * 2.0 ** -13   # ~ an fp16 ulp at |x| ~ 0.1
+        bump[:64] = 0
+        cen = (cen + bump).half().float()
+        cen[64 * 5:64 * 6] = base                      # one exact copy: exact ties, the lower index must win
+        corpus.centroids = cen.contiguous()
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=16)
+    Q, _ = synth.make_queries(corpus, 11, 32, seed=4)
+    Q[3, 20:] = 0.0
+    q_lens = torch.tensor([32, 32, 9, 20, 32, 1, 32, 32, 17, 32, 32], dtype=torch.int32)
+    for (ncells, thr, ndocs) in [(1, 0.5, 64), (2, 0.45, 256), (4, 0.4, 1024), (8, 0.3, 256), (2, -1.0, 64)]:
+        res = {}
+        for impl in (None, "f16"):
+            ctx = nat.options(FLMR_S0_IMPL=impl) if impl else contextlib.nullcontext()
+            with ctx:
+                p, s, c = scorer.search_batch(Q, max(ndocs // 4, 1), ncells, thr, ndocs, 32, q_lens=q_lens)
+                scorer.check()
+                taps = [[scorer.tap(t, q) for t in (nat.TAP_IDX_BITS, nat.TAP_CELLS, nat.TAP_CANDIDATES)] for q in range(Q.size(0))]
+                res[impl] = (p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), taps)
+        a, b = res[None], res["f16"]
+        for q in range(Q.size(0)):
+            for x, y, name in zip(a[3][q], b[3][q], ("idx", "cells", "candidates")):
+                assert np.array_equal(x, y), (ties, ncells, thr, q, name)
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), (ties, ncells, thr)
+    # cells of the default path against the oracle's top-ncells (value desc, index asc) on the full table of the same kernel family
+    for ncells in (2, 4):
+        for q in (0, 4):
+            scorer.search_batch(Q[q:q + 1], 16, ncells, 0.45, 64, 32)
+            cells = scorer.tap(nat.TAP_CELLS)
+            scorer.search_batch(Q[q:q + 1], 16, ncells, 0.45, 64, 32, full_table=True)
+            cs = scorer.tap(nat.TAP_CENTROID_SCORES)[:, :32]
+            assert np.array_equal(cells, orc.select_cells(cs, ncells)), (ties, ncells, q)
