@@ -1111,34 +1111,49 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) tl.merge_xor(m);
             cur_k = -1;
-            for (int j0 = 0; j0 < a.nblk; j0 += 64) {
-                const int j = j0 + lane;
-                const float A = j < a.nblk ? a.part_val[((size_t)b * a.nblk + j) * a.ncol + col] : FLMR_NEG_INF;
-                bool chosen = false;
-                for (int m = 0; m < ntasks; m++) chosen |= (sel[wave][m] >> 24) == k && (sel[wave][m] & 0xffffff) == j;
-                float vn = FLMR_NEG_INF;
+            // the column's block maxima, sixteen 64-block groups in flight at a time (one dependent round trip per group would
+            // cost ~2 us each here: one workgroup per CU, nothing else to switch to)
+            for (int jb = 0; jb < a.nblk; jb += 64 * 16) {
+                float Av[16];
 #pragma unroll
-                for (int t = 0; t < NC; t++) vn = (t == a.ncells - 1) ? tl.v[t] : vn;
-                unsigned long long need = __ballot(j < a.nblk && !chosen && !(A + err < vn));
-                while (need) {
-                    const int src = __ffsll((long long)need) - 1;
-                    need &= need - 1;
-                    // (the list may have improved since the ballot: re-test this block against it)
-                    const float Aj = __shfl(A, src, 64);
-                    vn = FLMR_NEG_INF;
+                for (int u = 0; u < 16; u++) {
+                    const int j = jb + 64 * u + lane;
+                    Av[u] = j < a.nblk ? a.part_val[((size_t)b * a.nblk + j) * a.ncol + col] : FLMR_NEG_INF;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int j0 = jb + 64 * u;
+                    if (j0 >= a.nblk) break;   // wave-uniform
+                    const int j = j0 + lane;
+                    const float A = Av[u];
+                    float vn = FLMR_NEG_INF;
 #pragma unroll
                     for (int t = 0; t < NC; t++) vn = (t == a.ncells - 1) ? tl.v[t] : vn;
-                    if (Aj + err < vn) continue;
-                    if (lane == 0) sel[wave][4 * NC] = (k << 24) | (j0 + src);   // the scratch task slot
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane != 0) tl.init();
-                    issue(avA, 4 * NC);
-                    cur_k = k;              // compute() must not take this for a column change
-                    compute(avA, 4 * NC);
+                    unsigned long long need = __ballot(j < a.nblk && !(A + err < vn));
+                    while (need) {
+                        const int src = __ffsll((long long)need) - 1;
+                        need &= need - 1;
+                        const int jj = j0 + src;
+                        bool chosen = false;   // (wave-uniform) one of the blocks the pipelined pass already recomputed
+                        for (int m = 0; m < ntasks; m++) chosen |= (sel[wave][m] >> 24) == k && (sel[wave][m] & 0xffffff) == jj;
+                        if (chosen) continue;
+                        // (the list may have improved since the ballot: re-test this block against it)
+                        const float Aj = __shfl(A, src, 64);
+                        vn = FLMR_NEG_INF;
 #pragma unroll
-                    for (int m = 32; m >= 1; m >>= 1) tl.merge_xor(m);
-                    __builtin_amdgcn_wave_barrier();
+                        for (int t = 0; t < NC; t++) vn = (t == a.ncells - 1) ? tl.v[t] : vn;
+                        if (Aj + err < vn) continue;
+                        if (lane == 0) sel[wave][4 * NC] = (k << 24) | jj;   // the scratch task slot
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane != 0) tl.init();
+                        issue(avA, 4 * NC);
+                        cur_k = k;              // compute() must not take this for a column change
+                        compute(avA, 4 * NC);
+#pragma unroll
+                        for (int m = 32; m >= 1; m >>= 1) tl.merge_xor(m);
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
             }
             write_cells(col);
