@@ -44,7 +44,7 @@ enum flmr_opt_id {
     FLMR_OPT_CAND_IMPL,      // atomic: first candidate-generation implementation
     FLMR_OPT_S1_NO_HITMAP,   // set: no hit prefilter
     FLMR_OPT_S1_IMPL,        // scan: code-scanning stage 1 for every query
-    FLMR_OPT_S2_IMPL,        // xcd | walk | lds | ldsb | regs: force the XCD-sliced gather / the dense walk / the LDS-DMA gather (4-wave blocks; 16-wave blocks with the query operand in LDS) / the register gather (default: cost model)
+    FLMR_OPT_S2_IMPL,        // xcda (approximate-then-refine on the sliced kernel: the default where the sliced kernel is) | xcd | walk | lds | ldsb | regs: force the XCD-sliced gather / the dense walk / the LDS-DMA gather (4-wave blocks; 16-wave blocks with the query operand in LDS) / the register gather (default: cost model)
     FLMR_OPT_S0_STAGED,      // set: staged epilogue for every tile
     FLMR_OPT_S3_NO_MULTIQ,   // set: single-tile MaxSim kernel for long queries too
     FLMR_OPT_S3_IMPL,        // cw (default for Nq <= 32): (c.q + w.q) * 1/norm with table-decoded weights; regs / dma: decompress-normalise-split kernel with register / LDS-DMA row gathers; f32: fp32-MFMA kernel
@@ -158,6 +158,9 @@ struct flmr_s0_args {
     // the lo products are computed only for the tiles that can hold a surviving row, the block maxima stay hi-only and
     // s0_select_cells verifies its choice against that bound (flmr_stage0.hip).  q_err == NULL: both products everywhere.
     float* q_err;            // [nqueries, ncol] rigorous bound on |c . q_lo| / 2048 (+ the combine's rounding), written by s0_q_err_kernel
+    float* q_err_buf;        // where s0_q_err_kernel writes (the sparse query-stationary path always fills it: stage 2's
+                             // approximate-then-refine form reads it too); q_err == q_err_buf when stage 0 itself uses the bound
+    float* q_err_sum;        // [nqueries] bound on |approximate - full| for a passage's stage-2 score (sum over the columns + summation rounding)
     float cen_norm_max;      // >= max_c ||c||_2
 };
 int flmr_launch_centroid_scores(flmr_s0_args& a, hipStream_t st);
@@ -236,6 +239,21 @@ int flmr_launch_filter_stage2_xcd(const flmr_filter_args& f, const int32_t* pids
                                   const _Float16* q_hi, const _Float16* q_lo, float* part, int64_t part_stride, hipStream_t st);
 bool flmr_stage2_xcd_pays(const flmr_index* ix);
 size_t flmr_stage2_xcd_part_floats(const flmr_index* ix, int64_t nqueries, int64_t ndocs);
+// hi_only: the hi products alone (the fp16 numerics mode, where they ARE the scores; or the approximate pass of the
+// approximate-then-refine form below)
+int flmr_launch_filter_stage2_xcd_ex(const flmr_filter_args& f, const int32_t* pids, int64_t pid_stride, const int32_t* counts,
+                                     int32_t max_count, uint64_t* keys, int64_t key_stride, const flmr_index* ix,
+                                     const _Float16* q_hi, const _Float16* q_lo, float* part, int64_t part_stride, bool hi_only,
+                                     hipStream_t st);
+// Stage-2 survivor selection from APPROXIMATE keys (hi-only scores, each within err_sum[q] of the full one): the passages
+// certainly inside the top n go straight to out_pids, the passages within 2 err of the cut form the band whose full scores
+// decide the rest (flmr_launch_s2_refine_finish after the band has been rescored).
+int flmr_launch_s2_refine_plan(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t max_count, int32_t nqueries,
+                               int32_t n, const float* err_sum, int32_t* out_pids, int64_t out_stride, int32_t* band_pids,
+                               int64_t band_stride, int32_t* band_count, int32_t* need, int32_t* def_count, hipStream_t st);
+int flmr_launch_s2_refine_finish(const uint64_t* band_keys, int64_t key_stride, const int32_t* band_count, const int32_t* need,
+                                 const int32_t* def_count, int32_t max_count, int32_t nqueries, int32_t* out_pids,
+                                 int64_t out_stride, int32_t* n_out, hipStream_t st);
 // top-n of count[q] keys, unordered output (radix select); n_out[q] = min(n, count[q])
 int flmr_launch_select_topn(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t nqueries,
                             int32_t n, int32_t* out_pids, int64_t out_stride, int32_t* n_out, hipStream_t st,

@@ -1039,6 +1039,95 @@ int flmr_launch_sort_topn(const uint64_t* keys, int64_t key_stride, const int32_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stage-2 survivor selection, approximate-then-refine (the default for whole batches on the sliced kernel).
+// The sliced kernel's hi products alone give every passage's stage-2 score to within E = err_sum[query] (flmr_stage0.hip:
+// s0_q_err_kernel) at 84 % of the full kernel's time.  With a* = the n-th largest approximate score, a passage with
+// a > a* + 2E is certainly among the n best by FULL score and one with a < a* - 2E certainly is not (full scores differ from
+// the approximate ones by <= E, and so does the n-th order statistic); only the band |a - a*| <= 2E (a few per cent of the
+// survivors) is rescored with both products by the gather kernel, and the n - #certain best of the band by full
+// (score, pid) complete the list -- the SET filter_pids.cpp:143-157 selects, not its order: stage 3 rescores every member
+// anyway and the final ranking is by those scores.  grid = nqueries, block = 1024; LDS = the sorted keys.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void s2_refine_plan_kernel(const uint64_t* keys, int64_t key_stride, const int32_t* counts,
+                                                              int32_t npow2, int32_t n, const float* __restrict__ err_sum,
+                                                              int32_t* out_pids, int64_t out_stride, int32_t* band_pids,
+                                                              int64_t band_stride, int32_t* band_count, int32_t* need,
+                                                              int32_t* def_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);
+    __shared__ int bounds[2];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int cnt = counts[b];
+    for (int i = tid; i < npow2; i += blockDim.x) s[i] = (i < cnt) ? keys[(size_t)b * key_stride + i] : 0ull;
+    __syncthreads();
+    flmr_bitonic_sort_desc<unsigned long long>(s, npow2);
+    if (cnt <= n) {   // nothing to select: every survivor goes on
+        for (int i = tid; i < cnt; i += blockDim.x) out_pids[(size_t)b * out_stride + i] = flmr_key_pid(s[i]);
+        if (tid == 0) { band_count[b] = 0; need[b] = 0; def_count[b] = cnt; }
+        return;
+    }
+    if (tid == 0) {
+        const float astar = flmr_key_score(s[n - 1]), E2 = 2.0f * err_sum[b];
+        const float hi = astar + E2, lo = astar - E2;
+        // sorted descending: i0 = #keys with score > hi (certainly in), i1 = #keys with score >= lo (not certainly out)
+        int a = 0, z = n - 1;             // score(s[n-1]) = a* <= hi, so i0 <= n - 1
+        while (a < z) { const int mid = (a + z) >> 1; if (flmr_key_score(s[mid]) > hi) a = mid + 1; else z = mid; }
+        bounds[0] = a;
+        a = n; z = cnt;                   // score(s[n-1]) = a* >= lo, so i1 >= n
+        while (a < z) { const int mid = (a + z) >> 1; if (flmr_key_score(s[mid]) >= lo) a = mid + 1; else z = mid; }
+        bounds[1] = a;
+    }
+    __syncthreads();
+    const int i0 = bounds[0], i1 = bounds[1];
+    for (int i = tid; i < i0; i += blockDim.x) out_pids[(size_t)b * out_stride + i] = flmr_key_pid(s[i]);
+    for (int i = tid; i < i1 - i0; i += blockDim.x) band_pids[(size_t)b * band_stride + i] = flmr_key_pid(s[i0 + i]);
+    if (tid == 0) { band_count[b] = i1 - i0; need[b] = n - i0; def_count[b] = i0; }
+}
+
+__global__ __launch_bounds__(1024) void s2_refine_finish_kernel(const uint64_t* band_keys, int64_t key_stride,
+                                                                const int32_t* band_count, const int32_t* need,
+                                                                const int32_t* def_count, int32_t npow2, int32_t* out_pids,
+                                                                int64_t out_stride, int32_t* n_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int cnt = band_count[b], take = need[b], base = def_count[b];
+    if (tid == 0) n_out[b] = base + take;
+    if (cnt == 0) return;   // (block-uniform)
+    // the band is usually a few dozen passages: sort only the power of two that holds it
+    int np = 2;
+    while (np < cnt) np <<= 1;
+    if (np > npow2) np = npow2;
+    for (int i = tid; i < np; i += blockDim.x) s[i] = (i < cnt) ? band_keys[(size_t)b * key_stride + i] : 0ull;
+    __syncthreads();
+    flmr_bitonic_sort_desc<unsigned long long>(s, np);
+    for (int i = tid; i < take; i += blockDim.x) out_pids[(size_t)b * out_stride + base + i] = flmr_key_pid(s[i]);
+}
+
+int flmr_launch_s2_refine_plan(const uint64_t* keys, int64_t key_stride, const int32_t* counts, int32_t max_count, int32_t nqueries,
+                               int32_t n, const float* err_sum, int32_t* out_pids, int64_t out_stride, int32_t* band_pids,
+                               int64_t band_stride, int32_t* band_count, int32_t* need, int32_t* def_count, hipStream_t st) {
+    if (max_count > FLMR_MAX_NDOCS) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "s2 refine: %d keys > %d", max_count, FLMR_MAX_NDOCS);
+    int npow2 = 2;
+    while (npow2 < max_count) npow2 <<= 1;
+    hipLaunchKernelGGL(s2_refine_plan_kernel, dim3(nqueries), dim3(1024), (size_t)npow2 * 8, st, keys, key_stride, counts, npow2, n,
+                       err_sum, out_pids, out_stride, band_pids, band_stride, band_count, need, def_count);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
+int flmr_launch_s2_refine_finish(const uint64_t* band_keys, int64_t key_stride, const int32_t* band_count, const int32_t* need,
+                                 const int32_t* def_count, int32_t max_count, int32_t nqueries, int32_t* out_pids,
+                                 int64_t out_stride, int32_t* n_out, hipStream_t st) {
+    int npow2 = 2;
+    while (npow2 < max_count) npow2 <<= 1;
+    hipLaunchKernelGGL(s2_refine_finish_kernel, dim3(nqueries), dim3(1024), (size_t)npow2 * 8, st, band_keys, key_stride, band_count,
+                       need, def_count, npow2, out_pids, out_stride, n_out);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Helpers of the exact sharded protocol (SURVEY 8e "exact-parity mode"): keys travel between ranks as
 // u64 = order-preserving(score) << 32 | GLOBAL pid, 0 = empty slot.
 // ------------------------------------------------------------------------------------------------

@@ -29,6 +29,8 @@ struct flmr_searcher {
     flmr_options opt;           // variant switches, snapshot taken at flmr_searcher_create
     _Float16* q_hi; _Float16* q_lo;
     float* q_err;               // [max_queries, ncol_max] per-column error bound of the hi-only stage-0 scores
+    float* q_err_sum;           // [max_queries] error bound of a passage's hi-only stage-2 score
+    int32_t* s2_band; int32_t* s2_band_count; int32_t* s2_need; int32_t* s2_def; uint64_t* keys2b;   // stage 2, approximate-then-refine
     uint32_t* hit_bits; int32_t* hit_valid; int32_t* key_count; int32_t* chunk_hits;
     int32_t* s1_slot; int32_t* s2_slot;   // sharded protocol: position of each local survivor / finalist in the global list
     float* s2_part;             // XCD-sliced stage 2: per (query, slice, survivor) column maxima (NULL when the index has no split table)
@@ -119,6 +121,12 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     WS(q_hi, B * (size_t)s->ncol_max * FLMR_DIM);
     WS(q_lo, B * (size_t)s->ncol_max * FLMR_DIM);
     WS(q_err, B * (size_t)s->ncol_max);
+    WS(q_err_sum, B);
+    WS(s2_band, B * (size_t)nd);
+    WS(s2_band_count, B);
+    WS(s2_need, B);
+    WS(s2_def, B);
+    WS(keys2b, B * (size_t)nd);
     WS(hit_bits, B * (size_t)s->bitmap_words);
     WS(hit_valid, B);
     WS(key_count, B);
@@ -153,7 +161,7 @@ extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
     if (!s) return FLMR_OK;
     void* ptrs[] = {s->cs, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
                     s->keys1, s->s1_pids, s->s1_count, s->keys2, s->s2_pids, s->s2_count, s->keys3, s->doc_scores,
-                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->q_err, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->chunk_hits, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part};
+                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->q_err, s->q_err_sum, s->s2_band, s->s2_band_count, s->s2_need, s->s2_def, s->keys2b, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->chunk_hits, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part};
     for (void* p : ptrs) (void)hipFree(p);
     if (s->status_host) (void)hipHostFree(s->status_host);
     if (s->status_ev) (void)hipEventDestroy(s->status_ev);
@@ -382,7 +390,9 @@ static int prepare_ctx(run_ctx& c, flmr_searcher* s, const float* Q, const int32
     a0.cells = s->cells; a0.ncell = s->ncell; a0.max_cells = s->max_cells;
     a0.q_hi = s->q_hi; a0.q_lo = s->q_lo; a0.centroids_f16_exact = ix->centroids_f16_exact;
     // "hi first" stage 0: on unless the fp16 numerics mode makes it moot (q_lo = 0) or FLMR_S0_IMPL asks for another kernel
+    a0.q_err_buf = f16num_early(s) ? nullptr : s->q_err;
     a0.q_err = (!f16num_early(s) && !s->opt.has(FLMR_OPT_S0_IMPL)) ? s->q_err : nullptr;
+    a0.q_err_sum = s->q_err_sum;
     a0.cen_norm_max = ix->cen_norm_max;
     a0.centroids_f16 = ix->centroids_f16;
     a0.part_rows = 0;
@@ -490,6 +500,34 @@ static int stage_s2(run_ctx& c, bool whole_batch) {
     return FLMR_OK;
 }
 
+// S2 of a whole batch + the selection of the ndocs/4 survivors -> s->s2_pids / s2_count.
+// Default on the sliced kernel (sparse path, CPU-path numerics, the batch's error bounds at hand): hi-only pass, plan, full
+// rescoring of the band by the gather kernel, finish (flmr_filter.hip) -- the same SET as the sorted form.  FLMR_S2_IMPL set to
+// anything but "xcda" keeps the full-score forms and the sorted list (taps, cross-check tests).
+static int stage_s2_select(run_ctx& c) {
+    flmr_searcher* s = c.s;
+    const flmr_index* ix = s->ix;
+    const flmr_options& o = s->opt;
+    const int nd4m = s->maxp.ndocs / 4;
+    const bool bounds = c.sparse && !c.f.f16_round && c.a0.q_err_buf != nullptr && c.f.ncol == 32 &&
+                        c.a0.centroids_f16 && (int64_t)ix->K * 256 < (1ll << 32) && !o.is(FLMR_OPT_S0_IMPL, "f16rs");
+    const bool approx = bounds && s->s2_part && (o.is(FLMR_OPT_S2_IMPL, "xcda") || (!o.has(FLMR_OPT_S2_IMPL) && flmr_stage2_xcd_pays(ix) &&
+                        !(ix->codes_sorted && ix->centroids_f16_tiled && flmr_stage2_walk_pays(ix, c.nqueries, c.p.ndocs))));
+    if (!approx) {
+        RUN(stage_s2(c, true));
+        return flmr_launch_sort_topn(s->keys2, s->maxp.ndocs, s->s1_count, c.p.ndocs, c.nqueries, c.p.ndocs / 4, s->s2_pids,
+                                     nullptr, nd4m, s->s2_count, 0, 0, c.st);
+    }
+    RUN(flmr_launch_filter_stage2_xcd_ex(c.f, s->s1_pids, s->maxp.ndocs, s->s1_count, c.p.ndocs, s->keys2, s->maxp.ndocs, ix,
+                                         s->q_hi, s->q_lo, s->s2_part, s->maxp.ndocs, true, c.st));
+    RUN(flmr_launch_s2_refine_plan(s->keys2, s->maxp.ndocs, s->s1_count, c.p.ndocs, c.nqueries, c.p.ndocs / 4, s->q_err_sum,
+                                   s->s2_pids, nd4m, s->s2_band, s->maxp.ndocs, s->s2_band_count, s->s2_need, s->s2_def, c.st));
+    RUN(flmr_launch_filter_stage2_mfma(c.f, s->s2_band, s->maxp.ndocs, s->s2_band_count, c.p.ndocs, s->keys2b, s->maxp.ndocs,
+                                       ix->centroids_f16, s->q_hi, s->q_lo, c.st));
+    return flmr_launch_s2_refine_finish(s->keys2b, s->maxp.ndocs, s->s2_band_count, s->s2_need, s->s2_def, c.p.ndocs, c.nqueries,
+                                        s->s2_pids, nd4m, s->s2_count, c.st);
+}
+
 // S3 over s->s2_pids / s2_count -> s->keys3 / doc_scores (slot-aligned with s2_pids)
 static int stage_s3(run_ctx& c) {
     flmr_searcher* s = c.s;
@@ -509,10 +547,9 @@ extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32
     run_ctx c(s);
     RUN(prepare_ctx(c, s, Q, q_lens, nqueries, nq, p, stream));
     RUN(stage_s0_s1(c, nullptr));
-    // ---- S2: full centroid MaxSim over the survivors, keep ndocs/4 in (score,pid) order ----------------
-    RUN(stage_s2(c, true));
-    RUN(flmr_launch_sort_topn(s->keys2, s->maxp.ndocs, s->s1_count, p->ndocs, nqueries, p->ndocs / 4, s->s2_pids,
-                              nullptr, s->maxp.ndocs / 4, s->s2_count, 0, 0, c.st));
+    // ---- S2: full centroid MaxSim over the survivors, keep ndocs/4 (in (score,pid) order, or -- approximate-then-refine --
+    // as the same set) ----------------
+    RUN(stage_s2_select(c));
     RUN(mark(c));
     // ---- S3: decompress + normalise + MaxSim --------------------------------------------------------
     RUN(stage_s3(c));

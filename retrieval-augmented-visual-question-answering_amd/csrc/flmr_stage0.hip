@@ -636,9 +636,16 @@ int flmr_max_row_norm(const float* dev, int64_t rows, float* host_result) {
 // and s0_select_cells verifies its block choice; every stored value and every decision is still the full sequence's.
 // grid = nqueries, block = 64 (lane = column, two columns per lane for ncol = 64 .. 128)
 // ------------------------------------------------------------------------------------------------
+// q_err_sum[query] bounds the difference between a passage's stage-2 score from hi-only column maxima and from the full ones:
+// per column |max_t s - max_t ah| <= err, plus what two k-ascending fp32 sums of <= 128 terms of magnitude <= ||c|| ||q|| can differ
+// by through rounding (2 * 127 * 2^-24 * sum |terms|).
 __global__ __launch_bounds__(64) void s0_q_err_kernel(const _Float16* __restrict__ q_hi, const _Float16* __restrict__ q_lo, int ncol,
-                                                      float cen_norm_max, float* __restrict__ q_err) {
+                                                      const int32_t* __restrict__ q_lens, int nq, int nq_cand, float cen_norm_max,
+                                                      float* __restrict__ q_err, float* __restrict__ q_err_sum) {
     const int b = blockIdx.x;
+    const int qlen = q_lens ? q_lens[b] : nq;
+    const int nqc = qlen < nq_cand ? qlen : nq_cand;
+    float esum = 0.0f, qmax = 0.0f;
     for (int col = threadIdx.x; col < ncol; col += 64) {
         const _Float16* ph = q_hi + ((size_t)b * ncol + col) * FLMR_DIM;
         const _Float16* pl = q_lo + ((size_t)b * ncol + col) * FLMR_DIM;
@@ -648,8 +655,13 @@ __global__ __launch_bounds__(64) void s0_q_err_kernel(const _Float16* __restrict
             sl = fmaf(l, l, sl);
             sq = fmaf(x, x, sq);
         }
-        q_err[(size_t)b * ncol + col] = cen_norm_max * (sqrtf(sl) * (1.001f / 2048.0f) + sqrtf(sq) * 2.5e-7f);
+        const float e = cen_norm_max * (sqrtf(sl) * (1.001f / 2048.0f) + sqrtf(sq) * 2.5e-7f);
+        q_err[(size_t)b * ncol + col] = e;
+        if (col < nqc) { esum += e; qmax = fmaxf(qmax, sqrtf(sq)); }
     }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { esum += __shfl_xor(esum, m, 64); qmax = fmaxf(qmax, __shfl_xor(qmax, m, 64)); }
+    if (threadIdx.x == 0 && q_err_sum) q_err_sum[b] = 1.01f * esum + 1.6e-5f * (float)nqc * cen_norm_max * qmax * 1.001f;
 }
 
 int flmr_convert_f16(const float* dev, size_t n, _Float16* out) {
@@ -753,7 +765,7 @@ static int launch_s0_t(flmr_s0_args& a, hipStream_t st, int impl) {
         const bool sparse = !a.full_table && a.ncol == 32 && !flmr_opts().has(FLMR_OPT_S0_STAGED);
         const dim3 grid((a.nblk + S0_WAVES - 1) / S0_WAVES, qsplit), block(64 * S0_WAVES);
         const bool qs = sparse && a.centroids_f16 && (int64_t)a.K * 256 < (1ll << 32) && !flmr_opts().is(FLMR_OPT_S0_IMPL, "f16rs");
-        if (!qs) a.q_err = nullptr;   // the block maxima of the other kernels are the full values: s0_select_cells must not assume otherwise
+        if (!qs) { a.q_err = nullptr; a.q_err_buf = nullptr; }   // the block maxima of the other kernels are the full values: s0_select_cells must not assume otherwise
         if (qs) {
             // query-stationary: 16 queries per workgroup, the table cut into as many slices (multiples of 64 rows) as fill the chip
             const int ngroups = (int)flmr_ceil_div(a.nqueries, 8 * S0Q_QT);
@@ -764,11 +776,13 @@ static int launch_s0_t(flmr_s0_args& a, hipStream_t st, int impl) {
             const int rows_per_slice = (int)flmr_round_up(flmr_ceil_div(a.K, slices), 64);
             slices = (int)flmr_ceil_div(a.K, rows_per_slice);
             const size_t ldsq = (size_t)8 * 32 * S0_LDS_STRIDE * sizeof(float) + (size_t)S0Q_NBUF * 2 * 8192;
+            if (a.q_err_buf && !a.q_hi_only)   // the bounds of this batch's queries (stage 0's own shortcut and stage 2's read them)
+                hipLaunchKernelGGL(s0_q_err_kernel, dim3(a.nqueries), dim3(64), 0, st, a.q_hi, a.q_lo, a.ncol, a.q_lens, a.nq, a.nq_cand,
+                                   a.cen_norm_max, a.q_err_buf, a.q_err_sum);
             if (a.q_hi_only) {
                 FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_qs<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
                 hipLaunchKernelGGL(s0_centroid_scores_qs<true>, dim3(ngroups, slices), dim3(512), ldsq, st, a, rows_per_slice);
             } else if (a.q_err) {
-                hipLaunchKernelGGL(s0_q_err_kernel, dim3(a.nqueries), dim3(64), 0, st, a.q_hi, a.q_lo, a.ncol, a.cen_norm_max, a.q_err);
                 FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_qs<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
                 hipLaunchKernelGGL((s0_centroid_scores_qs<false, true>), dim3(ngroups, slices), dim3(512), ldsq, st, a, rows_per_slice);
             } else {

@@ -477,6 +477,14 @@ size_t flmr_stage2_xcd_part_floats(const flmr_index* ix, int64_t nqueries, int64
 int flmr_launch_filter_stage2_xcd(const flmr_filter_args& f, const int32_t* pids, int64_t pid_stride, const int32_t* counts,
                                   int32_t max_count, uint64_t* keys, int64_t key_stride, const flmr_index* ix,
                                   const _Float16* q_hi, const _Float16* q_lo, float* part, int64_t part_stride, hipStream_t st) {
+    return flmr_launch_filter_stage2_xcd_ex(f, pids, pid_stride, counts, max_count, keys, key_stride, ix, q_hi, q_lo, part, part_stride,
+                                            f.f16_round != 0, st);
+}
+
+int flmr_launch_filter_stage2_xcd_ex(const flmr_filter_args& f, const int32_t* pids, int64_t pid_stride, const int32_t* counts,
+                                     int32_t max_count, uint64_t* keys, int64_t key_stride, const flmr_index* ix,
+                                     const _Float16* q_hi, const _Float16* q_lo, float* part, int64_t part_stride, bool hi_only,
+                                     hipStream_t st) {
     if (max_count <= 0) return FLMR_OK;
     if (f.ncol != 32) FLMR_FAIL(FLMR_ERR_INVALID, "stage-2 recompute needs one column tile");
     if (!ix->doc_splits || !ix->codes_sorted || !part) FLMR_FAIL(FLMR_ERR_INVALID, "stage-2 sliced kernel needs the sorted codes and their split table");
@@ -486,7 +494,7 @@ int flmr_launch_filter_stage2_xcd(const flmr_filter_args& f, const int32_t* pids
     const int64_t grid = (int64_t)nsl * f.nqueries * G;
     if (grid > 0x7fffffffLL) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "stage-2 grid too large");
     const size_t lds = (size_t)X2_WAVES * X2_WAVE_LDS;
-    if (f.f16_round) {
+    if (hi_only) {
         FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_stage2_xcd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(filter_stage2_xcd_kernel<true>, dim3((unsigned)grid), dim3(256), lds, st, f, pids, pid_stride, counts, part, part_stride,
                            ix->centroids_f16, q_hi, q_lo, ix->codes_sorted, ix->doc_splits, nsl, G

@@ -1397,3 +1397,34 @@ def test_s0_hi_first_equals_full_products(hip, ties):
             scorer.search_batch(Q[q:q + 1], 16, ncells, 0.45, 64, 32, full_table=True)
             cs = scorer.tap(nat.TAP_CENTROID_SCORES)[:, :32]
             assert np.array_equal(cells, orc.select_cells(cs, ncells)), (ties, ncells, q)
+
+
+@pytest.mark.parametrize("nbits,doclen,K,npass,policy", [
+    (2, (0, 200), 2048, 6000, (2, 0.45, 256)),
+    (2, 64, 512, 70_000, (2, 0.3, 1024)),
+    (4, (10, 90), 1000, 40_000, (4, 0.4, 4096)),
+    (2, 128, 4096, 30_000, (2, 0.45, 1024)),
+])
+def test_stage2_approximate_then_refine_selects_the_same_set(hip, nbits, doclen, K, npass, policy):
+    """Stage 2's default on the sliced kernel (FLMR_S2_IMPL=xcda): hi-only scores for every survivor, full rescoring only of
+    the band around the cut, certified by the batch's error bound -- must select exactly the SET the full-score kernel selects
+    (the order of the stage-2 list is not part of the contract: stage 3 rescores every member), and therefore return a final
+    ranking that is bit-identical, also for short queries, empty passages and survivor counts below ndocs / 4."""
+    torch, nat = hip["torch"], hip["native"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    ncells, thr, ndocs = policy
+    corpus = synth.make_corpus(npass, doclen, K, nbits, seed=91, device="cuda")
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=16)
+    Q, _ = synth.make_queries(corpus, 13, 32, seed=6)
+    q_lens = torch.tensor([32, 32, 5, 32, 20, 32, 1, 32, 32, 32, 17, 32, 32], dtype=torch.int32)
+    outs = {}
+    for impl in ("xcd", "xcda"):
+        with nat.options(FLMR_S2_IMPL=impl):
+            p, s, c = scorer.search_batch(Q, max(ndocs // 4, 1), ncells, thr, ndocs, 32, q_lens=q_lens)
+            scorer.check()
+            outs[impl] = (p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), [scorer.tap(nat.TAP_STAGE2, q) for q in range(Q.size(0))])
+    a, b = outs["xcd"], outs["xcda"]
+    for q in range(Q.size(0)):
+        assert sorted(a[3][q].tolist()) == sorted(b[3][q].tolist()), q
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
