@@ -1031,7 +1031,9 @@ def test_stage2_xcd_sliced_equals_gather(hip, nbits, doclen, K, npass, policy):
     scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=16)
     ncells, thr, ndocs = policy
     outs = {}
-    impls = ("lds", "xcd", "ldsb") if K < 32768 else ("lds", None)
+    # None = no switch set: at K = 32768 that is the approximate-then-refine form of the sliced kernel, whose stage-2 list is the
+    # same SET in another order (the measured-loser forms regs / ldsb live in the FLMR_EXPERIMENTAL_VARIANTS build only)
+    impls = ("lds", "xcd") if K < 32768 else ("lds", "xcd", None)
     for impl in impls:
         with nat.options(**({"FLMR_S2_IMPL": impl} if impl else {})):
             for tag, ql in (("full", None), ("ragged", q_lens)):
@@ -1044,7 +1046,10 @@ def test_stage2_xcd_sliced_equals_gather(hip, nbits, doclen, K, npass, policy):
         for tag in ("full", "ragged"):
             a, b = outs[impls[0], tag], outs[other, tag]
             for q in range(Q.size(0)):
-                assert np.array_equal(a[3][q], b[3][q]), ("stage-2 finalists", other, tag, q)
+                if other is None:
+                    assert sorted(a[3][q].tolist()) == sorted(b[3][q].tolist()), ("stage-2 finalists (set)", other, tag, q)
+                else:
+                    assert np.array_equal(a[3][q], b[3][q]), ("stage-2 finalists", other, tag, q)
             assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), (other, tag)
 
 
