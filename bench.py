@@ -307,9 +307,13 @@ def main():
             # gathered from L2 / the Infinity Cache, not from HBM), Q
             "s3_maxsim": (4 + B) * nfin_tok + 2 * d * K / args.batch + 2 * 2 * d * args.nq,
         }
+        # EXECUTED MFMA flops.  Stage 0 and stage 2 run "hi first" since round 3: one fp16 product per score everywhere, the
+        # second (lo) product only where a decision can depend on it -- the tiles that can hold a surviving row in stage 0
+        # (< 2 % of them), the passages within the error band of the cut in stage 2 (~5 %, rescored by the gather kernel with
+        # both products: counted below as 0.1 of a pass)
         per_kernel_flops = {
-            "s0_centroid_scores": 2.0 * 2 * K * d * nq_s0,                # hi + lo products
-            "s2_filter_sort": 2.0 * 2 * ns_tok * d * nq_s0,
+            "s0_centroid_scores": 2.0 * 1.02 * K * d * nq_s0,
+            "s2_filter_sort": 2.0 * 1.1 * ns_tok * d * nq_s0,
             # centroid + weight form: c.q_hi, c.q_lo, w_hi.q_hi, w_hi.q_lo, w_lo.q_hi (five executed products per useful one)
             "s3_maxsim": 5.0 * 2 * nfin_tok * d * args.nq,
         }
@@ -372,6 +376,8 @@ def main():
                 "note": ("achieved = the kernel's own compulsory bytes (or split-MFMA flops) per step / its HIP-event time per step "
                          "(summed over the step's sub-batches; events recorded on the launch stream in a second pass of the "
                          "same K steps, ms_per_step_with_stage_events); "
+                         "stages 0 and 2 execute ONE fp16 product per score since round 3 (the lo product only where a decision can "
+                         "depend on it), so their flops are the useful ones -- round 2's 0.26 counted two products; "
                          "stage 2 is limited by neither roof: it moves one 256-byte fp16 centroid row per survivor token "
                          "(gathered_row_GBs) -- from the Infinity Cache in the gather form (measured ceiling 9.3-9.6 TB/s), "
                          "from an L2-resident table slice per XCD in the default sliced form (69 % L2 hits, ceiling 23-32 TB/s, "
