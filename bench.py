@@ -521,9 +521,9 @@ def main():
     if rank == 0 and not use_dist and not args.no_extras:
         subs = []
 
-        def sub(name, sc, batches, targets, kk, note):
+        def sub(name, sc, batches, targets, kk, note, pol=None):
             try:
-                pol = k_policy(kk)
+                pol = pol or k_policy(kk)
                 dt_, _, rec, _ = timed(sc, batches, targets, kk, pol, 6, 2, collect_stages=False)
                 subs.append({"name": name, "value": args.batch * 6 / dt_, "unit": "queries/sec", "ms_per_step": dt_ / 6 * 1e3,
                              "recall_at_5": rec, "note": note})
@@ -553,6 +553,10 @@ def main():
                                                      "inputs resident on the device, 200 calls after 20 warm-up calls"}
         sub("k5", scorer, Qs, tgts, 5, "same index, k=5 (same pruning policy as k=100, searcher.py:92-107; 5 results returned)")
         sub("k500", scorer, Qs, tgts, 500, "same index, k=500 policy (ncells=4, thr=0.4, ndocs=4096)")
+        # a threshold so low that ~9 k centroids per query pass it (> the 1024 the scatter stage 1 is sized for): those queries take
+        # the code-scanning stage 1 -- the cost of leaving the tuned path, which the headline number never shows
+        sub("thr0.25_code_scan", scorer, Qs[:2], tgts[:2], k, "same index, centroid_score_threshold=0.25: more surviving centroids than the scatter "
+            "stage 1 holds (1024), every query falls back to the code-scanning stage 1", pol=(2, 0.25, 1024))
         try:   # what a config with total_visible_gpus = 1 (FLMR_executor.py:784) selects: the reference's CUDA-branch arithmetic
             scf = IndexScorer(device_index=scorer.device_index, max_batch=min(args.batch, args.sub_batch), streams=args.streams,
                               numerics="gpu-fp16")
