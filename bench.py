@@ -551,6 +551,20 @@ def main():
             lat.append({"failed": repr(e)})
         out["latency"] = {"per_call": lat, "note": "wall time of one search_batch call (k=100 policy) incl. launch + device sync, "
                                                      "inputs resident on the device, 200 calls after 20 warm-up calls"}
+        # the same batches through the host side of Searcher._search_all_Q: device results -> {qid: [(pid, rank, score)] * k} (the
+        # Ranking layout the executors read, searcher.py:81-89).  Python object construction, not the GPU, bounds this layer.
+        try:
+            from ravqa_amd.searcher import Searcher as _S
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for i in range(3):
+                lists = _S.ranking_lists(*scorer.search_batch(Qs[i % nb], k, ncells, thr, ndocs, 32), k)
+            dt_api = (time.perf_counter() - t0_) / 3
+            out["api_layer"] = {"queries_per_sec": args.batch / dt_api, "ms_per_step": dt_api * 1e3, "results_per_query": len(lists[0]),
+                                "note": "search_batch + Searcher.ranking_lists (bulk device->host copy, one tolist per array, "
+                                        "(pid, rank, score) tuples): what a caller of _search_all_Q observes per 1024 queries"}
+        except Exception as e:  # noqa: BLE001
+            out["api_layer"] = {"failed": repr(e)}
         sub("k5", scorer, Qs, tgts, 5, "same index, k=5 (same pruning policy as k=100, searcher.py:92-107; 5 results returned)")
         sub("k500", scorer, Qs, tgts, 500, "same index, k=500 policy (ncells=4, thr=0.4, ndocs=4096)")
         # a threshold so low that ~9 k centroids per query pass it (> the 1024 the scatter stage 1 is sized for): those queries take

@@ -88,14 +88,20 @@ class Ranking:
                     rows.append([float(v) if "." in v else int(v) for v in line.strip().split("\t")])
             data = rows
         if isinstance(data, dict):
-            self.flat_ranking = [(qid, *rest) for qid, sub in data.items() for rest in sub]
+            self._flat = None        # built on first use (tolist / save): the executors read todict() only
             self.data = data
         else:
-            self.flat_ranking = data
+            self._flat = data
             grouped = {}
             for qid, *rest in data:
                 grouped.setdefault(qid, []).append(tuple(rest))
             self.data = grouped
+
+    @property
+    def flat_ranking(self):
+        if self._flat is None:
+            self._flat = [(qid, *rest) for qid, sub in self.data.items() for rest in sub]
+        return self._flat
 
     def provenance(self):
         return self._provenance

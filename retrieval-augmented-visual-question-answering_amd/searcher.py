@@ -132,6 +132,15 @@ class Searcher:
         Qc = Qc * (torch.arange(Q.size(1), device=Q.device).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(-1)
         return Qc, lens
 
+    @staticmethod
+    def ranking_lists(pids, scores, counts, k):
+        """Device results [n, k] -> the Ranking layout [[(pid, rank, score)] * count] (searcher.py:81-89, :132: ranks are 1..k).
+        One bulk transfer + one tolist per array: converting row by row costs 0.14 ms per query in tensor slicing alone --
+        more than the whole device path (7 us per query)."""
+        P, S, C = pids.cpu().tolist(), scores.cpu().tolist(), counts.cpu().tolist()
+        ranks = list(range(1, k + 1))
+        return [list(zip(P[i][:n], ranks, S[i][:n])) for i, n in enumerate(C)]
+
     # ---- embedding entry points -----------------------------------------------------------------------------------
     def _search_all_Q(self, queries, Q, k, filter_fn=None, progress=True, remove_zero_tensors=False):
         qids = list(queries.keys())
@@ -148,12 +157,9 @@ class Searcher:
             kk = min(k, max(c.ndocs // 4, 1))
             pids, scores, counts = self.ranker.search_batch(Qb, kk, c.ncells, c.centroid_score_threshold, c.ndocs,
                                                             c.query_maxlen, q_lens=q_lens)
-            pids, scores, counts = pids.cpu(), scores.cpu(), counts.cpu().tolist()
             if hasattr(self.ranker, "check"):
                 self.ranker.check()   # deferred device-side errors of the batches above (candidate bound, q_lens range)
-            all_scored = []
-            for i, n in enumerate(counts):
-                all_scored.append(list(zip(pids[i, :n].tolist(), range(1, k + 1), scores[i, :n].tolist())))
+            all_scored = self.ranking_lists(pids, scores, counts, k)
         data = dict(zip(qids, all_scored))
         provenance = self.Provenance()
         provenance.source = "Searcher::search_all"
