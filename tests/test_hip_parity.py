@@ -1376,13 +1376,13 @@ def test_s0_hi_first_equals_full_products(hip, ties):
         cen = (cen + bump).half().float()
         cen[64 * 5:64 * 6] = base                      # one exact copy: exact ties, the lower index must win
         corpus.centroids = cen.contiguous()
-    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=16)
-    Q, _ = synth.make_queries(corpus, 11, 32, seed=4)
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=32)
+    Q, _ = synth.make_queries(corpus, 22, 32, seed=4)    # (>= 16 queries per call: below that stage 0 keeps both products)
     Q[3, 20:] = 0.0
     Q[7] *= 16.0                                                                  # FLMR's un-normalised visual tokens
     Q[8] *= torch.logspace(-3, 1.2, 32, device="cuda").unsqueeze(1)               # mixed magnitudes inside one query
     Q[9, ::2] *= 1e-4                                                             # rows near the fp16 subnormal range
-    q_lens = torch.tensor([32, 32, 9, 20, 32, 1, 32, 32, 17, 32, 32], dtype=torch.int32)
+    q_lens = torch.tensor([32, 32, 9, 20, 32, 1, 32, 32, 17, 32, 32] * 2, dtype=torch.int32)
     for (ncells, thr, ndocs) in [(1, 0.5, 64), (2, 0.45, 256), (4, 0.4, 1024), (8, 0.3, 256), (2, -1.0, 64), (2, 6.5, 256)]:
         res = {}
         for impl in (None, "f16"):
