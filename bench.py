@@ -400,6 +400,7 @@ def main():
                        "parallelism": (f"index sharded by passage over {world} GPUs, " + (("stage 0 replicated, " if args.replicate_stage0 else "stage 0 split by query + exchange of idx bitsets/cells, ") + "all-gather of stage-1 keys + SUM all-reduces of slot-aligned stage-2/3 keys, result identical to the unsharded index" if exact else "all-gather of per-shard top-k")) if world > 1 else "1 GPU",
                        "queries_per_step": args.batch, "sub_batch": min(args.batch, args.sub_batch), "streams": args.streams},
             "recall_at_5": recall5, "roofline": roof, "cpu_baseline": None, "stage_ms_per_step": stage_ms,
+            "toolchain": _native.toolchain().splitlines(),   # the compiler the loaded library was built with
             "ms_per_step_with_stage_events": ms_per_step_events,
             "candidates_per_query": P_mean, "cells_per_query": ncell_mean,
             "hbm_copy_GBs": copy_gbs, "index_build_s": t_build, "workspace_GB": scorer.workspace_bytes() / 1e9,

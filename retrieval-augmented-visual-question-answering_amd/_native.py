@@ -51,6 +51,17 @@ def hipcc_path():
     return "hipcc"
 
 
+def _record_toolchain(lib_path, flags):
+    """The compiler a binary came from, written beside it: the hand-scheduled kernels (inline-asm loads with counted waits)
+    are verified bit-exact with THIS toolchain; bench.py reports the string."""
+    try:
+        ver = subprocess.run([hipcc_path(), "--version"], capture_output=True, text=True).stdout.strip().splitlines()
+        with open(lib_path + ".toolchain", "w") as f:
+            f.write("\n".join(ver[:2]) + "\nflags: " + " ".join(flags) + "\n")
+    except OSError:
+        pass
+
+
 def build_native(force=False, verbose=False, extra_flags=(), lib_path=None, obj_dir=None):
     """Compile csrc/*.hip for gfx950 into lib/libflmr_hip.so (cross-compiles without a GPU).  One object per source,
     compiled in parallel and only when the source or a header is newer; `extra_flags` (e.g. -DFLMR_EXPERIMENTAL_VARIANTS,
@@ -70,6 +81,8 @@ def build_native(force=False, verbose=False, extra_flags=(), lib_path=None, obj_
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
             jobs.append(base + ["-c", src, "-o", obj])
     if not jobs and os.path.exists(lib_path) and all(os.path.getmtime(lib_path) >= os.path.getmtime(o) for o in objs):
+        if not os.path.exists(lib_path + ".toolchain"):
+            _record_toolchain(lib_path, base[1:6] + list(extra_flags))
         return lib_path
 
     def run(cmd):
@@ -81,7 +94,17 @@ def build_native(force=False, verbose=False, extra_flags=(), lib_path=None, obj_
         list(ex.map(run, jobs))
     os.makedirs(os.path.dirname(lib_path), exist_ok=True)
     run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib_path])
+    _record_toolchain(lib_path, base[1:6] + list(extra_flags))
     return lib_path
+
+
+def toolchain():
+    """The hipcc / clang version lines recorded when lib/libflmr_hip.so was built ("" if the record is missing)."""
+    try:
+        with open(LIB_PATH + ".toolchain") as f:
+            return f.read().strip()
+    except OSError:
+        return ""
 
 
 _lib = None

@@ -22,6 +22,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/flmr_hip.h but not exported"
     assert declared == set(_native.EXPORTED_SYMBOLS)
     assert lib.flmr_abi_version() == _native.ABI_VERSION == int(re.search(r"#define FLMR_ABI_VERSION (\d+)", header).group(1))
+    # the compiler the binary came from is recorded beside it (the hand-scheduled kernels are verified with that toolchain)
+    assert "clang version" in _native.toolchain() and "gfx950" in _native.toolchain()
 
 
 def test_product_path_fails_loudly_without_device():
