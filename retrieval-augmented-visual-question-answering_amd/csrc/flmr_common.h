@@ -39,7 +39,7 @@ extern thread_local char flmr_err_buf[512];
 // snapshot (flmr_opt_scope): nothing on the per-batch launch path calls getenv, and the environment cannot flip a running
 // searcher to another kernel path.
 enum flmr_opt_id {
-    FLMR_OPT_S0_IMPL = 0,    // (unset: fp16-split, query-stationary + "hi first" on the sparse path) | f16 (the same kernel with both products everywhere) | f16rs (row-stationary fp16 kernel) | f32 | mfma | valu
+    FLMR_OPT_S0_IMPL = 0,    // (unset: fp16-split, query-stationary + "hi first" on the sparse path) | qs1 ("hi first" with the dense epilogue inside the loop) | f16 (both products everywhere) | f16rs (row-stationary fp16 kernel) | f32 | mfma | valu
     FLMR_OPT_FULL_TABLE,     // set: keep the whole centroid-score table
     FLMR_OPT_CAND_IMPL,      // atomic: first candidate-generation implementation
     FLMR_OPT_S1_NO_HITMAP,   // set: no hit prefilter

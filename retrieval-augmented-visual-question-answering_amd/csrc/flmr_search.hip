@@ -342,7 +342,7 @@ static bool sparse_path(const flmr_searcher* s, int ncol) {
     const flmr_index* ix = s->ix;
     const flmr_options& o = s->opt;
     const bool f16_path = ix->centroids_f16_exact && ix->centroids_f16 && (ix->K % 64 == 0) &&
-                          !(o.has(FLMR_OPT_S0_IMPL) && !o.is(FLMR_OPT_S0_IMPL, "f16") && !o.is(FLMR_OPT_S0_IMPL, "f16rs"));
+                          !(o.has(FLMR_OPT_S0_IMPL) && !o.is(FLMR_OPT_S0_IMPL, "f16") && !o.is(FLMR_OPT_S0_IMPL, "f16rs") && !o.is(FLMR_OPT_S0_IMPL, "qs1"));
     return f16_path && ncol == 32 && !s->full_table && !o.has(FLMR_OPT_FULL_TABLE);
 }
 
@@ -393,7 +393,7 @@ static int prepare_ctx(run_ctx& c, flmr_searcher* s, const float* Q, const int32
     a0.q_err_buf = f16num_early(s) ? nullptr : s->q_err;
     // (batches under 16 queries keep both products in stage 0: the kernel is short there anyway, and the cell selection's redo pass --
     // one near-tie column in most queries -- would add 10 % to the latency of a single-query call)
-    a0.q_err = (!f16num_early(s) && !s->opt.has(FLMR_OPT_S0_IMPL) && nqueries >= 16) ? s->q_err : nullptr;
+    a0.q_err = (!f16num_early(s) && (!s->opt.has(FLMR_OPT_S0_IMPL) || s->opt.is(FLMR_OPT_S0_IMPL, "qs1")) && nqueries >= 16) ? s->q_err : nullptr;
     a0.q_err_sum = s->q_err_sum;
     a0.cen_norm_max = ix->cen_norm_max;
     a0.centroids_f16 = ix->centroids_f16;

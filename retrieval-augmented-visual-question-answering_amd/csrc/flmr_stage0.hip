@@ -422,10 +422,11 @@ __global__ __launch_bounds__(64 * S0_WAVES, S0_OCC) void s0_centroid_scores_f16(
 //
 // A step handles one 64-row block = two tiles (one block barrier per 64 MFMAs of a wave).
 // vmcnt: a step's VMEM operations are fixed so that the wait for a block's pieces can leave the younger STORES outstanding
-// (stores retire slowly and share the counter): step p issues the two DMA pieces of block p + AHEAD first, then per query two
-// idx-word stores and one block-maximum store -- 8 operations.  The pieces of block p were the first two operations of step
-// p - AHEAD = p - 2: younger are the rest of that step (6) and one full step (8): vmcnt(14); in the first two steps (pieces
-// from the prologue) 2 and 8.  (The rare dense epilogue's row stores only add to that.)
+// (stores retire slowly and share the counter): step p issues the two DMA pieces of block p + AHEAD first, then one
+// block-maximum store per query -- 2 + QT operations.  The pieces of block p were the first two operations of step
+// p - AHEAD = p - 2: younger are the rest of that step (QT) and one full step (2 + QT): vmcnt(2 + 2 QT); in the first two
+// steps (pieces from the prologue) 2 and 2 + QT.  (The rare dense epilogue's row and idx-word stores only add to that: the
+// idx words are zeroed by the launcher, and only a tile with a surviving row stores one.)
 // grid = (ceil(nqueries / 16), slices), block = 512; dynamic LDS = 8 x 4.5 KB staging + S0Q_NBUF x 16 KB blocks.
 // ------------------------------------------------------------------------------------------------
 #define S0Q_QT 2
@@ -446,7 +447,8 @@ __device__ __forceinline__ void s0q_wait_vm() {
 template <bool HI_ONLY, bool APPROX = false>
 __global__ __launch_bounds__(512, 1) void s0_centroid_scores_qs(flmr_s0_args a, int rows_per_slice) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform for the compiler too: the queries' addresses stay in scalar registers
     const int i = lane & 31, h = lane >> 5;
     float* stage = reinterpret_cast<float*>(smem) + wave * 32 * S0_LDS_STRIDE;
     char* const abuf = smem + 8 * 32 * S0_LDS_STRIDE * sizeof(float);
@@ -501,9 +503,64 @@ __global__ __launch_bounds__(512, 1) void s0_centroid_scores_qs(flmr_s0_args a, 
     for (int p = 0; p < S0Q_AHEAD; p++) dma_block(p);
 
     const int c4 = (lane & 7) * 4;  // first of the 4 columns this lane stores in the dense epilogue
+    // wave-uniform per query (scalar registers): the columns that count, as a ballot mask
+    unsigned long long colmask[S0Q_QT];
+    bool full_cols[S0Q_QT];
+#pragma unroll
+    for (int q = 0; q < S0Q_QT; q++) {
+        const int n = __builtin_amdgcn_readfirstlane(nqc[q]);
+        full_cols[q] = n >= 32;
+        colmask[q] = full_cols[q] ? ~0ull : (((1ull << n) - 1ull) * 0x100000001ull);
+    }
+    // maximum of a tile's 16 accumulator registers as ONE chain (v_max3): the tree form makes the compiler canonicalise each
+    // raw MFMA output first (20 instructions instead of 9)
+    auto tile_max = [](const float* v) {
+        float m = fmaxf(v[0], v[1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) m = fmaxf(fmaxf(m, v[r]), v[r + 1]);
+        return m;
+    };
+    // the rare dense epilogue of (tile, query): FULL values of the tile's rows -> stage, surviving rows -> cs, their idx word
+    auto dense = [&](int q, int rbase_, const f32x16& ah, const f32x16& al) {
+        int rbase = rbase_;
+        asm volatile("" : "+s"(rbase));   // (keeps this branch's address arithmetic inside the branch: it is rare)
+        const int b = bq[q];
+        float* cs_b = a.cs + (size_t)b * a.K * a.ncol;
+        const int nvalid4 = nqc[q] - c4;
+        uint32_t idxw = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; r++) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * S0_LDS_STRIDE + i] = HI_ONLY ? ah[r] : fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int mrow = 0; mrow < 4; mrow++) {
+            const int R = (lane >> 3) + 8 * mrow;
+            const float4 v4 = *reinterpret_cast<const float4*>(stage + R * S0_LDS_STRIDE + c4);
+            float m4;
+            if (full_cols[q]) {
+                m4 = fmaxf(fmaxf(v4.x, v4.y), fmaxf(v4.z, v4.w));
+            } else {
+                m4 = nvalid4 > 0 ? v4.x : FLMR_NEG_INF;
+                m4 = fmaxf(m4, nvalid4 > 1 ? v4.y : FLMR_NEG_INF);
+                m4 = fmaxf(m4, nvalid4 > 2 ? v4.z : FLMR_NEG_INF);
+                m4 = fmaxf(m4, nvalid4 > 3 ? v4.w : FLMR_NEG_INF);
+            }
+            unsigned long long bal = __ballot(m4 >= a.thr);  // byte j of `bal` = the 8 lanes of row 8*mrow + j
+            bal |= bal >> 4; bal |= bal >> 2; bal |= bal >> 1;
+            bal &= 0x0101010101010101ull;
+            const uint32_t byte = (uint32_t)((bal * 0x0102040810204080ull) >> 56);
+            idxw |= byte << (8 * mrow);
+            if ((byte >> (lane >> 3)) & 1u) *reinterpret_cast<float4*>(cs_b + (size_t)(rbase + R) * a.ncol + c4) = v4;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // (the idx words start at zero -- cleared by the launcher -- so only a tile that went through here stores one)
+        if (lane == 0 && idxw != 0u) a.idx_bits[(size_t)b * a.idx_words + (rbase >> 5)] = idxw;
+    };
+    uint32_t aoff[8];   // this lane's eight 16-byte pieces inside a tile buffer (rows XOR-swizzled by the DMA)
+#pragma unroll
+    for (int s = 0; s < 8; s++) aoff[s] = (uint32_t)(i * 256 + (((8 * h + s) ^ (i & 15)) << 4));
     for (int p = 0; p < nblocks; p++) {
         // ---- block p: this wave's pieces have landed, then everybody's ----
-        if (p == 0) s0q_wait_vm<2>(); else if (p == 1) s0q_wait_vm<8>(); else s0q_wait_vm<14>();
+        if (p == 0) s0q_wait_vm<2>(); else if (p == 1) s0q_wait_vm<2 + S0Q_QT>(); else s0q_wait_vm<2 + 2 * S0Q_QT>();
         __syncthreads();
         dma_block(p + S0Q_AHEAD);  // (its buffer was read a step ago at the latest: every wave has passed this barrier since)
         float cmax[S0Q_QT];
@@ -513,75 +570,345 @@ __global__ __launch_bounds__(512, 1) void s0_centroid_scores_qs(flmr_s0_args a, 
         for (int u = 0; u < 2; u++) {
             f16x8 av[8];
             {
-                const char* pa = abuf + ((p % S0Q_NBUF) * 2 + u) * 8192 + i * 256;
+                const char* pa = abuf + __builtin_amdgcn_readfirstlane(((p % S0Q_NBUF) * 2 + u) * 8192);   // (scalar: one add per read)
 #pragma unroll
-                for (int s = 0; s < 8; s++) av[s] = *reinterpret_cast<const f16x8*>(pa + (((8 * h + s) ^ (i & 15)) << 4));
+                for (int s = 0; s < 8; s++) av[s] = *reinterpret_cast<const f16x8*>(pa + aoff[s]);
             }
             const int rbase = row_begin + 64 * p + 32 * u;
+            if constexpr (HI_ONLY || APPROX) {
+                // one product per score: the MFMAs of all the wave's queries first, then the maxima -- the second query's
+                // MFMAs run under the first one's reduction
+                f32x16 ahq[S0Q_QT];
 #pragma unroll
-            for (int q = 0; q < S0Q_QT; q++) {
-                f32x16 ah, al;
+                for (int q = 0; q < S0Q_QT; q++) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
+                    for (int r = 0; r < 16; r++) ahq[q][r] = 0.0f;
 #pragma unroll
-                for (int s = 0; s < 8; s++) {
-                    ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[q][s], ah, 0, 0, 0);
-                    if constexpr (!HI_ONLY && !APPROX) al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[q][s], al, 0, 0, 0);
+                    for (int s = 0; s < 8; s++) ahq[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[q][s], ahq[q], 0, 0, 0);
                 }
-                const int b = bq[q];
-                const bool full_cols = nqc[q] >= 32;
-                const unsigned long long colmask = full_cols ? ~0ull : (((1ull << nqc[q]) - 1ull) * 0x100000001ull);
-                float v[16];
+                float tmax[S0Q_QT];
 #pragma unroll
-                for (int r = 0; r < 16; r++) v[r] = (HI_ONLY || APPROX) ? ah[r] : fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+                for (int q = 0; q < S0Q_QT; q++) {
+                    float v[16];
 #pragma unroll
-                for (int r = 0; r < 8; r++) v[r] = fmaxf(v[r], v[r + 8]);
+                    for (int r = 0; r < 16; r++) v[r] = ahq[q][r];
+                    tmax[q] = tile_max(v);
+                    cmax[q] = fmaxf(cmax[q], tmax[q]);
+                }
+                // (every reduction is complete -- the accumulators are dead -- before the first rare branch)
 #pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], v[r + 4]);
-                const float tmax = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                cmax[q] = fmaxf(cmax[q], tmax);
-                uint32_t idxw = 0u;
-                if ((__ballot(tmax + qe[q] >= a.thr) & colmask) != 0ull) {  // wave-uniform and rare: some row of this tile survives (APPROX: may survive)
-                    if constexpr (APPROX) {   // now the lo products of this tile (the A fragments are still in registers)
+                for (int q = 0; q < S0Q_QT; q++) asm volatile("" : "+v"(tmax[q]));
 #pragma unroll
-                        for (int s = 0; s < 8; s++) al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[q][s], al, 0, 0, 0);
-                    }
-                    float* cs_b = a.cs + (size_t)b * a.K * a.ncol;
-                    const int nvalid4 = nqc[q] - c4;
+                for (int q = 0; q < S0Q_QT; q++) {
+                    if ((__ballot(tmax[q] + qe[q] >= a.thr) & colmask[q]) != 0ull) {  // wave-uniform and rare: some row of this tile survives (APPROX: may survive)
+                        // both products of this tile, recomputed (the A fragments are still in registers; the same sequences, so
+                        // the same bits): keeping the hi accumulators of all queries alive across this branch would spill
+                        f32x16 ah2, al2;
 #pragma unroll
-                    for (int r = 0; r < 16; r++) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * S0_LDS_STRIDE + i] = HI_ONLY ? ah[r] : fmaf(al[r], 1.0f / 2048.0f, ah[r]);
-                    __builtin_amdgcn_wave_barrier();
+                        for (int r = 0; r < 16; r++) { ah2[r] = 0.0f; al2[r] = 0.0f; }
 #pragma unroll
-                    for (int mrow = 0; mrow < 4; mrow++) {
-                        const int R = (lane >> 3) + 8 * mrow;
-                        const float4 v4 = *reinterpret_cast<const float4*>(stage + R * S0_LDS_STRIDE + c4);
-                        float m4;
-                        if (full_cols) {
-                            m4 = fmaxf(fmaxf(v4.x, v4.y), fmaxf(v4.z, v4.w));
-                        } else {
-                            m4 = nvalid4 > 0 ? v4.x : FLMR_NEG_INF;
-                            m4 = fmaxf(m4, nvalid4 > 1 ? v4.y : FLMR_NEG_INF);
-                            m4 = fmaxf(m4, nvalid4 > 2 ? v4.z : FLMR_NEG_INF);
-                            m4 = fmaxf(m4, nvalid4 > 3 ? v4.w : FLMR_NEG_INF);
+                        for (int s = 0; s < 8; s++) {
+                            ah2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[q][s], ah2, 0, 0, 0);
+                            if constexpr (APPROX) al2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[q][s], al2, 0, 0, 0);
                         }
-                        unsigned long long bal = __ballot(m4 >= a.thr);  // byte j of `bal` = the 8 lanes of row 8*mrow + j
-                        bal |= bal >> 4; bal |= bal >> 2; bal |= bal >> 1;
-                        bal &= 0x0101010101010101ull;
-                        const uint32_t byte = (uint32_t)((bal * 0x0102040810204080ull) >> 56);
-                        idxw |= byte << (8 * mrow);
-                        if ((byte >> (lane >> 3)) & 1u) *reinterpret_cast<float4*>(cs_b + (size_t)(rbase + R) * a.ncol + c4) = v4;
+                        dense(q, rbase, ah2, al2);
                     }
-                    __builtin_amdgcn_wave_barrier();
                 }
-                if (lane == 0) a.idx_bits[(size_t)b * a.idx_words + (rbase >> 5)] = idxw;
-                if (u == 1) {  // end of the 64-row block: its column maxima, for the cell selection
+            } else {
+#pragma unroll
+                for (int q = 0; q < S0Q_QT; q++) {
+                    f32x16 ah, al;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
+#pragma unroll
+                    for (int s = 0; s < 8; s++) {
+                        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[q][s], ah, 0, 0, 0);
+                        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[q][s], al, 0, 0, 0);
+                    }
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) v[r] = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+                    const float tmax = tile_max(v);
+                    cmax[q] = fmaxf(cmax[q], tmax);
+                    if ((__ballot(tmax >= a.thr) & colmask[q]) != 0ull) dense(q, rbase, ah, al);
+                }
+            }
+            if (u == 1) {  // end of the 64-row block: its column maxima, for the cell selection
+#pragma unroll
+                for (int q = 0; q < S0Q_QT; q++) {
                     const float m = flmr_xhalf_max(cmax[q]);
-                    if (lane < 32) a.part_val[((size_t)b * a.nblk + (rbase >> 6)) * a.ncol + i] = (i < nqc[q]) ? m : FLMR_NEG_INF;
+                    if (lane < 32) a.part_val[((size_t)bq[q] * a.nblk + (rbase >> 6)) * a.ncol + i] = (i < nqc[q]) ? m : FLMR_NEG_INF;
                 }
             }
         }
     }
     s0q_wait_vm<0>();  // the DMA of the repeated tiles past the end must have landed before the LDS is released
+}
+
+// ------------------------------------------------------------------------------------------------
+// S0a, query-stationary, "hi first" (APPROX) and fp16-numerics (HI_ONLY) paths: the main loop has NO rare branch.
+// s0_centroid_scores_qs<.., APPROX> above tests every (tile, query) and runs the dense epilogue -- lo products, staging, row
+// stores -- inline; that keeps the queries' lo images (64 VGPRs) resident for a branch taken by < 1 % of the tiles, leaves
+// one register set for the A fragments, and -- the workgroup's eight waves being phase-locked by the block barrier -- makes
+// every tile an LDS phase (all waves fetch their fragments: 64 KB at 128 B/clk) FOLLOWED by an MFMA phase: the matrix pipe
+// measured 40 % busy.  Here a flagged (tile, query) only appends its index to a per-wave list; the main loop holds the hi
+// images, BOTH tiles' fragments of a block (requested together right after the barrier, so the second tile's fetch runs
+// under the first tile's MFMAs) and nothing else.  After the loop every wave works through its own list without any block
+// barrier: the queries' lo images are loaded then (the fragment registers are free), the tile's rows come straight from the
+// table into fragment layout, both products are recomputed with the same MFMA sequences -- the same bits -- and the dense
+// epilogue is the one above.  Block maxima (hi-only values, as s0_select_cells expects on this path) and idx words /
+// surviving rows are identical to the inline form.
+// grid = (ceil(nqueries / 16), slices <= 8192 rows each), block = 512;
+// dynamic LDS = 8 x 4.5 KB staging + S0Q_NBUF x 16 KB blocks + 8 x S0Q2_FCAP flagged-tile entries (u16).
+// ------------------------------------------------------------------------------------------------
+#define S0Q2_MAX_SLICE_ROWS 8192
+#ifndef S0Q2_WAVES
+#define S0Q2_WAVES 8    // (12 -- three waves per SIMD, 24 queries per workgroup -- measured slower: the waves that do not move tiles wait for the movers)
+#endif
+#ifdef S0Q_PROFILE   // development only: s_memtime clocks of wave 0 of every workgroup per phase, printed by the launcher
+__device__ unsigned long long s0q_prof[8];
+#define S0Q_STAMP(k) do { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); pt[k] += now_ - plast; plast = now_; } while (0)
+#else
+#define S0Q_STAMP(k) do { } while (0)
+#endif
+#define S0Q2_FCAP (S0Q2_MAX_SLICE_ROWS / 32 * S0Q_QT)   // every (tile, query) of a slice could be flagged
+#ifndef S0Q2_SBT
+#define S0Q2_SBT 4     // tiles per step ("super-block" of 128 rows): one workgroup barrier per 4 x 16 MFMAs of a wave (2: measured the same)
+#endif
+#define S0Q2_AHEAD 3   // super-blocks requested ahead: at the barrier of step P super-block P + 1 has landed (its first tile is fetched one step early)
+#define S0Q2_NBUF 4    // super-block buffers of S0Q2_SBT x 8 KB (the staging rows of the deferred pass reuse them)
+
+template <bool HI_ONLY>
+__global__ __launch_bounds__(64 * S0Q2_WAVES, 1) void s0_centroid_scores_qs2(flmr_s0_args a, int rows_per_slice) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    float* stage = reinterpret_cast<float*>(smem) + wave * 32 * S0_LDS_STRIDE;   // deferred pass only: aliases the tile buffers
+    char* const abuf = smem;
+    uint16_t* const flist = reinterpret_cast<uint16_t*>(abuf + S0Q2_NBUF * S0Q2_SBT * 8192) + wave * S0Q2_FCAP;
+    const uint32_t abuf_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)abuf);
+    const int row_begin = blockIdx.y * rows_per_slice;
+    const int row_end = row_begin + rows_per_slice < a.K ? row_begin + rows_per_slice : a.K;  // multiples of 64
+    const int ntiles = (row_end - row_begin) >> 5;
+    if (ntiles <= 0) return;
+#ifdef S0Q_PROFILE
+    long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long plast = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    int bq[S0Q_QT], nqc[S0Q_QT];
+    float qe[S0Q_QT];
+    f16x8 bh[S0Q_QT][8];
+#pragma unroll
+    for (int q = 0; q < S0Q_QT; q++) {
+        const int b = (blockIdx.x * S0Q2_WAVES + wave) * S0Q_QT + q;
+        bq[q] = b < a.nqueries ? b : a.nqueries - 1;
+        const int qlen = a.q_lens ? a.q_lens[bq[q]] : a.nq;
+        nqc[q] = qlen < a.nq_cand ? qlen : a.nq_cand;
+        qe[q] = HI_ONLY ? 0.0f : a.q_err[(size_t)bq[q] * a.ncol + i];
+        const f16x8* ph = reinterpret_cast<const f16x8*>(a.q_hi + ((size_t)bq[q] * a.ncol + i) * FLMR_DIM + 64 * h);
+#pragma unroll
+        for (int s = 0; s < 8; s++) bh[q][s] = ph[s];
+    }
+#pragma unroll
+    for (int q = 0; q < S0Q_QT; q++)
+#pragma unroll
+        for (int s = 0; s < 8; s++) asm volatile("" : "+v"(bh[q][s])::"memory");
+
+    const int prow = 4 * wave + (lane >> 4);
+    const uint32_t poff = (uint32_t)((((lane & 15) ^ (prow & 15)) << 4));
+    const int nblocks = ntiles / S0Q2_SBT;   // super-blocks (the launcher cuts slices in multiples of 32 * S0Q2_SBT rows)
+    const bool mover = wave < 8;   // (wave-uniform)
+    auto dma_block = [&](int p) {
+        if (!mover) return;
+        const int pp = p < nblocks ? p : nblocks - 1;
+#pragma unroll
+        for (int u = 0; u < S0Q2_SBT; u++) {
+            const uint32_t voff = (uint32_t)(row_begin + 32 * S0Q2_SBT * pp + 32 * u + prow) * 256u + poff;  // K * 256 < 4 GB (launcher)
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(abuf_lds + ((p % S0Q2_NBUF) * S0Q2_SBT + u) * 8192 + wave * 1024);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(voff), "s"(dst), "s"(a.centroids_f16) : "memory", "m0");
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < S0Q2_AHEAD; p++) dma_block(p);
+
+    unsigned long long colmask[S0Q_QT];
+    bool full_cols[S0Q_QT];
+#pragma unroll
+    for (int q = 0; q < S0Q_QT; q++) {
+        const int n = __builtin_amdgcn_readfirstlane(nqc[q]);
+        full_cols[q] = n >= 32;
+        colmask[q] = full_cols[q] ? ~0ull : (((1ull << n) - 1ull) * 0x100000001ull);
+    }
+    auto tile_max = [](const f32x16& v) {   // one chain (v_max3): a tree makes the compiler canonicalise every raw MFMA output
+        float m = fmaxf(v[0], v[1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) m = fmaxf(fmaxf(m, v[r]), v[r + 1]);
+        return m;
+    };
+    uint32_t aoff[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) aoff[s] = (uint32_t)(i * 256 + (((8 * h + s) ^ (i & 15)) << 4));
+    int nflag = 0;   // wave-uniform
+    S0Q_STAMP(0);
+
+    // Software pipeline over the tiles: the fragments of a tile are fetched while the MFMAs of the tile before it run (the first
+    // tile of super-block P + 1 during step P) -- otherwise the eight waves, phase-locked by the barrier, all fetch (64 KB at
+    // 128 B/clk) and then all multiply.  For that the barrier of step P certifies super-block P + 1.
+    // VMEM order of a moving wave: prologue D0 D1 D2 (S0Q2_SBT operations each); step P: D(P+3), then one block-maximum store per
+    // query and 64-row block.  Own pieces of super-block P + 1 (the first operations of step P - 2): younger are that step's
+    // stores and one full step.
+    constexpr int ST = S0Q2_SBT / 2 * S0Q_QT;   // stores of a step
+    f16x8 avA[8], avB[8];
+    if (mover) s0q_wait_vm<S0Q2_SBT * (S0Q2_AHEAD - 1)>();   // D0
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; s++) avA[s] = *reinterpret_cast<const f16x8*>(abuf + aoff[s]);
+    auto tile = [&](const f16x8 (&av)[8], int t, float (&cmax)[S0Q_QT]) {   // MFMAs + maxima + flags of tile t (of the slice)
+        f32x16 acc[S0Q_QT];
+#pragma unroll
+        for (int q = 0; q < S0Q_QT; q++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[q][r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 8; s++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[q][s], acc[q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < S0Q_QT; q++) {
+            const float tmax = tile_max(acc[q]);
+            cmax[q] = fmaxf(cmax[q], tmax);
+            // wave-uniform and rare: some row of this tile survives (or, with the lo products still missing, may survive)
+            if ((__ballot(tmax + qe[q] >= a.thr) & colmask[q]) != 0ull) {
+                if (lane == 0) flist[nflag] = (uint16_t)(t * S0Q_QT + q);
+                nflag++;
+            }
+        }
+    };
+    auto fetch = [&](f16x8 (&av)[8], int buf_tile) {   // buf_tile = (super-block % NBUF) * SBT + tile
+        const char* const pt_ = abuf + __builtin_amdgcn_readfirstlane(buf_tile * 8192);
+#pragma unroll
+        for (int s = 0; s < 8; s++) av[s] = *reinterpret_cast<const f16x8*>(pt_ + aoff[s]);
+    };
+    for (int p = 0; p < nblocks; p++) {
+        if (mover) {
+            if (p == 0) s0q_wait_vm<S0Q2_SBT>(); else if (p == 1) s0q_wait_vm<S0Q2_SBT + ST>(); else s0q_wait_vm<S0Q2_SBT + 2 * ST>();
+        }
+        S0Q_STAMP(1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this wave's reads of the buffer about to be refilled are complete)
+        __syncthreads();
+        S0Q_STAMP(2);
+        dma_block(p + S0Q2_AHEAD);
+        const int bt = (p % S0Q2_NBUF) * S0Q2_SBT, bn = ((p + 1) % S0Q2_NBUF) * S0Q2_SBT;
+#pragma unroll
+        for (int u2 = 0; u2 < S0Q2_SBT / 2; u2++) {   // one 64-row block: tiles 2 u2 (in A) and 2 u2 + 1 (B)
+            fetch(avB, bt + 2 * u2 + 1);
+            float cmax[S0Q_QT];
+#pragma unroll
+            for (int q = 0; q < S0Q_QT; q++) cmax[q] = FLMR_NEG_INF;
+            tile(avA, S0Q2_SBT * p + 2 * u2, cmax);
+            fetch(avA, 2 * u2 + 2 < S0Q2_SBT ? bt + 2 * u2 + 2 : bn);   // (the last one: first tile of the next super-block)
+            tile(avB, S0Q2_SBT * p + 2 * u2 + 1, cmax);
+#pragma unroll
+            for (int q = 0; q < S0Q_QT; q++) {   // the 64-row block's column maxima, for the cell selection
+                const float m = flmr_xhalf_max(cmax[q]);
+                if (lane < 32)
+                    a.part_val[((size_t)bq[q] * a.nblk + ((row_begin + 32 * S0Q2_SBT * p + 64 * u2) >> 6)) * a.ncol + i] = (i < nqc[q]) ? m : FLMR_NEG_INF;
+            }
+        }
+        S0Q_STAMP(3);
+    }
+    s0q_wait_vm<0>();  // (the DMA of the repeated tiles past the end has landed; nothing hand-counted is outstanding below)
+    asm volatile("" ::: "memory");
+    __syncthreads();   // the tile buffers become the waves' staging rows
+    S0Q_STAMP(4);
+#ifdef S0Q_PROFILE
+    auto prof_out = [&]() {
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < 6; k++) atomicAdd(&s0q_prof[k], (unsigned long long)pt[k]);
+            atomicAdd(&s0q_prof[6], (unsigned long long)nblocks);
+            atomicAdd(&s0q_prof[7], 1ull);
+        }
+    };
+    if (nflag == 0) { prof_out(); return; }
+#else
+    if (nflag == 0) return;
+#endif
+
+    // ---- the flagged tiles: both products, dense epilogue (per wave, no block barrier) ----
+    // Latency-bound (a few entries per wave): every query's lo image is requested up front, and the rows of entry e + 1 while
+    // entry e is worked on.
+    const int c4 = (lane & 7) * 4;
+    f16x8 bl[S0Q_QT][8];
+    if constexpr (!HI_ONLY) {
+#pragma unroll
+        for (int q = 0; q < S0Q_QT; q++) {
+            const f16x8* pl = reinterpret_cast<const f16x8*>(a.q_lo + ((size_t)bq[q] * a.ncol + i) * FLMR_DIM + 64 * h);
+#pragma unroll
+            for (int s = 0; s < 8; s++) bl[q][s] = pl[s];
+        }
+    }
+    auto rows_of = [&](int e, f16x8 (&av)[8]) {   // fragment layout straight from the table
+        const int ent = __builtin_amdgcn_readfirstlane((int)flist[e < nflag ? e : nflag - 1]);
+        const f16x8* pr = reinterpret_cast<const f16x8*>(a.centroids_f16 + (size_t)(row_begin + 32 * (ent / S0Q_QT) + i) * FLMR_DIM + 64 * h);
+#pragma unroll
+        for (int s = 0; s < 8; s++) av[s] = pr[s];
+    };
+    f16x8 av[8], avn[8];
+    rows_of(0, av);
+    for (int e = 0; e < nflag; e++) {
+        const int ent = __builtin_amdgcn_readfirstlane((int)flist[e]);
+        const int rbase = row_begin + 32 * (ent / S0Q_QT);
+        rows_of(e + 1, avn);   // (past the end: the last entry again)
+#pragma unroll
+        for (int q = 0; q < S0Q_QT; q++) {
+            if (ent % S0Q_QT != q) continue;   // wave-uniform
+            const int b = bq[q];
+            float* const cs_b = a.cs + (size_t)b * a.K * a.ncol;
+            const int nvalid4 = nqc[q] - c4;
+            f32x16 ah, al;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[q][s], ah, 0, 0, 0);
+                if constexpr (!HI_ONLY) al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[q][s], al, 0, 0, 0);
+            }
+            uint32_t idxw = 0u;
+#pragma unroll
+            for (int r = 0; r < 16; r++) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * S0_LDS_STRIDE + i] = HI_ONLY ? ah[r] : fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int mrow = 0; mrow < 4; mrow++) {
+                const int R = (lane >> 3) + 8 * mrow;
+                const float4 v4 = *reinterpret_cast<const float4*>(stage + R * S0_LDS_STRIDE + c4);
+                float m4;
+                if (full_cols[q]) {
+                    m4 = fmaxf(fmaxf(v4.x, v4.y), fmaxf(v4.z, v4.w));
+                } else {
+                    m4 = nvalid4 > 0 ? v4.x : FLMR_NEG_INF;
+                    m4 = fmaxf(m4, nvalid4 > 1 ? v4.y : FLMR_NEG_INF);
+                    m4 = fmaxf(m4, nvalid4 > 2 ? v4.z : FLMR_NEG_INF);
+                    m4 = fmaxf(m4, nvalid4 > 3 ? v4.w : FLMR_NEG_INF);
+                }
+                unsigned long long bal = __ballot(m4 >= a.thr);  // byte j of `bal` = the 8 lanes of row 8*mrow + j
+                bal |= bal >> 4; bal |= bal >> 2; bal |= bal >> 1;
+                bal &= 0x0101010101010101ull;
+                const uint32_t byte = (uint32_t)((bal * 0x0102040810204080ull) >> 56);
+                idxw |= byte << (8 * mrow);
+                if ((byte >> (lane >> 3)) & 1u) *reinterpret_cast<float4*>(cs_b + (size_t)(rbase + R) * a.ncol + c4) = v4;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // (the staged tile has been read before the next one overwrites it)
+            if (lane == 0 && idxw != 0u) a.idx_bits[(size_t)b * a.idx_words + (rbase >> 5)] = idxw;
+        }
+#pragma unroll
+        for (int s = 0; s < 8; s++) av[s] = avn[s];
+    }
+#ifdef S0Q_PROFILE
+    S0Q_STAMP(5);
+    prof_out();
+#endif
 }
 
 __global__ void check_f16_exact_kernel(const float* x, size_t n, int* flag) {
@@ -772,14 +1099,48 @@ static int launch_s0_t(flmr_s0_args& a, hipStream_t st, int impl) {
             int slices = (int)flmr_ceil_div(512, ngroups);  // (256 .. 768 workgroups measure the same)
             const int max_slices = a.K / 64;
             if (slices > max_slices) slices = max_slices;
+            const int min_slices = (int)flmr_ceil_div(a.K, S0Q2_MAX_SLICE_ROWS);   // (the flagged-tile lists hold a whole slice)
+            if (slices < min_slices) slices = min_slices;
             if (slices < 1) slices = 1;
             const int rows_per_slice = (int)flmr_round_up(flmr_ceil_div(a.K, slices), 64);
             slices = (int)flmr_ceil_div(a.K, rows_per_slice);
             const size_t ldsq = (size_t)8 * 32 * S0_LDS_STRIDE * sizeof(float) + (size_t)S0Q_NBUF * 2 * 8192;
+            // the kernel stores an idx word only for a tile with a surviving row
+            FLMR_HIP(hipMemsetAsync(a.idx_bits, 0, (size_t)a.nqueries * a.idx_words * sizeof(uint32_t), st));
             if (a.q_err_buf && !a.q_hi_only)   // the bounds of this batch's queries (stage 0's own shortcut and stage 2's read them)
                 hipLaunchKernelGGL(s0_q_err_kernel, dim3(a.nqueries), dim3(64), 0, st, a.q_hi, a.q_lo, a.ncol, a.q_lens, a.nq, a.nq_cand,
                                    a.cen_norm_max, a.q_err_buf, a.q_err_sum);
-            if (a.q_hi_only) {
+            const bool inline_dense = flmr_opts().is(FLMR_OPT_S0_IMPL, "qs1");   // A/B: the form with the dense epilogue in the loop
+            if ((a.q_hi_only || a.q_err) && !inline_dense && a.K % (32 * S0Q2_SBT) == 0) {
+                const size_t ldsq2 = (size_t)S0Q2_NBUF * S0Q2_SBT * 8192 + (size_t)S0Q2_WAVES * S0Q2_FCAP * sizeof(uint16_t);
+                const int ngroups2 = (int)flmr_ceil_div(a.nqueries, S0Q2_WAVES * S0Q_QT);
+                int slices2 = 512 / ngroups2;   // (rounded down: a few workgroups over 2 x 256 would cost a third round)
+                if (slices2 > a.K / (32 * S0Q2_SBT)) slices2 = a.K / (32 * S0Q2_SBT);
+                if (slices2 < min_slices) slices2 = min_slices;
+                if (slices2 < 1) slices2 = 1;
+                const int rows_per_slice2 = (int)flmr_round_up(flmr_ceil_div(a.K, slices2), 32 * S0Q2_SBT);
+                slices2 = (int)flmr_ceil_div(a.K, rows_per_slice2);
+                const int slices = slices2, rows_per_slice = rows_per_slice2;   // (shadow: this branch's own cut)
+                if (a.q_hi_only) {
+                    FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_qs2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq2));
+                    hipLaunchKernelGGL(s0_centroid_scores_qs2<true>, dim3(ngroups2, slices), dim3(64 * S0Q2_WAVES), ldsq2, st, a, rows_per_slice);
+                } else {
+                    FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_qs2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq2));
+                    hipLaunchKernelGGL(s0_centroid_scores_qs2<false>, dim3(ngroups2, slices), dim3(64 * S0Q2_WAVES), ldsq2, st, a, rows_per_slice);
+                }
+#ifdef S0Q_PROFILE
+                {
+                    unsigned long long hh[8];
+                    (void)hipDeviceSynchronize();
+                    (void)hipMemcpyFromSymbol(hh, HIP_SYMBOL(s0q_prof), sizeof(hh));
+                    fprintf(stderr, "[s0q] workgroups %llu x %d slices rows %d; s_memtime ticks per workgroup: prologue %.0f | per block: dma wait %.1f barrier %.1f body %.1f | "
+                                    "drain %.0f deferred %.0f (blocks per workgroup %.1f)\n", hh[7], slices, rows_per_slice, (double)hh[0] / hh[7],
+                            (double)hh[1] / hh[6], (double)hh[2] / hh[6], (double)hh[3] / hh[6], (double)hh[4] / hh[7], (double)hh[5] / hh[7], (double)hh[6] / hh[7]);
+                    unsigned long long z[8] = {};
+                    (void)hipMemcpyToSymbol(HIP_SYMBOL(s0q_prof), z, sizeof(z));
+                }
+#endif
+            } else if (a.q_hi_only) {
                 FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_qs<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq));
                 hipLaunchKernelGGL(s0_centroid_scores_qs<true>, dim3(ngroups, slices), dim3(512), ldsq, st, a, rows_per_slice);
             } else if (a.q_err) {

@@ -493,7 +493,11 @@ int flmr_launch_filter_stage2_xcd_ex(const flmr_filter_args& f, const int32_t* p
     const int nsl = ix->nslices;
     const int64_t grid = (int64_t)nsl * f.nqueries * G;
     if (grid > 0x7fffffffLL) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "stage-2 grid too large");
+#ifdef X2_LDS_PAD   // development probe: a larger request leaves one workgroup per CU (half the tiles in flight, one wave per SIMD)
+    const size_t lds = (size_t)X2_WAVES * X2_WAVE_LDS + X2_LDS_PAD;
+#else
     const size_t lds = (size_t)X2_WAVES * X2_WAVE_LDS;
+#endif
     if (hi_only) {
         FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_stage2_xcd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(filter_stage2_xcd_kernel<true>, dim3((unsigned)grid), dim3(256), lds, st, f, pids, pid_stride, counts, part, part_stride,

@@ -1385,18 +1385,21 @@ def test_s0_hi_first_equals_full_products(hip, ties):
     q_lens = torch.tensor([32, 32, 9, 20, 32, 1, 32, 32, 17, 32, 32] * 2, dtype=torch.int32)
     for (ncells, thr, ndocs) in [(1, 0.5, 64), (2, 0.45, 256), (4, 0.4, 1024), (8, 0.3, 256), (2, -1.0, 64), (2, 6.5, 256)]:
         res = {}
-        for impl in (None, "f16"):
+        # None: hi first with the flagged tiles' dense epilogue deferred to the end of the kernel (the default); "qs1": the same
+        # shortcut with the dense epilogue inside the loop; "f16": both products everywhere
+        for impl in (None, "qs1", "f16"):
             ctx = nat.options(FLMR_S0_IMPL=impl) if impl else contextlib.nullcontext()
             with ctx:
                 p, s, c = scorer.search_batch(Q, max(ndocs // 4, 1), ncells, thr, ndocs, 32, q_lens=q_lens)
                 scorer.check()
                 taps = [[scorer.tap(t, q) for t in (nat.TAP_IDX_BITS, nat.TAP_CELLS, nat.TAP_CANDIDATES)] for q in range(Q.size(0))]
                 res[impl] = (p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), taps)
-        a, b = res[None], res["f16"]
-        for q in range(Q.size(0)):
-            for x, y, name in zip(a[3][q], b[3][q], ("idx", "cells", "candidates")):
-                assert np.array_equal(x, y), (ties, ncells, thr, q, name)
-        assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), (ties, ncells, thr)
+        for other in ("qs1", "f16"):
+            a, b = res[None], res[other]
+            for q in range(Q.size(0)):
+                for x, y, name in zip(a[3][q], b[3][q], ("idx", "cells", "candidates")):
+                    assert np.array_equal(x, y), (ties, other, ncells, thr, q, name)
+            assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), (ties, other, ncells, thr)
     # cells of the default path against the oracle's top-ncells (value desc, index asc) on the full table of the same kernel family
     for ncells in (2, 4):
         for q in (0, 4):
