@@ -106,6 +106,9 @@ static int x2_slices_for(int64_t K) {
     const size_t per_slice = ((size_t)4 << 20) + ((size_t)1 << 18);
     int n = X2_XCDS;
     while (n < X2_MAX_SLICES && table > per_slice * (size_t)n) n += X2_XCDS;
+#ifdef X2_FORCE_SLICES   // development probe (profiles/build_variant.py): e.g. 16 half-L2 slices at K = 131072
+    if (n < X2_FORCE_SLICES) n = X2_FORCE_SLICES;
+#endif
     return n;
 }
 
