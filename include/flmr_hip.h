@@ -109,7 +109,8 @@ int flmr_index_info(const flmr_index_t* index, flmr_index_info_t* out_info);
  * residual decompression + L2 normalisation + MaxSim, S4 top-k.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct flmr_search_params {
-    int32_t k;                        /* results per query; policy defaults are the host's job (searcher.py:92-118) */
+    int32_t k;                        /* results per query = width of the caller's output rows (>= 1; NOT a workspace bound: rows are
+                                       * padded past the ndocs/4 finalists); policy defaults are the host's job (searcher.py:92-118) */
     int32_t ncells;                   /* 1..8 */
     float centroid_score_threshold;   /* idx = max_j score >= thr (index_storage.py:116) */
     int32_t ndocs;                    /* S1 keeps ndocs, S2 keeps ndocs/4 (filter_pids.cpp:126-164); 4..8192 */
