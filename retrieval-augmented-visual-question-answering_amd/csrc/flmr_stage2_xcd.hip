@@ -373,9 +373,9 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     if constexpr (HI_ONLY) {
-                        // (compiler-visible maxima: an inline-asm instruction reading the accumulators right after the MFMAs would
-                        // have to carry the MFMA -> VALU wait states itself; in the other branch the fmas are what the compiler sees)
-                        mq[k] = fmaxf(fmaxf(ah[4 * k], ah[4 * k + 1]), fmaxf(ah[4 * k + 2], ah[4 * k + 3]));
+                        // (folded straight into `cm` below, as a v_max3 chain from an already canonical value: a maximum of raw
+                        // MFMA outputs makes the compiler canonicalise each of them first -- five instructions per octet, not two)
+                        mq[k] = 0.0f;
                     } else {
                         const float v0 = fmaf(al[4 * k], 1.0f / 2048.0f, ah[4 * k]), v1 = fmaf(al[4 * k + 1], 1.0f / 2048.0f, ah[4 * k + 1]);
                         const float v2 = fmaf(al[4 * k + 2], 1.0f / 2048.0f, ah[4 * k + 2]), v3 = fmaf(al[4 * k + 3], 1.0f / 2048.0f, ah[4 * k + 3]);
@@ -397,7 +397,14 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
                         cm = -9999.0f;  // filter_pids.cpp:30-33
                         jcur = j;
                     }
-                    cm = x2_max(cm, mq[k]);
+                    if constexpr (HI_ONLY) {
+                        // (compiler-visible: an inline-asm instruction reading the accumulators right after the MFMAs would have to
+                        // carry the MFMA -> VALU wait states itself)
+                        cm = fmaxf(fmaxf(cm, ah[4 * k]), ah[4 * k + 1]);
+                        cm = fmaxf(fmaxf(cm, ah[4 * k + 2]), ah[4 * k + 3]);
+                    } else {
+                        cm = x2_max(cm, mq[k]);
+                    }
                 }
                 X2_STAMP(7);
             }
