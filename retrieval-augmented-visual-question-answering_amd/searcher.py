@@ -137,9 +137,17 @@ class Searcher:
         """Device results [n, k] -> the Ranking layout [[(pid, rank, score)] * count] (searcher.py:81-89, :132: ranks are 1..k).
         One bulk transfer + one tolist per array: converting row by row costs 0.14 ms per query in tensor slicing alone --
         more than the whole device path (7 us per query)."""
-        P, S, C = pids.cpu().tolist(), scores.cpu().tolist(), counts.cpu().tolist()
-        ranks = list(range(1, k + 1))
-        return [list(zip(P[i][:n], ranks, S[i][:n])) for i, n in enumerate(C)]
+        import numpy as np
+        P, S, C = pids.cpu().numpy(), scores.cpu().numpy(), counts.cpu().tolist()
+        if P.ndim != 2 or P.shape[1] == 0:
+            return [[] for _ in C]
+        # the tuples are built in C by a structured array's tolist() (15 ms per 1024 x 100 against 23 ms for zip over three
+        # lists); values are the same Python ints / floats (float32 widened, as Tensor.tolist() gives them)
+        rec = np.empty(P.shape, dtype=[("pid", np.int32), ("rank", np.int32), ("score", np.float32)])
+        rec["pid"], rec["score"] = P, S
+        rec["rank"] = np.arange(1, P.shape[1] + 1, dtype=np.int32)
+        rows = rec.tolist()
+        return [row if n >= len(row) else row[:max(n, 0)] for row, n in zip(rows, C)]
 
     # ---- embedding entry points -----------------------------------------------------------------------------------
     def _search_all_Q(self, queries, Q, k, filter_fn=None, progress=True, remove_zero_tensors=False):

@@ -361,3 +361,20 @@ def test_synth_shard_local_generation_equals_sliced_corpus(doclen):
             assert a.pid_base == b.pid_base == lo
             Qa, ta = synth.make_queries(a, 5, 32)
             assert torch.equal(Qa, Qf) and torch.equal(ta, tf)
+
+
+def test_ranking_lists_layout():
+    """Searcher.ranking_lists: device rows [n, k] -> [[(pid, rank, score)] * count] (searcher.py:81-89, :132) -- the same
+    Python values as zip over Tensor.tolist(), counts honoured, ranks 1..k."""
+    from ravqa_amd.searcher import Searcher
+    g = torch.Generator().manual_seed(3)
+    n, k = 37, 12
+    P = torch.randint(0, 10_000_000, (n, k), dtype=torch.int32, generator=g)
+    S = torch.rand((n, k), generator=g) * 30 - 5
+    C = torch.randint(0, k + 1, (n,), dtype=torch.int32, generator=g)
+    C[0], C[1] = k, 0
+    got = Searcher.ranking_lists(P, S, C, k)
+    want = [list(zip(P[i, :m].tolist(), range(1, k + 1), S[i, :m].tolist())) for i, m in enumerate(C.tolist())]
+    assert got == want
+    assert all(type(t) is tuple and type(t[0]) is int and type(t[1]) is int and type(t[2]) is float for row in got for t in row)
+    assert Searcher.ranking_lists(P[:0], S[:0], C[:0], k) == []
