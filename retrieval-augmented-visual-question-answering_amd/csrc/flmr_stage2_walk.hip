@@ -428,7 +428,11 @@ bool flmr_stage2_walk_pays(const flmr_index* ix, int nqueries, int max_count) {
     const int64_t nitems = (int64_t)nqueries * nchunks;
     if (nitems * 2 < cu_count()) return false;
     const double tokens = (double)max_count * ((double)ix->N / (double)(ix->num_passages > 0 ? ix->num_passages : 1));
-    return (double)ix->K * nchunks <= 0.6 * tokens;   // measured break-even: K = 0.8 x tokens (see the header)
+    // measured break-even against the gather form: K = 0.8 x tokens (see the header).  Where the XCD-sliced kernel runs -- and with
+    // it the approximate-then-refine selection -- the walk has to beat 2.95 ms instead of 3.8: at 1024 survivors x 128 tokens the
+    // walk takes 2.43 ms at K = 32768 and 3.51 ms at K = 65536 (linear in K), the sliced form 2.79 and 2.95: break-even K = 46 k
+    const double factor = flmr_stage2_xcd_pays(ix) ? 0.35 : 0.6;
+    return (double)ix->K * nchunks <= factor * tokens;
 }
 
 int flmr_launch_filter_stage2_walk(const flmr_filter_args& f, const int32_t* pids, int64_t pid_stride, const int32_t* counts,
