@@ -1439,3 +1439,46 @@ def test_stage2_approximate_then_refine_selects_the_same_set(hip, nbits, doclen,
     for q in range(Q.size(0)):
         assert sorted(a[3][q].tolist()) == sorted(b[3][q].tolist()), q
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_search_vs_oracle(hip, seed):
+    """Seeded random shapes through the DEFAULT path of a batched call (>= 16 queries: "hi first" stage 0 with its deferred
+    pass, approximate-then-refine stage 2 where the sliced kernel runs, scatter stage 1) against the oracle: K any multiple of
+    128, every nbits, ragged passages with empties, short queries via q_lens, ncells 1..4, thresholds around the policy values,
+    more than one 32768-passage chunk in some cases.  Eight queries of each batch are ranked by the oracle."""
+    from oracle import oracle as orc
+    torch = hip["torch"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    rng = np.random.default_rng(1000 + seed)
+    K = 128 * int(rng.integers(4, 80))
+    nbits = int(rng.choice([1, 2, 4, 8]))
+    npass = int(rng.choice([3000, 9000, 20000, 40000, 70000]))
+    lo = int(rng.integers(0, 12))
+    doclen = (lo, lo + int(rng.integers(8, 90)))
+    nqueries = int(rng.integers(16, 49))
+    nq = int(rng.choice([32, 32, 24, 17]))
+    ncells = int(rng.integers(1, 5))
+    thr = float(rng.choice([0.3, 0.4, 0.45, 0.5, 0.55]))
+    ndocs = int(rng.choice([64, 256, 1024]))
+    corpus = synth.make_corpus(npass, doclen, K, nbits, seed=300 + seed, device="cuda")
+    Q, _ = synth.make_queries(corpus, nqueries, nq, seed=400 + seed)
+    q_lens = torch.from_numpy(rng.integers(1, nq + 1, size=nqueries).astype(np.int32))
+    q_lens[::3] = nq
+    arrays = synth.corpus_to_arrays(corpus)
+    scorer = IndexScorer(arrays=arrays, max_batch=64)
+    oi = orc.OracleIndex(arrays.dim, arrays.nbits, arrays.codes, arrays.residuals, arrays.doclens, arrays.ivf,
+                         arrays.ivf_lengths, arrays.centroids, arrays.bucket_weights)
+    p, s, c = scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=q_lens)
+    scorer.check()
+    Qh = Q.cpu().numpy()
+    for i in list(range(0, nqueries, max(1, nqueries // 8)))[:8]:
+        ql = int(q_lens[i])
+        rp, rs, ncand = oi.rank(Qh[i, :ql], ncells, thr, ndocs, 32)
+        n = int(c[i])
+        if ncand < ndocs:
+            assert n == min(ncand, ndocs // 4), (seed, i, n, ncand)
+            continue
+        tie_aware_equal(rp, rs, p[i, :n].cpu().numpy(), s[i, :n].cpu().numpy(), tol=SCORE_TOL)
