@@ -145,7 +145,7 @@ def test_cfg5_one_shard_view_nbits8(hip):
     _check(hip, corpus, 32, {100: 8, 500: 2}, ks=(100, 500), max_batch=8, local_queries=True)
 
 
-def _exact_protocol_on_one_device(torch, ops, shards, Q, k, ncells, thr, ndocs, split_stage0=True, truncate=True):
+def _exact_protocol_on_one_device(torch, ops, shards, Q, k, ncells, thr, ndocs, split_stage0=True, truncate=True, fallback=False):
     """All ranks' phases of ShardedSearcher.search_batch_exact run in sequence on ONE device: the all-gathers are
     torch.stack / cat, the SUM all-reduces a sum over the stack (exactly the data movement of distributed.py)."""
     W, B = len(shards), Q.size(0)
@@ -167,7 +167,10 @@ def _exact_protocol_on_one_device(torch, ops, shards, Q, k, ncells, thr, ndocs, 
     if m < ndocs:   # each shard ships its m best keys + the certificate (distributed.py: the default exchange)
         g = torch.stack([ops.topn_keys(k_, m, ordered=False) for k_ in k1])                     # [W, B, m]
         s1, violated = merge_truncated(g, ndocs, ops.topn_keys)
-        assert not bool(violated)
+        if fallback and bool(violated):   # skewed shards: what search_batch_exact(check=True) does -- the full exchange
+            s1 = ops.topn_keys(torch.stack(k1).permute(1, 0, 2).reshape(B, -1), ndocs, ordered=False)
+        else:
+            assert not bool(violated)
     else:
         g = torch.stack(k1)                                                 # [W, B, ndocs]
         s1 = ops.topn_keys(g.permute(1, 0, 2).reshape(B, -1), ndocs, ordered=False)
@@ -223,5 +226,40 @@ def test_cfg4_sharded_into_8_exact_protocol_equals_unsharded(hip):
                 # an unsharded survivor also survives in its shard (fewer competitors): same exact score, and it is in the
                 # merged list unless k superset documents outrank it
                 assert (pid in fast and fast[pid] == sc_) or sc_ <= kth, (k, q, pid)
+    for sh in shards + [single]:
+        sh.close_searcher()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_sharded_exact_protocol_equals_unsharded(hip, seed):
+    """Seeded random shapes and shard counts (2..8, passage counts that do not divide evenly, shards smaller than ndocs, ragged
+    passages with empties, short queries): every rank's probe -> phase1_probed -> phase2 -> phase3 on this one device with the
+    exchanges of distributed.py, query-split or replicated stage 0, truncated or full phase-1 exchange -- bit-identical to the
+    unsharded search_batch."""
+    torch = hip["torch"]
+    from ravqa_amd import ops, synth
+    from ravqa_amd.scorer import IndexScorer
+    rng = np.random.default_rng(7000 + seed)
+    W = int(rng.integers(2, 9))
+    K = 128 * int(rng.integers(8, 48))
+    nbits = int(rng.choice([2, 4, 8]))
+    npass = int(rng.choice([2500, 7001, 20003, 50007]))
+    lo = int(rng.integers(0, 10))
+    doclen = (lo, lo + int(rng.integers(10, 80)))
+    B = int(rng.integers(5, 40))
+    k, ncells, thr, ndocs = [(100, 2, 0.45, 1024), (10, 1, 0.5, 64), (40, 3, 0.4, 256)][int(rng.integers(0, 3))]
+    corpus = synth.make_corpus(npass, doclen, K, nbits, seed=500 + seed, device="cuda")
+    single = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=64)
+    shards = [IndexScorer(device_index=synth.corpus_device_index(synth.shard_corpus(corpus, r, W)), max_batch=64) for r in range(W)]
+    Q, _ = synth.make_queries(corpus, B, 32, seed=600 + seed)
+    p_ref, s_ref, c_ref = single.search_batch(Q, k, ncells, thr, ndocs, 32)
+    single.check()
+    split = bool(rng.integers(0, 2))
+    trunc = bool(rng.integers(0, 2))
+    p, s, c = _exact_protocol_on_one_device(torch, ops, shards, Q, k, ncells, thr, ndocs, split_stage0=split, truncate=trunc, fallback=True)
+    for sh in shards:
+        sh.check()
+    assert torch.equal(c, c_ref) and torch.equal(p, p_ref) and torch.equal(s, s_ref), (seed, W, K, nbits, npass, B, k, split, trunc)
     for sh in shards + [single]:
         sh.close_searcher()
