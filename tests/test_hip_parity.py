@@ -1482,3 +1482,62 @@ def test_fuzz_search_vs_oracle(hip, seed):
             assert n == min(ncand, ndocs // 4), (seed, i, n, ncand)
             continue
         tie_aware_equal(rp, rs, p[i, :n].cpu().numpy(), s[i, :n].cpu().numpy(), tol=SCORE_TOL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_ops_vs_oracle(hip, seed):
+    """The four extension ops (b3) on seeded random shapes against the oracle: filter_pids (ids in order, random centroid-score
+    tables incl. exact ties, random idx masks, npids below and above ndocs), decompress_residuals (bytes as uint32), the
+    ragged gather of rows of every element size, segmented_maxsim with empty segments."""
+    from oracle import oracle as orc
+    torch, ops = hip["torch"], hip["ops"]
+    from ravqa_amd import synth
+    rng = np.random.default_rng(9000 + seed)
+    K = int(rng.integers(40, 600))
+    nbits = int(rng.choice([1, 2, 4, 8]))
+    npass = int(rng.integers(300, 3000))
+    corpus = synth.make_corpus(npass, (0, int(rng.integers(5, 70))), max(64, (K // 64) * 64), nbits, seed=700 + seed, device="cuda")
+    a = synth.corpus_to_arrays(corpus)
+    K = a.num_centroids
+    oi = orc.OracleIndex(a.dim, a.nbits, a.codes, a.residuals, a.doclens, a.ivf, a.ivf_lengths, a.centroids, a.bucket_weights)
+    doclens = torch.from_numpy(np.asarray(a.doclens)).long()
+    offsets = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(doclens, 0)])
+    # ---- filter_pids ----
+    nq = int(rng.choice([8, 17, 32]))
+    cs = rng.standard_normal((K, nq)).astype(np.float32) * 0.3
+    cs[rng.integers(0, K, size=K // 8)] = np.float32(0.25)                       # whole rows tying
+    idx = cs.max(axis=1) >= np.float32(rng.choice([0.2, 0.45, 0.6]))
+    for npids, ndocs in ((int(rng.integers(1, 60)), 256), (min(npass, int(rng.integers(300, 2500))), int(rng.choice([64, 256])))):
+        pids = np.sort(rng.choice(npass, size=npids, replace=False)).astype(np.int32)
+        want = oi.filter_pids(pids, cs, idx, ndocs)
+        got = ops.filter_pids(torch.from_numpy(pids), torch.from_numpy(cs), torch.from_numpy(np.asarray(a.codes)), doclens, offsets,
+                              torch.from_numpy(idx), ndocs)
+        assert np.array_equal(got.cpu().numpy(), want), (seed, npids, ndocs)
+    # ---- decompress_residuals ----
+    pids = rng.choice(npass, size=int(rng.integers(1, 200)), replace=True).astype(np.int32)
+    rev, lut = orc.codec_tables(nbits)
+    D = ops.decompress_residuals(torch.from_numpy(pids), doclens, offsets, torch.from_numpy(np.asarray(a.bucket_weights)),
+                                 torch.from_numpy(rev), torch.from_numpy(lut), torch.from_numpy(np.asarray(a.residuals)),
+                                 torch.from_numpy(np.asarray(a.codes)), torch.from_numpy(np.asarray(a.centroids)), 128, nbits)
+    assert np.array_equal(D.cpu().numpy().view(np.uint32), oi.decompress(pids).view(np.uint32)), seed
+    # ---- segmented_lookup: rows of 1, 4, 8, 64, 256 bytes ----
+    nseg_all = int(rng.integers(5, 400))
+    lens_all = rng.integers(0, 40, size=nseg_all).astype(np.int64)
+    offs_all = np.concatenate([[0], np.cumsum(lens_all)[:-1]]).astype(np.int64)
+    sel = rng.integers(0, nseg_all, size=int(rng.integers(1, 300)))
+    for dt, width in ((np.uint8, 1), (np.int32, 1), (np.int64, 1), (np.float32, 16), (np.float16, 128)):
+        inp = rng.integers(0, 100, size=(int(lens_all.sum()) + 8, width)).astype(dt)
+        if width == 1:
+            inp = inp[:, 0]
+        want = orc.segmented_lookup(inp, lens_all[sel], offs_all[sel])
+        got = ops.segmented_lookup(torch.from_numpy(inp), torch.from_numpy(sel), torch.from_numpy(lens_all[sel]), torch.from_numpy(offs_all[sel]))
+        got = got[0] if isinstance(got, tuple) else got
+        assert got.cpu().numpy().tobytes() == np.asarray(want if not isinstance(want, tuple) else want[0]).tobytes(), (seed, dt, width)
+    # ---- segmented_maxsim ----
+    lens = rng.integers(0, 50, size=int(rng.integers(1, 120))).astype(np.int64)
+    sc = rng.standard_normal((int(lens.sum()), nq)).astype(np.float32)
+    out = ops.segmented_maxsim(torch.from_numpy(sc), torch.from_numpy(lens))
+    want = orc.segmented_maxsim(sc, lens)
+    assert np.max(np.abs(out.cpu().numpy() - want), initial=0.0) <= 1e-5 * max(1, nq)
+    assert bool((out.cpu().numpy()[lens == 0] == 0.0).all())
