@@ -1291,7 +1291,11 @@ static int launch_maxsim_f16_t(const flmr_maxsim_args& a, hipStream_t st) {
                (flmr_opts().is(FLMR_OPT_S3_IMPL, "cw") || !flmr_opts().has(FLMR_OPT_S3_IMPL))) {
         // centroid + weight form on the LDS-DMA pipeline (the default for one query tile; 32-bit row offsets: table < 4 GB)
         const size_t tabw = NBITS == 8 ? 256 : 256 * (8 / NBITS);
+#ifdef S3_LDS_PAD   // development probe: a larger request leaves one workgroup per CU (one wave per SIMD)
+        const size_t lds4 = ((tabw + (size_t)4 * (nqp + 32)) * sizeof(float) + 15) / 16 * 16 + 4 * 16384 + 4 * 2048 + S3_LDS_PAD;
+#else
         const size_t lds4 = ((tabw + (size_t)4 * (nqp + 32)) * sizeof(float) + 15) / 16 * 16 + 4 * 16384 + 4 * 2048;
+#endif
         FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_f16_dma_kernel<NBITS, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
         hipLaunchKernelGGL((maxsim_f16_dma_kernel<NBITS, true>), dim3(a.nqueries, G), dim3(256), lds4, st, a, ix->codes, ix->residuals,
