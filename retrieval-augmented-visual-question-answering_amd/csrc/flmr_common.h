@@ -162,6 +162,9 @@ struct flmr_s0_args {
                              // approximate-then-refine form reads it too); q_err == q_err_buf when stage 0 itself uses the bound
     float* q_err_sum;        // [nqueries] bound on |approximate - full| for a passage's stage-2 score (sum over the columns + summation rounding)
     float cen_norm_max;      // >= max_c ||c||_2
+    int32_t grp_blocks;      // set by flmr_launch_centroid_scores: > 0 = the kernel it picked ALSO left one column maximum per `grp_blocks`
+                             // consecutive 64-row blocks, as floats [nqueries, nblk / grp_blocks, ncol] in the part_idx buffer (unused on
+                             // that path): s0_select_cells reads those first and only the best groups' block maxima after them
 };
 int flmr_launch_centroid_scores(flmr_s0_args& a, hipStream_t st);
 int flmr_launch_select_cells(const flmr_s0_args& a, hipStream_t st);

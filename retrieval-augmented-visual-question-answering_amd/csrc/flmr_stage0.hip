@@ -676,6 +676,12 @@ __device__ unsigned long long s0q_prof[8];
 #define S0Q2_SBT 4     // tiles per step ("super-block" of 128 rows): one workgroup barrier per 4 x 16 MFMAs of a wave (2: measured the same)
 #endif
 #define S0Q2_AHEAD 3   // super-blocks requested ahead: at the barrier of step P super-block P + 1 has landed (its first tile is fetched one step early)
+#ifdef S0_NO_GROUPS   // development A/B: no coarse level
+#define S0Q2_GROUPS false
+#else
+#define S0Q2_GROUPS true
+#endif
+#define S0Q2_GRP 8     // 64-row blocks per group of the coarse column maxima (512 rows; a multiple of the blocks of a step)
 #define S0Q2_NBUF 4    // super-block buffers of S0Q2_SBT x 8 KB (the staging rows of the deferred pass reuse them)
 
 template <bool HI_ONLY>
@@ -789,6 +795,12 @@ __global__ __launch_bounds__(64 * S0Q2_WAVES, 1) void s0_centroid_scores_qs2(flm
 #pragma unroll
         for (int s = 0; s < 8; s++) av[s] = *reinterpret_cast<const f16x8*>(pt_ + aoff[s]);
     };
+    // the coarse level: one column maximum per S0Q2_GRP blocks (s0_select_cells reads these 32 KB per query first, and block maxima
+    // of the best groups only), when the launcher cut the slices on group boundaries
+    const bool groups = a.grp_blocks == S0Q2_GRP;
+    float gmax[S0Q_QT];
+#pragma unroll
+    for (int q = 0; q < S0Q_QT; q++) gmax[q] = FLMR_NEG_INF;
     for (int p = 0; p < nblocks; p++) {
         if (mover) {
             if (p == 0) s0q_wait_vm<S0Q2_SBT>(); else if (p == 1) s0q_wait_vm<S0Q2_SBT + ST>(); else s0q_wait_vm<S0Q2_SBT + 2 * ST>();
@@ -811,8 +823,18 @@ __global__ __launch_bounds__(64 * S0Q2_WAVES, 1) void s0_centroid_scores_qs2(flm
 #pragma unroll
             for (int q = 0; q < S0Q_QT; q++) {   // the 64-row block's column maxima, for the cell selection
                 const float m = flmr_xhalf_max(cmax[q]);
+                gmax[q] = fmaxf(gmax[q], m);
                 if (lane < 32)
                     a.part_val[((size_t)bq[q] * a.nblk + ((row_begin + 32 * S0Q2_SBT * p + 64 * u2) >> 6)) * a.ncol + i] = (i < nqc[q]) ? m : FLMR_NEG_INF;
+            }
+        }
+        if (groups && (p + 1) % (S0Q2_GRP * 2 / S0Q2_SBT) == 0) {   // (wave-uniform) a group of S0Q2_GRP blocks is complete
+            const int g = (row_begin + 32 * S0Q2_SBT * p) / (64 * S0Q2_GRP);
+            float* const grp = reinterpret_cast<float*>(a.part_idx);
+#pragma unroll
+            for (int q = 0; q < S0Q_QT; q++) {
+                if (lane < 32) grp[((size_t)bq[q] * (a.nblk / S0Q2_GRP) + g) * a.ncol + i] = (i < nqc[q]) ? gmax[q] : FLMR_NEG_INF;
+                gmax[q] = FLMR_NEG_INF;
             }
         }
         S0Q_STAMP(3);
@@ -1084,6 +1106,7 @@ template <int NC>
 static int launch_s0_t(flmr_s0_args& a, hipStream_t st, int impl) {
     const int qsplit = a.nqueries < 8 ? a.nqueries : 8;
     a.nblk = (int)flmr_ceil_div(a.K, impl == S0_F16 ? 32 * S0_RT : 128);
+    a.grp_blocks = 0;
     a.part_rows = impl == S0_F16 ? 32 * S0_RT : 0;
     if (impl == S0_F16) {
         hipLaunchKernelGGL(s0_split_q, dim3((a.ncol * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens,
@@ -1118,8 +1141,13 @@ static int launch_s0_t(flmr_s0_args& a, hipStream_t st, int impl) {
                 if (slices2 > a.K / (32 * S0Q2_SBT)) slices2 = a.K / (32 * S0Q2_SBT);
                 if (slices2 < min_slices) slices2 = min_slices;
                 if (slices2 < 1) slices2 = 1;
-                const int rows_per_slice2 = (int)flmr_round_up(flmr_ceil_div(a.K, slices2), 32 * S0Q2_SBT);
+                // slices on group boundaries when the table allows it: the kernel then also leaves the coarse column maxima
+                const bool grp = a.K % (64 * S0Q2_GRP) == 0 && a.part_idx != nullptr && a.nblk == a.K / 64 && S0Q2_GROUPS;
+                const int slice_unit = grp ? 64 * S0Q2_GRP : 32 * S0Q2_SBT;
+                if (grp && slices2 > a.K / slice_unit) slices2 = a.K / slice_unit;
+                const int rows_per_slice2 = (int)flmr_round_up(flmr_ceil_div(a.K, slices2), slice_unit);
                 slices2 = (int)flmr_ceil_div(a.K, rows_per_slice2);
+                a.grp_blocks = grp ? S0Q2_GRP : 0;
                 const int slices = slices2, rows_per_slice = rows_per_slice2;   // (shadow: this branch's own cut)
                 if (a.q_hi_only) {
                     FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s0_centroid_scores_qs2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq2));
@@ -1287,7 +1315,10 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
             bfrag[hl][st][ln] = *reinterpret_cast<const f16x8*>(src);
         }
     }
-    if (pre) {
+    // (with the coarse level of column maxima -- a.grp_blocks -- the pipelined path below reads 32 KB + the best groups' blocks
+    // per query instead of all 256 KB: no scan here)
+    const bool coarse = a.grp_blocks > 0 && pre && !a.full_table && a.centroids_f16 != nullptr && a.part_rows == 32 * S0_RT;
+    if (pre && !coarse) {
         if constexpr (NC <= 2) {
         // 16-byte loads: lane = (row phase lane >> 3, four columns 4 * (lane & 7)), eight in flight per lane.  The scan
         // moves 256 KB per query and measures ~4 TB/s over the chip at 256 queries whatever the depth (8 or 32 in flight,
@@ -1358,11 +1389,69 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
         __shared__ int redo_i[SC_WAVES][4][NC];
         if (lane == 0) redo_n[wave] = 0;
         int ntasks = 0;
-        for (int k = 0; wave + SC_WAVES * k < nqc; k++) {
+        // With the coarse level: the NL best blocks of a column lie in its NL best GROUPS (a block's maximum is at most its
+        // group's; order by (value desc, index asc) on both levels: a group ahead of another holds a block ahead of every
+        // block of the other).  The group maxima of ALL of this wave's columns are requested together (128 bytes apart, ~2 us
+        // away), then the NL x grp_blocks block maxima of every column's winners together: two round trips per wave, not per column.
+        constexpr int KW = 32 / SC_WAVES;   // columns per wave
+        flmr_toplist<NL> cbt[KW];
+        if (coarse) {
+            const int G = a.grp_blocks, ngrp = a.nblk / G;   // (G == 8: eight groups' blocks per sweep of the wave)
+            const float* const grp = reinterpret_cast<const float*>(a.part_idx) + (size_t)b * ngrp * a.ncol;
+            flmr_toplist<NL> gt[KW];
+#pragma unroll
+            for (int k = 0; k < KW; k++) gt[k].init();
+            for (int g0 = 0; g0 < ngrp; g0 += 64 * 4) {
+                float gv4[KW][4];
+#pragma unroll
+                for (int k = 0; k < KW; k++)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int g = g0 + 64 * u + lane, col = wave + SC_WAVES * k;
+                        gv4[k][u] = (g < ngrp && col < nqc) ? grp[(size_t)g * a.ncol + col] : FLMR_NEG_INF;
+                    }
+#pragma unroll
+                for (int k = 0; k < KW; k++)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) gt[k].insert_ascending(gv4[k][u], (g0 + 64 * u + lane < ngrp) ? g0 + 64 * u + lane : 0x7fffffff);
+            }
+#pragma unroll
+            for (int k = 0; k < KW; k++)
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) gt[k].merge_xor(m);
+            constexpr int SW = (NL + 7) / 8;   // sweeps of eight groups
+            float bv[KW][SW];
+            int bi[KW][SW];
+#pragma unroll
+            for (int k = 0; k < KW; k++)
+#pragma unroll
+                for (int w = 0; w < SW; w++) {
+                    int gsel = 0x7fffffff;
+#pragma unroll
+                    for (int t = 0; t < NL; t++) gsel = (t == 8 * w + (lane >> 3)) ? gt[k].id[t] : gsel;
+                    const int col = wave + SC_WAVES * k;
+                    const bool ok = gsel < ngrp && col < nqc;
+                    bi[k][w] = ok ? gsel * G + (lane & 7) : 0x7fffffff;
+                    bv[k][w] = ok ? a.part_val[((size_t)b * a.nblk + bi[k][w]) * a.ncol + col] : FLMR_NEG_INF;
+                }
+#pragma unroll
+            for (int k = 0; k < KW; k++) {
+                cbt[k].init();
+#pragma unroll
+                for (int w = 0; w < SW; w++) cbt[k].insert(bv[k][w], bi[k][w]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KW; k++) {
+            if (wave + SC_WAVES * k >= nqc) break;
             const int col = wave + SC_WAVES * k;
             flmr_toplist<NL> bt;
             bt.init();
-            for (int e = lane; e < SC_WAVES * NL; e += 64) bt.insert(pre_v[e / NL][col][e % NL], pre_i[e / NL][col][e % NL]);
+            if (coarse) {
+                bt = cbt[k];
+            } else {
+                for (int e = lane; e < SC_WAVES * NL; e += 64) bt.insert(pre_v[e / NL][col][e % NL], pre_i[e / NL][col][e % NL]);
+            }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) bt.merge_xor(m);
             float gv = FLMR_NEG_INF;
