@@ -652,14 +652,16 @@ __global__ __launch_bounds__(512, 1) void s0_centroid_scores_qs(flmr_s0_args a, 
 // one register set for the A fragments, and -- the workgroup's eight waves being phase-locked by the block barrier -- makes
 // every tile an LDS phase (all waves fetch their fragments: 64 KB at 128 B/clk) FOLLOWED by an MFMA phase: the matrix pipe
 // measured 40 % busy.  Here a flagged (tile, query) only appends its index to a per-wave list; the main loop holds the hi
-// images, BOTH tiles' fragments of a block (requested together right after the barrier, so the second tile's fetch runs
-// under the first tile's MFMAs) and nothing else.  After the loop every wave works through its own list without any block
+// images and TWO fragment sets -- every tile's fragments are requested while the MFMAs of the tile before it run (the first
+// tile of the next step during this one: the barrier of step P certifies super-block P + 1) -- and nothing else; it also
+// leaves one column maximum per S0Q2_GRP blocks for the cell selection.  After the loop every wave works through its own list without any block
 // barrier: the queries' lo images are loaded then (the fragment registers are free), the tile's rows come straight from the
 // table into fragment layout, both products are recomputed with the same MFMA sequences -- the same bits -- and the dense
 // epilogue is the one above.  Block maxima (hi-only values, as s0_select_cells expects on this path) and idx words /
 // surviving rows are identical to the inline form.
-// grid = (ceil(nqueries / 16), slices <= 8192 rows each), block = 512;
-// dynamic LDS = 8 x 4.5 KB staging + S0Q_NBUF x 16 KB blocks + 8 x S0Q2_FCAP flagged-tile entries (u16).
+// grid = (ceil(nqueries / (2 S0Q2_WAVES)), slices <= 8192 rows each), block = 64 S0Q2_WAVES;
+// dynamic LDS = S0Q2_NBUF x S0Q2_SBT x 8 KB tile buffers (reused as 8 x 4.5 KB staging rows by the deferred pass) + S0Q2_WAVES x
+// S0Q2_FCAP flagged-tile entries (u16).
 // ------------------------------------------------------------------------------------------------
 #define S0Q2_MAX_SLICE_ROWS 8192
 #ifndef S0Q2_WAVES
