@@ -391,9 +391,13 @@ static int prepare_ctx(run_ctx& c, flmr_searcher* s, const float* Q, const int32
     a0.q_hi = s->q_hi; a0.q_lo = s->q_lo; a0.centroids_f16_exact = ix->centroids_f16_exact;
     // "hi first" stage 0: on unless the fp16 numerics mode makes it moot (q_lo = 0) or FLMR_S0_IMPL asks for another kernel
     a0.q_err_buf = f16num_early(s) ? nullptr : s->q_err;
-    // (batches under 16 queries keep both products in stage 0: the kernel is short there anyway, and the cell selection's redo pass --
-    // one near-tie column in most queries -- would add 10 % to the latency of a single-query call)
-    a0.q_err = (!f16num_early(s) && (!s->opt.has(FLMR_OPT_S0_IMPL) || s->opt.is(FLMR_OPT_S0_IMPL, "qs1")) && nqueries >= 16) ? s->q_err : nullptr;
+    // (any batch size since the cell selection reads the coarse level of maxima this path leaves: a single-query call takes 0.309 ms
+    // with it, 0.322 ms with both products everywhere; before the coarse level the selection's serial pass over a near-tie column
+    // -- most queries have one -- made the shortcut a loss under 16 queries)
+#ifndef S0_HIFIRST_MIN_QUERIES
+#define S0_HIFIRST_MIN_QUERIES 1
+#endif
+    a0.q_err = (!f16num_early(s) && (!s->opt.has(FLMR_OPT_S0_IMPL) || s->opt.is(FLMR_OPT_S0_IMPL, "qs1")) && nqueries >= S0_HIFIRST_MIN_QUERIES) ? s->q_err : nullptr;
     a0.q_err_sum = s->q_err_sum;
     a0.cen_norm_max = ix->cen_norm_max;
     a0.centroids_f16 = ix->centroids_f16;
