@@ -1377,7 +1377,7 @@ def test_s0_hi_first_equals_full_products(hip, ties):
         cen[64 * 5:64 * 6] = base                      # one exact copy: exact ties, the lower index must win
         corpus.centroids = cen.contiguous()
     scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=32)
-    Q, _ = synth.make_queries(corpus, 22, 32, seed=4)    # (>= 16 queries per call: below that stage 0 keeps both products)
+    Q, _ = synth.make_queries(corpus, 22, 32, seed=4)
     Q[3, 20:] = 0.0
     Q[7] *= 16.0                                                                  # FLMR's un-normalised visual tokens
     Q[8] *= torch.logspace(-3, 1.2, 32, device="cuda").unsqueeze(1)               # mixed magnitudes inside one query
