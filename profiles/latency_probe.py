@@ -1,6 +1,12 @@
 """p50 / p99 wall time of one search_batch call of 1, 8 and 32 queries on the bench corpus (launch + device sync included)."""
-import sys, time, statistics, torch
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ravqa_amd
 from ravqa_amd import synth
 from ravqa_amd.scorer import IndexScorer
