@@ -157,8 +157,8 @@ struct flmr_s0_args {
     // "hi first" stage 0 (sparse query-stationary path): the hi products alone give every score to within q_err[query][column];
     // the lo products are computed only for the tiles that can hold a surviving row, the block maxima stay hi-only and
     // s0_select_cells verifies its choice against that bound (flmr_stage0.hip).  q_err == NULL: both products everywhere.
-    float* q_err;            // [nqueries, ncol] rigorous bound on |c . q_lo| / 2048 (+ the combine's rounding), written by s0_q_err_kernel
-    float* q_err_buf;        // where s0_q_err_kernel writes (the sparse query-stationary path always fills it: stage 2's
+    float* q_err;            // [nqueries, ncol] rigorous bound on |c . q_lo| / 2048 (+ the combine's rounding), written by s0_prepare_kernel
+    float* q_err_buf;        // where s0_prepare_kernel writes (the sparse query-stationary path always fills it: stage 2's
                              // approximate-then-refine form reads it too); q_err == q_err_buf when stage 0 itself uses the bound
     float* q_err_sum;        // [nqueries] bound on |approximate - full| for a passage's stage-2 score (sum over the columns + summation rounding)
     float cen_norm_max;      // >= max_c ||c||_2

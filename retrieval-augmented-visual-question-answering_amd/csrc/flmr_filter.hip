@@ -1041,7 +1041,7 @@ int flmr_launch_sort_topn(const uint64_t* keys, int64_t key_stride, const int32_
 // ------------------------------------------------------------------------------------------------
 // Stage-2 survivor selection, approximate-then-refine (the default for whole batches on the sliced kernel).
 // The sliced kernel's hi products alone give every passage's stage-2 score to within E = err_sum[query] (flmr_stage0.hip:
-// s0_q_err_kernel) at 84 % of the full kernel's time.  With a* = the n-th largest approximate score, a passage with
+// s0_prepare_kernel) at 84 % of the full kernel's time.  With a* = the n-th largest approximate score, a passage with
 // a > a* + 2E is certainly among the n best by FULL score and one with a < a* - 2E certainly is not (full scores differ from
 // the approximate ones by <= E, and so does the n-th order statistic); only the band |a - a*| <= 2E (a few per cent of the
 // survivors) is rescored with both products by the gather kernel, and the n - #certain best of the band by full

@@ -990,29 +990,66 @@ int flmr_max_row_norm(const float* dev, int64_t rows, float* host_result) {
 // q_err_sum[query] bounds the difference between a passage's stage-2 score from hi-only column maxima and from the full ones:
 // per column |max_t s - max_t ah| <= err, plus what two k-ascending fp32 sums of <= 128 terms of magnitude <= ||c|| ||q|| can differ
 // by through rounding (2 * 127 * 2^-24 * sum |terms|).
-__global__ __launch_bounds__(64) void s0_q_err_kernel(const _Float16* __restrict__ q_hi, const _Float16* __restrict__ q_lo, int ncol,
-                                                      const int32_t* __restrict__ q_lens, int nq, int nq_cand, float cen_norm_max,
-                                                      float* __restrict__ q_err, float* __restrict__ q_err_sum) {
-    const int b = blockIdx.x;
+// (computed by s0_prepare_kernel below, together with the query images)
+
+// ------------------------------------------------------------------------------------------------
+// Everything the query-stationary stage-0 kernels need from a query, in ONE launch (one column tile: ncol == 32): the fp16
+// hi / lo images (s0_split_q), the per-column bounds of "hi first" and their per-query sum for stage 2 (the expressions above; the 128 squares of a column are summed by eight threads and a shuffle tree instead of one thread in dimension
+// order -- the bound's 1e-3 relative slack covers either order's rounding by two orders of magnitude), and the query's idx
+// words cleared (the kernels store a word only for a tile with a surviving row).  grid = nqueries, block = 256: thread t owns
+// dimensions 16 (t % 8) .. + 15 of column t / 8.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void s0_prepare_kernel(const float* __restrict__ Q, const int32_t* __restrict__ q_lens, int nq, int nq_cand,
+                                                         _Float16* __restrict__ q_hi, _Float16* __restrict__ q_lo, int hi_only,
+                                                         float cen_norm_max, float* __restrict__ q_err, float* __restrict__ q_err_sum,
+                                                         uint32_t* __restrict__ idx_bits, int idx_words) {
+    __shared__ float s_e[32], s_q[32];
+    const int b = blockIdx.x, t = threadIdx.x;
     const int qlen = q_lens ? q_lens[b] : nq;
     const int nqc = qlen < nq_cand ? qlen : nq_cand;
-    float esum = 0.0f, qmax = 0.0f;
-    for (int col = threadIdx.x; col < ncol; col += 64) {
-        const _Float16* ph = q_hi + ((size_t)b * ncol + col) * FLMR_DIM;
-        const _Float16* pl = q_lo + ((size_t)b * ncol + col) * FLMR_DIM;
-        float sl = 0.0f, sq = 0.0f;
-        for (int j = 0; j < FLMR_DIM; j++) {
-            const float l = (float)pl[j], x = fmaf(l, 1.0f / 2048.0f, (float)ph[j]);
-            sl = fmaf(l, l, sl);
-            sq = fmaf(x, x, sq);
-        }
-        const float e = cen_norm_max * (sqrtf(sl) * (1.001f / 2048.0f) + sqrtf(sq) * 2.5e-7f);
-        q_err[(size_t)b * ncol + col] = e;
-        if (col < nqc) { esum += e; qmax = fmaxf(qmax, sqrtf(sq)); }
-    }
+    const int col = t >> 3, d0 = 16 * (t & 7);
+    float v[16];
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { esum += __shfl_xor(esum, m, 64); qmax = fmaxf(qmax, __shfl_xor(qmax, m, 64)); }
-    if (threadIdx.x == 0 && q_err_sum) q_err_sum[b] = 1.01f * esum + 1.6e-5f * (float)nqc * cen_norm_max * qmax * 1.001f;
+    for (int j = 0; j < 16; j++) v[j] = 0.0f;
+    if (col < nqc) {
+        const float4* src = reinterpret_cast<const float4*>(Q + ((size_t)b * nq + col) * FLMR_DIM + d0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const float4 x = src[j]; v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w; }
+    }
+    f16x8 hv[2], lv[2];
+    float sl = 0.0f, sq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const _Float16 hi = (_Float16)v[j];
+        const _Float16 lo = hi_only ? (_Float16)0.0f : (_Float16)((v[j] - (float)hi) * 2048.0f);
+        hv[j >> 3][j & 7] = hi;
+        lv[j >> 3][j & 7] = lo;
+        const float l = (float)lo, x = fmaf(l, 1.0f / 2048.0f, (float)hi);
+        sl = fmaf(l, l, sl);
+        sq = fmaf(x, x, sq);
+    }
+    f16x8* ph = reinterpret_cast<f16x8*>(q_hi + ((size_t)b * 32 + col) * FLMR_DIM + d0);
+    f16x8* pl = reinterpret_cast<f16x8*>(q_lo + ((size_t)b * 32 + col) * FLMR_DIM + d0);
+    ph[0] = hv[0]; ph[1] = hv[1];
+    pl[0] = lv[0]; pl[1] = lv[1];
+    for (int w = t; w < idx_words; w += 256) idx_bits[(size_t)b * idx_words + w] = 0u;
+    if (q_err) {   // (block-uniform)
+#pragma unroll
+        for (int m = 4; m >= 1; m >>= 1) { sl += __shfl_xor(sl, m, 64); sq += __shfl_xor(sq, m, 64); }
+        const float e = cen_norm_max * (sqrtf(sl) * (1.001f / 2048.0f) + sqrtf(sq) * 2.5e-7f);
+        if ((t & 7) == 0) {
+            q_err[(size_t)b * 32 + col] = e;
+            s_e[col] = col < nqc ? e : 0.0f;
+            s_q[col] = col < nqc ? sqrtf(sq) : 0.0f;
+        }
+        __syncthreads();
+        if (t < 32) {
+            float esum = s_e[t], qmax = s_q[t];
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) { esum += __shfl_xor(esum, m, 64); qmax = fmaxf(qmax, __shfl_xor(qmax, m, 64)); }
+            if (t == 0 && q_err_sum) q_err_sum[b] = 1.01f * esum + 1.6e-5f * (float)nqc * cen_norm_max * qmax * 1.001f;
+        }
+    }
 }
 
 int flmr_convert_f16(const float* dev, size_t n, _Float16* out) {
@@ -1111,8 +1148,16 @@ static int launch_s0_t(flmr_s0_args& a, hipStream_t st, int impl) {
     a.grp_blocks = 0;
     a.part_rows = impl == S0_F16 ? 32 * S0_RT : 0;
     if (impl == S0_F16) {
-        hipLaunchKernelGGL(s0_split_q, dim3((a.ncol * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens,
-                           a.nq, a.nq_cand, a.ncol, a.q_hi, a.q_lo, a.q_hi_only);
+        const bool sparse_ = !a.full_table && a.ncol == 32 && !flmr_opts().has(FLMR_OPT_S0_STAGED);
+        const bool qs_ = sparse_ && a.centroids_f16 && (int64_t)a.K * 256 < (1ll << 32) && !flmr_opts().is(FLMR_OPT_S0_IMPL, "f16rs");
+        if (qs_) {   // images, bounds and cleared idx words in one launch
+            float* const eb = (a.q_err_buf && !a.q_hi_only) ? a.q_err_buf : nullptr;
+            hipLaunchKernelGGL(s0_prepare_kernel, dim3(a.nqueries), dim3(256), 0, st, a.Q, a.q_lens, a.nq, a.nq_cand, a.q_hi, a.q_lo,
+                               a.q_hi_only, a.cen_norm_max, eb, a.q_err_sum, a.idx_bits, a.idx_words);
+        } else {
+            hipLaunchKernelGGL(s0_split_q, dim3((a.ncol * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens,
+                               a.nq, a.nq_cand, a.ncol, a.q_hi, a.q_lo, a.q_hi_only);
+        }
         const size_t lds = (size_t)S0_WAVES * 32 * S0_LDS_STRIDE * sizeof(float) + (S0_DMA_B ? (size_t)2 * S0_DCH * 2 * 8192 : (size_t)S0_CH * 2 * 32 * S0_BROW * sizeof(_Float16));
         const bool sparse = !a.full_table && a.ncol == 32 && !flmr_opts().has(FLMR_OPT_S0_STAGED);
         const dim3 grid((a.nblk + S0_WAVES - 1) / S0_WAVES, qsplit), block(64 * S0_WAVES);
@@ -1130,11 +1175,7 @@ static int launch_s0_t(flmr_s0_args& a, hipStream_t st, int impl) {
             const int rows_per_slice = (int)flmr_round_up(flmr_ceil_div(a.K, slices), 64);
             slices = (int)flmr_ceil_div(a.K, rows_per_slice);
             const size_t ldsq = (size_t)8 * 32 * S0_LDS_STRIDE * sizeof(float) + (size_t)S0Q_NBUF * 2 * 8192;
-            // the kernel stores an idx word only for a tile with a surviving row
-            FLMR_HIP(hipMemsetAsync(a.idx_bits, 0, (size_t)a.nqueries * a.idx_words * sizeof(uint32_t), st));
-            if (a.q_err_buf && !a.q_hi_only)   // the bounds of this batch's queries (stage 0's own shortcut and stage 2's read them)
-                hipLaunchKernelGGL(s0_q_err_kernel, dim3(a.nqueries), dim3(64), 0, st, a.q_hi, a.q_lo, a.ncol, a.q_lens, a.nq, a.nq_cand,
-                                   a.cen_norm_max, a.q_err_buf, a.q_err_sum);
+            // (the idx words were cleared and the bounds of this batch's queries written by s0_prepare_kernel above)
             const bool inline_dense = flmr_opts().is(FLMR_OPT_S0_IMPL, "qs1");   // A/B: the form with the dense epilogue in the loop
             if ((a.q_hi_only || a.q_err) && !inline_dense && a.K % (32 * S0Q2_SBT) == 0) {
                 const size_t ldsq2 = (size_t)S0Q2_NBUF * S0Q2_SBT * 8192 + (size_t)S0Q2_WAVES * S0Q2_FCAP * sizeof(uint16_t);
