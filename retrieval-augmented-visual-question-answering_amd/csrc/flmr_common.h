@@ -295,6 +295,7 @@ struct flmr_maxsim_args {
     _Float16* q_hi;           // scratch [nqueries, round_up(nq,32), 128]: fp16 split of Q (nullable -> fp32 MFMA kernel)
     _Float16* q_lo;
     int32_t gpu_fp16;         // FLMR_NUMERICS_GPU_FP16: the reference's CUDA-path scoring (fp16 embeddings, -9999 padding, no clamp)
+    int32_t q_split_done;     // 1: q_hi / q_lo already hold this batch's images (stage 0 made the same ones: nq <= 32 <= nq_cand)
 };
 int flmr_launch_maxsim(const flmr_maxsim_args& a, hipStream_t st);
 

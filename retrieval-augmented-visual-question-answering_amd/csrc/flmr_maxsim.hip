@@ -1267,8 +1267,9 @@ static int launch_maxsim_f16_t(const flmr_maxsim_args& a, hipStream_t st) {
     const int nqp = (int)flmr_round_up(a.nq, 32);
     const size_t lds = (size_t)256 * (8 / NBITS) * sizeof(float) + (size_t)4 * nqp * sizeof(float);
     if (lds > 64 * 1024) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nq=%d too large for the MaxSim kernel's LDS column maxima", a.nq);
-    hipLaunchKernelGGL(s3_split_q, dim3((nqp * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens, a.nq, nqp,
-                       a.q_hi, a.q_lo);
+    if (!a.q_split_done)
+        hipLaunchKernelGGL(s3_split_q, dim3((nqp * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens, a.nq, nqp,
+                           a.q_hi, a.q_lo);
     // waves per query: enough to fill the chip, at most 64 documents per wave, at least 1
     int G = (int)flmr_ceil_div(4096, 4 * (int64_t)a.nqueries);
     const int gmin = (int)flmr_ceil_div(a.max_count, 4 * 64);

@@ -535,7 +535,8 @@ static int stage_s2_select(run_ctx& c) {
 }
 
 // S3 over s->s2_pids / s2_count -> s->keys3 / doc_scores (slot-aligned with s2_pids)
-static int stage_s3(run_ctx& c) {
+// `s0_images`: stage 0 of THIS call split the same queries (flmr_search_batch; not the phase entry points)
+static int stage_s3(run_ctx& c, bool s0_images) {
     flmr_searcher* s = c.s;
     flmr_maxsim_args m{};
     m.ix = s->ix; m.Q = c.Q; m.q_lens = c.q_lens; m.nqueries = c.nqueries; m.nq = c.nq;
@@ -543,6 +544,12 @@ static int stage_s3(run_ctx& c) {
     m.keys = s->keys3; m.key_stride = s->maxp.ndocs / 4; m.scores = s->doc_scores;
     m.q_hi = s->q3_hi; m.q_lo = s->q3_lo;
     m.gpu_fp16 = c.f.f16_round;
+    // Stage 0's fp16 images ARE stage 3's when every query row is a candidate-generation column (nq <= 32 <= nq_cand): rows
+    // below min(q_len, nq) real, the rest zero, one tile of 32 -- no second split launch
+    if (s0_images && c.sparse && !c.f.f16_round && c.nq <= 32 && c.nqc == c.nq && c.ncol == 32) {
+        m.q_hi = s->q_hi; m.q_lo = s->q_lo;
+        m.q_split_done = 1;
+    }
     return flmr_launch_maxsim(m, c.st);
 }
 
@@ -558,7 +565,7 @@ extern "C" int flmr_search_batch(flmr_searcher_t* s, const float* Q, const int32
     RUN(stage_s2_select(c));
     RUN(mark(c));
     // ---- S3: decompress + normalise + MaxSim --------------------------------------------------------
-    RUN(stage_s3(c));
+    RUN(stage_s3(c, true));
     RUN(mark(c));
     // ---- S4: final ranking, global pids ---------------------------------------------------------------
     RUN(flmr_launch_sort_topn(s->keys3, s->maxp.ndocs / 4, s->s2_count, p->ndocs / 4, nqueries, p->k, out_pids,
@@ -660,7 +667,7 @@ extern "C" int flmr_search_phase3(flmr_searcher_t* s, const float* Q, const int3
     if (n_in > p->ndocs / 4) FLMR_FAIL(FLMR_ERR_INVALID, "n_in=%d > ndocs/4=%d", n_in, p->ndocs / 4);
     RUN(flmr_launch_filter_local_keys(global_s2, nqueries, n_in, s->ix->pid_base, s->ix->num_passages, s->s2_pids,
                                       s->maxp.ndocs / 4, s->s2_count, c.st, s->s2_slot));
-    RUN(stage_s3(c));
+    RUN(stage_s3(c, false));
     return flmr_launch_export_keys_slotted(s->keys3, s->maxp.ndocs / 4, s->s2_count, s->s2_slot, nqueries,
                                            (uint64_t)s->ix->pid_base, p->ndocs / 4, out_keys, c.st);
 }
