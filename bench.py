@@ -422,7 +422,7 @@ def main():
             nqs = min(args.cpu_queries, args.batch)
             all_threads = torch.get_num_threads()
             if orc.ref_available():
-                ref = orc.RefCpuScorer(oi)
+                ref = orc.RefCpuScorer(oi, threads=0)   # 0: leave torch's thread count alone (timed at all threads, then at 8)
                 ref.rank(Qh[0], ncells, thr, ndocs)   # warm
                 t0_ = time.perf_counter()
                 res = [ref.rank(Qh[i], ncells, thr, ndocs) for i in range(nqs)]

@@ -250,9 +250,17 @@ class RefCpuScorer:
     """IndexScorer.rank with the reference's compiled C++ stages and torch-CPU ops for the Python glue
     (TPC/search/index_storage.py:86-182, candidate_generation.py:12-64, colbert.py:289-311)."""
 
-    def __init__(self, oi: OracleIndex):
+    # The reference ops spawn at::get_num_threads() pthreads per call (filter_pids.cpp:85-104); on a 256-thread host the
+    # default is ~9x slower than 8 threads (bench.py cpu_baseline.value_all_threads), and results are bit-identical for any
+    # thread count (SURVEY 8c), so the checker pins itself to 8 unless told otherwise.
+    THREADS = int(os.environ.get("FLMR_REF_THREADS", "8"))
+
+    def __init__(self, oi: OracleIndex, threads=None):
         import torch
         self.t = torch
+        threads = self.THREADS if threads is None else threads
+        if threads > 0 and torch.get_num_threads() != threads:
+            torch.set_num_threads(threads)
         self.codes = torch.from_numpy(oi.codes)
         self.residuals = torch.from_numpy(oi.residuals)
         self.doclens = torch.from_numpy(oi.doclens)
