@@ -16,7 +16,8 @@ SOURCES = ["flmr_index.hip", "flmr_stage0.hip", "flmr_candidates.hip", "flmr_fil
 HEADERS = ["flmr_common.h", "flmr_device.h"]
 
 FLMR_MEM_HOST, FLMR_MEM_DEVICE = 0, 1
-(TAP_CENTROID_SCORES, TAP_IDX_BITS, TAP_CELLS, TAP_CANDIDATES, TAP_STAGE1, TAP_STAGE2, TAP_DOC_SCORES) = range(7)
+(TAP_CENTROID_SCORES, TAP_IDX_BITS, TAP_CELLS, TAP_CANDIDATES, TAP_STAGE1, TAP_STAGE2, TAP_DOC_SCORES, TAP_Q_ERR,
+ TAP_Q_ERR_SUM) = range(9)
 NUM_STAGES = 9
 ABI_VERSION = 3
 
@@ -189,6 +190,13 @@ def load(require_device=True):
         if rc != 0 or n.value < 1:
             raise FlmrNativeError("no MI355X / HIP device visible: " + _lib.flmr_last_error().decode())
     return _lib
+
+
+def device_visible():
+    """True when the library loads AND reports at least one HIP device (a missing / mismatching library still raises)."""
+    lib = load(require_device=False)
+    n = C.c_int(0)
+    return lib.flmr_device_count(C.byref(n)) == 0 and n.value >= 1
 
 
 options_epoch = 0  # bumped by set_option(): IndexScorer re-creates its native searcher so the new switches apply

@@ -6,11 +6,17 @@
 // already loaded in the process (the one that created the caller's ncclComm_t -- mixing two RCCL instances would not
 // work), falling back to a regular dlopen of librccl.so.1.  A process that never calls these functions never loads RCCL.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <mutex>
 
 #include "flmr_common.h"
+
+// The handful of RCCL / NCCL ABI names this file needs, declared here so that building libflmr_hip.so does not require the
+// RCCL headers (the symbols themselves come from the process at run time).  Values are those of nccl.h (stable since NCCL 2).
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt32 = 2, ncclUint64 = 5, ncclFloat32 = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
 
 namespace {
 struct rccl_api {
@@ -86,10 +92,14 @@ extern "C" int flmr_topk_allgather(void* comm, int32_t nranks, const float* scor
     ncclComm_t c = reinterpret_cast<ncclComm_t>(comm);
     const size_t n = (size_t)nqueries * k;
     // one fused launch for the two arrays (they travel together: 8 bytes per result)
+    // (the group is ALWAYS closed: returning between start and end would leave it open and wedge the caller's next collective;
+    // the first error is the one reported)
     FLMR_RCCL(api, api->group_start());
-    FLMR_RCCL(api, api->all_gather(scores, gathered_scores, n, ncclFloat32, c, st));
-    FLMR_RCCL(api, api->all_gather(pids, gathered_pids, n, ncclInt32, c, st));
-    FLMR_RCCL(api, api->group_end());
+    ncclResult_t first = api->all_gather(scores, gathered_scores, n, ncclFloat32, c, st);
+    if (first == ncclSuccess) first = api->all_gather(pids, gathered_pids, n, ncclInt32, c, st);
+    const ncclResult_t ended = api->group_end();
+    if (first == ncclSuccess) first = ended;
+    if (first != ncclSuccess) FLMR_FAIL(FLMR_ERR_HIP, "ncclAllGather (top-k exchange) -> %s", api->error_string(first));
     return flmr_merge_topk(gathered_scores, gathered_pids, nranks, nqueries, k, out_scores, out_pids, out_counts, stream);
 }
 

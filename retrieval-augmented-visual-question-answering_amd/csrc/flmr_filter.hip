@@ -1054,8 +1054,7 @@ __global__ __launch_bounds__(1024) void s2_refine_plan_kernel(const uint64_t* ke
                                                               int64_t band_stride, int32_t* band_count, int32_t* need,
                                                               int32_t* def_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);
-    __shared__ int bounds[2];
+    unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);   // (no static LDS: npow2 = 8192 takes all 64 KB)
     const int b = blockIdx.x, tid = threadIdx.x;
     const int cnt = counts[b];
     for (int i = tid; i < npow2; i += blockDim.x) s[i] = (i < cnt) ? keys[(size_t)b * key_stride + i] : 0ull;
@@ -1066,19 +1065,17 @@ __global__ __launch_bounds__(1024) void s2_refine_plan_kernel(const uint64_t* ke
         if (tid == 0) { band_count[b] = 0; need[b] = 0; def_count[b] = cnt; }
         return;
     }
-    if (tid == 0) {
-        const float astar = flmr_key_score(s[n - 1]), E2 = 2.0f * err_sum[b];
-        const float hi = astar + E2, lo = astar - E2;
-        // sorted descending: i0 = #keys with score > hi (certainly in), i1 = #keys with score >= lo (not certainly out)
-        int a = 0, z = n - 1;             // score(s[n-1]) = a* <= hi, so i0 <= n - 1
-        while (a < z) { const int mid = (a + z) >> 1; if (flmr_key_score(s[mid]) > hi) a = mid + 1; else z = mid; }
-        bounds[0] = a;
-        a = n; z = cnt;                   // score(s[n-1]) = a* >= lo, so i1 >= n
-        while (a < z) { const int mid = (a + z) >> 1; if (flmr_key_score(s[mid]) >= lo) a = mid + 1; else z = mid; }
-        bounds[1] = a;
-    }
-    __syncthreads();
-    const int i0 = bounds[0], i1 = bounds[1];
+    // every thread runs the two searches itself (same addresses across the block: LDS broadcasts, no barrier, no shared pair).
+    // The band edges are rounded OUTWARD: a* +- 2E evaluated in fp32 may land an ulp inside the exact interval.
+    const float astar = flmr_key_score(s[n - 1]), E2 = 2.0f * err_sum[b];
+    const float hi = nextafterf(astar + E2, INFINITY), lo = nextafterf(astar - E2, -INFINITY);
+    // sorted descending: i0 = #keys with score > hi (certainly in), i1 = #keys with score >= lo (not certainly out)
+    int a = 0, z = n - 1;             // score(s[n-1]) = a* <= hi, so i0 <= n - 1
+    while (a < z) { const int mid = (a + z) >> 1; if (flmr_key_score(s[mid]) > hi) a = mid + 1; else z = mid; }
+    const int i0 = a;
+    a = n; z = cnt;                   // score(s[n-1]) = a* >= lo, so i1 >= n
+    while (a < z) { const int mid = (a + z) >> 1; if (flmr_key_score(s[mid]) >= lo) a = mid + 1; else z = mid; }
+    const int i1 = a;
     for (int i = tid; i < i0; i += blockDim.x) out_pids[(size_t)b * out_stride + i] = flmr_key_pid(s[i]);
     for (int i = tid; i < i1 - i0; i += blockDim.x) band_pids[(size_t)b * band_stride + i] = flmr_key_pid(s[i0 + i]);
     if (tid == 0) { band_count[b] = i1 - i0; need[b] = n - i0; def_count[b] = i0; }

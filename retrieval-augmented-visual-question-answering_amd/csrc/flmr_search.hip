@@ -40,6 +40,7 @@ struct flmr_searcher {
     int32_t last_nqueries, last_ncol, last_ndocs, last_full_table;
     flmr_cand_args last_ca{};   // candidate-stage arguments of the last batch (lazy FLMR_TAP_CANDIDATES in scatter mode)
     bool last_scatter = false;
+    bool last_hi_first = false; // the last batch's stage 0 wrote q_err / q_err_sum (FLMR_TAP_Q_ERR*)
     hipStream_t last_stream;
     bool profiling;
     bool full_table;  // keep the whole centroid-score table (needed by the CENTROID_SCORES tap / retrieve())
@@ -410,6 +411,7 @@ static int prepare_ctx(run_ctx& c, flmr_searcher* s, const float* Q, const int32
     f.f16_round = f16num ? 1 : 0;
     s->last_nqueries = nqueries; s->last_ncol = ncol; s->last_ndocs = p->ndocs; s->last_stream = c.st;
     s->last_full_table = a0.full_table;
+    s->last_hi_first = c.sparse && a0.q_err_buf != nullptr && (int64_t)ix->K * 256 < (1ll << 32) && !s->opt.is(FLMR_OPT_S0_IMPL, "f16rs");
     return FLMR_OK;
 }
 
@@ -738,6 +740,10 @@ extern "C" int flmr_searcher_tap(flmr_searcher_t* s, int32_t what, int32_t q, vo
         case FLMR_TAP_DOC_SCORES:
             FLMR_HIP(hipMemcpy(&c, s->s2_count + q, 4, hipMemcpyDeviceToHost));
             n = c; src = s->doc_scores + (size_t)q * nd4; break;
+        case FLMR_TAP_Q_ERR:
+            n = s->last_hi_first ? 32 : 0; src = s->q_err + (size_t)q * s->ncol_max; break;
+        case FLMR_TAP_Q_ERR_SUM:
+            n = s->last_hi_first ? 1 : 0; src = s->q_err_sum + q; break;
         default: FLMR_FAIL(FLMR_ERR_INVALID, "unknown tap %d", what);
     }
     *count = n;

@@ -2,6 +2,7 @@
 (TPC/data/queries.py:11-48, TPC/data/ranking.py:25-55, TPC/data/collection.py, TPC/infra/provenance.py).
 Plain containers: dict in, dict out.  File formats: tab-separated `qid<TAB>text` queries and
 `qid<TAB>pid<TAB>rank<TAB>score` rankings, as the reference reads / writes them."""
+from collections.abc import Sequence as _Sequence
 import inspect
 import os
 
@@ -74,6 +75,96 @@ class Queries:
         if isinstance(obj, cls):
             return obj
         raise AssertionError(f"obj has type {type(obj)} which is not compatible with cast()")
+
+
+class RankedList(_Sequence):
+    """One query's ranked list, `[(pid, rank, score), ...]` (searcher.py:81-89, :132: ranks are 1..k), as a read-only sequence over
+    two numpy rows of the bulk device->host copy.  Tuples are built when they are READ -- an element, a slice, an iteration --
+    and hold the same Python ints / floats `Tensor.tolist()` gives (float32 widened).  Building 1024 x 100 tuples eagerly costs
+    10 ms per 1024 queries, more than the whole device path (7 ms): a caller that reads `ranking.todict()[qid][:5]` never pays it.
+    Compares equal to the list of tuples it stands for; `+` and slicing return plain lists."""
+    __slots__ = ("_p", "_s", "_rows")
+
+    def __init__(self, pids, scores):
+        self._p, self._s, self._rows = pids, scores, None
+
+    def _all(self):
+        if self._rows is None:
+            self._rows = list(zip(self._p.tolist(), range(1, len(self._p) + 1), self._s.tolist()))
+        return self._rows
+
+    def __len__(self):
+        return len(self._p)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            start, stop, step = i.indices(len(self._p))
+            if self._rows is None and step == 1:     # the common read: a prefix
+                stop = max(stop, start)
+                return list(zip(self._p[start:stop].tolist(), range(start + 1, stop + 1), self._s[start:stop].tolist()))
+            return self._all()[i]
+        if self._rows is not None:
+            return self._rows[i]
+        n = len(self._p)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("ranked list index out of range")
+        return (int(self._p[i]), i + 1, float(self._s[i]))
+
+    def __iter__(self):
+        return iter(self._all())
+
+    def __eq__(self, other):
+        if isinstance(other, RankedList):
+            other = other._all()
+        return isinstance(other, (list, tuple)) and self._all() == list(other)
+
+    __hash__ = None
+
+    def __add__(self, other):
+        return self._all() + list(other)
+
+    def __radd__(self, other):
+        return list(other) + self._all()
+
+    def __repr__(self):
+        return repr(self._all())
+
+    def tolist(self):
+        return list(self._all())
+
+
+def ranked_lists(pids, scores, counts):
+    """numpy [n, k] pids / scores + counts -> [RankedList] (rows cut to their count)."""
+    return [RankedList(pids[i, :c], scores[i, :c]) for i, c in enumerate(counts)]
+
+
+def lazy_flat_ranking(base):
+    """A subclass of a Ranking class (this package's or the reference's `colbert.data.Ranking`, ranking.py:25-55) whose
+    `flat_ranking` -- [(qid, pid, rank, score)] over all queries, which the reference builds in its constructor -- is built on
+    first use (`tolist()` / `save()`): the executors read `todict()` only (FLMR_executor.py:794).  Same name, module and
+    behaviour otherwise; `isinstance(r, base)` holds."""
+    class Ranking(base):
+        def _prepare_data(self, data):
+            if isinstance(data, dict):
+                self._lazy_flat = None
+                return data
+            return super()._prepare_data(data)
+
+        @property
+        def flat_ranking(self):
+            if self.__dict__.get("_lazy_flat") is None:
+                self._lazy_flat = [(qid, *rest) for qid, sub in self.data.items() for rest in sub]
+            return self._lazy_flat
+
+        @flat_ranking.setter
+        def flat_ranking(self, value):
+            self._lazy_flat = value
+
+    Ranking.__module__, Ranking.__qualname__, Ranking.__doc__ = base.__module__, base.__qualname__, base.__doc__
+    Ranking.reference_class = base
+    return Ranking
 
 
 class Ranking:

@@ -28,6 +28,7 @@ search (`src/executors/FLMR_executor.py:833`) and the RAG re-scoring (`src/model
 reaches the MI355X kernel in a drop-in run, while training (in-batch negatives under autograd) is untouched.
 """
 import importlib
+import warnings
 import sys
 
 _saved = []          # [(object, attribute name, previous value or _MISSING)]
@@ -74,23 +75,43 @@ def make_colbert_score_dispatch(reference_colbert_score):
     HIP path (flmr_colbert_score_padded: fp16-split MFMA, -9999 padding, no clamp, fp32 accumulation) when the call is
     forward-only -- grad mode off, or no input requires grad -- and the shape is the kernel's ('colbert' interaction,
     3-D Q / D with Q.size(0) in {1, B}, floating inputs).  Everything else -- autograd (training), 'flipr', odd ranks --
-    goes to the reference's own expression, unchanged.  There is NO host fallback for the forward-only case: without
-    libflmr_hip.so / a HIP device the call raises FlmrNativeError.  The result has D_padded's dtype and lives where the
+    goes to the reference's own expression, unchanged.
+
+    This function replaces a GLOBAL of the caller's package, so it must not break flows that never had a GPU: when NO HIP
+    device is visible in the process (a CPU-only validation run of the reference) the call is not intercepted at all -- it
+    goes to the reference's expression, with one RuntimeWarning.  With a device visible there is no host fallback: a missing
+    or broken libflmr_hip.so raises FlmrNativeError.  (The search path -- Searcher / IndexScorer -- never passes through.)
+
+    Arithmetic: as in the reference Q is first rounded to D_padded's dtype (colbert.py:280: `Q.to(dtype=D_padded.dtype)`);
+    the products of those values are then exact and accumulated in fp32, and only the final per-passage score is rounded to
+    D_padded's dtype -- for half / bf16 inputs the reference rounds the [B, Ld, Nq] score matrix and the column sums as well,
+    so scores can differ from it in the last fp16 / bf16 digit (fp32 inputs: within 1e-4, tests).  The result lives where the
     reference would have put it (the inputs' device; cuda when use_gpu)."""
     import torch
+    state = {"warned": False}
+
+    def reference(Q, D_padded, D_mask, config, use_gpu):
+        if config is None:
+            return reference_colbert_score(Q, D_padded, D_mask, use_gpu=use_gpu)
+        return reference_colbert_score(Q, D_padded, D_mask, config=config, use_gpu=use_gpu)
 
     def colbert_score(Q, D_padded, D_mask, config=None, use_gpu=False):
-        from . import ops
+        from . import _native, ops
         interaction = getattr(config, "interaction", "colbert") if config is not None else "colbert"
         forward_only = not (torch.is_grad_enabled() and (Q.requires_grad or D_padded.requires_grad))
         shape_ok = (torch.is_tensor(Q) and torch.is_tensor(D_padded) and Q.dim() == 3 and D_padded.dim() == 3
                     and Q.size(0) in (1, D_padded.size(0)) and Q.size(-1) == D_padded.size(-1)
                     and Q.is_floating_point() and D_padded.is_floating_point() and D_padded.size(0) > 0 and D_padded.size(1) > 0)
         if not (forward_only and shape_ok and interaction == "colbert"):
-            if config is None:
-                return reference_colbert_score(Q, D_padded, D_mask, use_gpu=use_gpu)
-            return reference_colbert_score(Q, D_padded, D_mask, config=config, use_gpu=use_gpu)
-        out = ops.colbert_score_padded(Q.detach(), D_padded.detach(), D_mask)      # f32 on the device
+            return reference(Q, D_padded, D_mask, config, use_gpu)
+        if not _native.device_visible():
+            if not state["warned"]:
+                state["warned"] = True
+                warnings.warn("ravqa_amd: no HIP device is visible in this process -- colbert_score calls are left to the "
+                              "reference's torch expression (the HIP scorer takes them when a device is present)", RuntimeWarning)
+            return reference(Q, D_padded, D_mask, config, use_gpu)
+        Qr = Q.detach().to(dtype=D_padded.dtype)                                   # colbert.py:280
+        out = ops.colbert_score_padded(Qr, D_padded.detach(), D_mask)              # f32 on the device
         dev = torch.device("cuda") if use_gpu else D_padded.device
         return out.to(device=dev, dtype=D_padded.dtype)
 
@@ -165,9 +186,11 @@ def install(level="searcher", package="colbert", require_device=False, scoring=T
     except (ImportError, AttributeError):   # text encoding is optional on the search path
         checkpoint_cls = None
     reference_searcher = searcher_mod.Searcher
+    from .data import lazy_flat_ranking
 
+    # (Ranking: the reference's class with its eager flat list deferred -- a subclass, so isinstance / save / tolist hold)
     bound = {"ColBERTConfig": infra.ColBERTConfig, "Run": infra.Run, "Collection": data.Collection,
-             "Queries": data.Queries, "Ranking": data.Ranking, "Provenance": prov.Provenance,
+             "Queries": data.Queries, "Ranking": lazy_flat_ranking(data.Ranking), "Provenance": prov.Provenance,
              "IndexScorer": IndexScorer, "Checkpoint": checkpoint_cls, "reference_class": reference_searcher,
              "__doc__": "colbert.Searcher running on libflmr_hip.so (installed by ravqa_amd.install())",
              "__module__": package + ".searcher"}

@@ -71,10 +71,10 @@ class IndexScorer:
 
     def __init__(self, index_path=None, use_gpu=True, arrays: IndexArrays = None, device_index: DeviceIndex = None,
                  max_batch=256, streams=1, numerics=None):
-        """numerics: "cpu" (default; FLMR_NUMERICS env overrides the default) = the reference's CPU-path arithmetic, the
+        """numerics: "cpu" (default; FLMR_NUMERICS=gpu-fp16 overrides the default) = the reference's CPU-path arithmetic, the
         pinned claim; "gpu-fp16" = the reference's CUDA-path arithmetic (fp16 scores / embeddings, -9999 padding, no
-        clamp: index_storage.py:113-158) -- what `Searcher` selects when the caller's config assigns
-        total_visible_gpus > 0, as FLMR_executor.py:784 does on a single GPU.  Either way everything runs on the MI355X.
+        clamp: index_storage.py:113-158) -- opt-in (see `Searcher`); an index that mode cannot serve (centroids not
+        fp16-representable, K % 64 != 0) falls back to "cpu" with a warning.  Either way everything runs on the MI355X.
         max_batch: queries per native call (one workspace holds that many); a larger batch is cut into sub-batches.
         streams: the sub-batches of one search_batch call are dealt round-robin to this many native searchers, each on
         its own HIP stream, joined with the caller's stream at both ends.  Default 1: with the join a stream-ordered call
@@ -84,7 +84,8 @@ class IndexScorer:
         if arrays is None and device_index is None:
             arrays = load_index_arrays(index_path)
         import os
-        self.numerics = numerics or os.environ.get("FLMR_NUMERICS") or "cpu"
+        env = os.environ.get("FLMR_NUMERICS")
+        self.numerics = numerics or (env if env in self.NUMERICS else None) or "cpu"   # ("reference" is resolved by Searcher)
         if self.numerics not in self.NUMERICS:
             raise ValueError(f"numerics must be one of {sorted(self.NUMERICS)}, got {self.numerics!r}")
         self.index_path = index_path
@@ -92,6 +93,13 @@ class IndexScorer:
         self.arrays = arrays if arrays is not None else device_index.arrays
         self.device_index = device_index or DeviceIndex(self.arrays)
         self._lib = _native.load(require_device=True)
+        if self.numerics == "gpu-fp16":
+            info = self.device_index.info()
+            if not (info["centroids_f16_exact"] and self.arrays.num_centroids % 64 == 0):
+                import warnings
+                warnings.warn("ravqa_amd: this index cannot run the gpu-fp16 numerics mode (it needs fp16-representable centroids "
+                              "and K % 64 == 0); using the CPU-path arithmetic (numerics='cpu') instead", RuntimeWarning)
+                self.numerics = "cpu"
         self.max_batch = int(max_batch)
         self._searcher = None       # slot 0: the only one single-chunk calls, the phased protocol and taps use
         self._searcher_key = None
@@ -307,9 +315,10 @@ class IndexScorer:
         K = self.arrays.num_centroids
         cap = {_native.TAP_CENTROID_SCORES: K * 128, _native.TAP_IDX_BITS: (K + 31) // 32,
                _native.TAP_CELLS: 1024, _native.TAP_CANDIDATES: self.arrays.num_passages,
-               _native.TAP_STAGE1: 8192, _native.TAP_STAGE2: 2048, _native.TAP_DOC_SCORES: 2048}[what]
-        dt = {_native.TAP_CENTROID_SCORES: np.float32, _native.TAP_IDX_BITS: np.uint32,
-              _native.TAP_DOC_SCORES: np.float32}.get(what, np.int32)
+               _native.TAP_STAGE1: 8192, _native.TAP_STAGE2: 2048, _native.TAP_DOC_SCORES: 2048,
+               _native.TAP_Q_ERR: 32, _native.TAP_Q_ERR_SUM: 1}[what]
+        dt = {_native.TAP_CENTROID_SCORES: np.float32, _native.TAP_IDX_BITS: np.uint32, _native.TAP_DOC_SCORES: np.float32,
+              _native.TAP_Q_ERR: np.float32, _native.TAP_Q_ERR_SUM: np.float32}.get(what, np.int32)
         buf = np.empty(max(cap, 1), dtype=dt)
         cnt = C.c_int64(0)
         _native.check(self._lib.flmr_searcher_tap(self._tap_from or self._searcher, what, query, buf.ctypes.data, cap, C.byref(cnt)))

@@ -17,11 +17,17 @@ Boundary value types are class attributes (`ColBERTConfig`, `Run`, `Collection`,
 derives a subclass bound to the reference package's classes, so that inside the RA-VQA executors the objects that
 go in (`ColBERTConfig`, `Queries`, the `Run()` context) and come out (`Ranking`, `.config`) ARE the reference's.
 
-Numerics: `config.total_visible_gpus == 0` selects the reference's CPU-path numerics (fp32, zero-clamped MaxSim) --
-it does NOT mean "stay on the host", the HIP path always runs.  `total_visible_gpus > 0` selects the reference's
-CUDA-path numerics in the reference (fp16 centroids / embeddings, -9999 padding, `index_storage.py:113-149`); see
-`IndexScorer` for how this build treats that request.
+Numerics: the DEFAULT is the reference's CPU-path arithmetic (fp32, zero-clamped MaxSim) whatever
+`config.total_visible_gpus` says -- it is the arithmetic the golden vectors pin, and `total_visible_gpus == 0` never
+meant "stay on the host" here: the HIP path always runs.  In the reference `total_visible_gpus > 0` selects its CUDA
+branch (fp16 centroids / embeddings, -9999 padding, `index_storage.py:113-149`).  This build has that arithmetic as a mode
+("gpu-fp16"), checked against the reference's expressions on CPU half tensors but NOT against its CUDA kernels, so it is
+opt-in: `Searcher(..., numerics="reference")` or `FLMR_NUMERICS=reference` follows the reference's selection (gpu-fp16 when
+the caller assigned total_visible_gpus > 0, as FLMR_executor.py:784 does on one GPU), `numerics="gpu-fp16"` forces it,
+`"cpu"` (default) keeps the pinned arithmetic.  An index the fp16 mode cannot serve (centroids not fp16-representable, K not
+a multiple of 64) falls back to "cpu" with a warning.  The chosen mode is logged (logger "ravqa_amd") and kept in `.numerics`.
 """
+import logging
 import os
 import warnings
 
@@ -44,7 +50,7 @@ class Searcher:
     Checkpoint = None   # the reference's colbert.modeling.checkpoint.Checkpoint when installed over the reference package
 
     def __init__(self, index, checkpoint=None, collection=None, config=None, disable_gpu=True, query_encoder=None,
-                 max_batch=256):
+                 max_batch=256, numerics=None):
         cfg_cls = self.ColBERTConfig
         initial_config = cfg_cls.from_existing(config, self.Run().config)
         if config is not None:  # searcher.py:27 (the reference dereferences `config` unconditionally)
@@ -59,14 +65,20 @@ class Searcher:
         self.query_encoder = query_encoder
         self._checkpoint_model = None
         use_gpu = (self.config.total_visible_gpus or 0) > 0
-        # searcher.py:42-45: total_visible_gpus > 0 selects the reference's CUDA branch.  When the CALLER assigned it (the
-        # executor does on a single GPU, FLMR_executor.py:784) this build runs that branch's arithmetic ("gpu-fp16": fp16
-        # centroid scores and embeddings, -9999 padding, no clamp; index_storage.py:113-158) so a 1-GPU run ranks like the
-        # reference's 1-GPU run; a value that is merely the config default keeps the CPU-path arithmetic, which is what
-        # total_visible_gpus = 0 (every multi-GPU run, FLMR_executor.py:779-781) means and what the golden vectors pin.
+        # searcher.py:42-45: total_visible_gpus > 0 selects the reference's CUDA branch.  Here that arithmetic is an opt-in
+        # mode (module docstring): "reference" follows the reference's selection when the CALLER assigned the value (the
+        # executor does on a single GPU, FLMR_executor.py:784; a mere config default does not count), "gpu-fp16" forces it,
+        # "cpu" -- the default, what total_visible_gpus = 0 (every multi-GPU run, FLMR_executor.py:779-781) means and what
+        # the golden vectors pin -- keeps the CPU-path arithmetic.
+        requested = numerics or os.environ.get("FLMR_NUMERICS") or "cpu"
+        if requested not in ("cpu", "gpu-fp16", "reference"):
+            raise ValueError(f"numerics must be 'cpu', 'gpu-fp16' or 'reference', got {requested!r}")
         explicit = config is not None and "total_visible_gpus" in getattr(config, "assigned", {})
-        self.numerics = "gpu-fp16" if (use_gpu and explicit) else "cpu"
-        self.ranker = self.IndexScorer(self.index, use_gpu, max_batch=max_batch, numerics=self.numerics)
+        mode = ("gpu-fp16" if (use_gpu and explicit) else "cpu") if requested == "reference" else requested
+        self.ranker = self.IndexScorer(self.index, use_gpu, max_batch=max_batch, numerics=mode)
+        self.numerics = getattr(self.ranker, "numerics", mode) or mode    # (the scorer falls back to "cpu" where fp16 is unsupported)
+        logging.getLogger("ravqa_amd").info("Searcher(%s): numerics %s (requested %s, total_visible_gpus=%s)", self.index,
+                                            self.numerics, requested, self.config.total_visible_gpus)
 
     def _cast_collection(self, obj):
         """Collection.cast, but lazy: the search path never reads passage text, so a missing / unset collection is not
@@ -133,21 +145,23 @@ class Searcher:
         return Qc, lens
 
     @staticmethod
-    def ranking_lists(pids, scores, counts, k):
+    def ranking_lists(pids, scores, counts, k, lazy=True):
         """Device results [n, k] -> the Ranking layout [[(pid, rank, score)] * count] (searcher.py:81-89, :132: ranks are 1..k).
-        One bulk transfer + one tolist per array: converting row by row costs 0.14 ms per query in tensor slicing alone --
-        more than the whole device path (7 us per query)."""
+        One bulk transfer per array; each query's list is a `data.RankedList` over its two numpy rows, which builds the tuples
+        when they are read (lazy=False: plain lists now, built by a structured array's tolist() -- 10 ms per 1024 x 100, more than
+        the device path's 7 ms, which is why it is no longer what `_search_all_Q` does)."""
         import numpy as np
         P, S, C = pids.cpu().numpy(), scores.cpu().numpy(), counts.cpu().tolist()
         if P.ndim != 2 or P.shape[1] == 0:
             return [[] for _ in C]
-        # the tuples are built in C by a structured array's tolist() (15 ms per 1024 x 100 against 23 ms for zip over three
-        # lists); values are the same Python ints / floats (float32 widened, as Tensor.tolist() gives them)
+        C = [min(max(int(n), 0), P.shape[1]) for n in C]
+        if lazy:
+            return _data.ranked_lists(P, S, C)
         rec = np.empty(P.shape, dtype=[("pid", np.int32), ("rank", np.int32), ("score", np.float32)])
         rec["pid"], rec["score"] = P, S
         rec["rank"] = np.arange(1, P.shape[1] + 1, dtype=np.int32)
         rows = rec.tolist()
-        return [row if n >= len(row) else row[:max(n, 0)] for row, n in zip(rows, C)]
+        return [row if n >= len(row) else row[:n] for row, n in zip(rows, C)]
 
     # ---- embedding entry points -----------------------------------------------------------------------------------
     def _search_all_Q(self, queries, Q, k, filter_fn=None, progress=True, remove_zero_tensors=False):

@@ -89,9 +89,14 @@ with Run().context(RunConfig(nranks=1, rank=0, root=TMP, experiment="temp_index_
     assert calls[1] == ("search_batch", (2, 32, 128), 5, 2, 0.45, 1024, 32), calls
     assert searcher.config.ndocs == 1024                                 # the policy is sticky on the config (searcher.py:92-118)
     assert searcher.ranker.numerics == "cpu"                             # total_visible_gpus=0: the CPU-path arithmetic
-    # FLMR_executor.py:784 on a single GPU: total_visible_gpus=1 -> the reference's CUDA-branch arithmetic (SURVEY 8f-4)
+    # FLMR_executor.py:784 on a single GPU (total_visible_gpus=1): still the pinned CPU-path arithmetic by default; the
+    # reference's CUDA-branch arithmetic (SURVEY 8f-4) is opt-in -- numerics="reference" follows the reference's selection
     s1 = ns["Searcher"](index="temp_index.nbits=2", config=ColBERTConfig(total_visible_gpus=1))
-    assert calls[-1] == (index_dir, True) and s1.ranker.numerics == "gpu-fp16" and s1.numerics == "gpu-fp16"
+    assert calls[-1] == (index_dir, True) and s1.ranker.numerics == "cpu" and s1.numerics == "cpu"
+    s2 = ns["Searcher"](index="temp_index.nbits=2", config=ColBERTConfig(total_visible_gpus=1), numerics="reference")
+    assert s2.ranker.numerics == "gpu-fp16" and s2.numerics == "gpu-fp16"
+    s3 = ns["Searcher"](index="temp_index.nbits=2", config=ColBERTConfig(total_visible_gpus=0), numerics="reference")
+    assert s3.numerics == "cpu"
 
 # ---- the scoring head: ColBERT.score -> colbert_score (colbert/modeling/colbert.py:217-224,268-286), what
 # FLMR_executor.py:833 (exhaustive search) and rag_model_blip.py:435 (RAG re-score) call ---------------------------
@@ -107,6 +112,8 @@ def device_stand_in(Q, D, M):          # this container has no GPU: the checker 
     return torch.from_numpy(orc.colbert_score_padded(Q.numpy(), D.numpy(), np.asarray(M).reshape(D.shape[0], D.shape[1])))
 import ravqa_amd.ops as rops
 real_op, rops.colbert_score_padded = rops.colbert_score_padded, device_stand_in
+import ravqa_amd._native as rnat
+real_visible, rnat.device_visible = rnat.device_visible, (lambda: True)   # (pretend the device the stand-in plays is there)
 class Model:                           # the attributes ColBERT.score reads (colbert.py:217-224)
     colbert_config = ColBERTConfig()
     use_gpu = False
@@ -127,13 +134,15 @@ with torch.no_grad():
     mc.colbert_score(Qg, Dp, Mp)                                                   # grad mode off: forward-only again
 assert len(hip_calls) == 3 and hip_calls[-1][3] is False
 rops.colbert_score_padded = real_op
-if not torch.cuda.is_available():      # no silent host fallback for the forward-only case
-    try:
-        with torch.no_grad():
-            mc.colbert_score(Qp, Dp, Mp)
-        raise SystemExit("expected FlmrNativeError")
-    except ravqa_amd.FlmrNativeError:
-        pass
+rnat.device_visible = real_visible
+if not torch.cuda.is_available():      # no device in the process: the call is NOT intercepted (a CPU-only run of the
+    import warnings                    # reference keeps working), and says so once
+    with warnings.catch_warnings(record=True) as w, torch.no_grad():
+        warnings.simplefilter("always")
+        got = mc.colbert_score(Qp, Dp, Mp)
+        mc.colbert_score(Qp, Dp, Mp)
+    assert torch.equal(got, ref_colbert_score(Qp, Dp, Mp))
+    assert sum("no HIP device" in str(x.message) for x in w) == 1, [str(x.message) for x in w]
 
 ravqa_amd.uninstall()
 assert colbert.Searcher is ref_searcher and ixs.IndexScorer is ref_scorer and colbert.searcher.IndexScorer is ref_scorer
@@ -188,15 +197,17 @@ def test_install_mechanics_on_stand_in_package(tmp_path):
         out = mc.ColBERT().score(Q, D, M)                     # autograd needs it: the reference expression
         assert out.requires_grad and out.shape == (3,)
         seen = []
-        from ravqa_amd import ops
-        real = ops.colbert_score_padded
-        ops.colbert_score_padded = lambda q, d, m: (seen.append((q.requires_grad, tuple(m.shape))), mc.colbert_score.__wrapped__(q, d, m))[1]
+        from ravqa_amd import _native, ops
+        real, real_visible = ops.colbert_score_padded, _native.device_visible
+        ops.colbert_score_padded = lambda q, d, m: (seen.append((q.requires_grad, q.dtype, tuple(m.shape))), mc.colbert_score.__wrapped__(q.float(), d, m))[1]
+        _native.device_visible = lambda: True      # (the stand-in plays the device)
         try:
             with torch.no_grad():
                 out2 = mc.ColBERT().score(Q, D.half(), M.unsqueeze(-1))
         finally:
-            ops.colbert_score_padded = real
-        assert seen == [(False, (3, 7, 1))] and out2.dtype == torch.float16 and out2.device == D.device
+            ops.colbert_score_padded, _native.device_visible = real, real_visible
+        # Q reaches the scorer rounded to D's dtype (colbert.py:280), detached; the result is in D's dtype on D's device
+        assert seen == [(False, torch.float16, (3, 7, 1))] and out2.dtype == torch.float16 and out2.device == D.device
         ravqa_amd.uninstall()
         assert colbert.Searcher is ref_searcher and late.Searcher is ref_searcher and ixs.IndexScorer.marker == "reference-index-scorer"
         assert mc.colbert_score.marker == "reference-colbert-score" and ixs.colbert_score is mc.colbert_score

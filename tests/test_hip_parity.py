@@ -1327,9 +1327,10 @@ def test_gpu_fp16_numerics_mode_vs_reference_expressions(hip, case):
 
 
 def test_gpu_fp16_numerics_mode_through_the_searcher(hip, tmp_path):
-    """Searcher(config=ColBERTConfig(total_visible_gpus=1)) -- the executor's single-GPU call (FLMR_executor.py:784) -- selects
-    the CUDA-branch arithmetic; total_visible_gpus=0 keeps the pinned CPU-branch arithmetic.  Both find the planted passages;
-    the fp16 mode returns fp16-valued scores, also for a batch cut into sub-batches and for long queries."""
+    """Searcher(config=ColBERTConfig(total_visible_gpus=1), numerics="reference") -- the executor's single-GPU call
+    (FLMR_executor.py:784) with the opt-in that follows the reference's branch selection -- runs the CUDA-branch arithmetic;
+    without the opt-in, and with total_visible_gpus=0, the pinned CPU-branch arithmetic.  Both find the planted passages; the
+    fp16 mode returns fp16-valued scores, also for a batch cut into sub-batches and for long queries."""
     torch, pkg = hip["torch"], hip["pkg"]
     z = load_golden("idx_nb2")
     root = str(tmp_path / "ckpt")
@@ -1340,9 +1341,10 @@ def test_gpu_fp16_numerics_mode_through_the_searcher(hip, tmp_path):
         q = torch.from_numpy(z[f"{r}.Q"])
         Q[i, : q.size(0)] = q
     with pkg.Run().context(pkg.RunConfig(nranks=1, rank=0, root=root, experiment="e")):
-        s_gpu = pkg.Searcher(index="ix", config=pkg.ColBERTConfig(total_visible_gpus=1), max_batch=2)
-        s_cpu = pkg.Searcher(index="ix", config=pkg.ColBERTConfig(total_visible_gpus=0), max_batch=2)
-        assert s_gpu.ranker.numerics == "gpu-fp16" and s_cpu.ranker.numerics == "cpu"
+        s_gpu = pkg.Searcher(index="ix", config=pkg.ColBERTConfig(total_visible_gpus=1), max_batch=2, numerics="reference")
+        s_cpu = pkg.Searcher(index="ix", config=pkg.ColBERTConfig(total_visible_gpus=0), max_batch=2, numerics="reference")
+        s_def = pkg.Searcher(index="ix", config=pkg.ColBERTConfig(total_visible_gpus=1), max_batch=2)
+        assert s_gpu.ranker.numerics == "gpu-fp16" and s_cpu.ranker.numerics == "cpu" and s_def.numerics == "cpu"
         qs = pkg.Queries(data={i: f"q{i}" for i in range(len(recs))})
         r_gpu = s_gpu._search_all_Q(qs, Q, k=10, remove_zero_tensors=True).todict()
         r_cpu = s_cpu._search_all_Q(qs, Q, k=10, remove_zero_tensors=True).todict()

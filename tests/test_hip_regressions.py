@@ -1,0 +1,159 @@
+"""`-m gpu` regression tests for launch-path changes that went in without their own coverage (round 3's last two kernel
+commits), and for limits the advisor flagged.  Small shapes, seconds in all; they run right after the op-level parity tests.
+
+  * stage 3 reading stage 0's query images (nq <= 32 <= nq_cand): per-query lengths, garbage past a query's length, stale
+    images of an earlier, larger batch in the same workspace slots -- against the CPU oracle (TPC/searcher.py:120-126,
+    index_storage.py:77: the reference ranks Q[:q_len] and nothing else);
+  * s0_prepare_kernel's "hi first" bounds: q_err[k] >= |c . q_lo,k| / 2048 + half an ulp of the score for EVERY centroid, on
+    large-magnitude, un-normalised and near-subnormal query rows; q_err_sum >= the sum of the columns' bounds;
+  * ndocs = 8192 (the API maximum) through the approximate-then-refine stage 2 (64 KB of dynamic LDS in its plan kernel).
+"""
+import contextlib
+
+import numpy as np
+import pytest
+
+from conftest import tie_aware_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    import ravqa_amd
+    from ravqa_amd import _native
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    _native.load(require_device=True)
+    return dict(torch=torch, pkg=ravqa_amd, native=_native)
+
+
+def _oracle(corpus):
+    from oracle import oracle as orc
+    from ravqa_amd import synth
+    a = synth.corpus_to_arrays(corpus)
+    return orc.OracleIndex(a.dim, a.nbits, a.codes, a.residuals, a.doclens, a.ivf, a.ivf_lengths, a.centroids, a.bucket_weights)
+
+
+@pytest.mark.parametrize("nq", [32, 20, 7])
+def test_stage3_reuses_stage0_images_with_per_query_lengths(hip, nq):
+    torch = hip["torch"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    from ravqa_amd.searcher import Searcher
+    corpus = synth.make_corpus(6000, (3, 70), 2048, 4, seed=31, device="cuda")
+    oi = _oracle(corpus)
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=32)
+    ncells, thr, ndocs = 2, 0.45, 256
+    # an earlier, larger batch: 32 long, loud queries leave their images in every workspace slot
+    Qa, _ = synth.make_queries(corpus, 32, 32, seed=5)
+    scorer.search_batch(Qa * 16.0, ndocs // 4, ncells, thr, ndocs, 32)
+    scorer.check()
+    # the batch under test: fewer queries, ragged lengths, rows past a query's length hold garbage the reference never sees
+    Qb, _ = synth.make_queries(corpus, 13, nq, seed=6)
+    lens = [nq, 1, max(1, nq // 2), nq - 1, nq, 3 % nq + 1, nq, 0, nq, max(1, nq - 5), 2 % nq + 1, nq, nq // 3 + 1]
+    g = torch.Generator(device="cuda").manual_seed(9)
+    Qdirty = Qb.clone()
+    for i, n in enumerate(lens):
+        Qdirty[i, n:] = torch.randn((nq - n, 128), generator=g, device="cuda") * 3.0
+    q_lens = torch.tensor(lens, dtype=torch.int32)
+    p, s, c = scorer.search_batch(Qdirty, ndocs // 4, ncells, thr, ndocs, 32, q_lens=q_lens)
+    scorer.check()
+    p, s, c = p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy()
+    Qh = Qb.cpu().numpy()
+    checked = 0
+    for i, n in enumerate(lens):
+        if n == 0:      # an empty query: defined here (every candidate scores 0), the reference never ranks one
+            assert np.all(s[i, : int(c[i])] == 0.0)
+            continue
+        rp, rs, ncand = oi.rank(Qh[i, :n], ncells, thr, ndocs, 32)
+        if ncand < ndocs:
+            continue
+        m = int(c[i])
+        assert m == len(rp), (i, n, m, len(rp))
+        tie_aware_equal(rp, rs, p[i, :m], s[i, :m])
+        checked += 1
+    assert checked >= 8, checked
+    # remove_zero_tensors (searcher.py:120-126): zero rows in the MIDDLE of a query, compacted on the host, then the same path
+    Qz = Qb.clone()
+    Qz[:, 1::3] = 0.0
+    Qc, zl = Searcher._compact_nonzero_rows(Qz)
+    p2, s2, c2 = scorer.search_batch(Qc, ndocs // 4, ncells, thr, ndocs, 32, q_lens=zl)
+    scorer.check()
+    for i in (0, 4, 8):
+        keep = Qz[i].abs().sum(-1) != 0
+        rp, rs, ncand = oi.rank(Qz[i][keep].cpu().numpy(), ncells, thr, ndocs, 32)
+        if ncand >= ndocs:
+            m = int(c2[i])
+            tie_aware_equal(rp, rs, p2[i, :m].cpu().numpy(), s2[i, :m].cpu().numpy())
+    scorer.close_searcher()
+
+
+def test_hi_first_bounds_cover_the_lo_product_on_adversarial_queries(hip):
+    """q_err[k] must bound |s - a_hi| = |fl(a_hi + a_lo / 2048) - a_hi| for every centroid c: |a_lo| / 2048 + ulp/2(s), with
+    a_lo = c . q_lo (the fp16 image of 2048 (q - q_hi)) evaluated here in fp64 on the same images."""
+    torch, nat = hip["torch"], hip["native"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    K = 4096
+    corpus = synth.make_corpus(3000, (4, 40), K, 2, seed=41, device="cuda")
+    # a table with LARGE rows too (the bound scales with the largest centroid norm of the index)
+    cen = corpus.centroids.clone()
+    cen[100:200] *= 7.5
+    cen[300] = 0.0
+    corpus.centroids = cen.half().float().contiguous()
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=16)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    Q, _ = synth.make_queries(corpus, 8, 32, seed=8)
+    Q[1] *= 16.0                                                           # FLMR's un-normalised visual tokens
+    Q[2] *= 1000.0                                                         # far outside anything trained
+    Q[3] *= torch.logspace(-6, 1.5, 32, device="cuda").unsqueeze(1)        # rows whose hi image is subnormal in fp16
+    Q[4] = torch.randn((32, 128), generator=g, device="cuda") * 1e-7      # every lo image underflows
+    Q[5] = (torch.rand((32, 128), generator=g, device="cuda") < 0.5).float() * (1.0 + 2.0 ** -12)   # lo = the largest it can be
+    Q[6, :, ::2] = 0.0
+    Q[7] = Q[0] * 65000.0 / Q[0].abs().max()                               # hi at the top of fp16's range
+    scorer.search_batch(Q, 16, 2, 0.45, 64, 32)
+    scorer.check()
+    C = corpus.centroids.double().cpu().numpy()
+    cmax = float(np.sqrt((C ** 2).sum(1)).max())
+    for q in range(Q.size(0)):
+        err = scorer.tap(nat.TAP_Q_ERR, q)
+        esum = scorer.tap(nat.TAP_Q_ERR_SUM, q)
+        assert err.shape == (32,) and esum.shape == (1,), "the default path of this shape is hi first"
+        v = Q[q].cpu().numpy().astype(np.float32)
+        with np.errstate(over="ignore"):
+            hi = v.astype(np.float16)
+            lo = ((v - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+        assert np.all(np.isfinite(hi.astype(np.float32))), q
+        a_lo = C @ lo.astype(np.float64).T                                 # [K, 32]
+        s_full = C @ (hi.astype(np.float64) + lo.astype(np.float64) / 2048.0).T
+        need = np.abs(a_lo) / 2048.0 + np.abs(s_full) * 2.0 ** -24
+        worst = need.max(0)
+        assert np.all(err.astype(np.float64) >= worst), (q, float((worst - err).max()))
+        # not vacuous either: within 64x of the worst centroid for rows that have a lo image at all
+        live = worst > 1e-30
+        assert np.all(err[live] <= 64.0 * np.maximum(worst[live], cmax * np.abs(v).max() * 1e-7)), q
+        assert float(esum[0]) >= float(err.astype(np.float64).sum()), q
+    scorer.close_searcher()
+
+
+def test_ndocs_8192_through_approximate_then_refine(hip):
+    """The API maximum ndocs (FLMR_MAX_NDOCS): the refine plan sorts 8192 keys per query in 64 KB of dynamic LDS.  Default path
+    vs the full-score sorted form (FLMR_S2_IMPL=xcd) and vs the gather form: identical final output."""
+    torch, nat = hip["torch"], hip["native"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    corpus = synth.make_corpus(40_000, (8, 40), 8192, 2, seed=51, device="cuda")
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=8)
+    Q, _ = synth.make_queries(corpus, 6, 32, seed=2)
+    res = {}
+    for impl in ("xcda", "xcd", "lds"):
+        with nat.options(FLMR_S2_IMPL=impl):
+            p, s, c = scorer.search_batch(Q, 2048, 8, 0.3, 8192, 32)
+            scorer.check()
+            res[impl] = (p.cpu().numpy(), s.cpu().numpy().view(np.uint32), c.cpu().numpy())
+    assert int(res["lds"][2].min()) >= 1024, res["lds"][2]
+    for impl in ("xcda", "xcd"):
+        for x, y in zip(res[impl], res["lds"]):
+            assert np.array_equal(x, y), impl
+    scorer.close_searcher()
