@@ -526,8 +526,11 @@ def main():
             try:
                 pol = pol or k_policy(kk)
                 dt_, _, rec, _ = timed(sc, batches, targets, kk, pol, 6, 2, collect_stages=False)
+                st_ = {}
+                if not use_dist:   # the stage split of this shape, from a separate instrumented pass
+                    _, st_, _, _ = timed(sc, batches, targets, kk, pol, 2, 0, collect_stages=True)
                 subs.append({"name": name, "value": args.batch * 6 / dt_, "unit": "queries/sec", "ms_per_step": dt_ / 6 * 1e3,
-                             "recall_at_5": rec, "note": note})
+                             "recall_at_5": rec, "stage_ms_per_step": {n_: round(v_, 3) for n_, v_ in st_.items()}, "note": note})
             except Exception as e:
                 subs.append({"name": name, "value": None, "note": f"failed: {e!r}"})
 

@@ -56,7 +56,12 @@ int flmr_device_count(int* count);
  * the default for whole batches when the fp16 centroid table exceeds an L2 -- / row gather with 4-wave or 16-wave blocks /
  * dense table walk / register gather); FLMR_S3_IMPL = regs | dma | f32 (fused MaxSim for Nq <= 32: register row gathers /
  * LDS-DMA two tiles ahead, the default for nbits = 8 / fp32-MFMA kernel).  Every variant is bit-identical to the default
- * (tests/test_hip_parity.py). */
+ * (tests/test_hip_parity.py).
+ * One switch is a capacity, not a variant: FLMR_ROW_CAP = score rows a searcher keeps per query (64 .. 65535, default 16384,
+ * never more than K).  The default path stores the centroid scores of a query only for the centroids that pass
+ * centroid_score_threshold (the rows index_storage.py:116's `idx` selects; 128 bytes each) instead of the reference's
+ * K x nq_cand table per query (16.8 MB at K = 131072); a query with more surviving centroids than the capacity raises the
+ * deferred FLMR_ERR_CAPACITY of flmr_searcher_check. */
 int flmr_set_option(const char* name, const char* value);
 
 /* ------------------------------------------------------------------------------------------------

@@ -48,16 +48,25 @@ int flmr_build_chunk_table(const int32_t* ivf_pids, const int64_t* ivf_offsets, 
     return FLMR_OK;
 }
 
-// ---- qualifying centroids of each query: compact list of the set bits of idx (if few enough) -------------------------
-// grid = nqueries, block = 1024.  hit_valid[q] = 1 when the list fits and the qualifying lists are not longer than
-// `ratio` times the probed-cell lists: 2 when the hit set only prefilters the code-scanning stage 1 (beyond that marking
-// costs more than it saves), 8 when stage 1 itself is computed from those lists (32 LDS atomics per (centroid, passage)
-// pair against ~128 code reads per candidate).
+// ---- qualifying centroids of each query: compact list of the set bits of idx + their score rows ------------------------------
+// grid = nqueries, block = 1024.  qual[q][j] = the j-th surviving centroid (ascending), j < qmax (= the searcher's row capacity);
+// idx_prefix[q][w] = number of surviving centroids before idx word w (so rank(c) = prefix[c >> 5] + popc(word & below(c)));
+// hit_valid[q] = 1 when stage 1 can be computed from the surviving centroids' IVF lists: at most `smax` of them (the scatter
+// kernel's list ids) whose lists are not longer than `ratio` times the probed-cell lists: 2 when the hit set only prefilters
+// the code-scanning stage 1 (beyond that marking costs more than it saves), 8 when stage 1 itself is computed from those lists
+// (32 LDS atomics per (centroid, passage) pair against ~128 code reads per candidate).
+// rows_out != NULL (the sparse score table in its compact form): the 16 waves then compute the 32-column score row of every
+// listed centroid with the stage-0 fp16-split MFMA sequence (bitwise the values stage 0 computes: an output element depends
+// only on its A row and B column) into rows_out[q][j][0..31] -- the only score rows stages 1 of this query ever read.  Stage 0
+// itself stores none: the per-query K x 32 table (16.8 MB at K = 131072) no longer exists on this path.
 __global__ __launch_bounds__(1024) void qualifying_kernel(const uint32_t* idx_bits, int idx_words,
                                                           const int64_t* ivf_offsets, const int32_t* cells,
                                                           const int32_t* ncell, int max_cells, int32_t* qual,
-                                                          int32_t* nqual, int qmax, int32_t* hit_valid,
-                                                          int32_t* key_count, int ratio) {
+                                                          int32_t* nqual, int qmax, int smax, int32_t* hit_valid,
+                                                          int32_t* key_count, int ratio, uint32_t* idx_prefix,
+                                                          float* rows_out, const _Float16* __restrict__ cen16,
+                                                          const _Float16* __restrict__ q_hi, const _Float16* __restrict__ q_lo,
+                                                          int32_t* overflow) {
     __shared__ int scan_lds[17];
     __shared__ unsigned long long tot_q, tot_c;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -70,6 +79,7 @@ __global__ __launch_bounds__(1024) void qualifying_kernel(const uint32_t* idx_bi
         uint32_t bits = (w < idx_words) ? idx_bits[(size_t)b * idx_words + w] : 0u;
         int total;
         int pos = base + flmr_block_exclusive_scan(__popc(bits), scan_lds, &total);
+        if (idx_prefix && w < idx_words) idx_prefix[(size_t)b * idx_words + w] = (uint32_t)pos;
         while (bits) {
             const int c = w * 32 + __ffs(bits) - 1;
             bits &= bits - 1;
@@ -87,10 +97,48 @@ __global__ __launch_bounds__(1024) void qualifying_kernel(const uint32_t* idx_bi
     atomicAdd(&tot_q, mylen);
     atomicAdd(&tot_c, clen);
     __syncthreads();
+    const int n = base < qmax ? base : qmax;
     if (tid == 0) {
-        nqual[b] = base < qmax ? base : qmax;
-        hit_valid[b] = (base <= qmax) && (tot_q <= (unsigned long long)ratio * tot_c);
+        nqual[b] = n;
+        hit_valid[b] = (base <= smax) && (base <= qmax) && (tot_q <= (unsigned long long)ratio * tot_c);
         if (key_count) key_count[b] = 0;
+        if (rows_out && base > qmax && overflow) atomicExch(overflow + 2, 1);   // more surviving centroids than score rows (FLMR_ROW_CAP)
+    }
+    if (!rows_out || n == 0) return;   // (block-uniform)
+    // ---- the listed centroids' score rows, one 32-row MFMA tile per wave at a time ---------------------------------------
+    // (the list was written by this block: read it back past the L1, which may still hold a line of an earlier batch's list)
+    __threadfence_block();
+    const int lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
+    const int ntiles = (n + 31) >> 5;
+    if (wave >= ntiles) return;
+    f16x8 bh[8], bl[8];
+    {
+        const f16x8* ph = reinterpret_cast<const f16x8*>(q_hi + ((size_t)b * 32 + i) * FLMR_DIM + 64 * h);
+        const f16x8* pl = reinterpret_cast<const f16x8*>(q_lo + ((size_t)b * 32 + i) * FLMR_DIM + 64 * h);
+#pragma unroll
+        for (int s = 0; s < 8; s++) { bh[s] = ph[s]; bl[s] = pl[s]; }
+    }
+    float* const rows_b = rows_out + (size_t)b * qmax * 32;
+    for (int t = wave; t < ntiles; t += 16) {
+        const int e = t * 32 + i < n ? t * 32 + i : n - 1;
+        const int c = __hip_atomic_load(qual + (size_t)b * qmax + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const f16x8* pc = reinterpret_cast<const f16x8*>(cen16 + (size_t)c * FLMR_DIM + 64 * h);
+        f16x8 av[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) av[s] = pc[s];
+        f32x16 ah, al;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[s], ah, 0, 0, 0);
+            al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[s], al, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < n) rows_b[(size_t)row * 32 + i] = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+        }
     }
 }
 
@@ -304,7 +352,7 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     // its 32 column maxima are that centroid's score row (floored at the accumulators' start value), so their
     // ascending-k sum is a per-list constant.  Lane l of wave w owns list w + 16 l.
     if (scatter && lane < mq.n) {
-        const float4* r4 = reinterpret_cast<const float4*>(cs_b + (size_t)mq.c * 32);
+        const float4* r4 = reinterpret_cast<const float4*>(cs_b + (size_t)(a.cs_compact ? wave + S1S_WAVES * lane : mq.c) * 32);
         float sc = 0.0f;
 #pragma unroll
         for (int q4 = 0; q4 < 8; q4++) {
@@ -493,7 +541,8 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
                 issue(mq, bg, mq.s, mq.e, j0, gt);
 #pragma unroll
                 for (int u = 0; u < 4; u++)
-                    rowv[u] = s1s_enc(cs_b[(size_t)__builtin_amdgcn_readlane(mq.c, (j0 + u < mq.n) ? j0 + u : j0) * 32 + k]);
+                    rowv[u] = s1s_enc(cs_b[(size_t)(a.cs_compact ? wave + S1S_WAVES * ((j0 + u < mq.n) ? j0 + u : j0)
+                                                                     : __builtin_amdgcn_readlane(mq.c, (j0 + u < mq.n) ? j0 + u : j0)) * 32 + k]);
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     if (gt.sv[u] >= gt.ev[u]) continue;  // wave-uniform
@@ -509,7 +558,8 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
             // row (ds_max on the order-preserving int encoding, exact)
             for (int e = tid >> 5; e < qn; e += 2 * S1S_WAVES) {
                 const int ent = queue[e];
-                const int c = a.qual[(size_t)b * a.qmax + (ent & ((1 << S1S_IDBITS) - 1))];
+                const int lj = ent & ((1 << S1S_IDBITS) - 1);
+                const int c = a.cs_compact ? lj : a.qual[(size_t)b * a.qmax + lj];
                 atomicMax(&acc[(ent >> S1S_IDBITS) * S1S_STRIDE + k], s1s_enc(cs_b[(size_t)c * 32 + k]));
             }
             S1S_DRAIN();
@@ -662,7 +712,8 @@ __global__ __launch_bounds__(1024) void cand_emit_kernel(const uint32_t* cand_bi
 
 int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
     hipLaunchKernelGGL(qualifying_kernel, dim3(a.nqueries), dim3(1024), 0, st, a.idx_bits, a.idx_words, a.ivf_offsets, a.cells,
-                       a.ncell, a.max_cells, a.qual, a.nqual, a.qmax, a.hit_valid, a.scatter ? a.key_count : nullptr, a.scatter ? 8 : 2);
+                       a.ncell, a.max_cells, a.qual, a.nqual, a.qmax, 1 << S1S_IDBITS, a.hit_valid, a.scatter ? a.key_count : nullptr,
+                       a.scatter ? 8 : 2, a.idx_prefix, a.rows_out, a.cen16, a.q_hi, a.q_lo, a.overflow);
     if (a.scatter) {
         const size_t lds = (size_t)CAND_CHUNK_WORDS * (2 * sizeof(uint32_t) + 2 * sizeof(uint16_t)) +
                            ((size_t)S1S_SLOTS * S1S_STRIDE + 96 + 1024 + S1S_QCAP) * sizeof(int) + S1S_QCAP * sizeof(uint16_t);   // + scratch words of slot-less lanes, list constants, queue (+ its passages)

@@ -49,6 +49,7 @@ enum flmr_opt_id {
     FLMR_OPT_S3_NO_MULTIQ,   // set: single-tile MaxSim kernel for long queries too
     FLMR_OPT_S3_IMPL,        // cw (default for Nq <= 32): (c.q + w.q) * 1/norm with table-decoded weights; regs / dma: decompress-normalise-split kernel with register / LDS-DMA row gathers; f32: fp32-MFMA kernel
     FLMR_OPT_SCORE_IMPL,     // valu: plain-FMA padded scorer
+    FLMR_OPT_ROW_CAP,        // score rows a searcher keeps per query (64 .. 65535; default 16384, at most K): a query with more centroids above the threshold raises FLMR_ERR_CAPACITY
     FLMR_OPT_COUNT
 };
 struct flmr_options {
@@ -183,8 +184,13 @@ int flmr_launch_compact(const uint32_t* bitmap, int64_t bitmap_words, int64_t nu
                         int32_t* cand, int64_t cand_cap, int32_t* cand_count, int32_t* overflow, hipStream_t st);
 
 struct flmr_filter_args {
-    const float* cs;           // [nqueries, K, ncol]  (per-query stride K*ncol)
+    const float* cs;           // score rows: the full table [nqueries, K, ncol] (row = centroid id, stride K*ncol), or -- cs_compact --
+                               // only the rows of each query's surviving centroids, [nqueries, row_cap, ncol], row = RANK of the
+                               // centroid among the set bits of the query's idx mask (written by qualifying_kernel)
     int64_t cs_query_stride;
+    int32_t cs_compact;
+    int32_t row_cap;            // compact form: rows per query (a rank beyond it -- a query over capacity, flagged by qualifying_kernel -- is clamped)
+    const uint32_t* idx_prefix; // [nqueries, idx_words] exclusive popcount of the idx words before each word (compact rows' ranks)
     int32_t K, ncol, nq_cand, nqueries;
     const int32_t* q_lens;     // nullable (effective columns = min(q_len, nq_cand))
     const int32_t* codes;
@@ -209,6 +215,11 @@ struct flmr_cand_args {
     // stage 1 by scatter over the surviving centroids' IVF lists (cand_mark_score_kernel), for queries with hit_valid
     int32_t scatter;                 // 0: bitmaps only (stage 1 = filter_stage1_kernel for every query)
     const float* cs; int64_t cs_query_stride; int32_t nq_cand; const int32_t* q_lens;
+    // compact score rows (flmr_filter_args::cs_compact): qualifying_kernel computes them -- rows_out [nqueries, qmax, 32], row j =
+    // the j-th surviving centroid's scores, the stage-0 MFMA sequence on the fp16 centroid rows (bitwise the values stage 0
+    // computes) -- and `cs` points at the same buffer; rows_out == NULL: `cs` is the full table written by stage 0
+    float* rows_out; const _Float16* cen16; const _Float16* q_hi; const _Float16* q_lo; uint32_t* idx_prefix;
+    int32_t cs_compact;
     uint64_t* keys; int32_t* key_count;   // [nqueries, cand_cap] unordered stage-1 keys, [nqueries] running count
     int32_t* chunk_hits;                  // [nqueries, nchunks] candidates of the chunk that are in the hit set (scatter mode)
     int32_t n_select;                     // how many keys the selection after stage 1 keeps (ndocs)

@@ -3,6 +3,7 @@
 #include "flmr_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define FLMR_NEG_INF (-__builtin_huge_valf())

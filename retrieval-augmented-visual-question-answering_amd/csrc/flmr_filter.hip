@@ -51,60 +51,65 @@ __device__ __forceinline__ void emit_group(const float* tr /* [S1_GROUP][ncolp] 
     __builtin_amdgcn_wave_barrier();
 }
 
-// Per-block view of one query's surviving-centroid set: the K-bit mask, a per-word prefix popcount and the score
-// rows of the first S1_ROWCACHE surviving centroids, all in LDS.  A hit on a cached centroid costs two LDS reads
-// instead of a dependent trip to L2/HBM.
+// Per-block view of one query's surviving-centroid set: the K-bit mask and its per-word exclusive popcount (the rank of a
+// surviving centroid = its row in the compact score table), in LDS when they fit, else read through L1 / L2.
 struct s1_idx_view {
-    const uint32_t* bits;     // LDS (or global when the mask does not fit)
-    const uint16_t* prefix;   // LDS, saturating; nullptr when the mask is not LDS-resident
-    const float* rows;        // LDS [S1_ROWCACHE][ncol]
-    int nrows;                // number of cached rows
+    const uint32_t* bits;      // LDS (or global when the mask does not fit)
+    const uint16_t* prefix16;  // LDS copy of the prefix (set when the mask is LDS-resident)
+    const uint32_t* prefix32;  // global prefix (qualifying_kernel), used when the mask is not LDS-resident
+    int compact;               // 1: score rows are addressed by rank, 0: by centroid id (full table)
+    int row_cap;               // rows of the compact table (ranks are clamped to it: an over-capacity query is flagged, never read out of bounds)
 };
 
-// Fold the surviving-centroid hits of one 128-token chunk of TWO documents (one per half-wave) into the running
-// column maxima.  Lane i of a half holds tokens i, 32+i, 64+i, 96+i of its document (cd[0..3], -1 = no token);
-// lane k of a half also owns score column k (+32 per column tile).  Each loop iteration retires one hit per half.
-__device__ __forceinline__ void s1_fold_pair(const int* cd, const s1_idx_view& iv, const float* cs, int ncol, int T,
-                                             int nqc, int lane, float* per) {
+#define S1_HITS_MAX 128   // tokens per document chunk = the most hits a half-wave can list
+#define S1_PAIRS_IN_FLIGHT 4  // 8 documents = 16 code loads per wave in flight
+
+// The surviving-centroid hits of one 128-token chunk of TWO documents (one per half-wave) are LISTED: lane i of a half holds
+// tokens i, 32+i, 64+i, 96+i of its document (cd[0..3], -1 = no token); every hit appends the row id of its centroid -- the
+// centroid id (full table) or its rank among the query's surviving centroids (compact rows) -- to the half's list in LDS at a
+// position taken from a ballot.  Returns this half's number of hits (uniform over the half).
+__device__ __forceinline__ int s1_list_hits(const int* cd, const s1_idx_view& iv, int lane, uint16_t* list16, int* list32) {
     const int k = lane & 31, h = lane >> 5;
-    uint32_t wd[4];
-    uint32_t hm = 0;
+    int nh = 0;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-        wd[e] = cd[e] >= 0 ? iv.bits[cd[e] >> 5] : 0u;
-        hm |= (cd[e] >= 0 ? ((wd[e] >> (cd[e] & 31)) & 1u) : 0u) << e;
-    }
-    unsigned long long m = __ballot(hm != 0);
-    while (m) {  // wave-uniform
-        const uint32_t mh = h ? (uint32_t)(m >> 32) : (uint32_t)m;
-        const int src = mh ? (32 * h + __builtin_ctz(mh)) : -1;
-        // every lane prepares its first pending hit; only the two source lanes are read
-        const int fe = __builtin_ctz(hm | 16u);
-        const int code_f = fe == 0 ? cd[0] : fe == 1 ? cd[1] : fe == 2 ? cd[2] : cd[3];
-        const uint32_t word_f = fe == 0 ? wd[0] : fe == 1 ? wd[1] : fe == 2 ? wd[2] : wd[3];
-        int slot_f = 0x7fffffff;
-        if (hm && iv.prefix) slot_f = (int)iv.prefix[code_f >> 5] + __popc(word_f & ((1u << (code_f & 31)) - 1u));
-        const int c = __shfl(code_f, src < 0 ? lane : src, 64);
-        const int sl = __shfl(slot_f, src < 0 ? lane : src, 64);
-        if (src >= 0) {
-            const float* row = (sl < iv.nrows) ? (iv.rows + (size_t)sl * ncol) : (cs + (size_t)c * ncol);
-            FLMR_FOR_CT(ct, T) if (ct * 32 + k < nqc) per[ct] = fmaxf(per[ct], row[ct * 32 + k]);
+        const int c = cd[e];
+        const uint32_t wd = c >= 0 ? iv.bits[c >> 5] : 0u;
+        const bool hit = c >= 0 && ((wd >> (c & 31)) & 1u);
+        const unsigned long long bal = __ballot(hit);
+        const uint32_t mh = h ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+        if (hit) {
+            const int at = h * S1_HITS_MAX + nh + __popc(mh & ((1u << k) - 1u));
+            if (iv.compact) {
+                int rid = (int)(iv.prefix16 ? (uint32_t)iv.prefix16[c >> 5] : iv.prefix32[c >> 5]) + __popc(wd & ((1u << (c & 31)) - 1u));
+                list16[at] = (uint16_t)(rid < iv.row_cap ? rid : iv.row_cap - 1);
+            } else {
+                list32[at] = c;
+            }
         }
-        if (lane == src) hm &= hm - 1;
-        m = __ballot(hm != 0);
+        nh += __popc(mh);
     }
+    return nh;
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stage 1.  grid = (nqueries, G), block = 512 (8 waves).  Dynamic LDS: transposes + mask + prefix + row cache.
-// A wave takes 32 consecutive candidates at a time: lanes fetch the 32 (pid, offset, length) triples in parallel
-// (the NEXT group's pids are prefetched while the current group is processed); documents are then processed two
-// at a time, one per half-wave (lane i holds tokens i, 32+i, 64+i, 96+i), four pairs = 16 code loads in flight.
+// Stage 1 by code scan: what runs for a query with more surviving centroids than the scatter form takes (> 1024, or lists
+// longer than 8 x the probed cells') -- the usual case on a real corpus, the exception on the synthetic one.
+// Persistent workgroups (8 waves), XCD-aware: the work items are (query, part g of G) for the queries that need the scan
+// (every query when `skip` is NULL); item t belongs to XCD t % 8 and, inside it, to query (t / 8) / G -- workgroup L only takes
+// items congruent to L modulo the grid, and workgroup L runs on XCD L % 8 (probed at index open), so the workgroups resident on
+// one XCD work on a handful of queries at a time and their score rows (128 bytes per surviving centroid: 1 MB per query at
+// 9 k survivors) stay in that XCD's L2.
+// A wave takes 32 consecutive candidates at a time: lanes fetch the 32 (pid, offset, length) triples in parallel (the NEXT
+// group's pids are prefetched while the current group is processed); documents are processed two at a time, one per half-wave,
+// FOUR pairs per round: 16 code loads in flight, then the hits of all four pairs are listed, then their score rows are
+// gathered -- BATCH rows per pair and half in flight, one wait per batch (the first form retired one hit per iteration with a
+// DEPENDENT row load each: one L2 round trip per hit, 70 ms per 1024 queries at centroid_score_threshold = 0.25).
+// TM = column tiles the kernel is compiled for: 1 (nq_cand <= 32, eight rows per pair in flight) or 4 (two).
 // ------------------------------------------------------------------------------------------------
-#define S1_ROWCACHE 128
-#define S1_PAIRS_IN_FLIGHT 4  // 8 documents = 16 code loads per wave in flight
+#define S1_ITEMS_G 32   // parts per query
 
-template <bool USE_LDS_IDX>
+template <bool USE_LDS_IDX, int TM>
 __global__ __launch_bounds__(512) void filter_stage1_kernel(flmr_filter_args f, const uint32_t* idx_bits,
                                                             int32_t idx_words, const int32_t* cand,
                                                             int64_t cand_stride, const int32_t* cand_count,
@@ -113,125 +118,208 @@ __global__ __launch_bounds__(512) void filter_stage1_kernel(flmr_filter_args f, 
                                                             const uint8_t* hit_flags, const int32_t* skip) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int scan_lds[17];
-    const int b = blockIdx.x;
-    if (skip && skip[b]) return;  // this query's stage-1 keys were produced by cand_mark_score_kernel
+    __shared__ int s_nscan;
+    constexpr int BATCH = TM == 1 ? 8 : 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int P = cand_count[b];
-    const int qlen = f.q_lens ? f.q_lens[b] : f.nq_cand;
-    const int nqc = qlen < f.nq_cand ? qlen : f.nq_cand;
-    const int T = (f.nq_cand + 31) >> 5;  // column tiles of 32; f.ncol is the row stride of the score table
+    const int T = (f.nq_cand + 31) >> 5;  // column tiles of 32 (<= TM); f.ncol is the row stride of the score table
     const int ncolp = T * 32 + 1;
-    // LDS carve: [tr: S1_WAVES*S1_GROUP*ncolp f32][rows: S1_ROWCACHE*ncol f32][rowcode: S1_ROWCACHE i32][bits][prefix u16]
+    // LDS carve: [tr: S1_WAVES*S1_GROUP*ncolp f32][hit lists: S1_WAVES * PAIRS * 2 * S1_HITS_MAX u16 (compact) or i32][scan list:
+    // nqueries i32][bits][prefix u16]
     float* tr = reinterpret_cast<float*>(smem) + (size_t)wave * S1_GROUP * ncolp;
-    float* lrows = reinterpret_cast<float*>(smem) + (size_t)S1_WAVES * S1_GROUP * ncolp;
-    int* rowcode = reinterpret_cast<int*>(lrows + (size_t)S1_ROWCACHE * f.ncol);
-    uint32_t* lidx = reinterpret_cast<uint32_t*>(rowcode + S1_ROWCACHE);
+    char* after_tr = reinterpret_cast<char*>(reinterpret_cast<float*>(smem) + (size_t)S1_WAVES * S1_GROUP * ncolp);
+    const size_t list_elem = f.cs_compact ? sizeof(uint16_t) : sizeof(int);
+    char* my_lists = after_tr + (size_t)wave * S1_PAIRS_IN_FLIGHT * 2 * S1_HITS_MAX * list_elem;
+    int* scan_list = reinterpret_cast<int*>(after_tr + (size_t)S1_WAVES * S1_PAIRS_IN_FLIGHT * 2 * S1_HITS_MAX * list_elem);
+    uint32_t* lidx = reinterpret_cast<uint32_t*>(scan_list + f.nqueries);
     uint16_t* lpre = reinterpret_cast<uint16_t*>(lidx + idx_words);
-    const uint32_t* gidx = idx_bits + (size_t)b * idx_words;
-    const float* cs = f.cs + (size_t)b * f.cs_query_stride;
-    s1_idx_view iv;
-    iv.bits = gidx; iv.prefix = nullptr; iv.rows = lrows; iv.nrows = 0;
-    if (USE_LDS_IDX) {
-        // mask + saturating exclusive popcount prefix per word; remember the codes of the first S1_ROWCACHE set bits
+
+    // ---- which queries are scanned at all (usually none: every workgroup leaves here) ----
+    if (threadIdx.x == 0) s_nscan = 0;
+    __syncthreads();
+    {
         int base = 0;
-        for (int w0 = 0; w0 < idx_words; w0 += blockDim.x) {
-            const int w = w0 + threadIdx.x;
-            uint32_t bits = (w < idx_words) ? gidx[w] : 0u;
+        for (int q0 = 0; q0 < f.nqueries; q0 += blockDim.x) {
+            const int q = q0 + threadIdx.x;
+            const int need = (q < f.nqueries && !(skip && skip[q])) ? 1 : 0;
             int total;
-            int pos = base + flmr_block_exclusive_scan(__popc(bits), scan_lds, &total);
-            if (w < idx_words) {
-                lidx[w] = bits;
-                lpre[w] = (uint16_t)(pos < 65535 ? pos : 65535);
-            }
-            while (bits && pos < S1_ROWCACHE) {
-                const int bit = __ffs(bits) - 1;
-                bits &= bits - 1;
-                rowcode[pos++] = w * 32 + bit;
-            }
+            const int pos = base + flmr_block_exclusive_scan(need, scan_lds, &total);
+            if (need) scan_list[pos] = q;
             base += total;
+            __syncthreads();
         }
-        __syncthreads();
-        const int nrows = base < S1_ROWCACHE ? base : S1_ROWCACHE;
-        for (int e = threadIdx.x; e < nrows * f.ncol; e += blockDim.x)
-            lrows[e] = cs[(size_t)rowcode[e / f.ncol] * f.ncol + (e % f.ncol)];
-        __syncthreads();
-        iv.bits = lidx; iv.prefix = lpre; iv.nrows = nrows;
+        if (threadIdx.x == 0) s_nscan = base;
     }
-    const int32_t* cand_b = cand + (size_t)b * cand_stride;
-    uint64_t* keys_b = keys + (size_t)b * cand_stride;
-
-    const int waves_total = gridDim.y * S1_WAVES;
-    const int wid = blockIdx.y * S1_WAVES + wave;
+    __syncthreads();
+    const int nscan = s_nscan;
+    if (nscan == 0) return;
+    const int nscan8 = (nscan + 7) & ~7;
     const int k = lane & 31, h = lane >> 5;
-    const int gstride = waves_total * S1_GROUP;
+    const int nitems = nscan8 * S1_ITEMS_G;
 
-    // hit_bits (optional): passage bitmap = union of the IVF lists of the surviving centroids.  A candidate outside
-    // it contains no surviving centroid, so its stage-1 score is the all-miss value and its codes are never read.
-    const bool hits_on = hit_valid && hit_valid[b];
-    const uint32_t* hb = (hit_bits && hits_on && !hit_flags) ? hit_bits + (size_t)b * hit_words : nullptr;
-    const uint8_t* hf = (hit_flags && hits_on) ? hit_flags + (size_t)b * cand_stride : nullptr;  // aligned with cand
-    const float miss_score = flmr_miss_score(nqc, f.f16_round);
+    for (int t = blockIdx.x; t < nitems; t += gridDim.x) {
+        const int sidx = ((t >> 3) / S1_ITEMS_G) * 8 + (t & 7), part = (t >> 3) % S1_ITEMS_G;
+        if (sidx >= nscan) continue;   // (block-uniform)
+        const int b = scan_list[sidx];
+        const int P = cand_count[b];
+        const int qlen = f.q_lens ? f.q_lens[b] : f.nq_cand;
+        const int nqc = qlen < f.nq_cand ? qlen : f.nq_cand;
+        const uint32_t* gidx = idx_bits + (size_t)b * idx_words;
+        const float* cs = f.cs + (size_t)b * f.cs_query_stride;
+        s1_idx_view iv;
+        iv.bits = gidx; iv.prefix16 = nullptr; iv.compact = f.cs_compact; iv.row_cap = f.row_cap;
+        iv.prefix32 = f.idx_prefix ? f.idx_prefix + (size_t)b * idx_words : nullptr;
+        __syncthreads();   // (the previous item's readers of the mask are done)
+        if (USE_LDS_IDX) {
+            // mask + exclusive popcount prefix per word (saturating: the compact table holds fewer than 65535 rows)
+            int base = 0;
+            for (int w0 = 0; w0 < idx_words; w0 += blockDim.x) {
+                const int w = w0 + threadIdx.x;
+                const uint32_t bits = (w < idx_words) ? gidx[w] : 0u;
+                int total;
+                const int pos = base + flmr_block_exclusive_scan(__popc(bits), scan_lds, &total);
+                if (w < idx_words) {
+                    lidx[w] = bits;
+                    lpre[w] = (uint16_t)(pos < 65535 ? pos : 65535);
+                }
+                base += total;
+                __syncthreads();
+            }
+            iv.bits = lidx; iv.prefix16 = lpre;
+        }
+        const int32_t* cand_b = cand + (size_t)b * cand_stride;
+        uint64_t* keys_b = keys + (size_t)b * cand_stride;
+        const int wid = part * S1_WAVES + wave;
+        const int gstride = S1_ITEMS_G * S1_WAVES * S1_GROUP;
 
-    int my_pid = 0;
-    bool my_scan = false;
-    int g0 = wid * S1_GROUP;
-    if (g0 + lane < P && lane < S1_GROUP) {
-        my_pid = cand_b[g0 + lane];
-        my_scan = hf ? (hf[g0 + lane] != 0) : hb ? ((hb[my_pid >> 5] >> (my_pid & 31)) & 1u) : true;
-    }
-    for (; g0 < P; g0 += gstride) {
-        const int ndoc = (P - g0) < S1_GROUP ? (P - g0) : S1_GROUP;
-        // prefetch the next group's pids + hit bits
-        int nx_pid = 0;
-        bool nx_scan = false;
-        if (g0 + gstride + lane < P && lane < S1_GROUP) {
-            nx_pid = cand_b[g0 + gstride + lane];
-            nx_scan = hf ? (hf[g0 + gstride + lane] != 0) : hb ? ((hb[nx_pid >> 5] >> (nx_pid & 31)) & 1u) : true;
+        // hit_bits (optional): passage bitmap = union of the IVF lists of the surviving centroids.  A candidate outside
+        // it contains no surviving centroid, so its stage-1 score is the all-miss value and its codes are never read.
+        const bool hits_on = hit_valid && hit_valid[b];
+        const uint32_t* hb = (hit_bits && hits_on && !hit_flags) ? hit_bits + (size_t)b * hit_words : nullptr;
+        const uint8_t* hf = (hit_flags && hits_on) ? hit_flags + (size_t)b * cand_stride : nullptr;  // aligned with cand
+        const float miss_score = flmr_miss_score(nqc, f.f16_round);
+
+        int my_pid = 0;
+        bool my_scan = false;
+        int g0 = wid * S1_GROUP;
+        if (g0 + lane < P && lane < S1_GROUP) {
+            my_pid = cand_b[g0 + lane];
+            my_scan = hf ? (hf[g0 + lane] != 0) : hb ? ((hb[my_pid >> 5] >> (my_pid & 31)) & 1u) : true;
         }
-        int my_len = 0;
-        int64_t my_off = 0;
-        if (my_scan) {
-            my_off = f.offsets[my_pid];
-            my_len = (int)doc_len_of(f.doclens, f.offsets, my_pid);
-        }
-        unsigned long long todo = __ballot(my_scan);
-        while (todo) {  // wave-uniform: S1_PAIRS_IN_FLIGHT pairs of documents per round, one document per half-wave
+        for (; g0 < P; g0 += gstride) {
+            const int ndoc = (P - g0) < S1_GROUP ? (P - g0) : S1_GROUP;
+            // prefetch the next group's pids + hit bits
+            int nx_pid = 0;
+            bool nx_scan = false;
+            if (g0 + gstride + lane < P && lane < S1_GROUP) {
+                nx_pid = cand_b[g0 + gstride + lane];
+                nx_scan = hf ? (hf[g0 + gstride + lane] != 0) : hb ? ((hb[nx_pid >> 5] >> (nx_pid & 31)) & 1u) : true;
+            }
+            int my_len = 0;
+            int64_t my_off = 0;
+            if (my_scan) {
+                my_off = f.offsets[my_pid];
+                my_len = (int)doc_len_of(f.doclens, f.offsets, my_pid);
+            }
+            unsigned long long todo = __ballot(my_scan);
+            // Rounds of S1_PAIRS_IN_FLIGHT pairs of documents, one document per half-wave, software-pipelined: the codes of round
+            // r + 1 are requested as soon as round r's hits are listed (its code registers are dead then), so they travel while
+            // round r's score rows are gathered.  Codes are read once: non-temporal, they must not evict the score rows from L2.
             int jh[S1_PAIRS_IN_FLIGHT], len[S1_PAIRS_IN_FLIGHT];
             int64_t off[S1_PAIRS_IN_FLIGHT];
             int cd[S1_PAIRS_IN_FLIGHT][4];
+            auto prep = [&](int (&jh_)[S1_PAIRS_IN_FLIGHT], int (&len_)[S1_PAIRS_IN_FLIGHT], int64_t (&off_)[S1_PAIRS_IN_FLIGHT]) {
 #pragma unroll
-            for (int u = 0; u < S1_PAIRS_IN_FLIGHT; u++) {
-                const int ja = todo ? __builtin_ctzll(todo) : -1;
-                todo &= todo - 1;
-                const int jb = todo ? __builtin_ctzll(todo) : -1;
-                todo &= todo - 1;
-                jh[u] = h ? jb : ja;  // this half's document slot (-1: none)
-                const int j = jh[u] < 0 ? 0 : jh[u];
-                off[u] = shfl_i64(my_off, j);
-                len[u] = jh[u] < 0 ? 0 : __shfl(my_len, j, 64);
+                for (int u = 0; u < S1_PAIRS_IN_FLIGHT; u++) {
+                    const int ja = todo ? __builtin_ctzll(todo) : -1;
+                    todo &= todo - 1;
+                    const int jb = todo ? __builtin_ctzll(todo) : -1;
+                    todo &= todo - 1;
+                    jh_[u] = h ? jb : ja;  // this half's document slot (-1: none)
+                    const int j = jh_[u] < 0 ? 0 : jh_[u];
+                    off_[u] = shfl_i64(my_off, j);
+                    len_[u] = jh_[u] < 0 ? 0 : __shfl(my_len, j, 64);
 #pragma unroll
-                for (int e = 0; e < 4; e++) cd[u][e] = (32 * e + k < len[u]) ? f.codes[off[u] + 32 * e + k] : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < S1_PAIRS_IN_FLIGHT; u++) {
-                if (__ballot(jh[u] >= 0) == 0ull) break;  // wave-uniform
-                float per[4] = {-9999.0f, -9999.0f, -9999.0f, -9999.0f};
-                s1_fold_pair(cd[u], iv, cs, f.ncol, T, nqc, lane, per);
-                int t0 = 128;
-                while (__ballot(t0 < len[u])) {  // documents longer than 128 tokens
-                    int cx[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) cx[e] = (t0 + 32 * e + k < len[u]) ? f.codes[off[u] + t0 + 32 * e + k] : -1;
-                    s1_fold_pair(cx, iv, cs, f.ncol, T, nqc, lane, per);
-                    t0 += 128;
+                    for (int e = 0; e < 4; e++) cd[u][e] = (32 * e + k < len_[u]) ? __builtin_nontemporal_load(f.codes + off_[u] + 32 * e + k) : -1;
                 }
-                if (jh[u] >= 0) {
-                    FLMR_FOR_CT(ct, T) tr[jh[u] * ncolp + ct * 32 + k] = per[ct];
+            };
+            bool more = todo != 0ull;
+            if (more) prep(jh, len, off);
+            while (more) {  // wave-uniform
+                float per[S1_PAIRS_IN_FLIGHT][TM];
+#pragma unroll
+                for (int u = 0; u < S1_PAIRS_IN_FLIGHT; u++)
+#pragma unroll
+                    for (int ct = 0; ct < TM; ct++) per[u][ct] = -9999.0f;
+                int nh[S1_PAIRS_IN_FLIGHT];
+                auto list_round = [&](const int (&c_)[S1_PAIRS_IN_FLIGHT][4]) {
+                    int nmax = 0;
+#pragma unroll
+                    for (int u = 0; u < S1_PAIRS_IN_FLIGHT; u++) {
+                        nh[u] = s1_list_hits(c_[u], iv, lane, reinterpret_cast<uint16_t*>(my_lists) + u * 2 * S1_HITS_MAX,
+                                             reinterpret_cast<int*>(my_lists) + u * 2 * S1_HITS_MAX);
+                        const int n0 = __builtin_amdgcn_readlane(nh[u], 0), n1 = __builtin_amdgcn_readlane(nh[u], 32);
+                        nmax = nmax > n0 ? nmax : n0;
+                        nmax = nmax > n1 ? nmax : n1;
+                    }
+                    return nmax;
+                };
+                auto gather_round = [&](int nmax) {
+                    if (nmax == 0) return;   // wave-uniform
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    for (int j0 = 0; j0 < nmax; j0 += BATCH) {   // wave-uniform trip count
+                        float v[S1_PAIRS_IN_FLIGHT][BATCH][TM];
+#pragma unroll
+                        for (int u = 0; u < S1_PAIRS_IN_FLIGHT; u++)
+#pragma unroll
+                            for (int w = 0; w < BATCH; w++) {
+                                const bool ok = j0 + w < nh[u];
+                                const int at = (u * 2 + h) * S1_HITS_MAX + (ok ? j0 + w : 0);
+                                const int rid = f.cs_compact ? (int)reinterpret_cast<const uint16_t*>(my_lists)[at]
+                                                             : reinterpret_cast<const int*>(my_lists)[at];
+#pragma unroll
+                                for (int ct = 0; ct < TM; ct++)
+                                    v[u][w][ct] = (ok && ct < T && ct * 32 + k < nqc) ? cs[(size_t)rid * f.ncol + ct * 32 + k] : -9999.0f;
+                            }
+#pragma unroll
+                        for (int u = 0; u < S1_PAIRS_IN_FLIGHT; u++)
+#pragma unroll
+                            for (int w = 0; w < BATCH; w++)
+#pragma unroll
+                                for (int ct = 0; ct < TM; ct++) per[u][ct] = fmaxf(per[u][ct], v[u][w][ct]);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();   // (the lists are rewritten by the next chunk / round)
+                };
+                const int nmax0 = list_round(cd);
+                // this round's bookkeeping, then the next round's codes on their way
+                int cjh[S1_PAIRS_IN_FLIGHT], clen[S1_PAIRS_IN_FLIGHT];
+                int64_t coff[S1_PAIRS_IN_FLIGHT];
+#pragma unroll
+                for (int u = 0; u < S1_PAIRS_IN_FLIGHT; u++) { cjh[u] = jh[u]; clen[u] = len[u]; coff[u] = off[u]; }
+                more = todo != 0ull;
+                if (more) prep(jh, len, off);
+                gather_round(nmax0);
+                // documents longer than 128 tokens: further 128-token chunks of this round (rare)
+                for (int t0 = 128; __ballot(t0 < clen[0] || t0 < clen[1] || t0 < clen[2] || t0 < clen[3]) != 0ull; t0 += 128) {
+                    int cx[S1_PAIRS_IN_FLIGHT][4];
+#pragma unroll
+                    for (int u = 0; u < S1_PAIRS_IN_FLIGHT; u++)
+#pragma unroll
+                        for (int e = 0; e < 4; e++) cx[u][e] = (t0 + 32 * e + k < clen[u]) ? __builtin_nontemporal_load(f.codes + coff[u] + t0 + 32 * e + k) : -1;
+                    gather_round(list_round(cx));
                 }
+#pragma unroll
+                for (int u = 0; u < S1_PAIRS_IN_FLIGHT; u++)
+                    if (cjh[u] >= 0) {
+#pragma unroll
+                        for (int ct = 0; ct < TM; ct++)
+                            if (ct < T) tr[cjh[u] * ncolp + ct * 32 + k] = per[u][ct];
+                    }
             }
+            emit_group(tr, ncolp, nqc, ndoc, lane, my_pid, my_scan, miss_score, keys_b + g0, f.f16_round);
+            my_pid = nx_pid; my_scan = nx_scan;
         }
-        emit_group(tr, ncolp, nqc, ndoc, lane, my_pid, my_scan, miss_score, keys_b + g0, f.f16_round);
-        my_pid = nx_pid; my_scan = nx_scan;
     }
 }
 
@@ -300,24 +388,28 @@ int flmr_launch_filter_stage1(const flmr_filter_args& f, const uint32_t* idx_bit
                               const uint32_t* hit_bits, int64_t hit_words, const int32_t* hit_valid,
                               const uint8_t* hit_flags, hipStream_t st, const int32_t* skip) {
     const int T = (f.nq_cand + 31) >> 5;
+    if (T > 4) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "stage 1: nq_cand=%d > 128", f.nq_cand);
     const size_t tr_bytes = (size_t)S1_WAVES * S1_GROUP * (T * 32 + 1) * sizeof(float);
-    const size_t row_bytes = (size_t)S1_ROWCACHE * f.ncol * sizeof(float) + S1_ROWCACHE * sizeof(int);
+    const size_t list_bytes = (size_t)S1_WAVES * S1_PAIRS_IN_FLIGHT * 2 * S1_HITS_MAX * (f.cs_compact ? sizeof(uint16_t) : sizeof(int)) +
+                              (size_t)f.nqueries * sizeof(int);   // the waves' hit lists + the list of scanned queries
     const size_t idx_bytes = (size_t)idx_words * 4 + (size_t)idx_words * 2 + 16;
-    const bool lds_idx = tr_bytes + row_bytes + idx_bytes <= 100 * 1024;  // else probe the mask through L1/L2
-    if (lds_idx && tr_bytes + row_bytes + idx_bytes > 48 * 1024)
-        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_stage1_kernel<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(tr_bytes + row_bytes + idx_bytes)));
-    // enough blocks per query to fill the chip even for one query; waves stride over the candidates
-    int G = (int)flmr_ceil_div(256 * 4, f.nqueries);
-    if (G < 1) G = 1;
-    if (G > 128) G = 128;
-    dim3 grid(f.nqueries, G), block(S1_WAVES * 64);
-    if (lds_idx)
-        hipLaunchKernelGGL(filter_stage1_kernel<true>, grid, block, tr_bytes + row_bytes + idx_bytes, st, f, idx_bits,
-                           idx_words, cand, cand_stride, cand_count, keys, hit_bits, hit_words, hit_valid, hit_flags, skip);
-    else
-        hipLaunchKernelGGL(filter_stage1_kernel<false>, grid, block, tr_bytes + row_bytes, st, f, idx_bits, idx_words, cand,
-                           cand_stride, cand_count, keys, hit_bits, hit_words, hit_valid, hit_flags, skip);
+    const bool lds_idx = tr_bytes + list_bytes + idx_bytes <= 100 * 1024;  // else probe the mask (and its prefix) through L1/L2
+    if (f.cs_compact && !lds_idx && !f.idx_prefix) FLMR_FAIL(FLMR_ERR_INVALID, "compact score rows need the idx prefix");
+    const size_t lds = tr_bytes + list_bytes + (lds_idx ? idx_bytes : 0);
+    const void* fn = lds_idx ? (T == 1 ? reinterpret_cast<const void*>(filter_stage1_kernel<true, 1>) : reinterpret_cast<const void*>(filter_stage1_kernel<true, 4>))
+                             : (T == 1 ? reinterpret_cast<const void*>(filter_stage1_kernel<false, 1>) : reinterpret_cast<const void*>(filter_stage1_kernel<false, 4>));
+    if (lds > 48 * 1024) FLMR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // persistent workgroups: two rounds of the chip's resident workgroups (two per CU at this LDS size), a multiple of 8 so that
+    // workgroup L and its items share L % 8; never more than there are items
+    int64_t grid = 1024;
+    const int64_t max_items = (int64_t)((f.nqueries + 7) & ~7) * S1_ITEMS_G;
+    if (grid > max_items) grid = max_items;
+    dim3 g((unsigned)grid), block(S1_WAVES * 64);
+#define S1_LAUNCH(L, TMV) hipLaunchKernelGGL((filter_stage1_kernel<L, TMV>), g, block, lds, st, f, idx_bits, idx_words, cand, cand_stride, \
+                                             cand_count, keys, hit_bits, hit_words, hit_valid, hit_flags, skip)
+    if (lds_idx) { if (T == 1) S1_LAUNCH(true, 1); else S1_LAUNCH(true, 4); }
+    else { if (T == 1) S1_LAUNCH(false, 1); else S1_LAUNCH(false, 4); }
+#undef S1_LAUNCH
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }

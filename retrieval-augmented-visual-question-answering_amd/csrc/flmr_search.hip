@@ -22,8 +22,12 @@ struct flmr_searcher {
     float* cs; uint32_t* idx_bits; float* part_val; int32_t* part_idx; int32_t* cells; int32_t* ncell;
     uint32_t* bitmap; int32_t* cand; int32_t* cand_count; uint64_t* keys1; int32_t* s1_pids; int32_t* s1_count;
     uint64_t* keys2; int32_t* s2_pids; int32_t* s2_count; uint64_t* keys3; float* doc_scores;
-    int32_t* overflow;          // = status: device flags [0] candidate capacity exceeded, [1] q_lens outside [0, nq]
-    int32_t* status_host;       // pinned copy of the two flags, refreshed asynchronously after every batch
+    int32_t* overflow;          // = status: device flags [0] candidate capacity exceeded, [1] q_lens outside [0, nq], [2] more
+                                // surviving centroids than score rows (row_cap)
+    int32_t* status_host;       // pinned copy of the flags, refreshed asynchronously after every batch
+    float* rows;                // compact score rows [max_queries, row_cap, 32]: the sparse path's whole "score table"
+    uint32_t* idx_prefix;       // [max_queries, idx_words] ranks of the surviving centroids (qualifying_kernel)
+    int32_t row_cap;            // score rows per query: min(K, FLMR_ROW_CAP (default 16384))
     hipEvent_t status_ev; bool status_pending;
     int32_t* q_lens_ws;         // [max_queries] query lengths clamped to [0, nq]: what every kernel reads
     flmr_options opt;           // variant switches, snapshot taken at flmr_searcher_create
@@ -86,7 +90,7 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     const int nqc = maxp->nq_cand < max_nq ? maxp->nq_cand : max_nq;
     s->ncol_max = (int32_t)flmr_round_up(nqc, 32);
     s->idx_words = (int32_t)flmr_ceil_div(ix->K, 32);
-    s->nblk = (int32_t)flmr_ceil_div(ix->K, 32);  // upper bound on partial-list blocks (>= 32 rows each, kernel-dependent)
+    s->nblk = (int32_t)flmr_ceil_div(ix->K, 64);  // upper bound on partial-list blocks (64 rows each on the fp16 kernels, 128 on the fp32 ones)
     s->max_cells = nqc * maxp->ncells;
     s->nc_bucket = nc_bucket_of(maxp->ncells);
     s->bitmap_words = flmr_ceil_div(ix->num_passages > 0 ? ix->num_passages : 1, 32);
@@ -100,7 +104,19 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
         rc = ws_alloc(s, &s->ptr, (count));     \
         if (rc) { flmr_searcher_destroy(s); return rc; } \
     } while (0)
-    WS(cs, B * (size_t)ix->K * s->ncol_max);
+    // The full K x ncol score table per query (16.8 MB at K = 131072) is allocated on first use by a batch that needs it
+    // (full-table mode: taps / retrieve(), centroids that are not fp16-exact, nq_cand > 32); the default path keeps only the
+    // rows of each query's surviving centroids, at most row_cap of them (2 MB per query at the default).
+    s->cs = nullptr;
+    {
+        const char* rc_opt = s->opt.has(FLMR_OPT_ROW_CAP) ? s->opt.v[FLMR_OPT_ROW_CAP] : nullptr;
+        long cap = rc_opt ? atol(rc_opt) : 16384;
+        if (cap < 64) cap = 64;
+        if (cap > 65535) cap = 65535;   // (the code-scanning stage 1 keeps 16-bit ranks in LDS)
+        s->row_cap = (int32_t)(cap < ix->K ? cap : ix->K);
+    }
+    WS(rows, B * (size_t)s->row_cap * 32);
+    WS(idx_prefix, B * (size_t)s->idx_words);
     WS(idx_bits, B * (size_t)s->idx_words);
     WS(part_val, B * (size_t)s->nblk * s->ncol_max * s->nc_bucket);
     WS(part_idx, B * (size_t)s->nblk * s->ncol_max * s->nc_bucket);
@@ -117,7 +133,7 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     WS(s2_count, B);
     WS(keys3, B * (size_t)nd4);
     WS(doc_scores, B * (size_t)nd4);
-    WS(overflow, 2);
+    WS(overflow, 4);
     WS(q_lens_ws, B);
     WS(q_hi, B * (size_t)s->ncol_max * FLMR_DIM);
     WS(q_lo, B * (size_t)s->ncol_max * FLMR_DIM);
@@ -139,7 +155,7 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
         if (hipMalloc(reinterpret_cast<void**>(&s->s2_part), bytes) == hipSuccess) s->bytes += (int64_t)bytes;
         else { s->s2_part = nullptr; (void)hipGetLastError(); }
     }
-    s->qmax = 1024;
+    s->qmax = s->row_cap;
     WS(qual, B * (size_t)s->qmax);
     WS(nqual, B);
     WS(chunk_cnt, B * (size_t)ix->nchunks);
@@ -148,9 +164,9 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     WS(q3_hi, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
     WS(q3_lo, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
 #undef WS
-    FLMR_HIP(hipMemset(s->overflow, 0, 2 * sizeof(int32_t)));
-    FLMR_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->status_host), 2 * sizeof(int32_t), hipHostMallocDefault));
-    s->status_host[0] = s->status_host[1] = 0;
+    FLMR_HIP(hipMemset(s->overflow, 0, 4 * sizeof(int32_t)));
+    FLMR_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->status_host), 4 * sizeof(int32_t), hipHostMallocDefault));
+    s->status_host[0] = s->status_host[1] = s->status_host[2] = s->status_host[3] = 0;
     FLMR_HIP(hipEventCreateWithFlags(&s->status_ev, hipEventDisableTiming));
     for (int r = 0; r < FLMR_PROF_RING; r++)
         for (int i = 0; i <= FLMR_NUM_STAGES; i++) FLMR_HIP(hipEventCreate(&s->ev[r][i]));
@@ -160,7 +176,7 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
 
 extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
     if (!s) return FLMR_OK;
-    void* ptrs[] = {s->cs, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
+    void* ptrs[] = {s->cs, s->rows, s->idx_prefix, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
                     s->keys1, s->s1_pids, s->s1_count, s->keys2, s->s2_pids, s->s2_count, s->keys3, s->doc_scores,
                     s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->q_err, s->q_err_sum, s->s2_band, s->s2_band_count, s->s2_need, s->s2_def, s->keys2b, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->chunk_hits, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part};
     for (void* p : ptrs) (void)hipFree(p);
@@ -300,12 +316,16 @@ static int poll_status(flmr_searcher* s, bool wait) {
         FLMR_HIP(e);
     }
     s->status_pending = false;
-    const int32_t ovf = s->status_host[0], bad = s->status_host[1];
-    if (ovf || bad) {
-        s->status_host[0] = s->status_host[1] = 0;
+    const int32_t ovf = s->status_host[0], bad = s->status_host[1], rows_ovf = s->status_host[2];
+    if (ovf || bad || rows_ovf) {
+        s->status_host[0] = s->status_host[1] = s->status_host[2] = 0;
         // cleared IN ORDER on the searcher's stream: a synchronous memset on the null stream is not ordered against a later
         // batch already running on a non-blocking stream and could wipe that batch's flag
-        FLMR_HIP(hipMemsetAsync(s->overflow, 0, 2 * sizeof(int32_t), s->last_stream));
+        FLMR_HIP(hipMemsetAsync(s->overflow, 0, 4 * sizeof(int32_t), s->last_stream));
+        if (rows_ovf)
+            FLMR_FAIL(FLMR_ERR_CAPACITY, "an earlier batch had a query with more than %d centroids above centroid_score_threshold: the searcher "
+                      "keeps that many score rows per query and that query's stage-1 scores are not reliable -- raise the threshold, or "
+                      "set the option FLMR_ROW_CAP (up to 65535) before creating the searcher", s->row_cap);
         if (ovf)
             FLMR_FAIL(FLMR_ERR_CAPACITY, "an earlier batch produced more candidates than the workspace bound (cand_cap=%lld): its "
                       "candidate lists were truncated and its results are not reliable (is the IVF consistent with the codes?)",
@@ -317,7 +337,7 @@ static int poll_status(flmr_searcher* s, bool wait) {
 
 static int push_status(run_ctx& c) {
     flmr_searcher* s = c.s;
-    FLMR_HIP(hipMemcpyAsync(s->status_host, s->overflow, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c.st));
+    FLMR_HIP(hipMemcpyAsync(s->status_host, s->overflow, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c.st));
     FLMR_HIP(hipEventRecord(s->status_ev, c.st));
     s->status_pending = true;
     return FLMR_OK;
@@ -386,7 +406,18 @@ static int prepare_ctx(run_ctx& c, flmr_searcher* s, const float* Q, const int32
     const bool f16num = s->numerics == FLMR_NUMERICS_GPU_FP16;
     a0.thr = f16num ? f16_threshold(p->centroid_score_threshold) : p->centroid_score_threshold;
     a0.q_hi_only = f16num ? 1 : 0;
-    a0.cs = s->cs; a0.idx_bits = s->idx_bits; a0.idx_words = s->idx_words;
+    c.sparse = sparse_path(s, ncol);
+    if (!c.sparse && !s->cs) {   // first batch that needs the whole K x ncol table per query: allocate it now (synchronous, once)
+        const size_t bytes = (size_t)s->max_queries * (size_t)ix->K * s->ncol_max * sizeof(float);
+        if (hipMalloc(reinterpret_cast<void**>(&s->cs), bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            s->cs = nullptr;
+            FLMR_FAIL(FLMR_ERR_NOMEM, "the full centroid-score table needs %.1f GB for %d queries (full-table mode: taps, centroids that are "
+                      "not fp16-representable, nq_cand > 32): create the searcher for fewer queries", bytes / 1e9, s->max_queries);
+        }
+        s->bytes += (int64_t)bytes;
+    }
+    a0.cs = c.sparse ? nullptr : s->cs; a0.idx_bits = s->idx_bits; a0.idx_words = s->idx_words;
     a0.part_val = s->part_val; a0.part_idx = s->part_idx; a0.nblk = s->nblk;
     a0.cells = s->cells; a0.ncell = s->ncell; a0.max_cells = s->max_cells;
     a0.q_hi = s->q_hi; a0.q_lo = s->q_lo; a0.centroids_f16_exact = ix->centroids_f16_exact;
@@ -403,10 +434,11 @@ static int prepare_ctx(run_ctx& c, flmr_searcher* s, const float* Q, const int32
     a0.cen_norm_max = ix->cen_norm_max;
     a0.centroids_f16 = ix->centroids_f16;
     a0.part_rows = 0;
-    c.sparse = sparse_path(s, ncol);
     a0.full_table = c.sparse ? 0 : 1;
     flmr_filter_args& f = c.f;
-    f.cs = s->cs; f.cs_query_stride = (int64_t)ix->K * ncol; f.K = ix->K; f.ncol = ncol; f.nq_cand = nqc;
+    f.cs = c.sparse ? s->rows : s->cs; f.cs_query_stride = c.sparse ? (int64_t)s->row_cap * 32 : (int64_t)ix->K * ncol;
+    f.cs_compact = c.sparse ? 1 : 0; f.row_cap = s->row_cap; f.idx_prefix = s->idx_prefix;
+    f.K = ix->K; f.ncol = ncol; f.nq_cand = nqc;
     f.nqueries = nqueries; f.q_lens = q_lens; f.codes = ix->codes; f.doclens = nullptr; f.offsets = ix->doc_offsets;
     f.f16_round = f16num ? 1 : 0;
     s->last_nqueries = nqueries; s->last_ncol = ncol; s->last_ndocs = p->ndocs; s->last_stream = c.st;
@@ -451,7 +483,9 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
         // FLMR_S1_IMPL=scan keeps the code-scanning kernel for every query (A/B runs, cross-check tests)
         scatter = use_hits && c.ncol == 32 && !s->opt.is(FLMR_OPT_S1_IMPL, "scan");
         ca.scatter = scatter ? 1 : 0;
-        ca.cs = s->cs; ca.cs_query_stride = c.f.cs_query_stride; ca.nq_cand = c.nqc; ca.q_lens = c.q_lens;
+        ca.cs = c.f.cs; ca.cs_query_stride = c.f.cs_query_stride; ca.nq_cand = c.nqc; ca.q_lens = c.q_lens;
+        ca.cs_compact = c.f.cs_compact; ca.idx_prefix = s->idx_prefix;
+        ca.rows_out = c.sparse ? s->rows : nullptr; ca.cen16 = ix->centroids_f16; ca.q_hi = s->q_hi; ca.q_lo = s->q_lo;
         ca.keys = s->keys1; ca.key_count = s->key_count; ca.chunk_hits = s->chunk_hits; ca.n_select = c.p.ndocs;
         ca.f16_round = c.f.f16_round;
         RUN(flmr_launch_candidates_chunked(ca, st));
@@ -633,9 +667,7 @@ extern "C" int flmr_search_phase1_probed(flmr_searcher_t* s, const float* Q, con
     FLMR_HIP(hipMemcpyAsync(s->cells, cells, (size_t)nqueries * s->max_cells * sizeof(int32_t), hipMemcpyDeviceToDevice, c.st));
     FLMR_HIP(hipMemcpyAsync(s->ncell, ncell, (size_t)nqueries * sizeof(int32_t), hipMemcpyDeviceToDevice, c.st));
     RUN(mark(c));
-    RUN(flmr_launch_split_q(c.a0, c.st));
-    RUN(flmr_launch_qual_rows(s->idx_bits, s->idx_words, nqueries, s->cs, c.f.cs_query_stride, c.ncol, s->ix->centroids_f16,
-                              s->q_hi, s->q_lo, c.st));
+    RUN(flmr_launch_split_q(c.a0, c.st));   // (the score rows of the surviving centroids are rebuilt from the bitset by qualifying_kernel)
     RUN(mark(c));
     RUN(mark(c));
     return stage_cand_s1(c, out_keys);

@@ -148,7 +148,6 @@ __global__ __launch_bounds__(256) void s0_centroid_scores_mfma(flmr_s0_args a) {
 // tile once per 128 rows; the per-column top lists are carried across the 4 row tiles in registers, so the kernel
 // has no LDS and no block barrier.  grid = (ceil(K/512), QSPLIT), block = 256.
 // ------------------------------------------------------------------------------------------------
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // hi_only (FLMR_NUMERICS_GPU_FP16): the query is ROUNDED to fp16 like the reference's `Q.cuda().half()`
 // (candidate_generation.py:50-52): q_lo = 0 and every split kernel then computes the fp32-accumulated fp16 product.
@@ -383,7 +382,8 @@ __global__ __launch_bounds__(64 * S0_WAVES, S0_OCC) void s0_centroid_scores_f16(
                 // table store.  Sparse mode keeps only the rows of surviving centroids (all stage 1 ever reads; stage 2
                 // and the cell selection recompute what they need from the fp16 centroids), which removes the
                 // 4*K*32-byte-per-query table write -- the largest HBM stream of the whole path.
-                if (!sparse || ((byte >> (lane >> 3)) & 1u))
+                // (a.cs == NULL: the sparse path's compact form -- the surviving rows are computed by qualifying_kernel, nothing is stored here)
+                if (a.cs && (!sparse || ((byte >> (lane >> 3)) & 1u)))
                     *reinterpret_cast<float4*>(cs_b + (size_t)(rbase + R) * a.ncol + ct * 32 + c4) = v4;
             }
             __builtin_amdgcn_wave_barrier();
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(512, 1) void s0_centroid_scores_qs(flmr_s0_args a, 
             bal &= 0x0101010101010101ull;
             const uint32_t byte = (uint32_t)((bal * 0x0102040810204080ull) >> 56);
             idxw |= byte << (8 * mrow);
-            if ((byte >> (lane >> 3)) & 1u) *reinterpret_cast<float4*>(cs_b + (size_t)(rbase + R) * a.ncol + c4) = v4;
+            if (a.cs && ((byte >> (lane >> 3)) & 1u)) *reinterpret_cast<float4*>(cs_b + (size_t)(rbase + R) * a.ncol + c4) = v4;
         }
         __builtin_amdgcn_wave_barrier();
         // (the idx words start at zero -- cleared by the launcher -- so only a tile that went through here stores one)
@@ -742,11 +742,13 @@ __global__ __launch_bounds__(64 * S0Q2_WAVES, 1) void s0_centroid_scores_qs2(flm
 
     unsigned long long colmask[S0Q_QT];
     bool full_cols[S0Q_QT];
+    float qemax[S0Q_QT];   // the largest column bound of the query (wave-uniform): a row maximum is within it of the full one
 #pragma unroll
     for (int q = 0; q < S0Q_QT; q++) {
         const int n = __builtin_amdgcn_readfirstlane(nqc[q]);
         full_cols[q] = n >= 32;
         colmask[q] = full_cols[q] ? ~0ull : (((1ull << n) - 1ull) * 0x100000001ull);
+        qemax[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(flmr_half_wave_max(i < n ? qe[q] : 0.0f))));
     }
     auto tile_max = [](const f32x16& v) {   // one chain (v_max3): a tree makes the compiler canonicalise every raw MFMA output
         float m = fmaxf(v[0], v[1]);
@@ -785,10 +787,48 @@ __global__ __launch_bounds__(64 * S0Q2_WAVES, 1) void s0_centroid_scores_qs2(flm
         for (int q = 0; q < S0Q_QT; q++) {
             const float tmax = tile_max(acc[q]);
             cmax[q] = fmaxf(cmax[q], tmax);
-            // wave-uniform and rare: some row of this tile survives (or, with the lo products still missing, may survive)
+            // wave-uniform and rare on a corpus whose queries meet few centroids (1 % of the tiles at the policy thresholds of the
+            // synthetic corpus; MOST tiles once thousands of centroids pass the threshold): some row of this tile survives (or,
+            // with the lo products still missing, may survive).  The tile's idx word -- one bit per row: does the row's maximum
+            // over the query's columns reach the threshold -- is decided HERE from the hi products whenever no row's maximum lies
+            // within the bound of the threshold: a transpose-reduce leaves row (i >> 1)'s maximum over the 32 columns in lane i
+            // (16 cross-lane exchanges for the 16 x 32 values of a half-wave, not 16 x 5), a ballot collects the bits.  Only a
+            // tile with an ambiguous row goes on the list of the deferred pass (both products, dense epilogue).
             if ((__ballot(tmax + qe[q] >= a.thr) & colmask[q]) != 0ull) {
+#ifdef S0Q2_NO_INLINE_IDX   // development A/B: every flagged tile goes to the deferred pass (the form before round 4)
                 if (lane == 0) flist[nflag] = (uint16_t)(t * S0Q_QT + q);
                 nflag++;
+                continue;
+#endif
+                float v8[8];
+                const bool up = (i & 16) != 0;
+#pragma unroll
+                for (int r = 0; r < 8; r++) {   // lanes with bit 4 clear keep registers 0..7, the others 8..15
+                    float x0 = acc[q][r], x1 = acc[q][r + 8];
+                    if (!full_cols[q]) { x0 = i < nqc[q] ? x0 : FLMR_NEG_INF; x1 = i < nqc[q] ? x1 : FLMR_NEG_INF; }
+                    const float keep = up ? x1 : x0, send = up ? x0 : x1;
+                    v8[r] = fmaxf(keep, __shfl_xor(send, 16, 64));
+                }
+                float v4[4], v2[2];
+                const bool up3 = (i & 8) != 0, up2 = (i & 4) != 0, up1 = (i & 2) != 0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) v4[r] = fmaxf(up3 ? v8[r + 4] : v8[r], __shfl_xor(up3 ? v8[r] : v8[r + 4], 8, 64));
+#pragma unroll
+                for (int r = 0; r < 2; r++) v2[r] = fmaxf(up2 ? v4[r + 2] : v4[r], __shfl_xor(up2 ? v4[r] : v4[r + 2], 4, 64));
+                float rm = fmaxf(up1 ? v2[1] : v2[0], __shfl_xor(up1 ? v2[0] : v2[1], 2, 64));
+                rm = fmaxf(rm, __shfl_xor(rm, 1, 64));   // lane (i, h): the maximum of row r = i >> 1 (of this half's 16) over all columns
+                const unsigned long long amb = HI_ONLY ? 0ull : __ballot(rm + qemax[q] >= a.thr && rm - qemax[q] < a.thr);
+                if (amb != 0ull) {
+                    if (lane == 0) flist[nflag] = (uint16_t)(t * S0Q_QT + q);
+                    nflag++;
+                } else {
+                    // register r = 4 a + b of half h is row b + 8 a + 4 h: lane 32 h + 8 a + 2 b (and its odd twin) -> bit 8 a + 4 h + b
+                    unsigned long long y = __ballot(rm >= a.thr) & 0x5555555555555555ull;
+                    y = (y | (y >> 1)) & 0x3333333333333333ull;
+                    y = (y | (y >> 2)) & 0x0f0f0f0f0f0f0f0full;
+                    const uint32_t word = (uint32_t)y | ((uint32_t)(y >> 32) << 4);
+                    if (lane == 0 && word != 0u) a.idx_bits[(size_t)bq[q] * a.idx_words + ((row_begin >> 5) + t)] = word;
+                }
             }
         }
     };
@@ -920,7 +960,7 @@ __global__ __launch_bounds__(64 * S0Q2_WAVES, 1) void s0_centroid_scores_qs2(flm
                 bal &= 0x0101010101010101ull;
                 const uint32_t byte = (uint32_t)((bal * 0x0102040810204080ull) >> 56);
                 idxw |= byte << (8 * mrow);
-                if ((byte >> (lane >> 3)) & 1u) *reinterpret_cast<float4*>(cs_b + (size_t)(rbase + R) * a.ncol + c4) = v4;
+                if (a.cs && ((byte >> (lane >> 3)) & 1u)) *reinterpret_cast<float4*>(cs_b + (size_t)(rbase + R) * a.ncol + c4) = v4;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();   // (the staged tile has been read before the next one overwrites it)

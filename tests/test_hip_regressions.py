@@ -157,3 +157,44 @@ def test_ndocs_8192_through_approximate_then_refine(hip):
         for x, y in zip(res[impl], res["lds"]):
             assert np.array_equal(x, y), impl
     scorer.close_searcher()
+
+
+def test_many_surviving_centroids_code_scan_and_row_capacity(hip):
+    """Thousands of centroids above the threshold per query (what a real corpus gives at the policy thresholds; the synthetic
+    corpora have ~50): beyond the scatter stage 1's 1024 lists the code-scanning stage 1 runs, on the compact score rows
+    (row = rank of the centroid among the survivors) -- ranked lists against the CPU oracle.  A searcher created with fewer
+    score rows than a query needs reports FLMR_ERR_CAPACITY at the next sync point and stays usable."""
+    torch, nat = hip["torch"], hip["native"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    corpus = synth.make_corpus(30_000, (20, 60), 8192, 2, seed=61, device="cuda")
+    oi = _oracle(corpus)
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=16)
+    Q, _ = synth.make_queries(corpus, 12, 32, seed=3)
+    q_lens = torch.tensor([32, 32, 17, 32, 32, 5, 32, 32, 32, 32, 32, 32], dtype=torch.int32)
+    ncells, thr, ndocs = 2, 0.2, 256
+    p, s, c = scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=q_lens)
+    scorer.check()
+    nsurv = [int(np.unpackbits(scorer.tap(nat.TAP_IDX_BITS, q).view(np.uint8)).sum()) for q in range(Q.size(0))]
+    assert max(nsurv) > 1024, nsurv        # the shape under test: past the scatter kernel's list ids
+    p, s, c = p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy()
+    Qh = Q.cpu().numpy()
+    checked = 0
+    for i in range(Q.size(0)):
+        rp, rs, ncand = oi.rank(Qh[i, : int(q_lens[i])], ncells, thr, ndocs, 32)
+        if ncand < ndocs:
+            continue
+        m = int(c[i])
+        assert m == len(rp), (i, m, len(rp))
+        tie_aware_equal(rp, rs, p[i, :m], s[i, :m])
+        checked += 1
+    assert checked >= 8, checked
+    with nat.options(FLMR_ROW_CAP="256"):
+        scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=q_lens)
+        with pytest.raises(nat.FlmrNativeError, match="FLMR_ROW_CAP"):
+            scorer.check()
+        p2, s2, c2 = scorer.search_batch(Q, ndocs // 4, ncells, 0.6, ndocs, 32, q_lens=q_lens)   # few survivors: fine again
+        scorer.check()
+        p3, s3, c3 = IndexScorer(device_index=scorer.device_index, max_batch=16).search_batch(Q, ndocs // 4, ncells, 0.6, ndocs, 32, q_lens=q_lens)
+        assert torch.equal(p2, p3) and torch.equal(s2, s3) and torch.equal(c2, c3)
+    scorer.close_searcher()
