@@ -31,7 +31,6 @@ for (ncells, thr, ndocs, k) in pols:
     for i in range(2):
         scorer.search_batch(Qs[i % 2], k, ncells, thr, ndocs, 32, profile=True)
     st = {a: round(b / 2, 3) for a, b in scorer.stage_ms().items()}
-    nsurv = int(torch.from_numpy(scorer.tap(ravqa_amd._native.TAP_IDX_BITS, 0).view("uint8").copy()).to(torch.uint8).cpu().numpy().astype("uint8").view("uint8").size and
-                sum(bin(int(x)).count("1") for x in scorer.tap(ravqa_amd._native.TAP_IDX_BITS, 0)))
+    nsurv = sum(bin(int(x)).count("1") for x in scorer.tap(ravqa_amd._native.TAP_IDX_BITS, 0))
     print(json.dumps({"policy": [ncells, thr, ndocs, k], "queries_per_sec": round(1024 / dt), "ms_per_step": round(dt * 1e3, 3),
                       "surviving_centroids_q0": nsurv, "stage_ms": st}))

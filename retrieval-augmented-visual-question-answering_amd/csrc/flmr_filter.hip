@@ -65,29 +65,42 @@ struct s1_idx_view {
 #define S1_PAIRS_IN_FLIGHT 4  // 8 documents = 16 code loads per wave in flight
 
 // The surviving-centroid hits of one 128-token chunk of TWO documents (one per half-wave) are LISTED: lane i of a half holds
-// tokens i, 32+i, 64+i, 96+i of its document (cd[0..3], -1 = no token); every hit appends the row id of its centroid -- the
-// centroid id (full table) or its rank among the query's surviving centroids (compact rows) -- to the half's list in LDS at a
-// position taken from a ballot.  Returns this half's number of hits (uniform over the half).
+// tokens 4i .. 4i+3 of its document's chunk (cd[0..3], -1 = no token); every hit appends the row id of its centroid -- the
+// centroid id (full table) or its rank among the query's surviving centroids (compact rows) -- to the half's list in LDS, at a
+// position from ONE exclusive scan of the lanes' hit counts over the half (the order of a list does not matter: a maximum).
+// Returns this half's number of hits (uniform over the half).  ~35 instructions per lane and chunk: the scan of a candidate's
+// codes is instruction-bound long before it is bandwidth-bound.
 __device__ __forceinline__ int s1_list_hits(const int* cd, const s1_idx_view& iv, int lane, uint16_t* list16, int* list32) {
     const int k = lane & 31, h = lane >> 5;
-    int nh = 0;
+    uint32_t wd[4];
+    uint32_t hm = 0u;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-        const int c = cd[e];
-        const uint32_t wd = c >= 0 ? iv.bits[c >> 5] : 0u;
-        const bool hit = c >= 0 && ((wd >> (c & 31)) & 1u);
-        const unsigned long long bal = __ballot(hit);
-        const uint32_t mh = h ? (uint32_t)(bal >> 32) : (uint32_t)bal;
-        if (hit) {
-            const int at = h * S1_HITS_MAX + nh + __popc(mh & ((1u << k) - 1u));
+        wd[e] = cd[e] >= 0 ? iv.bits[cd[e] >> 5] : 0u;
+        hm |= ((cd[e] >= 0) ? ((wd[e] >> (cd[e] & 31)) & 1u) : 0u) << e;
+    }
+    const int cnt = __popc(hm);
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        const int y = __shfl_up(incl, d, 32);
+        if (k >= d) incl += y;
+    }
+    const int nh = __shfl(incl, 31, 32);
+    if (hm) {
+        int at = h * S1_HITS_MAX + incl - cnt;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if (!((hm >> e) & 1u)) continue;
+            const int c = cd[e];
             if (iv.compact) {
-                int rid = (int)(iv.prefix16 ? (uint32_t)iv.prefix16[c >> 5] : iv.prefix32[c >> 5]) + __popc(wd & ((1u << (c & 31)) - 1u));
+                const int rid = (int)(iv.prefix16 ? (uint32_t)iv.prefix16[c >> 5] : iv.prefix32[c >> 5]) + __popc(wd[e] & ((1u << (c & 31)) - 1u));
                 list16[at] = (uint16_t)(rid < iv.row_cap ? rid : iv.row_cap - 1);
             } else {
                 list32[at] = c;
             }
+            at++;
         }
-        nh += __popc(mh);
     }
     return nh;
 }
@@ -110,7 +123,7 @@ __device__ __forceinline__ int s1_list_hits(const int* cd, const s1_idx_view& iv
 #define S1_ITEMS_G 32   // parts per query
 
 template <bool USE_LDS_IDX, int TM>
-__global__ __launch_bounds__(512) void filter_stage1_kernel(flmr_filter_args f, const uint32_t* idx_bits,
+__global__ __launch_bounds__(512, 4) void filter_stage1_kernel(flmr_filter_args f, const uint32_t* idx_bits,
                                                             int32_t idx_words, const int32_t* cand,
                                                             int64_t cand_stride, const int32_t* cand_count,
                                                             uint64_t* keys, const uint32_t* hit_bits,
@@ -227,6 +240,22 @@ __global__ __launch_bounds__(512) void filter_stage1_kernel(flmr_filter_args f, 
             int jh[S1_PAIRS_IN_FLIGHT], len[S1_PAIRS_IN_FLIGHT];
             int64_t off[S1_PAIRS_IN_FLIGHT];
             int cd[S1_PAIRS_IN_FLIGHT][4];
+            // lane k of a half takes tokens t0 + 4k .. + 3 of its document: one 16-byte load (the codes of a passage are
+            // contiguous, 4-byte aligned); the lane that straddles the passage's end reads its tokens one by one (nothing is
+            // read past the end of the code array)
+            auto load_codes = [&](int (&c_)[4], int64_t o, int n, int t0) {
+                const int first = t0 + 4 * k;
+                c_[0] = c_[1] = c_[2] = c_[3] = -1;
+                if (first + 4 <= n) {
+                    typedef int s1_int4u __attribute__((ext_vector_type(4), aligned(4)));
+                    const s1_int4u v = __builtin_nontemporal_load(reinterpret_cast<const s1_int4u*>(f.codes + o + first));
+                    c_[0] = v.x; c_[1] = v.y; c_[2] = v.z; c_[3] = v.w;
+                } else if (first < n) {
+#pragma unroll
+                    for (int e = 0; e < 3; e++)
+                        if (first + e < n) c_[e] = __builtin_nontemporal_load(f.codes + o + first + e);
+                }
+            };
             auto prep = [&](int (&jh_)[S1_PAIRS_IN_FLIGHT], int (&len_)[S1_PAIRS_IN_FLIGHT], int64_t (&off_)[S1_PAIRS_IN_FLIGHT]) {
 #pragma unroll
                 for (int u = 0; u < S1_PAIRS_IN_FLIGHT; u++) {
@@ -238,8 +267,7 @@ __global__ __launch_bounds__(512) void filter_stage1_kernel(flmr_filter_args f, 
                     const int j = jh_[u] < 0 ? 0 : jh_[u];
                     off_[u] = shfl_i64(my_off, j);
                     len_[u] = jh_[u] < 0 ? 0 : __shfl(my_len, j, 64);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) cd[u][e] = (32 * e + k < len_[u]) ? __builtin_nontemporal_load(f.codes + off_[u] + 32 * e + k) : -1;
+                    load_codes(cd[u], off_[u], len_[u], 0);
                 }
             };
             bool more = todo != 0ull;
@@ -304,9 +332,7 @@ __global__ __launch_bounds__(512) void filter_stage1_kernel(flmr_filter_args f, 
                 for (int t0 = 128; __ballot(t0 < clen[0] || t0 < clen[1] || t0 < clen[2] || t0 < clen[3]) != 0ull; t0 += 128) {
                     int cx[S1_PAIRS_IN_FLIGHT][4];
 #pragma unroll
-                    for (int u = 0; u < S1_PAIRS_IN_FLIGHT; u++)
-#pragma unroll
-                        for (int e = 0; e < 4; e++) cx[u][e] = (t0 + 32 * e + k < clen[u]) ? __builtin_nontemporal_load(f.codes + coff[u] + t0 + 32 * e + k) : -1;
+                    for (int u = 0; u < S1_PAIRS_IN_FLIGHT; u++) load_codes(cx[u], coff[u], clen[u], t0);
                     gather_round(list_round(cx));
                 }
 #pragma unroll
