@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the k=5 / nbits=8 / ragged / Nq=832 sub-results")
     ap.add_argument("--replicate-stage0", action="store_true",
                     help="exact shard mode: every rank runs stage 0 for the whole batch instead of 1/N of the queries + an exchange")
+    ap.add_argument("--shard-depth", type=int, default=2,
+                    help="exact shard mode: sub-batches of a step in flight at once (each on its own native searcher): the exchange "
+                         "of one travels while the next computes; 1 = no pipelining")
     ap.add_argument("--shard-mode", choices=["exact", "fast"], default="exact",
                     help="N > 1: exact = three key exchanges, result bit-identical to the unsharded index (default); "
                          "fast = one all-gather of per-shard top-k (superset semantics)")
@@ -219,8 +222,10 @@ def main():
     def run_step(sc, Q, kk, pol, profile=False):
         if exact:
             # check=False: no host sync / flag exchange inside the timed steps; check_all() runs after them
-            return sharded.search_batch_exact(Q, kk, nq_cand=32, gather=host_gather if args.single_device_smoke else None,
-                                              split_stage0=not args.replicate_stage0, check=False)
+            # sub-batches of the step pipelined against the exchanges (--shard-depth in flight; 1 = one call for the whole step)
+            return sharded.search_batch_exact_pipelined(Q, kk, nq_cand=32, sub_batch=min(args.batch, args.sub_batch), depth=args.shard_depth,
+                                                        gather=host_gather if args.single_device_smoke else None,
+                                                        split_stage0=not args.replicate_stage0)
         p, s, c = sc.search_batch(Q, kk, pol[0], pol[1], pol[2], 32, profile=profile)   # query_maxlen = 32 (index_storage.py:77)
         if use_dist:
             if args.single_device_smoke:
@@ -271,19 +276,31 @@ def main():
     # ---- N > 1: wall time of every collective of the exact protocol, in separate un-timed steps ------------------------
     exchange_ms = None
     if exact:
-        sharded.timings = {}
+        sharded.timings = {}   # every exchange then runs synchronously between two events on the launch stream (no host sync inside)
         nprobe = 3
         for i in range(nprobe):
             run_step(scorer, Qs[i % nb], k, (ncells, thr, ndocs))
         barrier()
-        exchange_ms = {n: v / nprobe * 1e3 for n, v in sharded.timings.items()}
+        exchange_ms = {n: v / nprobe for n, v in sharded.exchange_ms().items()}
         sharded.timings = None
+        # the same steps with the sub-batches NOT pipelined, for the overlap the pipeline buys (same collectives, same results)
+        if args.shard_depth > 1 and args.batch > args.sub_batch:
+            depth_keep, args.shard_depth = args.shard_depth, 1
+            for i in range(2):
+                run_step(scorer, Qs[i % nb], k, (ncells, thr, ndocs))
+            barrier()
+            t0_ = time.perf_counter()
+            for i in range(args.steps):
+                run_step(scorer, Qs[i % nb], k, (ncells, thr, ndocs))
+            barrier()
+            exchange_ms["ms_per_step_unpipelined"] = (time.perf_counter() - t0_) / args.steps * 1e3
+            args.shard_depth = depth_keep
 
     out = None
     if rank == 0:
         # ---- workload statistics of the last batch (outside the timed region) ----------------------------------------
         sub_n = min(args.batch, args.sub_batch)
-        nlast = args.batch if exact else (args.batch - 1) % sub_n + 1   # taps index into the last sub-batch
+        nlast = (args.batch - 1) % sub_n + 1   # taps index into the last native call: never more queries than its smallest sub-batch
         P = [len(scorer.tap(_native.TAP_CANDIDATES, q)) for q in range(0, nlast, max(1, nlast // 32))]
         ncell = [len(scorer.tap(_native.TAP_CELLS, q)) for q in range(0, nlast, max(1, nlast // 32))]
         P_mean, ncell_mean = sum(P) / len(P), sum(ncell) / len(ncell)
@@ -407,8 +424,10 @@ def main():
         }
         if exchange_ms is not None:
             out["exchange_ms"] = exchange_ms
-            out["exchange_ms_note"] = ("wall time per collective of one step (device-synchronised around each call, separate "
-                                       "un-timed steps): the rest of ms_per_step is per-rank compute")
+            out["exchange_ms_note"] = ("duration of each collective of one step between two events on the launch stream (separate "
+                                       "un-timed steps, exchanges issued synchronously there); in the timed steps the sub-batches are "
+                                       "pipelined -- --shard-depth of them in flight, their collectives asynchronous -- and "
+                                       "ms_per_step_unpipelined is the same step as ONE protocol call per rank")
 
     # ---- CPU baseline (rank 0, N=1 only): the reference's own C++ stages + torch-CPU glue, bounded samples ----------------
     if rank == 0 and not use_dist and not args.no_cpu_baseline and args.cpu_queries > 0:

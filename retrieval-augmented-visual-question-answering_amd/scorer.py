@@ -115,6 +115,11 @@ class IndexScorer:
             self.ivf = _Strided(torch.from_numpy(self.arrays.ivf), torch.from_numpy(self.arrays.ivf_lengths))
             self.embeddings_strided = _EmbeddingsStrided(self.embeddings, self.doclens)
 
+    def clone(self, max_batch=None):
+        """Another scorer on the SAME resident index with its own native searcher (workspace): what a second in-flight
+        sub-batch of the pipelined sharded protocol runs on (the phases of a batch share workspace state)."""
+        return type(self)(device_index=self.device_index, max_batch=max_batch or self.max_batch, numerics=self.numerics)
+
     # ---- native searcher (workspace) management ---------------------------------------------------------
     def _get_searcher(self, nqueries, nq, p):
         key = (max(nqueries, 1), nq, p.ncells, p.ndocs, p.nq_cand)

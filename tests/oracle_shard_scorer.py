@@ -60,6 +60,12 @@ class OracleShardScorer:
         self.query_split = query_split
         self.calls = []
 
+    def clone(self):
+        """Another scorer on the same shard with its own phase state (a second in-flight sub-batch of the pipelined protocol)."""
+        other = OracleShardScorer(self.a, self.query_split)
+        other.calls = self.calls     # one call log per rank
+        return other
+
     # ---- stage 0 ------------------------------------------------------------------------------------------------
     def _stage0(self, q, qlen, nq_cand, ncells, thr):
         nqc = min(nq_cand, qlen)

@@ -115,7 +115,17 @@ def _exact_worker(rank, world, port, out_path, query_split, use_q_lens):
     for k in (100, 10):
         p, s, c = ss.search_batch_exact(Q, k, nq_cand=32, q_lens=q_lens)   # default gather / all_reduce: real gloo collectives
         res[k] = (p, s, c)
-    torch.save({"res": res, "calls": scorer.calls, "timings": ss.timings, "split_ok": dict(ss._split_ok)}, f"{out_path}.{rank}")
+    timings = dict(ss.timings)
+    # the same step cut into sub-batches with two of them in flight (search_batch_exact_pipelined): asynchronous collectives,
+    # one scorer per in-flight sub-batch, ragged last sub-batch -- must equal the whole-batch call bit for bit
+    ss.timings = None
+    Q7 = torch.cat([Q, Q[[2, 0]]])
+    ql7 = None if q_lens is None else torch.cat([q_lens, q_lens[[2, 0]]])
+    whole = ss.search_batch_exact(Q7, 100, nq_cand=32, q_lens=ql7)
+    piped = {sb: ss.search_batch_exact_pipelined(Q7, 100, nq_cand=32, q_lens=ql7, sub_batch=sb, depth=dp) for sb, dp in ((3, 2), (2, 3))}
+    ss.check_all()
+    torch.save({"res": res, "calls": scorer.calls, "timings": timings, "split_ok": dict(ss._split_ok), "whole": whole, "piped": piped},
+               f"{out_path}.{rank}")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -159,6 +169,9 @@ def test_exact_protocol_multirank_equals_unsharded(tmp_path, world, query_split,
             assert "phase1" in calls and "probe" not in calls and "gather_probe_state" not in res[r]["timings"]
         assert list(res[r]["split_ok"].values()) == [query_split] * len(res[r]["split_ok"])
         assert {"gather_stage1_keys", "reduce_stage2_keys", "reduce_stage3_keys"} <= set(res[r]["timings"])
+        for sb, got in res[r]["piped"].items():   # pipelined sub-batches == one call, on every rank
+            for a, b in zip(got, res[r]["whole"]):
+                assert torch.equal(a, b), (r, sb)
 
 
 def _vote_worker(rank, world, port, out_path):
