@@ -57,9 +57,10 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the k=5 / nbits=8 / ragged / Nq=832 sub-results")
     ap.add_argument("--replicate-stage0", action="store_true",
                     help="exact shard mode: every rank runs stage 0 for the whole batch instead of 1/N of the queries + an exchange")
-    ap.add_argument("--shard-depth", type=int, default=2,
+    ap.add_argument("--shard-depth", type=int, default=0,
                     help="exact shard mode: sub-batches of a step in flight at once (each on its own native searcher): the exchange "
-                         "of one travels while the next computes; 1 = no pipelining")
+                         "of one travels while the next computes; 1 = the whole step as ONE protocol call per rank; 0 (default) = "
+                         "calibrate: a few untimed steps of each, every rank takes the faster by the slowest rank's clock")
     ap.add_argument("--shard-mode", choices=["exact", "fast"], default="exact",
                     help="N > 1: exact = three key exchanges, result bit-identical to the unsharded index (default); "
                          "fast = one all-gather of per-shard top-k (superset semantics)")
@@ -262,6 +263,17 @@ def main():
         hits = [float((last[j][0][:, :5] == targets[j].unsqueeze(1).to(torch.int32)).any(dim=1).float().mean()) for j in last]
         return dt, {n: v / steps for n, v in stage_sum.items()}, sum(hits) / len(hits), last
 
+    shard_calibration = None
+    if exact and args.shard_depth <= 0:
+        # Pipelining the sub-batches hides the exchanges behind compute but runs every kernel on a quarter of the step's queries;
+        # which wins depends on what the exchanges cost on this node's fabric -- measured here, before the timed region, and
+        # decided identically on every rank (timed() MAX-reduces its wall time over the ranks).
+        cal = {}
+        for depth in (1, 2):
+            args.shard_depth = depth
+            cal[depth] = timed(scorer, Qs, tgts, k, (ncells, thr, ndocs), 4, 2, collect_stages=False)[0] / 4 * 1e3
+        args.shard_depth = 1 if (cal[1] <= cal[2] or args.batch <= args.sub_batch) else 2
+        shard_calibration = {"ms_per_step_depth1": cal[1], "ms_per_step_depth2": cal[2], "chosen_depth": args.shard_depth}
     dt, _, recall5, last = timed(scorer, Qs, tgts, k, (ncells, thr, ndocs), args.steps, args.warmup, collect_stages=False)
     # Per-stage HIP events (the roofline's kernel durations) come from a second pass over the same K steps: ten timing
     # events per native call cost 1.5 % of a step at one call per step and 6 % at four sub-batches (profiles/README.md),
@@ -422,6 +434,8 @@ def main():
             "candidates_per_query": P_mean, "cells_per_query": ncell_mean,
             "hbm_copy_GBs": copy_gbs, "index_build_s": t_build, "workspace_GB": scorer.workspace_bytes() / 1e9,
         }
+        if shard_calibration is not None:
+            out["shard_pipeline"] = shard_calibration
         if exchange_ms is not None:
             out["exchange_ms"] = exchange_ms
             out["exchange_ms_note"] = ("duration of each collective of one step between two events on the launch stream (separate "

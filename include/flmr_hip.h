@@ -298,6 +298,11 @@ int flmr_score_pids(const flmr_index_t* index, const float* Q, int32_t nq, const
  * Padded tokens score -9999 (no zero clamp); forward only. */
 int flmr_colbert_score_padded(const float* Q, int32_t q_batch, int32_t nq, const float* D, const uint8_t* mask,
                               int32_t B, int32_t Ld, int32_t dim, float* out, flmr_stream_t stream);
+/* The same kernel, stopped one step earlier: out_colmax f32 [B, nq] = the per-column maxima (-9999 padding) whose sum
+ * flmr_colbert_score_padded returns -- what colbert_score_reduce's 'flipr' interaction reduces differently (the 32 largest of
+ * the first 64 columns + the 8 largest of the rest, TPC/modeling/colbert.py:246-261). */
+int flmr_colbert_colmax_padded(const float* Q, int32_t q_batch, int32_t nq, const float* D, const uint8_t* mask, int32_t B,
+                               int32_t Ld, int32_t dim, float* out_colmax, flmr_stream_t stream);
 
 /* Merge per-shard top-k lists after the RCCL all-gather: scores f32[nshards, nqueries, k],
  * pids i32[nshards, nqueries, k] (-1 = empty) -> global top-k per query in descending (score,pid) order. */
@@ -332,6 +337,13 @@ int flmr_nearest_centroids(const float* centroids, int64_t K, const float* emb, 
                            flmr_stream_t stream);
 int flmr_compress_residuals(const float* centroids, int64_t K, const float* emb, const int32_t* codes, int64_t n,
                             const float* bucket_cutoffs, int32_t nbits, uint8_t* out_residuals, flmr_stream_t stream);
+/*   flmr_build_ivf          the inverted file of an index: for every centroid the ascending unique pids of the passages that
+ *                           hold a token assigned to it -- optimize_ivf, TPC/indexing/utils.py:8-53 (codes.sort() of
+ *                           collection_indexer.py:388-426, embedding id -> pid, unique per centroid).  codes i32 [n_tokens] in
+ *                           passage order, doc_offsets i64 [num_passages + 1]; ivf_pids must hold n_tokens entries (the
+ *                           bound), ivf_lengths i64 [K]; *total (HOST) = entries written.  Synchronises `stream`. */
+int flmr_build_ivf(const int32_t* codes, int64_t n_tokens, const int64_t* doc_offsets, int64_t num_passages, int32_t K,
+                   int32_t* ivf_pids, int64_t* ivf_lengths, int64_t* total, flmr_stream_t stream);
 
 #ifdef __cplusplus
 }

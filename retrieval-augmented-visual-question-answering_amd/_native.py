@@ -12,7 +12,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.environ.get("FLMR_HIP_LIB") or os.path.join(PKG_DIR, "lib", "libflmr_hip.so")  # override: A/B-ing kernel builds
 CSRC = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["flmr_index.hip", "flmr_stage0.hip", "flmr_candidates.hip", "flmr_filter.hip", "flmr_stage2_walk.hip", "flmr_stage2_xcd.hip", "flmr_maxsim.hip", "flmr_search.hip", "flmr_ops.hip", "flmr_build.hip", "flmr_collective.hip"]
+SOURCES = ["flmr_index.hip", "flmr_stage0.hip", "flmr_candidates.hip", "flmr_filter.hip", "flmr_stage2_walk.hip", "flmr_stage2_xcd.hip", "flmr_maxsim.hip", "flmr_search.hip", "flmr_ops.hip", "flmr_build.hip", "flmr_ivf.hip", "flmr_collective.hip"]
 HEADERS = ["flmr_common.h", "flmr_device.h"]
 
 FLMR_MEM_HOST, FLMR_MEM_DEVICE = 0, 1
@@ -139,6 +139,7 @@ _SIGS = {
     "flmr_select_keys": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "flmr_unpack_keys": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "flmr_nearest_centroids": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "flmr_build_ivf": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
     "flmr_compress_residuals": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
                                           C.c_void_p, C.c_void_p]),
     "flmr_searcher_tap": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
@@ -158,6 +159,8 @@ _SIGS = {
     "flmr_score_pids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "flmr_colbert_score_padded": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                             C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "flmr_colbert_colmax_padded": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                             C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "flmr_topk_allgather": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "flmr_keys_allgather": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

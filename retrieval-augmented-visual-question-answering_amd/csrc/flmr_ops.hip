@@ -222,7 +222,7 @@ extern "C" int flmr_score_pids(const flmr_index_t* ix, const float* Q, int32_t n
 
 // ---- colbert_score, padded variant (-9999 padding, no clamp) ------------------------------------------
 __global__ __launch_bounds__(256) void colbert_score_padded_kernel(const float* Q, int q_batch, int nq, const float* D,
-                                                                   const uint8_t* mask, int Ld, int dim, float* out) {
+                                                                   const uint8_t* mask, int Ld, int dim, float* out, float* colmax_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned int* colmax = reinterpret_cast<unsigned int*>(smem);  // order-preserving uint image of the fp32 max
     const int b = blockIdx.x;
@@ -241,7 +241,9 @@ __global__ __launch_bounds__(256) void colbert_score_padded_kernel(const float* 
         atomicMax(&colmax[j], flmr_f2ord(v));
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (colmax_out)   // the per-column maxima themselves ('flipr' sums the largest of them, colbert.py:246-261)
+        for (int k = threadIdx.x; k < nq; k += blockDim.x) colmax_out[(size_t)b * nq + k] = (Ld > 0) ? flmr_ord2f(colmax[k]) : FLMR_NEG_INF;
+    if (threadIdx.x == 0 && out) {
         float s = 0.0f;
         for (int k = 0; k < nq; k++) s += (Ld > 0) ? flmr_ord2f(colmax[k]) : FLMR_NEG_INF;
         out[b] = s;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void colbert_score_padded_mfma_kernel(const
                                                                            const _Float16* __restrict__ q_lo, int q_batch,
                                                                            int nq, int nqp, const float* __restrict__ D,
                                                                            const uint8_t* __restrict__ mask, int Ld,
-                                                                           float* out) {
+                                                                           float* out, float* colmax_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* bq = reinterpret_cast<_Float16*>(smem);                                          // [PS_QC][hi|lo][32][PS_BROW]
     unsigned int* colmax = reinterpret_cast<unsigned int*>(bq + PS_QC * 2 * 32 * PS_BROW);     // [nqp] order-preserving fp32 image
@@ -342,16 +344,18 @@ __global__ __launch_bounds__(256, 2) void colbert_score_padded_mfma_kernel(const
         }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (colmax_out)
+        for (int k = tid; k < nq; k += 256) colmax_out[(size_t)b * nq + k] = (Ld > 0) ? flmr_ord2f(colmax[k]) : FLMR_NEG_INF;
+    if (tid == 0 && out) {
         float sc = 0.0f;
         for (int k = 0; k < nq; k++) sc += (Ld > 0) ? flmr_ord2f(colmax[k]) : FLMR_NEG_INF;
         out[b] = sc;
     }
 }
 
-extern "C" int flmr_colbert_score_padded(const float* Q, int32_t q_batch, int32_t nq, const float* D, const uint8_t* mask,
-                                         int32_t B, int32_t Ld, int32_t dim, float* out, flmr_stream_t stream) {
-    if (!Q || !D || !mask || !out) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+static int score_padded(const float* Q, int32_t q_batch, int32_t nq, const float* D, const uint8_t* mask,
+                        int32_t B, int32_t Ld, int32_t dim, float* out, float* colmax_out, flmr_stream_t stream) {
+    if (!Q || !D || !mask || (!out && !colmax_out)) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
     if (q_batch != 1 && q_batch != B) FLMR_FAIL(FLMR_ERR_INVALID, "q_batch must be 1 or B");
     if (B <= 0) return FLMR_OK;
     if ((size_t)nq * 4 > 48 * 1024) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nq=%d too large", nq);
@@ -366,15 +370,28 @@ extern "C" int flmr_colbert_score_padded(const float* Q, int32_t q_batch, int32_
         const size_t lds = (size_t)PS_QC * 2 * 32 * PS_BROW * sizeof(_Float16) + (size_t)nqp * sizeof(unsigned int);
         FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(colbert_score_padded_mfma_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(colbert_score_padded_mfma_kernel, dim3(B), dim3(256), lds, st, qh, ql, q_batch, nq, nqp, D, mask, Ld, out);
+        hipLaunchKernelGGL(colbert_score_padded_mfma_kernel, dim3(B), dim3(256), lds, st, qh, ql, q_batch, nq, nqp, D, mask, Ld, out, colmax_out);
         FLMR_LAUNCH_CHECK();
         FLMR_HIP(hipStreamSynchronize(st));  // the split buffers are released on return
         return FLMR_OK;
     }
     hipLaunchKernelGGL(colbert_score_padded_kernel, dim3(B), dim3(256), (size_t)nq * 4, st, Q, q_batch, nq, D, mask, Ld, dim,
-                       out);
+                       out, colmax_out);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
+}
+
+extern "C" int flmr_colbert_score_padded(const float* Q, int32_t q_batch, int32_t nq, const float* D, const uint8_t* mask,
+                                         int32_t B, int32_t Ld, int32_t dim, float* out, flmr_stream_t stream) {
+    if (!out) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    return score_padded(Q, q_batch, nq, D, mask, B, Ld, dim, out, nullptr, stream);
+}
+
+// the per-column maxima [B, nq] before their sum: what colbert_score_reduce's 'flipr' interaction reduces (colbert.py:246-261)
+extern "C" int flmr_colbert_colmax_padded(const float* Q, int32_t q_batch, int32_t nq, const float* D, const uint8_t* mask,
+                                          int32_t B, int32_t Ld, int32_t dim, float* out_colmax, flmr_stream_t stream) {
+    if (!out_colmax) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    return score_padded(Q, q_batch, nq, D, mask, B, Ld, dim, nullptr, out_colmax, stream);
 }
 
 // ---- merge of per-shard top-k lists (after the RCCL all-gather) -----------------------------------------

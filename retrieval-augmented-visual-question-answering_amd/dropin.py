@@ -74,8 +74,8 @@ def make_colbert_score_dispatch(reference_colbert_score):
 
     HIP path (flmr_colbert_score_padded: fp16-split MFMA, -9999 padding, no clamp, fp32 accumulation) when the call is
     forward-only -- grad mode off, or no input requires grad -- and the shape is the kernel's ('colbert' interaction,
-    3-D Q / D with Q.size(0) in {1, B}, floating inputs).  Everything else -- autograd (training), 'flipr', odd ranks --
-    goes to the reference's own expression, unchanged.
+    or 'flipr' interaction, 3-D Q / D with Q.size(0) in {1, B}, floating inputs).  Everything else -- autograd (training), odd
+    ranks -- goes to the reference's own expression, unchanged.
 
     This function replaces a GLOBAL of the caller's package, so it must not break flows that never had a GPU: when NO HIP
     device is visible in the process (a CPU-only validation run of the reference) the call is not intercepted at all -- it
@@ -102,7 +102,7 @@ def make_colbert_score_dispatch(reference_colbert_score):
         shape_ok = (torch.is_tensor(Q) and torch.is_tensor(D_padded) and Q.dim() == 3 and D_padded.dim() == 3
                     and Q.size(0) in (1, D_padded.size(0)) and Q.size(-1) == D_padded.size(-1)
                     and Q.is_floating_point() and D_padded.is_floating_point() and D_padded.size(0) > 0 and D_padded.size(1) > 0)
-        if not (forward_only and shape_ok and interaction == "colbert"):
+        if not (forward_only and shape_ok and interaction in ("colbert", "flipr")):
             return reference(Q, D_padded, D_mask, config, use_gpu)
         if not _native.device_visible():
             if not state["warned"]:
@@ -111,7 +111,15 @@ def make_colbert_score_dispatch(reference_colbert_score):
                               "reference's torch expression (the HIP scorer takes them when a device is present)", RuntimeWarning)
             return reference(Q, D_padded, D_mask, config, use_gpu)
         Qr = Q.detach().to(dtype=D_padded.dtype)                                   # colbert.py:280
-        out = ops.colbert_score_padded(Qr, D_padded.detach(), D_mask)              # f32 on the device
+        if interaction == "flipr":   # colbert.py:246-261: the column maxima from the HIP kernel, their top-k sums here
+            assert config.query_maxlen == 64, ("for now", config)
+            cm = ops.colbert_colmax_padded(Qr, D_padded.detach(), D_mask)           # [B, Nq] f32 on the device
+            qm, K2 = config.query_maxlen, 8
+            out = cm[:, :qm].topk(qm // 2, dim=-1).values.sum(-1)
+            if K2 <= cm.size(1) - qm:
+                out = out + cm[:, qm:].topk(K2, dim=-1).values.sum(1)
+        else:
+            out = ops.colbert_score_padded(Qr, D_padded.detach(), D_mask)          # f32 on the device
         dev = torch.device("cuda") if use_gpu else D_padded.device
         return out.to(device=dev, dtype=D_padded.dtype)
 

@@ -27,8 +27,9 @@ class Indexer:
     ColBERTConfig = _config.ColBERTConfig
     Run = _config.Run
 
-    def __init__(self, checkpoint=None, config=None, doc_encoder=None):
+    def __init__(self, checkpoint=None, config=None, doc_encoder=None, build_backend=None):
         self.index_path = None
+        self.build_backend = build_backend   # None: the HIP kernels (indexing.HipBackend); tests of the host logic inject a torch one
         self.checkpoint = checkpoint
         self.checkpoint_config = self.ColBERTConfig.load_from_checkpoint(checkpoint) if isinstance(checkpoint, str) else None
         self.config = self.ColBERTConfig.from_existing(self.checkpoint_config, config, self.Run().config)
@@ -76,11 +77,12 @@ class Indexer:
             self.erase()
         if index_does_not_exist or overwrite != "reuse":
             embeddings, doclens = self._embeddings_of(collection)
-            if torch.cuda.is_available() and not embeddings.is_cuda:
-                embeddings = embeddings.cuda()
+            if self.build_backend is None and not embeddings.is_cuda:
+                embeddings = embeddings.cuda()   # the build runs on the MI355X (no host path: fails loudly without a device)
             cfg = {"query_maxlen": self.config.query_maxlen, "doc_maxlen": self.config.doc_maxlen,
                    "checkpoint": self.checkpoint if isinstance(self.checkpoint, str) else None, "index_name": name}
+            kw = {} if self.build_backend is None else {"backend": self.build_backend}
             arrays = build_index(embeddings, torch.as_tensor(doclens), nbits=self.config.nbits,
-                                 kmeans_niters=self.config.kmeans_niters, config=cfg)
+                                 kmeans_niters=self.config.kmeans_niters, config=cfg, **kw)
             arrays.save(self.index_path)
         return self.index_path

@@ -6,14 +6,18 @@ encoder -- the caller supplies the (already L2-normalised) token embeddings and 
 
   setup    num_partitions = 2^floor(log2(16*sqrt(N)))                                   (:93)
   train    k-means on a sample (the reference calls faiss.Kmeans(dim, K, niter=kmeans_niters, seed=123), :447-463; FAISS is
-           not available on ROCm here, so this is a plain Lloyd iteration with L2 assignment in torch -- same objective,
-           different RNG, hence validated by Recall, not bit-compared), centroids L2-normalised (:283) and stored as half;
-           bucket cut-offs / weights = quantiles of held-out residuals (:286-308)
-  index    nearest centroid by dot product, residual, bucketize, bit-pack            (synth.compress = residual.py:169-204)
-  finalize IVF = sorted unique pids per centroid                                    (synth.build_ivf = indexing/utils.py:8-53)
+           not available on ROCm here: spherical Lloyd iterations whose assignment step is the HIP argmax kernel -- same
+           objective on unit vectors, different RNG, hence validated by Recall, not bit-compared), centroids L2-normalised
+           (:283) and stored as half; bucket cut-offs / weights = quantiles of held-out residuals (:286-308)
+  index    nearest centroid by dot product, residual, bucketize, bit-pack            (residual.py:169-204)
+  finalize IVF = sorted unique pids per centroid                                    (indexing/utils.py:8-53)
 
-With the embeddings on the GPU the `index` step runs on the HIP kernels of csrc/flmr_build.hip (ops.compress); k-means and
-the quantiles use torch on the same device.
+Every heavy step runs on the MI355X through the C ABI (`ops`): the nearest-centroid argmax of k-means' assignment step and
+of the final compression (flmr_nearest_centroids: the stage-0 fp16-split MFMA kernel with an argmax epilogue), the residual
+bucketize + bit-pack (flmr_compress_residuals) and the IVF (flmr_build_ivf).  There is no host fallback in this module: the
+embeddings must be on the GPU (tests of the HOST logic -- sampling, the Lloyd loop, the bucket tables, the file format -- pass
+`backend=` an object with the same three functions restated in torch, tests/host_build_backend.py, exactly as they inject an
+encoder).
 """
 import math
 
@@ -23,43 +27,61 @@ from . import synth
 from .index import IndexArrays
 
 
+class HipBackend:
+    """The three device steps of the build, on libflmr_hip.so (fails loudly without it / without a device)."""
+
+    @staticmethod
+    def nearest_centroids(x, centroids):
+        from . import ops
+        return ops.nearest_centroids(x, centroids)
+
+    @staticmethod
+    def compress_residuals(x, centroids, codes, cutoffs, nbits):
+        from . import ops
+        return ops.compress_residuals(x, centroids, codes, cutoffs, nbits)
+
+    @staticmethod
+    def build_ivf(codes, doclens, K):
+        from . import ops
+        return ops.build_ivf(codes, doclens, K)
+
+
 def num_partitions_for(n_embeddings: int) -> int:
     return int(2 ** math.floor(math.log2(16 * math.sqrt(max(n_embeddings, 1)))))
 
 
-def _assign_l2(x, centroids, chunk=1 << 16):
-    """argmin_c ||x - c||^2 = argmax_c (x.c - |c|^2/2), chunked over x."""
-    half_sq = 0.5 * (centroids * centroids).sum(-1)
-    out = torch.empty(x.size(0), dtype=torch.long, device=x.device)
-    for i in range(0, x.size(0), chunk):
-        out[i:i + chunk] = (x[i:i + chunk] @ centroids.T - half_sq).argmax(dim=1)
-    return out
-
-
-def kmeans(sample, K, niters=4, seed=123):
-    """Lloyd's algorithm (L2), `niters` iterations from K distinct random sample points; empty clusters are re-seeded from
-    random points.  Returns fp32 centroids [K, dim]."""
+def kmeans(sample, K, niters=4, seed=123, backend=HipBackend, chunk=1 << 20):
+    """Spherical Lloyd iterations on unit-norm points (what the encoders emit, colbert.py:207: `normalize(D, p=2, dim=2)`):
+    `niters` rounds from K distinct random sample points; assignment = nearest centroid by dot product -- for unit vectors the
+    same choice as L2 -- through `backend.nearest_centroids` with the centroids re-normalised and rounded to fp16 each round
+    (the index stores them as half anyway, residual.py:161; the MFMA argmax needs fp16-representable rows); empty clusters
+    are re-seeded from random points.  The reference runs faiss.Kmeans (L2, its own RNG): same objective on the sphere,
+    different arithmetic, hence validated by Recall, never bit-compared.  Returns fp32 centroids [K, dim] (unit rows)."""
     g = torch.Generator(device=sample.device)
     g.manual_seed(seed)
     n = sample.size(0)
     if n < K:
         raise ValueError(f"k-means needs at least K={K} sample points, got {n}")
-    centroids = sample[torch.randperm(n, generator=g, device=sample.device)[:K]].clone().float()
+    sample = sample.float()
+    centroids = sample[torch.randperm(n, generator=g, device=sample.device)[:K]].clone()
     for _ in range(niters):
-        assign = _assign_l2(sample, centroids)
-        sums = torch.zeros_like(centroids).index_add_(0, assign, sample.float())
+        centroids = torch.nn.functional.normalize(centroids, dim=-1).half().float()
+        assign = torch.empty(n, dtype=torch.long, device=sample.device)
+        for i in range(0, n, chunk):
+            assign[i:i + chunk] = backend.nearest_centroids(sample[i:i + chunk], centroids).long()
+        sums = torch.zeros_like(centroids).index_add_(0, assign, sample)
         counts = torch.bincount(assign, minlength=K).to(sums.dtype)
         empty = counts == 0
         centroids = sums / counts.clamp(min=1).unsqueeze(1)
         if bool(empty.any()):
             ne = int(empty.sum())
-            centroids[empty] = sample[torch.randint(0, n, (ne,), generator=g, device=sample.device)].float()
-    return centroids
+            centroids[empty] = sample[torch.randint(0, n, (ne,), generator=g, device=sample.device)]
+    return torch.nn.functional.normalize(centroids, dim=-1)
 
 
 def build_index(embeddings, doclens, nbits=2, num_partitions=None, kmeans_niters=4, sample_size=None, seed=123,
-                heldout_fraction=0.05, chunk=1 << 20, config=None) -> IndexArrays:
-    """embeddings: float tensor [N, 128] (any device), doclens: int tensor [P] with sum N.  Returns host IndexArrays
+                heldout_fraction=0.05, chunk=1 << 20, config=None, backend=HipBackend) -> IndexArrays:
+    """embeddings: float tensor [N, 128] on the GPU, doclens: int tensor [P] with sum N.  Returns host IndexArrays
     (call `.save(path)` for the reference's directory layout)."""
     dev = embeddings.device
     N, dim = embeddings.shape
@@ -75,24 +97,21 @@ def build_index(embeddings, doclens, nbits=2, num_partitions=None, kmeans_niters
     sample = embeddings[perm].float()
     n_held = max(1, min(int(heldout_fraction * sample_size), 50_000))
     heldout, train = sample[:n_held], sample[n_held:] if sample_size - n_held >= K else sample
-    centroids = torch.nn.functional.normalize(kmeans(train, K, kmeans_niters, seed), dim=-1).half().float()
+    centroids = kmeans(train, K, kmeans_niters, seed, backend=backend).half().float()
     # ---- bucket tables from held-out residuals (:286-308) ----
-    held_codes = (centroids @ heldout.T).argmax(dim=0)
+    held_codes = backend.nearest_centroids(heldout, centroids).long()
     held_res = heldout - centroids[held_codes]
     cutoffs, weights = synth.bucket_tables(held_res, nbits)
     avg_residual = float(held_res.abs().mean())
     # ---- compress every embedding (residual.py:169-204) ----
     codes = torch.empty(N, dtype=torch.int32, device=dev)
     residuals = torch.empty((N, dim * nbits // 8), dtype=torch.uint8, device=dev)
-    if dev.type == "cuda":
-        from . import ops  # HIP kernels: fp16-split MFMA argmax + fused residual/bucketize/bit-pack (csrc/flmr_build.hip)
-        compress = lambda e: ops.compress(e, centroids, cutoffs, nbits)
-    else:  # host tensors (tests, tiny corpora): the torch restatement of the same steps
-        compress = lambda e: synth.compress(e, centroids, cutoffs, nbits)
     for i in range(0, N, chunk):
-        c, r = compress(embeddings[i:i + chunk].float())
-        codes[i:i + chunk], residuals[i:i + chunk] = c, r
-    ivf, ivf_lengths = synth.build_ivf(codes, doclens, K)
+        e = embeddings[i:i + chunk].float()
+        c = backend.nearest_centroids(e, centroids)
+        codes[i:i + chunk] = c
+        residuals[i:i + chunk] = backend.compress_residuals(e, centroids, c, cutoffs, nbits)
+    ivf, ivf_lengths = backend.build_ivf(codes, doclens, K)
     cpu = lambda t: t.detach().cpu().numpy()
     cfg = dict(config or {})
     cfg.setdefault("kmeans_niters", kmeans_niters)

@@ -95,6 +95,19 @@ def colbert_score_padded(Q, D_padded, D_mask):
     return out
 
 
+def colbert_colmax_padded(Q, D_padded, D_mask):
+    """The per-column maxima [B, Nq] of the padded MaxSim (-9999 padding) before their sum: what `colbert_score_reduce`
+    reduces -- by a plain sum for 'colbert', by top-k sums for 'flipr' (colbert.py:235-263)."""
+    lib = _native.load()
+    Qd, Dd = _d(Q, torch.float32), _d(D_padded, torch.float32)
+    B, Ld, dim = Dd.shape
+    md = _d(torch.as_tensor(D_mask).reshape(B, Ld), torch.bool).view(torch.uint8)
+    out = torch.empty((B, Qd.size(1)), dtype=torch.float32, device="cuda")
+    _native.check(lib.flmr_colbert_colmax_padded(_p(Qd), Qd.size(0), Qd.size(1), _p(Dd), _p(md), B, Ld, dim, _p(out),
+                                                 _native.stream_ptr()))
+    return out
+
+
 def merge_topk(scores, pids):
     """scores f32 / pids i32 [nshards, nqueries, k] (CUDA) -> merged (scores, pids, counts) [nqueries, k]."""
     lib = _native.load()
@@ -163,3 +176,22 @@ def compress(embs, centroids, bucket_cutoffs, nbits):
     """ResidualCodec.compress on the GPU -> (codes int32 [N], residuals uint8 [N, 16*nbits])."""
     codes = nearest_centroids(embs, centroids)
     return codes, compress_residuals(embs, centroids, codes, bucket_cutoffs, nbits)
+
+
+def build_ivf(codes, doclens, K):
+    """(ivf pids int32 [sum unique], ivf_lengths int64 [K]) of an index on the GPU: optimize_ivf (TPC/indexing/utils.py:8-53)
+    through flmr_build_ivf -- a stable device radix sort of (code, pid) by code, run flags, compaction."""
+    lib = _native.load()
+    cd = _d(codes, torch.int32)
+    dl = torch.as_tensor(doclens).to(device="cuda", dtype=torch.int64)
+    offsets = torch.zeros(dl.numel() + 1, dtype=torch.int64, device="cuda")
+    offsets[1:] = torch.cumsum(dl, 0)
+    n = cd.numel()
+    assert int(offsets[-1]) == n, "doclens must sum to the number of codes"
+    ivf = torch.empty(max(n, 1), dtype=torch.int32, device="cuda")
+    lengths = torch.empty(int(K), dtype=torch.int64, device="cuda")
+    import ctypes as C
+    total = C.c_int64(0)
+    _native.check(lib.flmr_build_ivf(_p(cd), n, _p(offsets), dl.numel(), int(K), _p(ivf), _p(lengths), C.byref(total), _native.stream_ptr()))
+    return ivf[: total.value].clone(), lengths
+

@@ -198,3 +198,67 @@ def test_many_surviving_centroids_code_scan_and_row_capacity(hip):
         p3, s3, c3 = IndexScorer(device_index=scorer.device_index, max_batch=16).search_batch(Q, ndocs // 4, ncells, 0.6, ndocs, 32, q_lens=q_lens)
         assert torch.equal(p2, p3) and torch.equal(s2, s3) and torch.equal(c2, c3)
     scorer.close_searcher()
+
+
+def test_build_ivf_matches_the_reference_written_ivf(hip):
+    """flmr_build_ivf (stable device radix sort of (code, pid) by code, run flags, compaction) against the IVF the REFERENCE's
+    optimize_ivf wrote for the golden indexes (TPC/indexing/utils.py:8-53), bit for bit, and against the torch.unique
+    restatement on a corpus with empty passages, a code that never occurs and 2.6 M tokens."""
+    torch = hip["torch"]
+    from conftest import INDEX_FIXTURES, load_golden
+    from ravqa_amd import ops, synth
+    for name in INDEX_FIXTURES:
+        z = load_golden(name)
+        a = hip["pkg"].IndexArrays.from_golden(z)
+        ivf, lens = ops.build_ivf(torch.from_numpy(a.codes), torch.from_numpy(a.doclens), a.num_centroids)
+        assert np.array_equal(ivf.cpu().numpy(), a.ivf) and np.array_equal(lens.cpu().numpy(), a.ivf_lengths), name
+    g = torch.Generator(device="cuda").manual_seed(5)
+    P, K = 40_000, 3000
+    doclens = torch.randint(0, 130, (P,), generator=g, device="cuda")
+    codes = torch.randint(0, K - 1, (int(doclens.sum()),), generator=g, device="cuda", dtype=torch.int32)   # code K - 1 never occurs
+    ivf, lens = ops.build_ivf(codes, doclens, K)
+    rivf, rlens = synth.build_ivf(codes, doclens, K)
+    assert torch.equal(ivf, rivf) and torch.equal(lens, rlens) and int(lens[K - 1]) == 0
+    e_ivf, e_lens = ops.build_ivf(codes[:0], doclens[:0], 8)
+    assert e_ivf.numel() == 0 and int(e_lens.sum()) == 0
+
+
+def test_flipr_interaction_through_the_scoring_dispatch(hip):
+    """colbert_score with config.interaction == 'flipr' (TPC/modeling/colbert.py:246-261: the 32 largest column maxima of the
+    first 64 query tokens + the 8 largest of the rest) reaches the HIP scorer too: flmr_colbert_colmax_padded returns the
+    column maxima, the top-k sums are taken on the device -- against the reference's expression restated in torch fp64."""
+    torch = hip["torch"]
+    from types import SimpleNamespace
+    from ravqa_amd import ops
+    from ravqa_amd.dropin import make_colbert_score_dispatch
+    g = torch.Generator().manual_seed(4)
+    B, Ld, Nq = 37, 45, 80
+    Q = torch.nn.functional.normalize(torch.randn(1, Nq, 128, generator=g), dim=-1)
+    D = torch.nn.functional.normalize(torch.randn(B, Ld, 128, generator=g), dim=-1)
+    mask = torch.rand(B, Ld, generator=g) < 0.8
+    mask[:, 0] = True
+
+    def reference(Q, D_padded, D_mask, config=None, use_gpu=False):   # colbert.py:235-286 in fp64
+        sc = D_padded.double() @ Q.double().permute(0, 2, 1)
+        sc[~D_mask.view(sc.size(0), sc.size(1)).bool()] = -9999
+        cm = sc.max(1).values
+        if config is not None and config.interaction == "flipr":
+            out = cm[:, :config.query_maxlen].topk(config.query_maxlen // 2, dim=-1).values.sum(-1)
+            if 8 <= cm.size(1) - config.query_maxlen:
+                out = out + cm[:, config.query_maxlen:].topk(8, dim=-1).values.sum(1)
+            return out
+        return cm.sum(-1)
+
+    calls = []
+    fn = make_colbert_score_dispatch(lambda *a, **k: (calls.append(1), reference(*a, **k))[1])
+    for nq in (Nq, 64, 70):     # with, without and with too few extra tokens for the second term
+        for cfg in (SimpleNamespace(interaction="flipr", query_maxlen=64), SimpleNamespace(interaction="colbert", query_maxlen=64)):
+            with torch.no_grad():
+                got = fn(Q[:, :nq], D, mask.unsqueeze(-1), config=cfg)
+            want = reference(Q[:, :nq], D, mask, config=cfg)
+            assert got.shape == (B,) and got.dtype == D.dtype and float((got.double() - want).abs().max()) <= 1e-4, (nq, cfg.interaction)
+    assert not calls      # every call above ran on the HIP scorer
+    cm = ops.colbert_colmax_padded(Q, D, mask).cpu()
+    sc = D.double() @ Q.double().permute(0, 2, 1)
+    sc[~mask] = -9999
+    assert float((cm.double() - sc.max(1).values).abs().max()) <= 1e-5

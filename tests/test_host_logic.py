@@ -213,7 +213,9 @@ def test_build_index_end_to_end_recall_with_oracle(tmp_path):
     doclens = torch.randint(4, 24, (P,), generator=g)
     topics = torch.randint(0, K_true, (int(doclens.sum()),), generator=g)
     embs = torch.nn.functional.normalize(protos[topics] + 0.05 * torch.randn(len(topics), 128, generator=g), dim=-1)
-    arrays = indexing.build_index(embs, doclens, nbits=2, num_partitions=64, kmeans_niters=6, sample_size=len(topics))
+    from host_build_backend import TorchBackend   # (host logic under test; the device steps are restated in torch)
+    arrays = indexing.build_index(embs, doclens, nbits=2, num_partitions=64, kmeans_niters=6, sample_size=len(topics),
+                                  backend=TorchBackend)
     arrays.save(str(tmp_path / "idx"))
     re = ravqa_amd.load_index_arrays(str(tmp_path / "idx"))
     assert re.num_centroids == 64 and re.num_embeddings == len(topics) and re.config["kmeans_niters"] == 6
@@ -272,7 +274,8 @@ def test_indexer_entry_point_builds_a_reference_format_index(tmp_path):
         return embs, doclens
 
     with Run().context(RunConfig(nranks=1, rank=0, root=str(tmp_path), experiment="exp")):
-        ix = Indexer(checkpoint=None, config=ColBERTConfig(nbits=4, kmeans_niters=4), doc_encoder=doc_encoder)
+        from host_build_backend import TorchBackend
+        ix = Indexer(checkpoint=None, config=ColBERTConfig(nbits=4, kmeans_niters=4), doc_encoder=doc_encoder, build_backend=TorchBackend)
         path = ix.index("my.index", passages, overwrite=False)
         assert path == os.path.join(str(tmp_path), "exp", "indexes/", "my.index") == ix.get_index() and calls == [P]
         with pytest.raises(AssertionError):
@@ -281,7 +284,7 @@ def test_indexer_entry_point_builds_a_reference_format_index(tmp_path):
         ix.index("my.index", (embs, doclens), overwrite=True)            # erased + rebuilt from an (embeddings, doclens) pair
         assert calls == [P]
         with pytest.raises(NotImplementedError):
-            Indexer(checkpoint=None, config=ColBERTConfig(nbits=4)).index("other", passages)
+            Indexer(checkpoint=None, config=ColBERTConfig(nbits=4), build_backend=TorchBackend).index("other", passages)
     a = ravqa_amd.load_index_arrays(path)
     assert (a.nbits, a.num_passages, a.num_embeddings) == (4, P, int(doclens.sum())) and a.check_ivf_invariant()
     oi = orc.OracleIndex(a.dim, a.nbits, a.codes, a.residuals, a.doclens, a.ivf, a.ivf_lengths, a.centroids, a.bucket_weights)
