@@ -16,6 +16,7 @@
  * defined) the restatement uses a k-ascending fp32 loop and the tests carry a tolerance.
  * Build: see oracle/Makefile (-O2 -ffp-contract=off so no FMA contraction changes bits).
  */
+#include <omp.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -329,9 +330,13 @@ ORC_API int orc_rank(const orc_index_t* ix, const float* Q, int nq, int nq_cand,
 
 /* Batched driver used by bench.py's cpu_baseline ("port") leg: one query per call semantics, queries
  * distributed over OpenMP threads.  out_* are [nqueries, k] (short lists padded with pid -1 / score 0). */
+static int orc_threads = 0;   /* 0: the OpenMP default; the caller sets the CPUs it may really use (cgroup quota, not nproc) */
+ORC_API void orc_set_threads(int n) { orc_threads = n > 0 ? n : 0; }
+
 ORC_API void orc_search_batch(const orc_index_t* ix, const float* Q, int nqueries, int nq, int nq_cand, int ncells,
                               float thr, int ndocs, int k, int32_t* out_pids, float* out_scores, int32_t* out_counts) {
-#pragma omp parallel for schedule(dynamic, 1)
+    const int nthreads = orc_threads > 0 ? orc_threads : omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
     for (int b = 0; b < nqueries; b++) {
         int cap = ndocs / 4 > 0 ? ndocs / 4 : 1;
         int32_t* p = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);

@@ -158,8 +158,7 @@ class OracleIndex:
     def search_batch(self, Q, k, ncells, thr, ndocs, nq_cand=32, threads=None):
         Q = _c(Q, np.float32)
         nqr, nq = Q.shape[0], Q.shape[1]
-        if threads:
-            os.environ["OMP_NUM_THREADS"] = str(threads)
+        lib().orc_set_threads(int(threads) if threads else effective_cpus())
         op = np.empty((nqr, k), dtype=np.int32)
         os_ = np.empty((nqr, k), dtype=np.float32)
         oc = np.empty(nqr, dtype=np.int32)
@@ -227,6 +226,19 @@ def segmented_lookup(inp, lengths, offsets):
 # ("reference" kind).  Needs torch (CPU) but never /root/reference at run time.
 # ---------------------------------------------------------------------------------------------
 _REF = {}
+
+
+def effective_cpus():
+    """CPUs this process may actually use: min(affinity, cgroup CPU quota).  The GPU boxes show 256 hardware threads under a
+    16-CPU quota: a pool sized from nproc spends its time throttled (a 256-thread OpenMP loop measured no faster than 8)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def ref_available():
