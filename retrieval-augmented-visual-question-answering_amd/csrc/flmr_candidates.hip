@@ -645,7 +645,11 @@ __global__ __launch_bounds__(1024) void cand_emit_kernel(const uint32_t* cand_bi
                                                          uint64_t* keys, const int32_t* q_lens, int nq_cand, int n_select, int f16_round) {
     __shared__ int scan_lds[17];
     __shared__ int base_lds;
-    const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    // (gridDim.y <= nchunks: a workgroup walks chunks blockIdx.y, + gridDim.y, ... -- on the scatter path nearly every query
+    // leaves at the first test below, and 8 k workgroups that only do that cost 11 us per launch against 4 for 1 k)
+    for (int ch = blockIdx.y; ch < nchunks; ch += gridDim.y) {
+    __syncthreads();   // (base_lds / scan_lds of the previous chunk have been read)
     if (skip && skip[b]) {
         // Stage 1 of this query was done by scatter: nobody reads the ascending list (taps rebuild it), and the keys of its
         // key_count[b] hit candidates are in place.  The other candidates all score the all-miss constant, below every hit:
@@ -656,7 +660,7 @@ __global__ __launch_bounds__(1024) void cand_emit_kernel(const uint32_t* cand_bi
         const int nqc = qlen < nq_cand ? qlen : nq_cand;
         if (nhit >= n_select && nqc > 0) {
             if (ch == 0 && tid == 0) cand_count[b] = (int32_t)(nhit < cand_cap ? nhit : cand_cap);
-            return;
+            return;   // (block-uniform, and the same for every chunk of this query)
         }
         if (tid == 0) base_lds = 0;
         __syncthreads();
@@ -682,7 +686,7 @@ __global__ __launch_bounds__(1024) void cand_emit_kernel(const uint32_t* cand_bi
             if (n > cand_cap) { atomicExch(overflow, 1); n = cand_cap; }
             cand_count[b] = (int32_t)n;
         }
-        return;
+        continue;
     }
     if (tid == 0) base_lds = 0;
     __syncthreads();
@@ -707,6 +711,7 @@ __global__ __launch_bounds__(1024) void cand_emit_kernel(const uint32_t* cand_bi
         int64_t n = (int64_t)base_lds + total;
         if (n > cand_cap) { atomicExch(overflow, 1); n = cand_cap; }
         cand_count[b] = (int32_t)n;
+    }
     }
 }
 
@@ -745,7 +750,9 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
                            a.qual, a.nqual, a.qmax, a.hit_valid, a.ivf_pids, a.ivf_offsets, a.chunk_tab, a.nchunks, a.cand_bits,
                            a.hit_bits, a.words, a.chunk_cnt);
     }
-    hipLaunchKernelGGL(cand_emit_kernel, dim3(a.nqueries, a.nchunks), dim3(1024), 0, st, a.cand_bits, a.hit_bits, a.words,
+    int ey = (int)flmr_ceil_div(1024, a.nqueries);   // ~1024 workgroups; every chunk its own workgroup for small batches
+    if (ey > a.nchunks) ey = a.nchunks;
+    hipLaunchKernelGGL(cand_emit_kernel, dim3(a.nqueries, a.scatter ? ey : a.nchunks), dim3(1024), 0, st, a.cand_bits, a.hit_bits, a.words,
                        a.chunk_cnt, a.nchunks, a.cand, a.cand_cap, a.cand_hit, a.cand_count, a.overflow,
                        a.scatter ? a.hit_valid : nullptr, a.key_count, a.chunk_hits, a.keys, a.q_lens, a.nq_cand, a.n_select, a.f16_round);
     FLMR_LAUNCH_CHECK();
