@@ -262,3 +262,51 @@ def test_flipr_interaction_through_the_scoring_dispatch(hip):
     sc = D.double() @ Q.double().permute(0, 2, 1)
     sc[~mask] = -9999
     assert float((cm.double() - sc.max(1).values).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_dense_survivor_sets_vs_oracle(hip, seed):
+    """Seeded shapes at LOW thresholds -- hundreds to thousands of centroids above centroid_score_threshold per query, most
+    stage-0 tiles flagged, the idx words decided inline from the hi products, compact score rows by rank, the code-scanning
+    stage 1 for the queries past the scatter form's limits and the scatter form for the others IN THE SAME BATCH -- against
+    the oracle.  Every nbits, ragged passages with empties, per-query lengths, K any multiple of 128, passages longer than one
+    128-token chunk in some cases."""
+    torch, nat = hip["torch"], hip["native"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    rng = np.random.default_rng(9000 + seed)
+    K = 128 * int(rng.integers(8, 96))
+    nbits = int(rng.choice([1, 2, 4, 8]))
+    npass = int(rng.choice([4000, 12000, 30000]))
+    lo = int(rng.integers(0, 10))
+    doclen = (lo, lo + int(rng.choice([20, 60, 150, 300])))
+    nqueries = int(rng.integers(9, 40))
+    nq = int(rng.choice([32, 32, 20]))
+    ncells = int(rng.integers(1, 4))
+    thr = float(rng.choice([0.08, 0.12, 0.18, 0.25]))
+    ndocs = int(rng.choice([64, 256]))
+    corpus = synth.make_corpus(npass, doclen, K, nbits, seed=700 + seed, device="cuda")
+    oi = _oracle(corpus)
+    Q, _ = synth.make_queries(corpus, nqueries, nq, seed=800 + seed)
+    Q[1::4] *= float(rng.choice([0.5, 2.0, 16.0]))        # some queries with far fewer / far more survivors than the others
+    q_lens = torch.from_numpy(rng.integers(1, nq + 1, size=nqueries).astype(np.int32))
+    q_lens[::3] = nq
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=64)
+    p, s, c = scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=q_lens)
+    scorer.check()
+    p, s, c = p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy()
+    Qh = Q.cpu().numpy()
+    nsurv, checked = [], 0
+    for i in list(range(0, nqueries, max(1, nqueries // 8)))[:8]:
+        nsurv.append(int(np.unpackbits(scorer.tap(nat.TAP_IDX_BITS, i).view(np.uint8)).sum()))
+        ql = int(q_lens[i])
+        rp, rs, ncand = oi.rank(Qh[i, :ql], ncells, thr, ndocs, 32)
+        n = int(c[i])
+        if ncand < ndocs:
+            assert n == min(ncand, ndocs // 4), (seed, i, n, ncand)
+            continue
+        mag = max(1.0, float(np.max(np.abs(rs))))
+        tie_aware_equal(rp, rs, p[i, :n], s[i, :n], gap=max(1e-5, 4 * 1.2e-7 * mag), tol=max(1e-4, 16 * 1.2e-7 * mag))
+        checked += 1
+    assert max(nsurv) >= 64, (seed, nsurv)
+    scorer.close_searcher()
