@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 F16_MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA peak (no sparsity)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.csv")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04", "pmc_summary.csv")
 
 
 def parse():
@@ -369,6 +369,11 @@ def main():
             if stage in per_kernel_flops:
                 r["TFLOPs"] = per_kernel_flops[stage] * args.batch / t_s / 1e12
                 r["mfma_frac"] = r["TFLOPs"] / F16_MFMA_PEAK_TFLOPS
+                # executed vs USEFUL products: S3 runs five fp16 products per useful one (the "c + w" split), stage 2 one (+ 10 %
+                # for the refinement band), stage 0 one
+                executed_per_useful = {"s3_maxsim": 5.0, "s2_filter_sort": 1.1}.get(stage, 1.0)
+                r["useful_TFLOPs"] = r["TFLOPs"] / executed_per_useful
+                r["useful_mfma_frac"] = r["useful_TFLOPs"] / F16_MFMA_PEAK_TFLOPS
             for kn, row in pmc.items():
                 if stage in kname and kname[stage] in kn and args.passages == 1_000_000 and world == 1 and args.nbits == 2:
                     # the summary holds bytes per kernel LAUNCH; a step launches each kernel once per sub-batch
@@ -399,7 +404,7 @@ def main():
                 "frac": dom["mfma_frac"] if mfma_bound else dom["hbm_frac"], "traffic": dom.get("traffic"),
                 "peak_measured": {"hbm_copy_GBs": copy_gbs, "note": "device-to-device copy (read + write) measured in this run; the spec "
                                   "figure above is what `frac` is priced against"},
-                "traffic_source": ("static: profiles/r03_pmc_summary.csv (rocprofv3 --pmc of this workload, 2*FETCH_SIZE + "
+                "traffic_source": ("static: profiles/r04/pmc_summary.csv (rocprofv3 --pmc of this workload, 2*FETCH_SIZE + "
                                    "WRITE_SIZE, bytes per launch x launches per step; not measured in this run)") if dom.get("traffic") else None,
                 "launch_ms": dom["launch_ms"],
                 "note": ("achieved = the kernel's own compulsory bytes (or split-MFMA flops) per step / its HIP-event time per step "
