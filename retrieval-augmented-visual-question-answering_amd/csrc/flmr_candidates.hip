@@ -715,6 +715,16 @@ __global__ __launch_bounds__(1024) void cand_emit_kernel(const uint32_t* cand_bi
     }
 }
 
+// the surviving centroids' list, ranks and compact score rows alone (FLMR_CAND_IMPL=atomic: the first candidate generation has no
+// use for the list, but stage 1 reads the rows)
+int flmr_launch_qualifying(const flmr_cand_args& a, hipStream_t st) {
+    hipLaunchKernelGGL(qualifying_kernel, dim3(a.nqueries), dim3(1024), 0, st, a.idx_bits, a.idx_words, a.ivf_offsets, a.cells,
+                       a.ncell, a.max_cells, a.qual, a.nqual, a.qmax, 1 << S1S_IDBITS, a.hit_valid, nullptr, 2, a.idx_prefix, a.rows_out,
+                       a.cen16, a.q_hi, a.q_lo, a.overflow);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
 int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
     hipLaunchKernelGGL(qualifying_kernel, dim3(a.nqueries), dim3(1024), 0, st, a.idx_bits, a.idx_words, a.ivf_offsets, a.cells,
                        a.ncell, a.max_cells, a.qual, a.nqual, a.qmax, 1 << S1S_IDBITS, a.hit_valid, a.scatter ? a.key_count : nullptr,

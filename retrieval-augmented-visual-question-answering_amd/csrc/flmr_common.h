@@ -226,6 +226,7 @@ struct flmr_cand_args {
     int32_t f16_round;                    // see flmr_filter_args
 };
 int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st);
+int flmr_launch_qualifying(const flmr_cand_args& a, hipStream_t st);   // list + ranks + compact score rows only
 int flmr_launch_cand_emit_all(const flmr_cand_args& a, hipStream_t st);
 int flmr_build_chunk_table(const int32_t* ivf_pids, const int64_t* ivf_offsets, int K, int64_t num_passages,
                            uint32_t** out_tab, int32_t* out_nchunks);

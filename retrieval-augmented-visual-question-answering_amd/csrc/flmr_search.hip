@@ -470,8 +470,8 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
     const bool use_hits = !s->opt.has(FLMR_OPT_S1_NO_HITMAP);
     bool scatter = false;
     s->last_scatter = false;
-    if (chunked) {
-        flmr_cand_args ca{};
+    flmr_cand_args ca{};
+    {
         ca.nqueries = c.nqueries; ca.idx_words = s->idx_words; ca.max_cells = s->max_cells; ca.qmax = s->qmax;
         ca.nchunks = ix->nchunks; ca.words = s->bitmap_words; ca.cand_cap = s->cand_cap;
         ca.idx_bits = s->idx_bits; ca.cells = s->cells; ca.ncell = s->ncell;
@@ -481,18 +481,21 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
         ca.cand = s->cand; ca.cand_hit = s->cand_hit; ca.cand_count = s->cand_count; ca.overflow = s->overflow;
         // stage 1 by scatter over the surviving centroids' IVF lists (single column tile, sparse or full table alike);
         // FLMR_S1_IMPL=scan keeps the code-scanning kernel for every query (A/B runs, cross-check tests)
-        scatter = use_hits && c.ncol == 32 && !s->opt.is(FLMR_OPT_S1_IMPL, "scan");
+        scatter = chunked && use_hits && c.ncol == 32 && !s->opt.is(FLMR_OPT_S1_IMPL, "scan");
         ca.scatter = scatter ? 1 : 0;
         ca.cs = c.f.cs; ca.cs_query_stride = c.f.cs_query_stride; ca.nq_cand = c.nqc; ca.q_lens = c.q_lens;
         ca.cs_compact = c.f.cs_compact; ca.idx_prefix = s->idx_prefix;
         ca.rows_out = c.sparse ? s->rows : nullptr; ca.cen16 = ix->centroids_f16; ca.q_hi = s->q_hi; ca.q_lo = s->q_lo;
         ca.keys = s->keys1; ca.key_count = s->key_count; ca.chunk_hits = s->chunk_hits; ca.n_select = c.p.ndocs;
         ca.f16_round = c.f.f16_round;
+    }
+    if (chunked) {
         RUN(flmr_launch_candidates_chunked(ca, st));
         s->last_ca = ca; s->last_scatter = scatter;
         RUN(mark(c));
         RUN(mark(c));  // (the hit set is produced by the same pass: the s1_hitmap stage is empty in this mode)
     } else {
+        if (c.sparse) RUN(flmr_launch_qualifying(ca, st));   // (the compact score rows stage 1 reads)
         RUN(flmr_launch_ivf_mark(s->cells, s->ncell, s->max_cells, c.nqueries, ix->ivf_pids, ix->ivf_offsets, s->bitmap,
                                  s->bitmap_words, st));
         RUN(flmr_launch_compact(s->bitmap, s->bitmap_words, ix->num_passages, c.nqueries, s->cand, s->cand_cap,

@@ -466,6 +466,7 @@ def test_candidate_generation_variants_agree(hip, scorers):
     outs = {}
     for tag, env in (("chunked", {}), ("atomic", {"FLMR_CAND_IMPL": "atomic"}), ("nohit", {"FLMR_S1_NO_HITMAP": "1"})):
         with nat.options(**env):
+            _search_one(hip, scorer, z, "rank0")   # (another query first: no variant may live off the previous one's workspace)
             pids, scores = _search_one(hip, scorer, z, "rank3")
             outs[tag] = (scorer.tap(nat.TAP_CANDIDATES), np.sort(scorer.tap(nat.TAP_STAGE1)), scorer.tap(nat.TAP_STAGE2), pids, scores)
     for tag in ("atomic", "nohit"):
