@@ -49,6 +49,7 @@ enum flmr_opt_id {
     FLMR_OPT_S3_NO_MULTIQ,   // set: single-tile MaxSim kernel for long queries too
     FLMR_OPT_S3_IMPL,        // cw (default for Nq <= 32): (c.q + w.q) * 1/norm with table-decoded weights; regs / dma: decompress-normalise-split kernel with register / LDS-DMA row gathers; f32: fp32-MFMA kernel
     FLMR_OPT_SCORE_IMPL,     // valu: plain-FMA padded scorer
+    FLMR_OPT_POISON,         // set (test runs): every batch starts with its per-query score rows, ranks and survivor lists filled with 0xFF -- a stage that lives off an earlier batch's workspace then produces NaNs / wild indices instead of passing
     FLMR_OPT_ROW_CAP,        // score rows a searcher keeps per query (64 .. 65535; default 16384, at most K): a query with more centroids above the threshold raises FLMR_ERR_CAPACITY
     FLMR_OPT_COUNT
 };

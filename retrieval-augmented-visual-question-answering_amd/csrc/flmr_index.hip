@@ -12,7 +12,7 @@ thread_local char flmr_err_buf[512] = {0};
 
 static const char* kOptNames[FLMR_OPT_COUNT] = {"FLMR_S0_IMPL", "FLMR_FULL_TABLE", "FLMR_CAND_IMPL", "FLMR_S1_NO_HITMAP",
                                                  "FLMR_S1_IMPL", "FLMR_S2_IMPL", "FLMR_S0_STAGED", "FLMR_S3_NO_MULTIQ",
-                                                 "FLMR_S3_IMPL", "FLMR_SCORE_IMPL", "FLMR_ROW_CAP"};
+                                                 "FLMR_S3_IMPL", "FLMR_SCORE_IMPL", "FLMR_POISON", "FLMR_ROW_CAP"};
 static flmr_options g_opts;
 static std::once_flag g_opts_once;
 static thread_local const flmr_options* t_active_opts = nullptr;

@@ -417,6 +417,14 @@ static int prepare_ctx(run_ctx& c, flmr_searcher* s, const float* Q, const int32
         }
         s->bytes += (int64_t)bytes;
     }
+    if (s->opt.has(FLMR_OPT_POISON)) {   // test runs: nothing may be read from an earlier batch's workspace
+        FLMR_HIP(hipMemsetAsync(s->rows, 0xFF, (size_t)nqueries * s->row_cap * 32 * sizeof(float), c.st));
+        FLMR_HIP(hipMemsetAsync(s->idx_prefix, 0xFF, (size_t)nqueries * s->idx_words * sizeof(uint32_t), c.st));
+        FLMR_HIP(hipMemsetAsync(s->qual, 0xFF, (size_t)nqueries * s->qmax * sizeof(int32_t), c.st));
+        FLMR_HIP(hipMemsetAsync(s->keys1, 0xFF, (size_t)nqueries * s->cand_cap * sizeof(uint64_t), c.st));
+        FLMR_HIP(hipMemsetAsync(s->keys2, 0xFF, (size_t)nqueries * s->maxp.ndocs * sizeof(uint64_t), c.st));
+        FLMR_HIP(hipMemsetAsync(s->keys3, 0xFF, (size_t)nqueries * (s->maxp.ndocs / 4) * sizeof(uint64_t), c.st));
+    }
     a0.cs = c.sparse ? nullptr : s->cs; a0.idx_bits = s->idx_bits; a0.idx_words = s->idx_words;
     a0.part_val = s->part_val; a0.part_idx = s->part_idx; a0.nblk = s->nblk;
     a0.cells = s->cells; a0.ncell = s->ncell; a0.max_cells = s->max_cells;
