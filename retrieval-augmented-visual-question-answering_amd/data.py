@@ -134,6 +134,16 @@ class RankedList(_Sequence):
     def tolist(self):
         return list(self._all())
 
+    # vectorised access for callers that can use arrays (no tuples are built): the executor's loop over
+    # `(pid, _, score)` (FLMR_executor.py:852-866) is `row.pids` / `row.scores`
+    @property
+    def pids(self):
+        return self._p
+
+    @property
+    def scores(self):
+        return self._s
+
 
 def ranked_lists(pids, scores, counts):
     """numpy [n, k] pids / scores + counts -> [RankedList] (rows cut to their count)."""

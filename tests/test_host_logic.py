@@ -401,6 +401,7 @@ def test_ranking_lists_layout():
                 r[len(w)]
             assert r + [r[-1]] * 2 == w + [w[-1]] * 2 if w else r + [] == []
             assert repr(r) == repr(w) and r.tolist() == w and (r == w) and not (r != w)
+            assert r.pids.tolist() == [t[0] for t in w] and r.scores.tolist() == [t[2] for t in w]
     # Ranking over lazy rows: todict() hands them through untouched, flat_ranking / save come out as before
     rows = Searcher.ranking_lists(P, S, C, k)
     qids = [f"q{i}" for i in range(n)]
