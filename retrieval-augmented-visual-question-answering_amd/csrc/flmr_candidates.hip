@@ -368,6 +368,13 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
         rsum[wave + S1S_WAVES * lane] = F16 ? flmr_round_f16(sc) : sc;   // (read after the first chunk's barriers)
     }
 
+    // Passages with MANY surviving centroids (a corpus whose clusters overlap: ~19 per hit passage on profiles/built_index_probe's
+    // 4096-topic corpus, 1.02 on the planted one) overflow the queue of multi-centroid pairs in every window; the window then
+    // takes the dense form (every pair folds its 32-column row).  Once a workgroup has seen that, its later chunks skip the
+    // counting pass and go dense at once (dense_hint, block-uniform).  (Folding the first group from the registers it was
+    // prefetched into, and keeping the first four lists' rows across chunks, cost the common path more in scalar spills --
+    // this kernel is register-bound -- than they saved the dense one.)
+    bool dense_hint = false;
     // The chunk bitmaps and the slots' pair counters start at zero and are LEFT at zero by whoever reads them last (the
     // bitmap words by their owner thread in the chunk's last key pass, a counter by the thread that turns it into a key),
     // so a chunk has no initialisation phase of its own.
@@ -509,18 +516,28 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
                 }
             }
         };
-        if (mq.n > 0) count_group(gq, bq0, 0);   // the entries kept from the marking pass
-        for (int j0 = 4; j0 < mq.n; j0 += 4) {
-            grp gt;
-            const begs bg = list_begs(mq, j0);
-            issue(mq, bg, mq.s, mq.e, j0, gt);
-            count_group(gt, bg, j0);
-            S1S_DRAIN();
+#ifdef S1S_NO_HINT   // development A/B (the hint costs the planted-centroid path 0.03 ms per step in scalar spills)
+        if (true) {
+#else
+        if (!dense_hint) {   // (block-uniform)
+#endif
+            if (mq.n > 0) count_group(gq, bq0, 0);   // the entries kept from the marking pass
+            for (int j0 = 4; j0 < mq.n; j0 += 4) {
+                grp gt;
+                const begs bg = list_begs(mq, j0);
+                issue(mq, bg, mq.s, mq.e, j0, gt);
+                count_group(gt, bg, j0);
+                S1S_DRAIN();
+            }
         }
         if (tid == 0 && win0 == 0) s_base = my_base;   // the chunk's key base: the atomic issued before the counting pass
         s1s_sync();
         S1S_STAMP(6);
+#ifdef S1S_NO_HINT
         const int qn = s_qn;
+#else
+        const int qn = dense_hint ? S1S_QCAP + 1 : s_qn;
+#endif
         const bool dense = qn > S1S_QCAP;   // block-uniform
         if (dense) {
             // More multi-centroid pairs than the queue holds: every pair of the window walks the 32 columns itself --
@@ -616,6 +633,7 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
         }
         s1s_sync();
         S1S_STAMP(8);
+        dense_hint = dense;
     }
     }
     // next chunk
