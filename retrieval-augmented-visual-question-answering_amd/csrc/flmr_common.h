@@ -172,8 +172,6 @@ int flmr_launch_centroid_scores(flmr_s0_args& a, hipStream_t st);
 int flmr_launch_select_cells(const flmr_s0_args& a, hipStream_t st);
 int flmr_launch_centroid_argmax(flmr_s0_args& a, int32_t* out_codes, hipStream_t st);  // index build: nearest centroid per column
 int flmr_launch_split_q(const flmr_s0_args& a, hipStream_t st);  // q_hi / q_lo images only (query-split stage 0)
-int flmr_launch_qual_rows(const uint32_t* idx_bits, int idx_words, int nqueries, float* cs, int64_t cs_query_stride, int ncol,
-                          const _Float16* cen16, const _Float16* q_hi, const _Float16* q_lo, hipStream_t st);
 int flmr_check_f16_exact(const float* dev, size_t n, int32_t* host_result);
 int flmr_convert_f16(const float* dev, size_t n, _Float16* out);
 int flmr_max_row_norm(const float* dev, int64_t rows, float* host_result);   // >= max_r ||row_r||_2 over [rows, 128] (rounded up)

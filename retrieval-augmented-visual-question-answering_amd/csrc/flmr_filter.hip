@@ -799,90 +799,8 @@ int flmr_launch_filter_stage2_mfma(const flmr_filter_args& f, const int32_t* pid
     return FLMR_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Score-table rows of the qualifying centroids, straight from the idx bitset (query-split stage 0: the rank that ran
-// stage 0 for a query ships only its bitset and cells; every rank rebuilds the sparse table rows it needs here).
-// grid = (nqueries, ceil(idx_words / 1024)), block = one wave.  Same fp16-split MFMA sequence as s0_centroid_scores_f16,
-// so every value is bitwise the one stage 0 would have stored.  Works for any number of qualifying centroids.
-// ------------------------------------------------------------------------------------------------
-#define QR_WORDS_PER_BLOCK 1024  // idx words walked by one wave, 64 at a time (almost all of them are zero)
-__global__ __launch_bounds__(64) void qual_rows_kernel(const uint32_t* __restrict__ idx_bits, int idx_words, float* cs,
-                                                       int64_t cs_query_stride, int ncol,
-                                                       const _Float16* __restrict__ cen16,
-                                                       const _Float16* __restrict__ q_hi,
-                                                       const _Float16* __restrict__ q_lo) {
-    __shared__ int list[64 * 32];
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const int i = lane & 31, h = lane >> 5;
-    s2h8 bh[8], bl[8];
-    bool have_b = false;
-    float* cs_b = cs + (size_t)b * cs_query_stride;
-    const int w_end = (blockIdx.y + 1) * QR_WORDS_PER_BLOCK < idx_words ? (blockIdx.y + 1) * QR_WORDS_PER_BLOCK : idx_words;
-    uint32_t wbits[QR_WORDS_PER_BLOCK / 64];  // all of this wave's words are requested up front
-#pragma unroll
-    for (int j = 0; j < QR_WORDS_PER_BLOCK / 64; j++) {
-        const int w = blockIdx.y * QR_WORDS_PER_BLOCK + 64 * j + lane;
-        wbits[j] = w < w_end ? idx_bits[(size_t)b * idx_words + w] : 0u;
-    }
-#pragma unroll
-    for (int j = 0; j < QR_WORDS_PER_BLOCK / 64; j++) {
-        const int w = blockIdx.y * QR_WORDS_PER_BLOCK + 64 * j + lane;
-        uint32_t bits = wbits[j];
-        if (__ballot(bits != 0u) == 0ull) continue;  // wave-uniform: nothing survives among these 2048 centroids
-        int incl = __popc(bits);
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        const int total = __shfl(incl, 63, 64);
-        int pos = incl - __popc(bits);
-        __syncthreads();  // (one wave: orders the previous round's list reads before these writes)
-        while (bits) {
-            list[pos++] = w * 32 + __ffs(bits) - 1;
-            bits &= bits - 1;
-        }
-        __syncthreads();
-        if (!have_b) {
-            const s2h8* ph = reinterpret_cast<const s2h8*>(q_hi + ((size_t)b * ncol + i) * FLMR_DIM + 64 * h);
-            const s2h8* pl = reinterpret_cast<const s2h8*>(q_lo + ((size_t)b * ncol + i) * FLMR_DIM + 64 * h);
-#pragma unroll
-            for (int s = 0; s < 8; s++) { bh[s] = ph[s]; bl[s] = pl[s]; }
-            have_b = true;
-        }
-        for (int t0 = 0; t0 < total; t0 += 32) {
-            const int e = t0 + i < total ? t0 + i : total - 1;
-            const int c = list[e];
-            const s2h8* pc = reinterpret_cast<const s2h8*>(cen16 + (size_t)c * FLMR_DIM + 64 * h);
-            s2h8 av[8];
-#pragma unroll
-            for (int s = 0; s < 8; s++) av[s] = pc[s];
-            f32x16 ah, al;
-#pragma unroll
-            for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
-#pragma unroll
-            for (int s = 0; s < 8; s++) {
-                ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[s], ah, 0, 0, 0);
-                al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[s], al, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int crow = __shfl(c, row, 64);
-                if (t0 + row < total) cs_b[(size_t)crow * ncol + i] = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
-            }
-        }
-    }
-}
-
-int flmr_launch_qual_rows(const uint32_t* idx_bits, int idx_words, int nqueries, float* cs, int64_t cs_query_stride, int ncol,
-                          const _Float16* cen16, const _Float16* q_hi, const _Float16* q_lo, hipStream_t st) {
-    if (ncol != 32) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "qual_rows needs a single column tile");
-    hipLaunchKernelGGL(qual_rows_kernel, dim3(nqueries, (idx_words + QR_WORDS_PER_BLOCK - 1) / QR_WORDS_PER_BLOCK), dim3(64), 0, st, idx_bits, idx_words, cs,
-                       cs_query_stride, ncol, cen16, q_hi, q_lo);
-    FLMR_LAUNCH_CHECK();
-    return FLMR_OK;
-}
+// (The score rows of the surviving centroids -- round 3's qual_rows_kernel, for the query-split stage 0 only -- are computed by
+// qualifying_kernel for every batch since round 4: flmr_candidates.hip.)
 
 int flmr_launch_filter_stage2(const flmr_filter_args& f, const int32_t* pids, int64_t pid_stride,
                               const int32_t* counts, int32_t max_count, uint64_t* keys, int64_t key_stride,
