@@ -230,6 +230,25 @@ class IndexScorer:
             self._profiled = list({id(h): h for h in self._profiled + [h for h, _ in slots]}.values())
         return out_p, out_s, out_c
 
+    def search_batch_checked(self, Q, k, ncells, centroid_score_threshold, ndocs, nq_cand=32, q_lens=None):
+        """search_batch + check() (a host sync), with the one recoverable deferred error handled: a query with more centroids
+        above the threshold than the searcher keeps score rows for (FLMR_ROW_CAP, default 16384 -- the reference has no such
+        limit) sends the call through the full K x nq_cand score table once more (allocated on first use, 16.8 MB per query at
+        K = 131072), with a warning.  What `Searcher._search_all_Q` calls."""
+        out = self.search_batch(Q, k, ncells, centroid_score_threshold, ndocs, nq_cand, q_lens=q_lens)
+        try:
+            self.check()
+        except _native.FlmrNativeError as e:
+            if "FLMR_ROW_CAP" not in str(e):
+                raise
+            import warnings
+            warnings.warn("ravqa_amd: a query has more centroids above centroid_score_threshold than the searcher keeps score rows "
+                          "for; repeating the batch with the full centroid-score table (slower; raise the threshold or set FLMR_ROW_CAP)",
+                          RuntimeWarning)
+            out = self.search_batch(Q, k, ncells, centroid_score_threshold, ndocs, nq_cand, q_lens=q_lens, full_table=True)
+            self.check()
+        return out
+
     # ---- exact sharded protocol (include/flmr_hip.h: flmr_search_phase1..3) -------------------------------------------
     def _phase_args(self, Q, k, ncells, thr, ndocs, nq_cand, q_lens):
         Qd = Q.to(device="cuda", dtype=torch.float32).contiguous()

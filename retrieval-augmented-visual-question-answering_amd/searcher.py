@@ -177,10 +177,14 @@ class Searcher:
             if remove_zero_tensors:
                 Qb, q_lens = self._compact_nonzero_rows(Q)
             kk = min(k, max(c.ndocs // 4, 1))
-            pids, scores, counts = self.ranker.search_batch(Qb, kk, c.ncells, c.centroid_score_threshold, c.ndocs,
-                                                            c.query_maxlen, q_lens=q_lens)
-            if hasattr(self.ranker, "check"):
-                self.ranker.check()   # deferred device-side errors of the batches above (candidate bound, q_lens range)
+            if hasattr(self.ranker, "search_batch_checked"):   # + the deferred device-side errors (candidate bound, q_lens range;
+                pids, scores, counts = self.ranker.search_batch_checked(Qb, kk, c.ncells, c.centroid_score_threshold, c.ndocs,   # score-row capacity: redone)
+                                                                        c.query_maxlen, q_lens=q_lens)
+            else:
+                pids, scores, counts = self.ranker.search_batch(Qb, kk, c.ncells, c.centroid_score_threshold, c.ndocs,
+                                                                c.query_maxlen, q_lens=q_lens)
+                if hasattr(self.ranker, "check"):
+                    self.ranker.check()
             all_scored = self.ranking_lists(pids, scores, counts, k)
         data = dict(zip(qids, all_scored))
         provenance = self.Provenance()

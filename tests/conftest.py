@@ -67,6 +67,8 @@ try:
     os.makedirs(_LOGDIR, exist_ok=True)
     _PROGRESS = os.environ.get("FLMR_TEST_PROGRESS", os.path.join(_LOGDIR, "pytest_progress.log"))
     _DUMP = open(os.path.join(_LOGDIR, "pytest_watchdog.log"), "a")
+    import atexit
+    atexit.register(_DUMP.close)
 except OSError:
     _PROGRESS, _DUMP = "", None
 
