@@ -1364,7 +1364,9 @@ __device__ unsigned long long sc_prof[8];
 #else
 #define SC_STAMP(k) do { } while (0)
 #endif
+#ifndef SC_WAVES
 #define SC_WAVES 8  // 512 threads: the MFMA recompute needs ~190 VGPRs (B 64 + A 64 + accumulators 32 + lists)
+#endif
 template <int NC>
 __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a) {
     __shared__ int raw[1024];
@@ -1630,6 +1632,13 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
                 }
             }
         };
+#if SC_WAVES > 8   // 16 waves (128 VGPRs each): ONE block's rows in flight per wave, the other three waves of the SIMD cover its latency
+        f16x8 avA[S0_RT][8];
+        for (int m = 0; m < ntasks; m++) {
+            issue(avA, m);
+            compute(avA, m);
+        }
+#else
         f16x8 avA[S0_RT][8], avB[S0_RT][8];
         if (ntasks > 0) issue(avA, 0);
         for (int m = 0; m < ntasks; m += 2) {
@@ -1638,6 +1647,7 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
             if (m + 2 < ntasks) issue(avA, m + 2);
             if (m + 1 < ntasks) compute(avB, m + 1);
         }
+#endif
         finish();
         // ---- parked columns: every block whose hi maximum + err reaches the current ncells-th best row is recomputed too (the
         // list can only improve, which only tightens the test: a block skipped earlier stays skippable) ----
