@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--cpu-queries", type=int, default=64, help="queries timed on the CPU baseline at all threads (0 = skip)")
     ap.add_argument("--cpu-queries-8t", type=int, default=64, help="queries timed on the CPU baseline at 8 threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-built-index", action="store_true", help="skip the built-index sub-result (~25 s: 128 M tokens indexed on the device)")
     ap.add_argument("--no-extras", action="store_true", help="skip the k=5 / nbits=8 / ragged / Nq=832 sub-results")
     ap.add_argument("--replicate-stage0", action="store_true",
                     help="exact shard mode: every rank runs stage 0 for the whole batch instead of 1/N of the queries + an exchange")
@@ -713,6 +714,24 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:
             subs.append({"name": "cfg5_shard", "value": None, "note": f"failed: {e!r}"})
+        # An index BUILT on the device from raw embeddings whose clusters overlap (SURVEY 8f-1 at config 4's size), then searched:
+        # what the planted-centroid corpus above cannot show -- k-means + compression + IVF end to end, and a stage 1 whose hit
+        # passages hold many surviving centroids (profiles/built_index_probe.py; --passages-sized, 4096 topics, k <= 100 policy)
+        if not args.no_built_index and args.passages == 1_000_000:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "profiles"))
+                import built_index_probe
+                rec = built_index_probe.run(args.passages, 128, args.nbits, 4096, policies=((2, 0.45, 1024, 100),), phases=False)
+                sr = rec.pop("search_thr0.45")
+                subs.append({"name": "built_index_overlapping_clusters", "value": sr["queries_per_sec"], "unit": "queries/sec",
+                             "ms_per_step": sr["ms_per_step"], "recall_at_5": sr["recall_at_5"], "stage_ms_per_step": sr["stage_ms"],
+                             "surviving_centroids_per_query": sr["surviving_centroids"], "candidates_per_query": sr["candidates"],
+                             "index_build": rec,
+                             "note": "1 M passages x 128 raw token embeddings (a token = a topic direction + a finer direction + noise, three "
+                                     "topics per passage) indexed end to end on the device by indexing.build_index (k-means with the HIP "
+                                     "argmax as its assignment step, compression, IVF by flmr_build_ivf), then searched with planted queries"})
+            except Exception as e:  # noqa: BLE001
+                subs.append({"name": "built_index_overlapping_clusters", "value": None, "note": f"failed: {e!r}"})
         out["sub_results"] = subs
 
     if rank == 0:
