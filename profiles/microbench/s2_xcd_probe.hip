@@ -58,12 +58,14 @@ int main(int argc, char** argv) {
                (size_t)prop.maxSharedMemoryPerMultiProcessor, (size_t)prop.sharedMemPerBlockOptin);
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const bool hi_only = argc > 3 && atoi(argv[3]) != 0;   // the approximate pass of "hi first" (one product)
+    printf("%s\n", hi_only ? "hi-only instantiation" : "both products");
     for (int rep = 0; rep < 3; rep++) {
 #ifdef X2_PROFILE
         CK(hipMemset(x2_prof_buffer, 0, 128));
 #endif
         CK(hipEventRecord(e0, 0));
-        if (flmr_launch_filter_stage2_xcd(f, d_pids, ND, d_counts, ND, d_keys, ND, &ix, d_qh, d_ql, d_part, ND, 0) != 0) { printf("launch failed: %s\n", flmr_err_buf); return 1; }
+        if (flmr_launch_filter_stage2_xcd_ex(f, d_pids, ND, d_counts, ND, d_keys, ND, &ix, d_qh, d_ql, d_part, ND, hi_only, 0) != 0) { printf("launch failed: %s\n", flmr_err_buf); return 1; }
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("K=%d nq=%d: sliced stage 2 + combine %.3f ms\n", K, NQ, ms);
