@@ -50,9 +50,15 @@ int main(int argc, char** argv) {
     f.K = K; f.ncol = 32; f.nq_cand = 32; f.nqueries = NQ; f.q_lens = nullptr; f.codes = nullptr; f.doclens = nullptr; f.offsets = ix.doc_offsets;
     {
         int nb = 0;
+#ifdef X2_ROWS_IN_REGS
+        const size_t lds = (size_t)X2_WAVES * X2R_WAVE_LDS;
+        printf("rows in registers: %d tiles in flight per wave, launch bound %d waves per SIMD\n", X2_ROWS_IN_REGS, X2_REG_MINW);
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, filter_stage2_xreg_kernel<true>, 64 * X2_WAVES, lds));
+#else
         const size_t lds = (size_t)X2_WAVES * X2_WAVE_LDS;
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_stage2_xcd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, filter_stage2_xcd_kernel<false>, 64 * X2_WAVES, lds));
+#endif
         hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
         printf("dynamic LDS per block %zu B, resident blocks per CU %d (LDS per CU %zu B, per block max %zu B)\n", lds, nb,
                (size_t)prop.maxSharedMemoryPerMultiProcessor, (size_t)prop.sharedMemPerBlockOptin);

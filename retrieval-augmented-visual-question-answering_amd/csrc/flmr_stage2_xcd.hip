@@ -27,6 +27,7 @@
 // gathers served from L2 instead of the fabric.
 #include "flmr_common.h"
 #include "flmr_device.h"
+#include <type_traits>
 
 #define X2_XCDS 8        // L2 domains a launch's workgroups are dealt to round-robin (SPX mode: checked at index open)
 #define X2_MAX_SLICES 32 // slices of the centroid table (a multiple of 8, chosen at index open so that a slice fits an L2)
@@ -39,6 +40,7 @@
 
 typedef _Float16 x2h8 __attribute__((ext_vector_type(8)));
 typedef float x2f16 __attribute__((ext_vector_type(16)));
+typedef uint32_t x2u4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // doc_splits[p * nsl + s] = number of codes of passage p below s * slice_rows (position in the sorted copy), s = 0..nsl-1
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
                 }
                 X2_STAMP(3);
                 X2_STAMP(4);
+#ifndef X2_LATE_DMA
 #pragma unroll
                 for (int gq = 0; gq < 8; gq++) {
                     const uint32_t dst = rowbuf_lds + (t & 1) * 8192 + gq * 1024;
@@ -356,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
                                  : "s"(cen16), "s"(dst), "v"(c[gq]), "v"(piece_off[gq])
                                  : "memory", "m0");
                 }
+#endif
                 X2_STAMP(5);
                 // ---- 32 tokens x 32 query tokens, fp16-split: same MFMA sequence as stage 0 and the gather kernel ----
                 x2f16 ah, al;
@@ -405,6 +409,17 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
                     } else {
                         cm = x2_max(cm, mq[k]);
                     }
+#ifdef X2_LATE_DMA   // development form: the row pieces of tile t+2 issued in the fold's VALU-only stretches, two per octet
+#pragma unroll
+                    for (int gq = 2 * k; gq < 2 * k + 2; gq++) {
+                        const uint32_t dst = rowbuf_lds + (t & 1) * 8192 + gq * 1024;
+                        uint32_t voff;
+                        asm volatile("s_mov_b32 m0, %2\n\tv_lshl_add_u32 %0, %3, 8, %4\n\tglobal_load_lds_dwordx4 %0, %1"
+                                     : "=&v"(voff)
+                                     : "s"(cen16), "s"(dst), "v"(c[gq]), "v"(piece_off[gq])
+                                     : "memory", "m0");
+                    }
+#endif
                 }
                 X2_STAMP(7);
             }
@@ -424,6 +439,200 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
     }
 #endif
 }
+
+// ------------------------------------------------------------------------------------------------
+// The same kernel with the rows IN FLIGHT IN REGISTERS instead of LDS (build flag -DX2_ROWS_IN_REGS=<depth>, development
+// form).  Why: the DMA form keeps two 8 KB row buffers per wave in LDS for as long as their rows are in flight, so LDS (160 KB)
+// caps a CU at 8 waves x 2 tiles = 128 KB of outstanding rows -- and throughput = outstanding bytes / latency.  Here a tile is
+// requested with plain 16-byte loads in the DMA's lane order (16 consecutive lanes per 256-byte row: the order the address path
+// coalesces, profiles/microbench/s2_reg_probe), stays in 32 VGPRs per lane while in flight, and only passes THROUGH an 8 KB
+// per-wave transit buffer (ds_write_b128 x 8, ds_read_b128 x 8 in MFMA operand order) when it is consumed: 9.5 KB of LDS per
+// wave, `depth` tiles in flight per wave, occupancy set by registers.  Every load is compiler-visible (no hand-counted waits):
+// the codes of tile t are requested 2 x depth tiles ahead, BEFORE the rows of tile t - 2 depth, so the in-order wait for those
+// rows has always covered them; the register rings are indexed statically (the loop is unrolled 2 x depth times).
+// Same rows, same MFMA sequence, same fold: bit-identical partial maxima.
+// ------------------------------------------------------------------------------------------------
+#ifdef X2_ROWS_IN_REGS
+#ifndef X2_REG_MINW
+#define X2_REG_MINW 2
+#endif
+#define X2R_WAVE_LDS (8192 + X2_OCT * 6)   // transit buffer + octet table
+template <bool HI_ONLY>
+__global__ __launch_bounds__(256, X2_REG_MINW) void filter_stage2_xreg_kernel(flmr_filter_args f, const int32_t* __restrict__ pids, int64_t pid_stride,
+                                                                               const int32_t* __restrict__ counts, float* __restrict__ part,
+                                                                               int64_t part_stride, const _Float16* __restrict__ cen16,
+                                                                               const _Float16* __restrict__ q_hi, const _Float16* __restrict__ q_lo,
+                                                                               const int32_t* __restrict__ codes_sorted,
+                                                                               const uint16_t* __restrict__ splits, int nsl, int G) {
+    constexpr int D = X2_ROWS_IN_REGS, CR = 2 * D, UN = CR;
+    static_assert(D >= 1 && D <= 4, "row tiles in flight per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int L = blockIdx.x;
+    const int rest = L >> 3;
+    const int b = rest % f.nqueries, gg = rest / f.nqueries;
+    const int g = gg % G;
+    const int sl = (gg / G) * X2_XCDS + (L & (X2_XCDS - 1));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int cnt = counts[b];
+    const int slot0 = (g * X2_WAVES + wave) * X2_DOCS;
+    if (slot0 >= cnt) return;
+    const int nd = cnt - slot0 < X2_DOCS ? cnt - slot0 : X2_DOCS;
+    char* const wbase = smem + (size_t)wave * X2R_WAVE_LDS;
+    char* const transit = wbase;
+    uint32_t* const opos = reinterpret_cast<uint32_t*>(wbase + 8192);
+    uint16_t* const ometa = reinterpret_cast<uint16_t*>(wbase + 8192 + X2_OCT * 4);
+    int run_len = 0;
+    uint32_t run_base = 0;
+    if (lane < nd) {
+        const int pid = pids[(size_t)b * pid_stride + slot0 + lane];
+        const int64_t off = f.offsets[pid];
+        const int len = (int)(f.doclens ? f.doclens[pid] : (f.offsets[pid + 1] - off));
+        const int start = splits[(size_t)pid * nsl + sl];
+        const int end = sl < nsl - 1 ? (int)splits[(size_t)pid * nsl + sl + 1] : len;
+        run_len = end - start;
+        run_base = (uint32_t)(off + start);
+    }
+    const int noct = (run_len + 7) >> 3;
+    int oend = noct;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(oend, d, 64);
+        if (lane >= d) oend += t;
+    }
+    if (__builtin_amdgcn_readlane(oend, 63) == 0) return;
+    x2h8 bh[8], bl[8];
+    {
+        const x2h8* ph = reinterpret_cast<const x2h8*>(q_hi + ((size_t)b * f.ncol + i) * FLMR_DIM + 64 * h);
+        const x2h8* pl = reinterpret_cast<const x2h8*>(q_lo + ((size_t)b * f.ncol + i) * FLMR_DIM + 64 * h);
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            bh[s] = ph[s];
+            if constexpr (!HI_ONLY) bl[s] = pl[s];
+        }
+    }
+    float* const prow = part + (((size_t)b * part_stride + slot0) * nsl + sl) * 32;
+    const int pstep = nsl * 32;
+    // lane -> (row 4 gq + (lane >> 4), 16-byte piece pbase ^ (4 gq & 15)) of load gq: piece p of row r lands at slot p ^ (r & 15)
+    const uint32_t pbase = (uint32_t)((lane & 15) ^ (lane >> 4));
+    const char* const cenb = reinterpret_cast<const char*>(cen16);
+
+    int jstart = 0, obase = 0;
+    while (jstart < 64) {
+        const unsigned long long fits = __ballot(lane >= jstart && oend - obase <= X2_OCT);
+        const int jend = jstart + __popcll(fits);
+        const int ntot = __builtin_amdgcn_readlane(oend, jend - 1) - obase;
+        if (lane >= jstart && lane < jend) {
+            const int first = oend - noct - obase;
+            for (int k = 0; k < noct; k++) {
+                opos[first + k] = run_base + 8 * k;
+                const int left = run_len - 8 * k;
+                ometa[first + k] = (uint16_t)(((left < 8 ? left : 8) - 1) | (lane << 3));
+            }
+        }
+        const int ntiles = (ntot + 3) >> 2;
+        if (ntiles > 0) {
+            auto tile_pos = [&](int t) -> uint32_t {
+                int o = 4 * t + ((lane >> 3) & 3);
+                o = o < ntot ? o : ntot - 1;
+                const int e = lane & 7, nv = ometa[o] & 7;
+                return opos[o] + (e < nv ? e : nv);
+            };
+            x2u4 vr[D][8];
+            int cdreg[CR];
+            auto load_rows = [&](x2u4 (&dst)[8], int code) __attribute__((always_inline)) {
+#pragma unroll
+                for (int gq = 0; gq < 8; gq++) {
+                    const uint32_t c = (uint32_t)__shfl(code, 4 * gq + (lane >> 4), 64);
+                    const uint32_t voff = (c << 8) | ((pbase ^ (uint32_t)((4 * gq) & 15)) << 4);
+                    dst[gq] = *reinterpret_cast<const x2u4*>(cenb + voff);
+                }
+            };
+            // prologue in the steady state's issue order (codes of the first 2 depth tiles, then the rows tile by tile), pinned
+            // by compiler barriers: the loop header merges this state with the back edge's
+#pragma unroll
+            for (int t = 0; t < CR; t++) cdreg[t] = codes_sorted[tile_pos(t)];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < D; t++) {
+                load_rows(vr[t], cdreg[t]);
+                asm volatile("" ::: "memory");
+            }
+            int jcur = __builtin_amdgcn_readfirstlane((int)(ometa[0] >> 3));
+            float cm = -9999.0f;
+            auto flush = [&](int j) {
+                const float v = flmr_xhalf_max(cm);
+                if (h == 0) prow[(unsigned)(j * pstep) + i] = v;
+            };
+            auto step = [&](auto U_, int t) __attribute__((always_inline)) {
+                constexpr int U = decltype(U_)::value;
+                // ---- tile t: registers -> transit buffer (the DMA's layout: 1 KB per load, lanes in order) ----
+#pragma unroll
+                for (int gq = 0; gq < 8; gq++) *reinterpret_cast<x2u4*>(transit + gq * 1024 + lane * 16) = vr[U % D][gq];
+                // ---- keep the pipeline full: codes of tile t + 2 depth, rows of tile t + depth ----
+                cdreg[U % CR] = codes_sorted[tile_pos(t + CR)];
+                load_rows(vr[U % D], cdreg[(U + D) % CR]);
+                // ---- tile t in MFMA operand order, its octets' passages ----
+                x2h8 av[8];
+#pragma unroll
+                for (int s = 0; s < 8; s++)
+                    av[s] = *reinterpret_cast<const x2h8*>(transit + i * 256 + (((8 * h + s) ^ (i & 15)) << 4));
+                int om;
+                {
+                    int o = 4 * t + (lane & 3);
+                    o = o < ntot ? o : ntot - 1;
+                    om = ometa[o] >> 3;
+                }
+                x2f16 ah, al;
+#pragma unroll
+                for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[s], ah, 0, 0, 0);
+                    if constexpr (!HI_ONLY) al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[s], al, 0, 0, 0);
+                }
+                float mq[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if constexpr (HI_ONLY) {
+                        mq[k] = 0.0f;
+                    } else {
+                        const float v0 = fmaf(al[4 * k], 1.0f / 2048.0f, ah[4 * k]), v1 = fmaf(al[4 * k + 1], 1.0f / 2048.0f, ah[4 * k + 1]);
+                        const float v2 = fmaf(al[4 * k + 2], 1.0f / 2048.0f, ah[4 * k + 2]), v3 = fmaf(al[4 * k + 3], 1.0f / 2048.0f, ah[4 * k + 3]);
+                        mq[k] = x2_max(x2_max3(v0, v1, v2), v3);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int j = __builtin_amdgcn_readlane(om, k);
+                    if (j != jcur) {
+                        flush(jcur);
+                        cm = -9999.0f;  // filter_pids.cpp:30-33
+                        jcur = j;
+                    }
+                    if constexpr (HI_ONLY) {
+                        cm = fmaxf(fmaxf(cm, ah[4 * k]), ah[4 * k + 1]);
+                        cm = fmaxf(fmaxf(cm, ah[4 * k + 2]), ah[4 * k + 3]);
+                    } else {
+                        cm = x2_max(cm, mq[k]);
+                    }
+                }
+            };
+            // (a step is only reachable through the one before it: the compiler's wait counts then know what is in flight)
+            for (int t0 = 0; t0 < ntiles; t0 += UN) {
+                step(std::integral_constant<int, 0>{}, t0);
+#define X2R_STEP(U) if constexpr (U < UN) { if (t0 + U >= ntiles) break; step(std::integral_constant<int, U>{}, t0 + U); }
+                X2R_STEP(1) X2R_STEP(2) X2R_STEP(3) X2R_STEP(4) X2R_STEP(5) X2R_STEP(6) X2R_STEP(7)
+#undef X2R_STEP
+            }
+            flush(jcur);
+        }
+        obase += ntot;
+        jstart = jend;
+        if (obase >= __builtin_amdgcn_readlane(oend, 63)) break;
+    }
+}
+#endif
 
 // one half-wave per survivor: maximum over the slices that hold tokens, k-ascending sum of the first nqc columns, key.
 // grid = (nqueries, ceil(max_count / 8)), block = 256
@@ -503,22 +712,27 @@ int flmr_launch_filter_stage2_xcd_ex(const flmr_filter_args& f, const int32_t* p
     const int nsl = ix->nslices;
     const int64_t grid = (int64_t)nsl * f.nqueries * G;
     if (grid > 0x7fffffffLL) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "stage-2 grid too large");
-#ifdef X2_LDS_PAD   // development probe: a larger request leaves one workgroup per CU (half the tiles in flight, one wave per SIMD)
+#ifdef X2_ROWS_IN_REGS
+    const size_t lds = (size_t)X2_WAVES * X2R_WAVE_LDS;
+#define X2_KERNEL filter_stage2_xreg_kernel
+#elif defined(X2_LDS_PAD)   // development probe: a larger request leaves one workgroup per CU (half the tiles in flight, one wave per SIMD)
     const size_t lds = (size_t)X2_WAVES * X2_WAVE_LDS + X2_LDS_PAD;
+#define X2_KERNEL filter_stage2_xcd_kernel
 #else
     const size_t lds = (size_t)X2_WAVES * X2_WAVE_LDS;
+#define X2_KERNEL filter_stage2_xcd_kernel
 #endif
     if (hi_only) {
-        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_stage2_xcd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(filter_stage2_xcd_kernel<true>, dim3((unsigned)grid), dim3(256), lds, st, f, pids, pid_stride, counts, part, part_stride,
+        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(X2_KERNEL<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(X2_KERNEL<true>, dim3((unsigned)grid), dim3(256), lds, st, f, pids, pid_stride, counts, part, part_stride,
                            ix->centroids_f16, q_hi, q_lo, ix->codes_sorted, ix->doc_splits, nsl, G
 #ifdef X2_PROFILE
                            , x2_prof_buffer
 #endif
         );
     } else {
-        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(filter_stage2_xcd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(filter_stage2_xcd_kernel<false>, dim3((unsigned)grid), dim3(256), lds, st, f, pids, pid_stride, counts, part, part_stride,
+        FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(X2_KERNEL<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(X2_KERNEL<false>, dim3((unsigned)grid), dim3(256), lds, st, f, pids, pid_stride, counts, part, part_stride,
                            ix->centroids_f16, q_hi, q_lo, ix->codes_sorted, ix->doc_splits, nsl, G
 #ifdef X2_PROFILE
                            , x2_prof_buffer
