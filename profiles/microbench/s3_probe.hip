@@ -14,10 +14,8 @@ const flmr_options& flmr_opts() { return g_opts; }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 int main(int argc, char** argv) {
-    const int K = 131072, P = 200000, L = 128, NQ = 1024, ND = 256, NBITS = 2;
-    const char* impl = argc > 1 ? argv[1] : "dma";
+    const int K = getenv("S3P_K") ? atoi(getenv("S3P_K")) : 131072, P = 200000, L = 128, NQ = 1024, ND = 256, NBITS = 2;   // S3P_K: a smaller (cache-resident) centroid table
     memset(&g_opts, 0, sizeof g_opts);
-    snprintf(g_opts.v[FLMR_OPT_S3_IMPL], sizeof g_opts.v[0], "%s", impl);
     std::mt19937 rng(1);
     std::vector<int32_t> codes((size_t)P * L);
     for (auto& c : codes) c = (int32_t)(rng() % K);
@@ -47,13 +45,44 @@ int main(int argc, char** argv) {
     flmr_maxsim_args a{};
     a.ix = &ix; a.Q = dQ; a.q_lens = nullptr; a.nqueries = NQ; a.nq = 32; a.pids = d_pids; a.pid_stride = ND; a.counts = d_counts;
     a.max_count = ND; a.keys = d_keys; a.key_stride = ND; a.scores = nullptr; a.q_hi = qh; a.q_lo = ql;
+    // "cw" / "lean": the index-side tables of the centroid + weight form, and the planned-tile kernel's workspace
+    {
+        std::vector<float> cen32(cen.size());
+        for (size_t t = 0; t < cen.size(); t++) cen32[t] = (float)cen[t];
+        CK(hipMalloc(&ix.centroids, cen32.size() * 4)); CK(hipMemcpy(ix.centroids, cen32.data(), cen32.size() * 4, hipMemcpyHostToDevice));
+        ix.max_doclen = L;
+        if (flmr_build_s3_tables(&ix) != 0 || !ix.inv_norm) { printf("no S3 tables\n"); return 1; }
+        a.plan_stride = (int64_t)ND * ((L + 31) / 32); a.plan_wcap = ND + 8;
+        CK(hipMalloc(&a.plan_desc, (size_t)NQ * a.plan_stride * sizeof(uint2)));
+        CK(hipMalloc(&a.plan_wbeg, (size_t)NQ * a.plan_wcap * 4));
+    }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int rep = 0; rep < 4; rep++) {
-        CK(hipEventRecord(e0, 0));
-        if (flmr_launch_maxsim(a, 0) != 0) { printf("launch failed: %s\n", flmr_err_buf); return 1; }
-        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
-        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        if (rep) printf("S3 (%s): %.3f ms per %d queries x %d finalists\n", impl, ms, NQ, ND);
+    std::vector<uint64_t> ref;
+    const char* impls[8]; int nimpl = 0;
+    for (int k = 1; k < argc && nimpl < 8; k++) impls[nimpl++] = argv[k];
+    if (!nimpl) impls[nimpl++] = "dma";
+    for (int v = 0; v < nimpl; v++) {
+        snprintf(g_opts.v[FLMR_OPT_S3_IMPL], sizeof g_opts.v[0], "%s", impls[v]);
+        CK(hipMemset(d_keys, 0xAB, (size_t)NQ * ND * 8));
+        for (int rep = 0; rep < 5; rep++) {
+            CK(hipEventRecord(e0, 0));
+            if (flmr_launch_maxsim(a, 0) != 0) { printf("launch failed: %s\n", flmr_err_buf); return 1; }
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) printf("S3 (%s): %.3f ms per %d queries x %d finalists\n", impls[v], ms, NQ, ND);
+        }
+        std::vector<uint64_t> got((size_t)NQ * ND);
+        CK(hipMemcpy(got.data(), d_keys, got.size() * 8, hipMemcpyDeviceToHost));
+        if (v == 0) ref = got;
+        else {
+            size_t bad = 0; double maxd = 0;
+            for (size_t t = 0; t < got.size(); t++) {
+                if (got[t] != ref[t]) bad++;
+                const double dd = fabs((double)flmr_key_score(got[t]) - (double)flmr_key_score(ref[t]));
+                if (dd > maxd) maxd = dd;
+            }
+            printf("   vs %s: %zu of %zu keys differ, max |dscore| %.3g\n", impls[0], bad, got.size(), maxd);
+        }
     }
     return 0;
 }

@@ -47,7 +47,7 @@ enum flmr_opt_id {
     FLMR_OPT_S2_IMPL,        // xcda (approximate-then-refine on the sliced kernel: the default where the sliced kernel is) | xcd | walk | lds | ldsb | regs: force the XCD-sliced gather / the dense walk / the LDS-DMA gather (4-wave blocks; 16-wave blocks with the query operand in LDS) / the register gather (default: cost model)
     FLMR_OPT_S0_STAGED,      // set: staged epilogue for every tile
     FLMR_OPT_S3_NO_MULTIQ,   // set: single-tile MaxSim kernel for long queries too
-    FLMR_OPT_S3_IMPL,        // cw (default for Nq <= 32): (c.q + w.q) * 1/norm with table-decoded weights; regs / dma: decompress-normalise-split kernel with register / LDS-DMA row gathers; f32: fp32-MFMA kernel
+    FLMR_OPT_S3_IMPL,        // lean (default for Nq <= 32: the cw arithmetic on planned tiles) | cw: (c.q + w.q) * 1/norm with table-decoded weights; regs / dma: decompress-normalise-split kernel with register / LDS-DMA row gathers; f32: fp32-MFMA kernel
     FLMR_OPT_SCORE_IMPL,     // valu: plain-FMA padded scorer
     FLMR_OPT_POISON,         // set (test runs): every batch starts with its per-query score rows, ranks and survivor lists filled with 0xFF -- a stage that lives off an earlier batch's workspace then produces NaNs / wild indices instead of passing
     FLMR_OPT_ROW_CAP,        // score rows a searcher keeps per query (64 .. 65535; default 16384, at most K): a query with more centroids above the threshold raises FLMR_ERR_CAPACITY
@@ -307,6 +307,11 @@ struct flmr_maxsim_args {
     _Float16* q_lo;
     int32_t gpu_fp16;         // FLMR_NUMERICS_GPU_FP16: the reference's CUDA-path scoring (fp16 embeddings, -9999 padding, no clamp)
     int32_t q_split_done;     // 1: q_hi / q_lo already hold this batch's images (stage 0 made the same ones: nq <= 32 <= nq_cand)
+    // workspace of the planned-tile kernels (nullable -> the kernels that walk the passages themselves):
+    uint2* plan_desc;         // [nqueries, plan_stride] one descriptor per 32-token tile of a query's finalists
+    int64_t plan_stride;      // >= max_count * ceil(max_doclen / 32)
+    int32_t* plan_wbeg;       // [nqueries, plan_wcap] first tile of every wave's share (+ the end)
+    int32_t plan_wcap;        // >= waves per query + 1
 };
 int flmr_launch_maxsim(const flmr_maxsim_args& a, hipStream_t st);
 

@@ -1261,6 +1261,398 @@ __global__ __launch_bounds__(64 * S3_MQW) void maxsim_f16_multiq_kernel(flmr_max
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// S3 on PLANNED tiles (round 5; the default for Nq <= 32, FLMR_S3_IMPL=lean; `cw` selects the kernel above).
+// maxsim_f16_dma_kernel<CW> spends ~500 instructions per 32-token tile, of which 40 are MFMAs: the walk over (passage, tile)
+// with its v_readlane chains, 64-bit position arithmetic, branches per window slot, the ring of codes in LDS, 32 v_mov to clear
+// the accumulators -- a wave issues one instruction every ~5 cycles, so the tile costs what its instruction count says
+// (6100 cycles per wave and tile measured, 1280 of them matrix pipe).  Here everything that is wave-uniform is decided
+// BEFORE the scoring kernel runs:
+//   * s3_plan_kernel (one workgroup per query) writes one 8-byte descriptor per tile of the query's finalists --
+//       .x  array position of the tile's first token (32-bit: the launcher requires N < 2^32)
+//       .y  first valid row | (end of valid rows) << 6 | (last tile of its passage) << 12 | passage slot << 13
+//     -- and the tile ranges of the query's waves (equal shares, cut at passage boundaries).  The LAST tile of a passage with
+//     >= 32 tokens is moved back to end at the passage's end: it re-scores up to 31 tokens of the tile before it, which a
+//     maximum does not see, and no tile of such a passage has padding rows.  A passage shorter than 32 tokens has one tile
+//     whose valid rows are a window [lo, hi) (the tile starts at the passage unless that would read past the arrays' end).
+//     Empty passages get their score (0) there; the pid half of every key is written there too.
+//   * the scoring wave reads its descriptors with scalar loads two tiles ahead; every VMEM address is an SGPR base (position
+//     arithmetic on the scalar unit) plus a per-lane constant; the tile's codes come straight into the registers of the lanes
+//     that move the rows (DMA instruction q moves rows {q, 8+q, 16+q, 24+q}: lane group j needs codes 8j..8j+7 = two
+//     global_load_dwordx4), no ring in LDS; the accumulators start from the MFMA's zero C operand; the per-passage sums wait
+//     in LDS ([column][passage], 16 passages) and are formed k-ascending by 16 lanes at once.
+// Arithmetic, accumulation order and the k-ascending sum are maxsim_f16_dma_kernel<CW>'s: bit-identical scores.
+// VMEM order per step g: codes(g+3) [2], residual bytes + 1/norm of tile g+2 [RL], rows of tile g+2 [8].  Top of step g needs
+// rows(g), residuals(g), codes(g+2): everything but the youngest 8 + RL operations (rows / residuals of tile g+1).  Requests
+// past the wave's last tile repeat the last tile (static counts, no branch); their data is never used.
+// grid = (nqueries, G), block = 256; LDS = table + 4 x (32 + 32 * 17 + 16) words + 4 x 16 KB.
+// ------------------------------------------------------------------------------------------------
+#define S3L_FLUSH 16                           // passages whose column maxima wait in LDS for their sums
+#define S3L_CBS 17                             // row stride (floats) of that [column][passage] matrix
+#define S3L_WAVE_WORDS (32 + 32 * S3L_CBS + S3L_FLUSH)
+#define S3L_MAX_DOCS 8192                      // finalists per query the plan kernel handles (its LDS prefix table)
+
+__global__ __launch_bounds__(256) void s3_plan_kernel(flmr_maxsim_args m, const int64_t* __restrict__ doc_offsets, int64_t N, int W) {
+    __shared__ int base_lds[S3L_MAX_DOCS + 1];
+    __shared__ int scan_lds[17];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int cnt = m.counts[b] < m.max_count ? m.counts[b] : m.max_count;
+    uint2* desc = m.plan_desc + (size_t)b * m.plan_stride;
+    int running = 0;
+    for (int d0 = 0; d0 < cnt; d0 += 256) {
+        const int d = d0 + tid;
+        int len = 0, pid = 0;
+        int64_t off = 0;
+        if (d < cnt) {
+            pid = m.pids[(size_t)b * m.pid_stride + d];
+            off = doc_offsets[pid];
+            len = (int)(doc_offsets[pid + 1] - off);
+            if (len < 0) len = 0;
+        }
+        const int nt = (len + 31) >> 5;
+        int total;
+        const int base = running + flmr_block_exclusive_scan(nt, scan_lds, &total);
+        running += total;
+        if (d < cnt) {
+            base_lds[d] = base;
+            const size_t ko = (size_t)b * m.key_stride + d;
+            if (len == 0) {  // the empty sum (segmented_maxsim.cpp: every column maximum stays 0)
+                if (m.keys) m.keys[ko] = flmr_make_key(0.0f, pid);
+                if (m.scores) m.scores[ko] = 0.0f;
+            } else if (m.keys) {
+                reinterpret_cast<uint32_t*>(m.keys)[2 * ko] = (uint32_t)pid;   // the score half comes from the scoring kernel
+            }
+            for (int t = 0; t < nt; t++) {
+                int64_t pos = off + 32 * (int64_t)t;
+                int lo = 0, hi = 32;
+                if (t == nt - 1) {
+                    if (len >= 32) pos = off + len - 32;
+                    else {
+                        if (pos + 32 > N) pos = N - 32;
+                        lo = (int)(off - pos); hi = lo + len;
+                    }
+                }
+                desc[base + t] = make_uint2((uint32_t)pos, (uint32_t)(lo | (hi << 6) | ((t == nt - 1) << 12) | (d << 13)));
+            }
+        }
+    }
+    if (tid == 0) base_lds[cnt] = running;
+    __syncthreads();
+    int* wb = m.plan_wbeg + (size_t)b * m.plan_wcap;
+    for (int w = tid; w <= W; w += 256) {
+        const int target = (int)(((int64_t)w * running) / W);
+        int lo = 0, hi = cnt;          // smallest d in [0, cnt] with base_lds[d] >= target
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (base_lds[mid] >= target) hi = mid; else lo = mid + 1;
+        }
+        wb[w] = w == W ? running : base_lds[lo];
+    }
+}
+
+// (residual byte kb of the lane's words) << SH in ONE instruction: the SDWA form of v_lshlrev selects the byte of its operand
+template <int BYTE>
+__device__ __forceinline__ uint32_t s3l_byte_shl(uint32_t word, uint32_t sh) {
+    uint32_t a;
+    if constexpr (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a) : "v"(sh), "v"(word));
+    else if constexpr (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a) : "v"(sh), "v"(word));
+    else if constexpr (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a) : "v"(sh), "v"(word));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a) : "v"(sh), "v"(word));
+    return a;
+}
+
+// s3cw_decode with one VALU instruction per residual byte (its LDS byte address) and the lo table S3L_LO_PAD bytes past the
+// hi table's end: at that distance the compiler cannot fuse a byte's hi and lo look-ups into one ds_read2st64_b64, whose four
+// result registers (hi pair | lo pair) then have to be moved apart -- 48 v_mov per tile -- because an MFMA operand is four
+// CONSECUTIVE registers of one kind.  `sh`: a register holding log2 (bytes per table entry).
+#define S3L_LO_PAD 64
+template <int NBITS, typename WordFn>
+__device__ __forceinline__ void s3l_decode(const char* tab, WordFn word, uint32_t sh, hf8 (&wh)[8], hf8 (&wl)[8]) {
+    constexpr int VPB = 8 / NBITS;
+    constexpr int LO = (NBITS == 8 ? 0 : 512 * VPB + S3L_LO_PAD);   // byte offset of the lo table
+    auto addr = [&](auto kbc) -> uint32_t {   // LDS byte offset of the entry of the lane's kb-th residual byte
+        constexpr int kb = decltype(kbc)::value;
+        return s3l_byte_shl<kb & 3>(word(kb >> 2), sh);
+    };
+#define S3L_KB(x) std::integral_constant<int, (x)>{}
+    auto step_s = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        s3u4 hpk, lpk;
+        if constexpr (VPB == 8) {
+            const uint32_t a0 = addr(S3L_KB(s));
+            hpk = *reinterpret_cast<const s3u4*>(tab + a0);
+            lpk = *reinterpret_cast<const s3u4*>(tab + LO + a0);
+        } else if constexpr (VPB == 4) {
+            const uint32_t a0 = addr(S3L_KB(2 * s)), a1 = addr(S3L_KB(2 * s + 1));
+            const uint2 h0 = *reinterpret_cast<const uint2*>(tab + a0), h1 = *reinterpret_cast<const uint2*>(tab + a1);
+            const uint2 l0 = *reinterpret_cast<const uint2*>(tab + LO + a0), l1 = *reinterpret_cast<const uint2*>(tab + LO + a1);
+            hpk = s3u4{h0.x, h0.y, h1.x, h1.y};
+            lpk = s3u4{l0.x, l0.y, l1.x, l1.y};
+        } else if constexpr (VPB == 2) {
+            const uint32_t a0 = addr(S3L_KB(4 * s)), a1 = addr(S3L_KB(4 * s + 1)), a2 = addr(S3L_KB(4 * s + 2)), a3 = addr(S3L_KB(4 * s + 3));
+            hpk = s3u4{*reinterpret_cast<const uint32_t*>(tab + a0), *reinterpret_cast<const uint32_t*>(tab + a1),
+                       *reinterpret_cast<const uint32_t*>(tab + a2), *reinterpret_cast<const uint32_t*>(tab + a3)};
+            lpk = s3u4{*reinterpret_cast<const uint32_t*>(tab + LO + a0), *reinterpret_cast<const uint32_t*>(tab + LO + a1),
+                       *reinterpret_cast<const uint32_t*>(tab + LO + a2), *reinterpret_cast<const uint32_t*>(tab + LO + a3)};
+        } else {   // one (hi | lo << 16) word per byte
+            uint32_t e[8];
+            e[0] = *reinterpret_cast<const uint32_t*>(tab + addr(S3L_KB(8 * s)));     e[1] = *reinterpret_cast<const uint32_t*>(tab + addr(S3L_KB(8 * s + 1)));
+            e[2] = *reinterpret_cast<const uint32_t*>(tab + addr(S3L_KB(8 * s + 2))); e[3] = *reinterpret_cast<const uint32_t*>(tab + addr(S3L_KB(8 * s + 3)));
+            e[4] = *reinterpret_cast<const uint32_t*>(tab + addr(S3L_KB(8 * s + 4))); e[5] = *reinterpret_cast<const uint32_t*>(tab + addr(S3L_KB(8 * s + 5)));
+            e[6] = *reinterpret_cast<const uint32_t*>(tab + addr(S3L_KB(8 * s + 6))); e[7] = *reinterpret_cast<const uint32_t*>(tab + addr(S3L_KB(8 * s + 7)));
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                hpk[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x05040100u);   // {e0.lo16, e1.lo16}
+                lpk[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x07060302u);   // {e0.hi16, e1.hi16}
+            }
+        }
+        wh[s] = __builtin_bit_cast(hf8, hpk);
+        wl[s] = __builtin_bit_cast(hf8, lpk);
+    };
+    step_s(S3L_KB(0)); step_s(S3L_KB(1)); step_s(S3L_KB(2)); step_s(S3L_KB(3));
+    step_s(S3L_KB(4)); step_s(S3L_KB(5)); step_s(S3L_KB(6)); step_s(S3L_KB(7));
+#undef S3L_KB
+}
+
+template <int NBITS>
+struct s3l_res {      // one lane's residual bytes (8 * NBITS) and 1 / norm of one tile, loaded from inline assembly
+    u32x4 q[(NBITS + 1) / 2];
+    float inv;
+    __device__ __forceinline__ void issue(uint32_t voff, const uint8_t* sbase, uint32_t ivoff, const float* ibase) {
+        if constexpr (NBITS == 1) {
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(*reinterpret_cast<u32x2*>(&q[0])) : "v"(voff), "s"(sbase) : "memory");
+        } else {
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(q[0]) : "v"(voff), "s"(sbase) : "memory");
+            if constexpr (NBITS >= 4) asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(q[1]) : "v"(voff), "s"(sbase) : "memory");
+            if constexpr (NBITS >= 8) {
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(q[2]) : "v"(voff), "s"(sbase) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:48" : "=v"(q[3]) : "v"(voff), "s"(sbase) : "memory");
+            }
+        }
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(inv) : "v"(ivoff), "s"(ibase) : "memory");
+    }
+    __device__ __forceinline__ void touch() {
+#pragma unroll
+        for (int k = 0; k < (NBITS + 1) / 2; k++) asm volatile("" : "+v"(q[k])::"memory");
+        asm volatile("" : "+v"(inv)::"memory");
+    }
+    __device__ __forceinline__ uint32_t word(int wi) const { return q[wi >> 2][wi & 3]; }
+};
+
+struct s3l_codes {    // the eight codes of the rows this lane's DMA instructions move
+    u32x4 lo, hi;
+    __device__ __forceinline__ void issue(uint32_t voff, const int32_t* sbase) {
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(lo) : "v"(voff), "s"(sbase) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(hi) : "v"(voff), "s"(sbase) : "memory");
+    }
+    __device__ __forceinline__ void touch() { asm volatile("" : "+v"(lo), "+v"(hi)::"memory"); }
+    __device__ __forceinline__ uint32_t at(int gq) const { return gq < 4 ? lo[gq] : hi[gq - 4]; }
+};
+
+template <int NBITS>
+__global__ __launch_bounds__(256, 2) void maxsim_lean_kernel(flmr_maxsim_args m, const int32_t* __restrict__ codes,
+                                                             const uint8_t* __restrict__ residuals,
+                                                             const _Float16* __restrict__ cen16,
+                                                             const uint32_t* __restrict__ wtab_g,
+                                                             const float* __restrict__ inv_norm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int VPB = 8 / NBITS, PACKED = FLMR_DIM * NBITS / 8, NB = 8 * NBITS;
+    constexpr int RL = (NBITS == 1 ? 1 : NBITS / 2) + 1;                  // residual + 1 / norm load instructions per tile
+    constexpr int TABW = NBITS == 8 ? 256 : 256 * VPB;                    // fragment tables (wtab16), 32-bit words
+    constexpr int HIW = NBITS == 8 ? 256 : 128 * VPB;                     // words of the hi table (NBITS = 8: the one combined table)
+    constexpr int TABL = NBITS == 8 ? 256 : TABW + S3L_LO_PAD / 4;        // words the tables take in LDS (lo table S3L_LO_PAD bytes further)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    // the fragment tables are a STATIC array: its LDS address is a constant that folds into the look-ups' offset fields (with the
+    // dynamic carve-out's base the compiler adds a register holding "0" to each of a tile's 16 addresses)
+    __shared__ __attribute__((aligned(16))) uint32_t tab_s[TABL];
+    float* const invs = reinterpret_cast<float*>(smem) + (size_t)wave * S3L_WAVE_WORDS;          // the tile's 32 row scales
+    float* const colbuf = invs + 32;                                                             // [32 columns][S3L_CBS]
+    int* const slots = reinterpret_cast<int*>(colbuf + 32 * S3L_CBS);                            // passage slot of each waiting sum
+    char* const rowbuf = smem + (4 * (size_t)S3L_WAVE_WORDS * 4 + 15) / 16 * 16 + (size_t)wave * 16384;
+    const uint32_t rowbuf_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)rowbuf);
+    for (int t = tid; t < TABW; t += 256) tab_s[t < HIW ? t : t + (TABL - TABW)] = wtab_g[t];
+    __syncthreads();
+
+    const int b = blockIdx.x;
+    const int W = gridDim.y * 4, w = blockIdx.y * 4 + wave;
+    const int32_t* wb = m.plan_wbeg + (size_t)b * m.plan_wcap;
+    const int tb = __builtin_amdgcn_readfirstlane(wb[w]), te = __builtin_amdgcn_readfirstlane(wb[w + 1]);
+    (void)W;
+    if (tb >= te) return;
+    const uint2* dq = m.plan_desc + (size_t)b * m.plan_stride;
+    // descriptors by SCALAR loads written as instructions (the compiler, unable to prove the buffer unwritten behind the asm
+    // statements' memory clobbers, makes them vector loads -- whose wait would drain the row pipeline); a load's result may be
+    // used after the next `s_waitcnt lgkmcnt(0)` and its touch()
+    auto ld_desc = [&](int t, u32x2& d) {
+        const int tc = t < te ? t : te - 1;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(d) : "s"(dq + tc) : "memory");
+    };
+    auto touch_desc = [&](u32x2& d) { asm volatile("" : "+s"(d)::"memory"); };
+    hf8 bh[8], bl[8];
+    {
+        const hf8* ph = reinterpret_cast<const hf8*>(m.q_hi + ((size_t)b * 32 + i) * FLMR_DIM + 64 * h);
+        const hf8* pl = reinterpret_cast<const hf8*>(m.q_lo + ((size_t)b * 32 + i) * FLMR_DIM + 64 * h);
+#pragma unroll
+        for (int s = 0; s < 8; s++) { bh[s] = ph[s]; bl[s] = pl[s]; }
+    }
+    // per-lane constants
+    const uint32_t res_voff = (uint32_t)(i * PACKED + h * NB), inv_voff = (uint32_t)(i * 4), code_voff = (uint32_t)((lane >> 4) * 32);
+    const uint32_t piece_base = (uint32_t)(((lane & 15) ^ (8 * ((lane >> 4) & 1))) << 4);   // row 8j + q: swizzle (8j + q) & 15
+    const uint32_t rd_base = (uint32_t)((4 * (i & 7) + (i >> 3)) * 256 + (((8 * h) ^ (i & 15)) << 4));   // row i sits in slot 4 (i & 7) + (i >> 3)
+
+    auto dma_rows = [&](int par, const s3l_codes& c) {
+#ifdef S3L_NO_DMA   // development probe (profiles/microbench/s3_probe.hip): the step without its row gather
+        return;
+#endif
+#pragma unroll
+        for (int gq = 0; gq < 8; gq++) {
+            const uint32_t dst = rowbuf_lds + par * 8192 + gq * 1024;
+            const uint32_t po = piece_base ^ (uint32_t)(gq << 4);
+            uint32_t voff;
+            asm volatile("s_mov_b32 m0, %2\n\tv_lshl_add_u32 %0, %3, 8, %4\n\tglobal_load_lds_dwordx4 %0, %1"
+                         : "=&v"(voff)
+                         : "s"(cen16), "s"(dst), "v"(c.at(gq)), "v"(po)
+                         : "memory", "m0");
+        }
+    };
+    auto issue_tile = [&](s3l_res<NBITS>& r, uint32_t pos) {
+        r.issue(res_voff, residuals + (size_t)pos * PACKED, inv_voff, inv_norm + pos);
+    };
+
+    s3l_res<NBITS> rE, rO;
+    s3l_codes cE, cO;
+    u32x2 d0, d1, d2;
+    ld_desc(tb, d0); ld_desc(tb + 1, d1); ld_desc(tb + 2, d2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    touch_desc(d0); touch_desc(d1); touch_desc(d2);
+    const uint32_t sh_entry = NBITS == 1 ? 4 : NBITS == 2 ? 3 : 2;   // log2 (bytes per table entry), in a register for the SDWA shifts
+    {
+#pragma unroll
+        for (int s = 0; s < 8; s++) asm volatile("" : "+v"(bh[s]), "+v"(bl[s])::"memory");
+        cE.issue(code_voff, codes + d0.x);
+        cO.issue(code_voff, codes + d1.x);
+        s3_wait_vm<0>();
+        cE.touch(); cO.touch();
+        issue_tile(rE, d0.x);
+        dma_rows(0, cE);
+        cE.issue(code_voff, codes + d2.x);
+        issue_tile(rO, d1.x);
+        dma_rows(1, cO);
+    }
+    float cmx = 0.0f;
+    int nd = 0;
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nd) {
+            float x[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) x[k] = colbuf[k * S3L_CBS + lane];
+            float sc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 32; k++) sc += x[k];   // k-ascending (columns >= q_len hold +0)
+            const size_t ko = (size_t)b * m.key_stride + slots[lane];
+            if (m.keys) reinterpret_cast<uint32_t*>(m.keys)[2 * ko + 1] = flmr_f2ord(sc);
+            if (m.scores) m.scores[ko] = sc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // one step: consume tile g (descriptor d0; rows in buffer `par`, residual bytes in r, whose registers take tile g+2's;
+    // cn holds the codes of tile g+2, cf takes those of tile g+3)
+    auto step = [&](int g, int par, s3l_res<NBITS>& r, s3l_codes& cn, s3l_codes& cf) {
+        u32x2 d3;
+        ld_desc(g + 3, d3);
+#ifdef S3L_NO_DMA
+        s3_wait_vm<RL>();
+#else
+        s3_wait_vm<8 + RL>();
+#endif
+        r.touch(); cn.touch();
+        hf8 c[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) c[s] = *reinterpret_cast<const hf8*>(rowbuf + par * 8192 + (rd_base ^ (uint32_t)(s << 4)));
+        hf8 ah[8], al[8];
+#ifdef S3L_NO_DECODE
+#pragma unroll
+        for (int s = 0; s < 8; s++) { ah[s] = c[s]; al[s] = c[7 - s]; }
+        asm volatile("" :: "v"(r.word(0)));
+#else
+        s3l_decode<NBITS>(reinterpret_cast<const char*>(tab_s), [&](int wi) { return r.word(wi); }, sh_entry, ah, al);
+#endif
+        {
+            const int lo = (int)(d0.y & 63u), hi = (int)((d0.y >> 6) & 63u);
+            if (h == 0) invs[i] = (i >= lo && i < hi) ? r.inv : 0.0f;
+        }
+        // the row buffer has been read (and the table look-ups are in): nothing may be scheduled across this point -- an LDS read
+        // that slipped below it could see the next tile's rows
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        touch_desc(d3);
+        cf.issue(code_voff, codes + d3.x);
+        issue_tile(r, d2.x);
+        dma_rows(par, cn);
+        f32x16 acch, accl;
+        {
+            const f32x16 z = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[0], bh[0], z, 0, 0, 0);
+            accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[0], bl[0], z, 0, 0, 0);
+        }
+#ifndef S3L_NO_MFMA
+#pragma unroll
+        for (int s = 1; s < 8; s++) {
+            acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[s], bh[s], acch, 0, 0, 0);
+            accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[s], bl[s], accl, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[s], acch, 0, 0, 0);
+            accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[s], accl, 0, 0, 0);
+            accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s], accl, 0, 0, 0);
+        }
+#else
+#pragma unroll
+        for (int s = 1; s < 8; s++) asm volatile("" :: "v"(c[s]), "v"(ah[s]), "v"(al[s]));
+#endif
+#ifdef S3L_NO_EPI
+        cmx = fmaxf(cmx, acch[0] + accl[5]);
+#else
+        cmx = fmaxf(cmx, s3cw_tile_max(acch, accl, invs, h));
+#endif
+        __builtin_amdgcn_wave_barrier();   // (the scales are read before the next step overwrites them)
+        if ((d0.y >> 12) & 1u) {   // last tile of its passage
+            const float vx = flmr_xhalf_max(cmx);
+            cmx = 0.0f;  // segmented_maxsim.cpp:58-59: the running max starts at zero
+            if (h == 0) colbuf[i * S3L_CBS + nd] = vx;
+            if (lane == 0) slots[nd] = (int)(d0.y >> 13);
+            nd++;
+            if (nd == S3L_FLUSH) { flush(); nd = 0; }
+        }
+        d0 = d1; d1 = d2; d2 = d3;
+    };
+    for (int g = tb; g < te; g += 2) {
+        step(g, 0, rE, cE, cO);
+        if (g + 1 >= te) break;
+        step(g + 1, 1, rO, cO, cE);
+    }
+    if (nd > 0) flush();
+    s3_wait_vm<0>();
+}
+
+template <int NBITS>
+static int launch_maxsim_lean_t(const flmr_maxsim_args& a, hipStream_t st, int G) {
+    const flmr_index* ix = a.ix;
+    const size_t lds = (4 * (size_t)S3L_WAVE_WORDS * 4 + 15) / 16 * 16 + 4 * 16384;   // (+ the static fragment tables)
+    hipLaunchKernelGGL(s3_plan_kernel, dim3(a.nqueries), dim3(256), 0, st, a, ix->doc_offsets, ix->N, 4 * G);
+    FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_lean_kernel<NBITS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(maxsim_lean_kernel<NBITS>, dim3(a.nqueries, G), dim3(256), lds, st, a, ix->codes, ix->residuals, ix->centroids_f16,
+                       ix->wtab16, ix->inv_norm);
+    return FLMR_OK;
+}
+
 template <int NBITS>
 static int launch_maxsim_f16_t(const flmr_maxsim_args& a, hipStream_t st) {
     const flmr_index* ix = a.ix;
@@ -1276,6 +1668,9 @@ static int launch_maxsim_f16_t(const flmr_maxsim_args& a, hipStream_t st) {
     if (G < gmin) G = gmin;
     if (G > (int)flmr_ceil_div(a.max_count, 4)) G = (int)flmr_ceil_div(a.max_count, 4);
     if (G < 1) G = 1;
+#ifdef S3L_G
+    G = S3L_G;
+#endif
     if (nqp > 32 && !flmr_opts().has(FLMR_OPT_S3_NO_MULTIQ)) {
         const size_t lds2 = (size_t)256 * (8 / NBITS) * sizeof(float) + (size_t)S3_QC * 2 * 32 * S3_BROW * sizeof(_Float16) +
                             (size_t)S3_MQW * (32 * S3_QC + 64) * sizeof(float);
@@ -1288,8 +1683,15 @@ static int launch_maxsim_f16_t(const flmr_maxsim_args& a, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(maxsim_f16_multiq_kernel<NBITS>, dim3(a.nqueries, G2), dim3(64 * S3_MQW), lds2, st, a, ix->codes,
                            ix->residuals, ix->doc_offsets, ix->centroids_f16, ix->wlut, nqp);
+    } else if (nqp == 32 && ix->inv_norm && ix->wtab16 && ((size_t)ix->K * 256 < ((size_t)1 << 32)) && a.plan_desc && a.plan_wbeg &&
+               ix->N >= 32 && ix->N < ((int64_t)1 << 32) && a.max_count <= S3L_MAX_DOCS && a.plan_wcap >= 4 * G + 1 &&
+               a.plan_stride >= (int64_t)a.max_count * ((ix->max_doclen + 31) / 32) &&
+               (flmr_opts().is(FLMR_OPT_S3_IMPL, "lean") || !flmr_opts().has(FLMR_OPT_S3_IMPL))) {
+        // planned tiles (the default for one query tile)
+        const int rc = launch_maxsim_lean_t<NBITS>(a, st, G);
+        if (rc) return rc;
     } else if (nqp == 32 && ix->inv_norm && ix->wtab16 && ((size_t)ix->K * 256 < ((size_t)1 << 32)) &&
-               (flmr_opts().is(FLMR_OPT_S3_IMPL, "cw") || !flmr_opts().has(FLMR_OPT_S3_IMPL))) {
+               (flmr_opts().is(FLMR_OPT_S3_IMPL, "cw") || flmr_opts().is(FLMR_OPT_S3_IMPL, "lean") || !flmr_opts().has(FLMR_OPT_S3_IMPL))) {
         // centroid + weight form on the LDS-DMA pipeline (the default for one query tile; 32-bit row offsets: table < 4 GB)
         const size_t tabw = NBITS == 8 ? 256 : 256 * (8 / NBITS);
 #ifdef S3_LDS_PAD   // development probe: a larger request leaves one workgroup per CU (one wave per SIMD)

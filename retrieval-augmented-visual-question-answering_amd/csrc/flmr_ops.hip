@@ -215,6 +215,15 @@ extern "C" int flmr_score_pids(const flmr_index_t* ix, const float* Q, int32_t n
         RUN(sc.alloc(&ql, (size_t)flmr_round_up(nq, 32) * FLMR_DIM));
         m.q_hi = qh; m.q_lo = ql;
     }
+    if (ix->centroids_f16_exact && nq <= 32 && ix->max_doclen > 0) {   // workspace of the planned-tile kernel (optional)
+        const int64_t stride = (int64_t)npids * ((ix->max_doclen + 31) / 32);
+        uint2* desc = nullptr;
+        int32_t* wbeg = nullptr;
+        if (stride * (int64_t)sizeof(uint2) <= ((int64_t)1 << 30) && sc.alloc(&desc, (size_t)stride) == FLMR_OK &&
+            sc.alloc(&wbeg, (size_t)npids + 8) == FLMR_OK) {
+            m.plan_desc = desc; m.plan_stride = stride; m.plan_wbeg = wbeg; m.plan_wcap = npids + 8;
+        }
+    }
     RUN(flmr_launch_maxsim(m, st));
     FLMR_HIP(hipStreamSynchronize(st));
     return FLMR_OK;

@@ -39,6 +39,7 @@ struct flmr_searcher {
     int32_t* s1_slot; int32_t* s2_slot;   // sharded protocol: position of each local survivor / finalist in the global list
     float* s2_part;             // XCD-sliced stage 2: per (query, slice, survivor) column maxima (NULL when the index has no split table)
     _Float16* q3_hi; _Float16* q3_lo;
+    uint2* s3_desc; int64_t s3_desc_stride; int32_t* s3_wbeg; int32_t s3_wcap;   // planned-tile S3 (NULL: the passage-walking kernel)
     int32_t* qual; int32_t* nqual; int32_t* chunk_cnt; uint8_t* cand_hit; int32_t qmax;
     // last call (for taps)
     int32_t last_nqueries, last_ncol, last_ndocs, last_full_table;
@@ -164,6 +165,19 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     WS(q3_hi, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
     WS(q3_lo, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
 #undef WS
+    {   // optional workspace of the planned-tile S3 kernel: one 8-byte descriptor per 32-token tile of a query's finalists
+        s->s3_desc_stride = (int64_t)nd4 * ((ix->max_doclen + 31) / 32);
+        s->s3_wcap = nd4 + 8;
+        const size_t db = B * (size_t)s->s3_desc_stride * sizeof(uint2), wb = B * (size_t)s->s3_wcap * sizeof(int32_t);
+        if (s->s3_desc_stride > 0 && db <= ((size_t)1 << 30) && hipMalloc(reinterpret_cast<void**>(&s->s3_desc), db) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&s->s3_wbeg), wb) == hipSuccess) {
+            s->bytes += (int64_t)(db + wb);
+        } else {
+            (void)hipGetLastError();
+            (void)hipFree(s->s3_desc); (void)hipFree(s->s3_wbeg);
+            s->s3_desc = nullptr; s->s3_wbeg = nullptr;
+        }
+    }
     FLMR_HIP(hipMemset(s->overflow, 0, 4 * sizeof(int32_t)));
     FLMR_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->status_host), 4 * sizeof(int32_t), hipHostMallocDefault));
     s->status_host[0] = s->status_host[1] = s->status_host[2] = s->status_host[3] = 0;
@@ -178,7 +192,7 @@ extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
     if (!s) return FLMR_OK;
     void* ptrs[] = {s->cs, s->rows, s->idx_prefix, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
                     s->keys1, s->s1_pids, s->s1_count, s->keys2, s->s2_pids, s->s2_count, s->keys3, s->doc_scores,
-                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->q_err, s->q_err_sum, s->s2_band, s->s2_band_count, s->s2_need, s->s2_def, s->keys2b, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->chunk_hits, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part};
+                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->q_err, s->q_err_sum, s->s2_band, s->s2_band_count, s->s2_need, s->s2_def, s->keys2b, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->chunk_hits, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part, s->s3_desc, s->s3_wbeg};
     for (void* p : ptrs) (void)hipFree(p);
     if (s->status_host) (void)hipHostFree(s->status_host);
     if (s->status_ev) (void)hipEventDestroy(s->status_ev);
@@ -591,6 +605,7 @@ static int stage_s3(run_ctx& c, bool s0_images) {
     m.keys = s->keys3; m.key_stride = s->maxp.ndocs / 4; m.scores = s->doc_scores;
     m.q_hi = s->q3_hi; m.q_lo = s->q3_lo;
     m.gpu_fp16 = c.f.f16_round;
+    m.plan_desc = s->s3_desc; m.plan_stride = s->s3_desc_stride; m.plan_wbeg = s->s3_wbeg; m.plan_wcap = s->s3_wcap;
     // Stage 0's fp16 images ARE stage 3's when every query row is a candidate-generation column (nq <= 32 <= nq_cand): rows
     // below min(q_len, nq) real, the rest zero, one tile of 32 -- no second split launch
     if (s0_images && c.sparse && !c.f.f16_round && c.nq <= 32 && c.nqc == c.nq && c.ncol == 32) {

@@ -154,7 +154,7 @@ def test_score_pids_fused_vs_oracle(hip, scorers, name):
         pd = torch.from_numpy(pids).cuda()
         # cw: (c.q + w.q) / norm with table-decoded weights (the default for one query tile); regs: decompress-normalise-split
         # wave-per-document kernel (also what long queries take); f32: the fp32-MFMA kernel
-        for impl in ("cw", "cwregs", "regs", "f32"):
+        for impl in ("lean", "cw", "cwregs", "regs", "f32"):
             with hip["native"].options(FLMR_S3_IMPL=impl):
                 out = torch.empty(len(pids), dtype=torch.float32, device="cuda")
                 hip["native"].check(scorer._lib.flmr_score_pids(scorer.device_index.handle, C.c_void_p(Qd.data_ptr()), Q.shape[0],
@@ -975,7 +975,7 @@ def test_s3_dma_kernel_equals_register_kernel(hip, nbits, doclen, npids):
     g = torch.Generator().manual_seed(5)
     pids = torch.randperm(6000, generator=g)[:npids].to(torch.int32).cuda()
     outs = {}
-    for impl in ("regs", "dma", "cw", "cwregs"):
+    for impl in ("regs", "dma", "cw", "cwregs", "lean"):
         with nat.options(FLMR_S3_IMPL=impl):
             res = []
             for nq in (32, 17):
@@ -997,8 +997,9 @@ def test_s3_dma_kernel_equals_register_kernel(hip, nbits, doclen, npids):
     # the centroid + weight form (the default) rounds differently -- (c.q + w.q) * 1/norm instead of ((c + w) / norm).q -- by
     # fp32-roundoff-class terms: same scores to a few 1e-6 at |score| <= 32, same passages except across such near-ties
     assert not np.any(outs["cw"][0] == -7.0)
-    for a, b in zip(outs["cw"], outs["cwregs"]):   # the two pipelines of the same arithmetic agree bit for bit
-        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+    for other in ("cwregs", "lean"):   # the pipelines of the same arithmetic agree bit for bit (lean: planned tiles, the default)
+        for a, b in zip(outs["cw"], outs[other]):
+            assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b), other
     for k in (0, 1):
         assert np.max(np.abs(outs["cw"][k] - outs["regs"][k])) <= 2e-5, (k, np.max(np.abs(outs["cw"][k] - outs["regs"][k])))
     for k in (2, 5):   # search results: pids / scores / counts
