@@ -14,7 +14,10 @@ const flmr_options& flmr_opts() { return g_opts; }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 int main(int argc, char** argv) {
-    const int K = getenv("S3P_K") ? atoi(getenv("S3P_K")) : 131072, P = 200000, L = 128, NQ = 1024, ND = 256, NBITS = 2;   // S3P_K: a smaller (cache-resident) centroid table
+    const int K = getenv("S3P_K") ? atoi(getenv("S3P_K")) : 131072, P = 200000, L = 128, ND = 256, NBITS = 2;
+    const int NQR = getenv("S3P_NQ") ? atoi(getenv("S3P_NQ")) : 32;          // S3P_NQ: query rows (> 32: the long-query kernels)
+    const int NQ = getenv("S3P_B") ? atoi(getenv("S3P_B")) : (NQR > 32 ? 256 : 1024);   // queries per launch
+    const int NQP = (NQR + 31) / 32 * 32;   // S3P_K: a smaller (cache-resident) centroid table
     memset(&g_opts, 0, sizeof g_opts);
     std::mt19937 rng(1);
     std::vector<int32_t> codes((size_t)P * L);
@@ -26,10 +29,10 @@ int main(int argc, char** argv) {
     std::vector<int32_t> pids((size_t)NQ * ND), counts(NQ, ND);
     for (auto& x : pids) x = (int32_t)(rng() % P);
     std::vector<_Float16> cen((size_t)K * 128);
-    for (auto& x : cen) x = (_Float16)((float)(rng() % 2001 - 1000) / 8000.0f);
-    std::vector<float> Q((size_t)NQ * 32 * 128), wl(256 * 4);
-    for (auto& x : Q) x = (float)(rng() % 2001 - 1000) / 8000.0f;
-    for (auto& x : wl) x = (float)(rng() % 2001 - 1000) / 80000.0f;
+    for (auto& x : cen) x = (_Float16)((float)((int)(rng() % 2001) - 1000) / 8000.0f);
+    std::vector<float> Q((size_t)NQ * NQR * 128), wl(256 * 4);
+    for (auto& x : Q) x = (float)((int)(rng() % 2001) - 1000) / 8000.0f;
+    for (auto& x : wl) x = (float)((int)(rng() % 2001) - 1000) / 80000.0f;
     flmr_index ix{};
     ix.K = K; ix.nbits = NBITS; ix.N = (int64_t)P * L; ix.num_passages = P; ix.centroids_f16_exact = 1; ix.packed_dim = 32;
     float* dQ; int32_t *d_pids, *d_counts; uint64_t* d_keys; _Float16 *qh, *ql;
@@ -41,9 +44,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dQ, Q.size() * 4)); CK(hipMemcpy(dQ, Q.data(), Q.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_pids, pids.size() * 4)); CK(hipMemcpy(d_pids, pids.data(), pids.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_counts, counts.size() * 4)); CK(hipMemcpy(d_counts, counts.data(), counts.size() * 4, hipMemcpyHostToDevice));
-    CK(hipMalloc(&d_keys, (size_t)NQ * ND * 8)); CK(hipMalloc(&qh, Q.size() * 2)); CK(hipMalloc(&ql, Q.size() * 2));
+    CK(hipMalloc(&d_keys, (size_t)NQ * ND * 8)); CK(hipMalloc(&qh, (size_t)NQ * NQP * 128 * 2)); CK(hipMalloc(&ql, (size_t)NQ * NQP * 128 * 2));
     flmr_maxsim_args a{};
-    a.ix = &ix; a.Q = dQ; a.q_lens = nullptr; a.nqueries = NQ; a.nq = 32; a.pids = d_pids; a.pid_stride = ND; a.counts = d_counts;
+    a.ix = &ix; a.Q = dQ; a.q_lens = nullptr; a.nqueries = NQ; a.nq = NQR; a.pids = d_pids; a.pid_stride = ND; a.counts = d_counts;
     a.max_count = ND; a.keys = d_keys; a.key_stride = ND; a.scores = nullptr; a.q_hi = qh; a.q_lo = ql;
     // "cw" / "lean": the index-side tables of the centroid + weight form, and the planned-tile kernel's workspace
     {
@@ -55,6 +58,7 @@ int main(int argc, char** argv) {
         a.plan_stride = (int64_t)ND * ((L + 31) / 32); a.plan_wcap = ND + 8;
         CK(hipMalloc(&a.plan_desc, (size_t)NQ * a.plan_stride * sizeof(uint2)));
         CK(hipMalloc(&a.plan_wbeg, (size_t)NQ * a.plan_wcap * 4));
+        if (NQR > 32) { a.colmax_cap = (int64_t)NQ * ND * NQP; CK(hipMalloc(&a.colmax_ws, (size_t)a.colmax_cap * 4)); }
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<uint64_t> ref;
@@ -69,10 +73,23 @@ int main(int argc, char** argv) {
             if (flmr_launch_maxsim(a, 0) != 0) { printf("launch failed: %s\n", flmr_err_buf); return 1; }
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            if (rep) printf("S3 (%s): %.3f ms per %d queries x %d finalists\n", impls[v], ms, NQ, ND);
+            if (rep) printf("S3 (%s): %.3f ms per %d queries (%d rows) x %d finalists\n", impls[v], ms, NQ, NQR, ND);
         }
+#ifdef S3Q_PROFILE
+        if (NQR > 32 && !strcmp(impls[v], "qs")) {
+            unsigned long long pr[64];
+            CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(s3q_prof), sizeof pr));
+            printf("   s_memtime ticks per round and wave (all launches): top-of-round wait | G + C issue | decode | consume | barrier\n");
+            for (int w = 0; w < 8; w++) {
+                const double n = (double)pr[w * 8 + 7];
+                printf("   wave %d: %8.1f %8.1f %8.1f %8.1f %8.1f   (%.0f rounds)\n", w, pr[w * 8] / n, pr[w * 8 + 1] / n, pr[w * 8 + 2] / n,
+                       pr[w * 8 + 3] / n, pr[w * 8 + 4] / n, n);
+            }
+        }
+#endif
         std::vector<uint64_t> got((size_t)NQ * ND);
         CK(hipMemcpy(got.data(), d_keys, got.size() * 8, hipMemcpyDeviceToHost));
+        printf("   scores[0..3] %.7g %.7g %.7g %.7g\n", flmr_key_score(got[0]), flmr_key_score(got[1]), flmr_key_score(got[2]), flmr_key_score(got[3]));
         if (v == 0) ref = got;
         else {
             size_t bad = 0; double maxd = 0;

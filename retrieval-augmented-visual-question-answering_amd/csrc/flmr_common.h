@@ -312,6 +312,8 @@ struct flmr_maxsim_args {
     int64_t plan_stride;      // >= max_count * ceil(max_doclen / 32)
     int32_t* plan_wbeg;       // [nqueries, plan_wcap] first tile of every wave's share (+ the end)
     int32_t plan_wcap;        // >= waves per query + 1
+    float* colmax_ws;         // long queries: [nqueries, key_stride, round_up(nq, 32)] per-passage column maxima (nullable)
+    int64_t colmax_cap;       // floats
 };
 int flmr_launch_maxsim(const flmr_maxsim_args& a, hipStream_t st);
 

@@ -1212,7 +1212,12 @@ __global__ __launch_bounds__(64 * S3_MQW) void maxsim_f16_multiq_kernel(flmr_max
             have_raw = false;
             for (int t = 0; t < ntiles; t++) {
                 hf8 ah[8], al[8];
+#ifdef S3M_NO_DECODE   // development probes (profiles/microbench/s3_probe.hip)
+#pragma unroll
+                for (int s = 0; s < 8; s++) { ah[s] = raw.c[s]; al[s] = raw.c[7 - s]; }
+#else
                 s3_decode_split<NBITS>(wlut, [&](int wi) { return (wi & 1) ? raw.r[wi >> 1].y : raw.r[wi >> 1].x; }, raw.c, raw.valid, ah, al);
+#endif
                 if (t + 1 < ntiles) {
                     s3_issue_rows<NBITS>(raw, cd, t + 1, off, len, i, h, codes, residuals, cen16);
                 } else if (j + 1 < ndw && nlen > 0) {
@@ -1227,15 +1232,23 @@ __global__ __launch_bounds__(64 * S3_MQW) void maxsim_f16_multiq_kernel(flmr_max
                     for (int s = 0; s < 8; s++) {
                         const hf8 bh = *reinterpret_cast<const hf8*>(bq + ((qt * 2 + 0) * 32 + i) * S3_BROW + 64 * h + 8 * s);
                         const hf8 bl = *reinterpret_cast<const hf8*>(bq + ((qt * 2 + 1) * 32 + i) * S3_BROW + 64 * h + 8 * s);
+#ifdef S3M_NO_MFMA
+                        if (s) { asm volatile("" :: "v"(bh), "v"(bl), "v"(ah[s]), "v"(al[s])); continue; }
+#endif
                         acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acch, 0, 0, 0);
                         accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, accl, 0, 0, 0);
                         accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, accm, 0, 0, 0);
                     }
                     float mx = 0.0f;  // segmented_maxsim.cpp:58-59: the running max starts at zero
+#ifdef S3M_NO_EPI
+                    mx = acch[0] + accl[3] + accm[7];
+                    if (mx == 12345.0f) colmax[qt * 32 + i] = mx;
+#else
 #pragma unroll
                     for (int r = 0; r < 16; r++) mx = fmaxf(mx, fmaf(accl[r] + accm[r], 1.0f / 2048.0f, acch[r]));
                     mx = flmr_xhalf_max(mx);
                     if (h == 0) colmax[qt * 32 + i] = fmaxf(colmax[qt * 32 + i], mx);
+#endif
                 }
             }
             // document done for this chunk: continue its k-ascending running sum with this chunk's columns
@@ -1653,12 +1666,442 @@ static int launch_maxsim_lean_t(const flmr_maxsim_args& a, hipStream_t st, int G
     return FLMR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// S3 for long queries, QUERY-STATIONARY (round 5; the default for Nq >= S3Q_MIN_NQP, FLMR_S3_IMPL=qs; `mq` selects the kernel above).
+// FLMR concatenates 32 text rows with 9 x 32 visual rows (Nq = 320, src/models/retriever/FLMR.py:73-99), PreFLMR goes to 832.
+// maxsim_f16_multiq_kernel keeps a token tile's A operand in registers and walks the query through LDS in chunks of 256
+// columns: every chunk re-gathers (register gathers: 512 tag look-ups per tile) and re-decodes every tile, each (tile, q-tile)
+// pays an LDS read-modify-write of the column maxima and a cross-half exchange, and its k-steps wait for their fragment
+// reads -- 39 % of the matrix pipe at Nq = 832 (profiles/r05/s3_multiq_ablation.txt).  Here the roles are swapped:
+//   * the QUERY sits in registers: each of a workgroup's 8 waves holds the hi / lo B fragments of up to two 32-row q-tiles
+//     (128 VGPRs), 16 q-tiles = 512 columns per workgroup "pass" (Nq = 320: one pass, 832: passes of 16 + 10 q-tiles);
+//   * the TOKEN TILES stream through LDS, gathered and decoded ONCE per pass, the work spread evenly: wave w issues DMA
+//     instruction w of every tile (rows {w, 8+w, 16+w, 24+w} -> a raw-row buffer, the planned-tile kernel's layout) and decodes
+//     k-step w of every tile (16 of the 128 dims of all 32 rows: one ds_read_b128 of the raw rows, NBITS table look-ups,
+//     (w + c) * 1/norm with the index's inv_norm, split into fp16 hi / lo, two ds_write_b128 into the tile's ring slot in
+//     fragment order); all 8 waves read every slot (16 ds_read_b128 per tile and wave feed 48 MFMAs);
+//   * rounds of 3 tiles, ring and raw buffers double-buffered (96 + 48 KB).  Round r, every wave: decode its k-step of the
+//     tiles of round r+1 -> ring[(r + 1) & 1]; request rows / residual bytes / scales of the tiles of round r+2 (codes asked for
+//     a round earlier) and the codes of round r+3; consume ring[r & 1]; vmcnt(0) (everything it waits for is a round old); ONE
+//     block barrier.  Tile descriptors (s3_plan_kernel) ride in SGPRs, four rounds deep;
+//   * ONE accumulator per q-tile: both operands are scaled by L = 64 before the fp16 split, x = hi + lo with lo = fp16(64 x -
+//     hi) -- not the 2048-fold residual the other kernels keep -- so hi.hi, hi.lo and lo.hi are products at ONE scale and add
+//     into the same registers (the lo products first, over all k-steps, then hi.hi: the small terms are summed before they meet
+//     the large ones).  No hi + lo / 2048 combine, half the accumulator registers, an epilogue of 8 v_max3 per q-tile; the
+//     column maximum is multiplied by 2^-12 once per passage.  |64 x| must stay below 65504: |Q| < 1000 (rows of an index are
+//     unit vectors).  lo is a normal fp16 number for |x| >= 2^-8 and loses nothing that matters below (absolute 2^-31 of x);
+//   * column maxima stay in registers until their passage ends (all waves see the same boundaries), then go to a
+//     [query][finalist][column] array; s3_colsum_kernel forms the k-ascending sums.
+// Scores differ from maxsim_f16_multiq_kernel's by fp32 roundoff (same decode up to the scaling, other accumulation order).
+// grid = (nqueries, passes * Y), block = 512; LDS = 144 KB + the static weight table.
+// ------------------------------------------------------------------------------------------------
+#define S3Q_R 3
+#define S3Q_SLOT 16384
+#define S3Q_RAW 8192
+#define S3Q_SCALE 64.0f
+#ifndef S3Q_MIN_NQP
+#define S3Q_MIN_NQP 288
+#endif
+
+// the query images of this kernel: hi = fp16(64 q), lo = fp16(64 q - hi); rows >= q_len (and the padding to a multiple of 32) zero
+__global__ __launch_bounds__(256) void s3q_split_q(const float* Q, const int32_t* q_lens, int nq, int nqp, _Float16* q_hi, _Float16* q_lo) {
+    const int b = blockIdx.y;
+    const int qlen = q_lens ? q_lens[b] : nq;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nqp * FLMR_DIM; e += gridDim.x * blockDim.x) {
+        const int row = e / FLMR_DIM;
+        float v = 0.0f;
+        if (row < qlen && row < nq) v = Q[((size_t)b * nq + row) * FLMR_DIM + (e % FLMR_DIM)] * S3Q_SCALE;
+        const _Float16 hi = (_Float16)v;
+        q_hi[(size_t)b * nqp * FLMR_DIM + e] = hi;
+        q_lo[(size_t)b * nqp * FLMR_DIM + e] = (_Float16)(v - (float)hi);
+    }
+}
+
+// 8 dims of one row (the lane's share of a k-step): weights by table, + centroid, * (64 / norm), split -> the hi / lo fragments
+// `bytes`: the NBITS residual bytes of those dims, low byte first
+template <int NBITS>
+__device__ __forceinline__ void s3q_decode_unit(const float* wlut, const uint32_t (&bytes)[2], const hf8& c, float inv64, hf8& ah, hf8& al) {
+    constexpr int VPB = 8 / NBITS;
+    float x[8];
+#pragma unroll
+    for (int bb = 0; bb < NBITS; bb++) {
+        const uint32_t byte = (bytes[bb >> 2] >> (8 * (bb & 3))) & 255u;
+        float wv[VPB];
+        s3_lut<VPB>(wlut, byte, wv);
+#pragma unroll
+        for (int l = 0; l < VPB; l++) {
+            const int dd = bb * VPB + l;
+            const uint32_t cpk = __builtin_bit_cast(s3u4, c)[dd >> 1];
+            x[dd] = (dd & 1) ? s3_add_f16<1>(cpk, wv[l]) : s3_add_f16<0>(cpk, wv[l]);
+        }
+    }
+    const float m1 = -1.0f;
+    s3u4 hpk, lpk;
+#pragma unroll
+    for (int pr = 0; pr < 4; pr++) {
+        s3v2 v = {x[2 * pr], x[2 * pr + 1]};
+        v *= inv64;
+        const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, s3h2));
+        uint32_t lo;
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(m1), "v"(v[0]));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(m1), "v"(v[1]));
+        hpk[pr] = hi;
+        lpk[pr] = lo;
+    }
+    ah = __builtin_bit_cast(hf8, hpk);
+    al = __builtin_bit_cast(hf8, lpk);
+}
+
+// max(running maximum, a lane's 16 rows, 0) (segmented_maxsim.cpp:58-59: the maximum starts at zero) in nine v_max3 written as
+// instructions: fmaxf on MFMA results first canonicalises every operand (ten more VALU operations per tile and q-tile, in a
+// kernel whose time is the sum of everything its SIMD issues)
+__device__ __forceinline__ float s3q_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float s3q_tile_max(float run, f32x16 acc) {
+    // the hazard recogniser does not look inside asm statements: the wait states between the last MFMA writing `acc` and its first
+    // VALU read (11 for an 8-pass MFMA) are ours -- one statement that owns the accumulator, so every read below depends on it
+    asm volatile("s_nop 7\n\ts_nop 4" : "+v"(acc));
+    const float a = s3q_max3(acc[0], acc[1], acc[2]), b = s3q_max3(acc[3], acc[4], acc[5]), c = s3q_max3(acc[6], acc[7], acc[8]);
+    const float d = s3q_max3(acc[9], acc[10], acc[11]), e = s3q_max3(acc[12], acc[13], acc[14]);
+    const float f = s3q_max3(acc[15], a, b), g = s3q_max3(c, d, e);
+    float r;
+    asm("v_max3_f32 %0, %1, %2, 0" : "=v"(r) : "v"(f), "v"(g));
+    return s3q_max3(r, run, r);
+}
+
+#ifdef S3Q_PROFILE   // development only: s_memtime ticks per round phase, summed per wave (index wave * 8 + phase), read by s3_probe
+__device__ unsigned long long s3q_prof[64];
+#define S3Q_STAMP(k) do { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); pt[k] += now_ - plast; plast = now_; } while (0)
+#else
+#define S3Q_STAMP(k) do { } while (0)
+#endif
+
+// NW waves per workgroup (each owns k-steps {w, w + NW, ..} of every tile and up to two q-tiles: 2 NW q-tiles per pass), R tiles
+// per round.  <8, 3> (the default): one workgroup per CU, the two waves of a SIMD staggered by hand.  <4, 1>: TWO workgroups
+// per CU (48 KB of LDS each), one wave per SIMD each -- their rounds and barriers are independent, so one workgroup's MFMAs fill
+// the matrix pipe while the other decodes, gathers or waits, without any hand-made stagger; the price is a decode per 8 instead
+// of 16 q-tiles, and it is the slower form (Nq = 832: 5.59 vs 5.03 ms per 256 queries: what a SIMD issues beside its MFMAs adds to
+// their time instead of hiding behind it, and this form issues more per MFMA).
+template <int NBITS, int NW, int R>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void maxsim_qs_kernel(flmr_maxsim_args m, const int32_t* __restrict__ codes,
+                                                        const uint8_t* __restrict__ residuals,
+                                                        const _Float16* __restrict__ cen16, const float* __restrict__ wlut_g,
+                                                        const float* __restrict__ inv_norm, int nqp, int npass, int per_pass) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int VPB = 8 / NBITS, PACKED = FLMR_DIM * NBITS / 8, NB = 8 * NBITS;
+    constexpr int KS = 8 / NW;             // k-steps (and DMA instructions) of a tile this wave handles
+    constexpr int U = R * KS;              // decode units per round
+    __shared__ __attribute__((aligned(16))) float wlut_s[256 * VPB];
+    char* const ring = smem;                                  // [2][R] decoded tiles: [k-step][hi | lo][lane] 16-byte fragments
+    char* const raw = smem + 2 * R * S3Q_SLOT;                // [2][R] gathered centroid rows
+    const uint32_t raw_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x;
+    const int pass = (int)blockIdx.y % npass, y = (int)blockIdx.y / npass;
+    const int32_t* wb = m.plan_wbeg + (size_t)b * m.plan_wcap;
+    const int tb = __builtin_amdgcn_readfirstlane(wb[y]), te = __builtin_amdgcn_readfirstlane(wb[y + 1]);
+    if (tb >= te) return;   // (the whole workgroup)
+    for (int t = tid; t < 256 * VPB; t += 64 * NW) wlut_s[t] = wlut_g[t];
+    const int ntiles = te - tb, nrounds = (ntiles + R - 1) / R;
+    const int nqt = nqp >> 5, qt0 = pass * per_pass;
+    const int npq = (nqt - qt0) < per_pass ? (nqt - qt0) : per_pass;   // q-tiles of this pass (<= 2 NW)
+    const int nt = (wave < npq ? 1 : 0) + (wave + NW < npq ? 1 : 0);   // q-tiles this wave owns: qt0 + wave, qt0 + wave + NW
+    const uint2* dq = m.plan_desc + (size_t)b * m.plan_stride + tb;
+    // descriptors by scalar loads written as instructions (see maxsim_lean_kernel); tile index relative to the workgroup's first
+    // tile, clamped into its range: work past either end repeats a real tile and is never used
+    auto ld_desc = [&](int t, u32x2& d) {
+        const int tc = t < ntiles ? (t < 0 ? 0 : t) : ntiles - 1;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(d) : "s"(dq + tc) : "memory");
+    };
+    auto touch_desc = [&](u32x2& d) { asm volatile("" : "+s"(d)::"memory"); };
+
+    hf8 bhA[8], blA[8], bhB[8], blB[8];
+    {
+        const hf8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        const size_t qb = (size_t)b * nqp;
+        const int ra = (qt0 + wave) * 32 + i, rb = (qt0 + wave + NW) * 32 + i;
+        const hf8* pha = reinterpret_cast<const hf8*>(m.q_hi + (qb + (nt >= 1 ? ra : 0)) * FLMR_DIM + 64 * h);
+        const hf8* pla = reinterpret_cast<const hf8*>(m.q_lo + (qb + (nt >= 1 ? ra : 0)) * FLMR_DIM + 64 * h);
+        const hf8* phb = reinterpret_cast<const hf8*>(m.q_hi + (qb + (nt >= 2 ? rb : 0)) * FLMR_DIM + 64 * h);
+        const hf8* plb = reinterpret_cast<const hf8*>(m.q_lo + (qb + (nt >= 2 ? rb : 0)) * FLMR_DIM + 64 * h);
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            bhA[s] = nt >= 1 ? pha[s] : z; blA[s] = nt >= 1 ? pla[s] : z;
+            bhB[s] = nt >= 2 ? phb[s] : z; blB[s] = nt >= 2 ? plb[s] : z;
+        }
+#pragma unroll
+        for (int s = 0; s < 8; s++) asm volatile("" : "+v"(bhA[s]), "+v"(blA[s]), "+v"(bhB[s]), "+v"(blB[s])::"memory");
+    }
+    // per-lane constants.  Gather: DMA instruction q of a tile moves rows {q, 8+q, 16+q, 24+q} (lane group j = lane >> 4: row 8j + q),
+    // 16-byte pieces XOR-swizzled by (row & 15), row r in slot 4 (r & 7) + (r >> 3) of the 8 KB buffer (maxsim_lean_kernel's layout);
+    // this wave issues instructions q = wave + e NW and decodes k-steps s = wave + e NW (e < KS): the offsets below are for e = 0,
+    // the others follow by XOR / add of compile-time constants.
+    const uint32_t code_voff = (uint32_t)(((lane >> 4) * 8 + wave) * 4);
+    const uint32_t piece_off = (uint32_t)((((lane & 15) ^ (8 * ((lane >> 4) & 1))) << 4) ^ (wave << 4));
+    const uint32_t res_voff = (uint32_t)(i * PACKED + h * NB + wave * NBITS), inv_voff = (uint32_t)(i * 4);
+    const uint32_t rd_off = (uint32_t)(((4 * (i & 7) + (i >> 3)) * 256 + (((8 * h) ^ (i & 15)) << 4)) ^ (wave << 4));   // piece 8h + wave of row i
+    const uint32_t wr_off = (uint32_t)(lane * 16 + 2 * wave * 1024);   // this lane's hi fragment of k-step `wave` inside a ring slot (lo: + 1024)
+    const uint32_t frag_off = (uint32_t)(lane * 16);
+
+    // in-flight state of the pipeline; unit u = k KS + e: tile k of the round, e-th of my k-steps
+    uint32_t cdv[U];              // codes of my DMA rows, tiles of round r+3 (after stage C of round r)
+    uint32_t rsv[U][2];           // residual bytes of my k-steps, tiles of round r+1 (what stage D of round r decodes)
+    float ivv[R];                 // 1 / norm of row i, same tiles
+    uint32_t rsn[U][2];           // the same for the tiles of round r+2: loaded by stage G of round r, moved to rsv / ivv at its end
+    float ivn[R];
+#pragma unroll
+    for (int u = 0; u < U; u++) { cdv[u] = 0; rsv[u][0] = 0; rsv[u][1] = 0; rsn[u][0] = 0; rsn[u][1] = 0; }
+#pragma unroll
+    for (int k = 0; k < R; k++) { ivv[k] = 0.0f; ivn[k] = 0.0f; }
+    auto touch_state = [&]() {
+#pragma unroll
+        for (int u = 0; u < U; u++) asm volatile("" : "+v"(cdv[u]), "+v"(rsn[u][0]), "+v"(rsn[u][1])::"memory");
+#pragma unroll
+        for (int k = 0; k < R; k++) asm volatile("" : "+v"(ivn[k])::"memory");
+    };
+    // descriptors of the tiles of rounds r (consume), r+1 (decode), r+2 (gather), r+3 (codes), and the ones being loaded (r+4)
+    u32x2 dM[R], dD[R], dG[R], dC[R], dN[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        ld_desc(-3 * R + k, dM[k]); ld_desc(-2 * R + k, dD[k]); ld_desc(-1 * R + k, dG[k]); ld_desc(k, dC[k]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < R; k++) { touch_desc(dM[k]); touch_desc(dD[k]); touch_desc(dG[k]); touch_desc(dC[k]); }
+    float cmxA = 0.0f, cmxB = 0.0f;
+    float* const cm_q = m.colmax_ws + (size_t)b * m.key_stride * (size_t)nqp + (size_t)(qt0 + wave) * 32 + i;
+    __syncthreads();
+#ifdef S3Q_PROFILE
+    long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long plast = (long long)__builtin_amdgcn_s_memtime();
+#endif
+
+    for (int r = -3; r < nrounds; r++) {
+#pragma unroll
+        for (int k = 0; k < R; k++) ld_desc((r + 4) * R + k, dN[k]);
+        // ---- stage D: my k-steps of the tiles of round r+1 -> ring[(r + 1) & 1] (rows landed and fenced at the end of round r-1) ----
+        auto stage_d = [&]() {
+            const int par = (r + 1) & 1;
+            const char* rw = raw + par * (R * S3Q_RAW);
+            char* wr = ring + par * (R * S3Q_SLOT) + wr_off;
+            hf8 c[U];
+#pragma unroll
+            for (int u = 0; u < U; u++)   // all raw-row reads first: one LDS round trip for the stage (k-step w + 4e: XOR, the bits are disjoint)
+                c[u] = *reinterpret_cast<const hf8*>(rw + (u / KS) * S3Q_RAW + (rd_off ^ (uint32_t)(((u % KS) * NW) << 4)));
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int k = u / KS, e = u % KS;
+                const int lo = (int)(dD[k].y & 63u), hi = (int)((dD[k].y >> 6) & 63u);
+                const float inv64 = (i >= lo && i < hi) ? ivv[k] * S3Q_SCALE : 0.0f;     // rows outside the passage become exact zeros
+                hf8 fa, fl;
+#ifdef S3Q_NO_DECODE
+                fa = c[u]; fl = c[u]; asm volatile("" :: "v"(inv64), "v"(rsv[u][0]));
+#else
+                s3q_decode_unit<NBITS>(wlut_s, rsv[u], c[u], inv64, fa, fl);
+#endif
+                *reinterpret_cast<hf8*>(wr + k * S3Q_SLOT + e * NW * 2048) = fa;
+                *reinterpret_cast<hf8*>(wr + k * S3Q_SLOT + e * NW * 2048 + 1024) = fl;
+            }
+        };
+        // <8, 3>: waves 0-3 decode, gather, consume; waves 4-7 gather, consume two tiles, decode, consume the third (the two waves of a
+        // SIMD decode at different times).  <4, 1>: decode, gather, consume.
+        bool decoded = false;
+        if (NW == 4 || wave < 4) { stage_d(); decoded = true; }
+        S3Q_STAMP(0);
+        // ---- stage G: my rows, residual bytes and scales of the tiles of round r+2; stage C: my codes of round r+3 ----
+        {
+            const uint32_t dst0 = raw_lds + (uint32_t)((r + 2) & 1) * (R * S3Q_RAW) + (uint32_t)wave * 1024;
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                const uint32_t pos = dG[k].x;
+                const uint8_t* rbase = residuals + (size_t)pos * PACKED;
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(ivn[k]) : "v"(inv_voff), "s"(inv_norm + pos) : "memory");
+#pragma unroll
+                for (int e = 0; e < KS; e++) {
+                    const int u = k * KS + e;
+                    const uint8_t* rb2 = rbase + e * NW * NBITS;
+                    if constexpr (NBITS == 1) asm volatile("global_load_ubyte %0, %1, %2" : "=v"(rsn[u][0]) : "v"(res_voff), "s"(rb2) : "memory");
+                    else if constexpr (NBITS == 2) asm volatile("global_load_ushort %0, %1, %2" : "=v"(rsn[u][0]) : "v"(res_voff), "s"(rb2) : "memory");
+                    else if constexpr (NBITS == 4) asm volatile("global_load_dword %0, %1, %2" : "=v"(rsn[u][0]) : "v"(res_voff), "s"(rb2) : "memory");
+                    else asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(*reinterpret_cast<u32x2*>(&rsn[u][0])) : "v"(res_voff), "s"(rb2) : "memory");
+#ifndef S3Q_NO_DMA
+                    const uint32_t dst = dst0 + k * S3Q_RAW + e * NW * 1024;
+                    const uint32_t po = piece_off ^ (uint32_t)((e * NW) << 4);
+                    uint32_t voff;
+                    asm volatile("s_mov_b32 m0, %2\n\tv_lshl_add_u32 %0, %3, 8, %4\n\tglobal_load_lds_dwordx4 %0, %1"
+                                 : "=&v"(voff)
+                                 : "s"(cen16), "s"(dst), "v"(cdv[u]), "v"(po)
+                                 : "memory", "m0");
+#endif
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(cdv[u]) : "v"(code_voff), "s"(codes + dC[u / KS].x + (u % KS) * NW) : "memory");
+        }
+        S3Q_STAMP(1);
+        // ---- stage M: consume ring[r & 1] ----
+#ifdef S3Q_NO_M
+        if (r == 12345 && nt > 0) {
+#else
+        if (r >= 0 && nt > 0) {
+#endif
+            const int nrt = (ntiles - r * R) < R ? (ntiles - r * R) : R;
+            const char* rbase = ring + (r & 1) * (R * S3Q_SLOT) + frag_off;
+            // One MFMA stream over the round's tiles: the fragments of k-step s+1 (of the next tile after a tile's last k-step) are
+            // requested before the MFMAs of k-step s, and the accumulators alternate by tile.  Per k-step: hi.lo and lo.hi first,
+            // then hi.hi.
+            const f32x16 z = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            f32x16 accA[2], accB[2];
+            hf8 fh[2], fl[2];
+            fh[0] = *reinterpret_cast<const hf8*>(rbase);
+            fl[0] = *reinterpret_cast<const hf8*>(rbase + 1024);
+            auto tile = [&](auto tc, auto ntc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int NT = decltype(ntc)::value;   // q-tiles this wave owns (compile-time inside the MFMA stream: no branches)
+                constexpr int P = t & 1;
+                const char* slot = rbase + t * S3Q_SLOT;
+                const uint32_t dy = dM[t].y;
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    const int cur = (t * 8 + s) & 1, nxt = cur ^ 1;
+                    if (s < 7) {
+                        fh[nxt] = *reinterpret_cast<const hf8*>(slot + (2 * s + 2) * 1024);
+                        fl[nxt] = *reinterpret_cast<const hf8*>(slot + (2 * s + 3) * 1024);
+                    } else if (t + 1 < R && t + 1 < nrt) {
+                        fh[nxt] = *reinterpret_cast<const hf8*>(slot + S3Q_SLOT);
+                        fl[nxt] = *reinterpret_cast<const hf8*>(slot + S3Q_SLOT + 1024);
+                    }
+                    accA[P] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[cur], blA[s], s ? accA[P] : z, 0, 0, 0);
+                    if constexpr (NT == 2) accB[P] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[cur], blB[s], s ? accB[P] : z, 0, 0, 0);
+                    accA[P] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[cur], bhA[s], accA[P], 0, 0, 0);
+                    if constexpr (NT == 2) accB[P] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[cur], bhB[s], accB[P], 0, 0, 0);
+                    accA[P] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[cur], bhA[s], accA[P], 0, 0, 0);
+                    if constexpr (NT == 2) accB[P] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[cur], bhB[s], accB[P], 0, 0, 0);
+                }
+                cmxA = s3q_tile_max(cmxA, accA[P]);
+                if constexpr (NT == 2) cmxB = s3q_tile_max(cmxB, accB[P]);
+                if ((dy >> 12) & 1u) {   // last tile of its passage: the column maxima leave the registers
+                    float* row = cm_q + (size_t)(dy >> 13) * (size_t)nqp;
+                    const float va = flmr_xhalf_max(cmxA) * (1.0f / (S3Q_SCALE * S3Q_SCALE));
+                    if (h == 0) row[0] = va;
+                    cmxA = 0.0f;  // segmented_maxsim.cpp:58-59: the running max starts at zero
+                    if constexpr (NT == 2) {
+                        const float vb = flmr_xhalf_max(cmxB) * (1.0f / (S3Q_SCALE * S3Q_SCALE));
+                        if (h == 0) row[NW * 32] = vb;
+                        cmxB = 0.0f;
+                    }
+                }
+            };
+            auto run = [&](auto ntc) {
+                tile(std::integral_constant<int, 0>{}, ntc);
+                if constexpr (R > 1) { if (nrt > 1) tile(std::integral_constant<int, 1>{}, ntc); }
+                if (!decoded) { stage_d(); decoded = true; }
+                if constexpr (R > 2) { if (nrt > 2) tile(std::integral_constant<int, 2>{}, ntc); }
+            };
+            if (nt == 2) run(std::integral_constant<int, 2>{});
+            else run(std::integral_constant<int, 1>{});
+        }
+        if (!decoded) stage_d();
+        S3Q_STAMP(2);
+        // everything this wave asked for in this round has landed (a consume phase ago) -- rows in LDS included -- before the
+        // barrier lets the other waves read them
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        touch_state();
+#pragma unroll
+        for (int k = 0; k < R; k++) touch_desc(dN[k]);
+        S3Q_STAMP(3);
+        __syncthreads();
+        S3Q_STAMP(4);
+#pragma unroll
+        for (int k = 0; k < R; k++) { dM[k] = dD[k]; dD[k] = dG[k]; dG[k] = dC[k]; dC[k] = dN[k]; ivv[k] = ivn[k]; }
+#pragma unroll
+        for (int u = 0; u < U; u++) { rsv[u][0] = rsn[u][0]; rsv[u][1] = rsn[u][1]; }
+    }
+#ifdef S3Q_PROFILE
+    if (lane == 0) {
+        for (int k = 0; k < 5; k++) atomicAdd(&s3q_prof[wave * 8 + k], (unsigned long long)pt[k]);
+        atomicAdd(&s3q_prof[wave * 8 + 7], (unsigned long long)(nrounds + 3));
+    }
+#endif
+}
+
+// k-ascending sums of the column maxima (the order of maxsim_f16_multiq_kernel and of the oracle); one thread per finalist
+__global__ __launch_bounds__(256) void s3_colsum_kernel(flmr_maxsim_args m, const int64_t* __restrict__ doc_offsets, int nqp) {
+    const int b = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
+    const int cnt = m.counts[b] < m.max_count ? m.counts[b] : m.max_count;
+    if (d >= cnt) return;
+    const int pid = m.pids[(size_t)b * m.pid_stride + d];
+    if (doc_offsets[pid + 1] - doc_offsets[pid] <= 0) return;   // empty passage: s3_plan_kernel wrote its score
+    const int qlen = m.q_lens ? m.q_lens[b] : m.nq;
+    const f32x4* row = reinterpret_cast<const f32x4*>(m.colmax_ws + ((size_t)b * m.key_stride + d) * nqp);
+    float s = 0.0f;
+    int k = 0;
+    for (; k + 4 <= qlen; k += 4) {
+        const f32x4 v = row[k >> 2];
+        s += v[0]; s += v[1]; s += v[2]; s += v[3];
+    }
+    for (; k < qlen; k++) s += reinterpret_cast<const float*>(row)[k];
+    const size_t ko = (size_t)b * m.key_stride + d;
+    if (m.keys) m.keys[ko] = flmr_make_key(s, pid);
+    if (m.scores) m.scores[ko] = s;
+}
+
+template <int NBITS, int NW, int R>
+static int launch_maxsim_qs_nw(const flmr_maxsim_args& a, hipStream_t st, int nqp) {
+    const flmr_index* ix = a.ix;
+    const int nqt = nqp / 32, npass = (nqt + 2 * NW - 1) / (2 * NW);
+    // q-tiles per pass: equal shares with two workgroups per CU (their waves land on all SIMDs), full passes first with one
+    const int per_pass = NW == 4 ? (nqt + npass - 1) / npass : 2 * NW;
+    // workgroups per (query, pass): enough to fill the chip a few times over, at least ~24 tiles each
+    int Y = (int)flmr_ceil_div(NW == 4 ? 2048 : 1024, (int64_t)a.nqueries * npass);
+    const int64_t tiles_bound = (int64_t)a.max_count * ((ix->max_doclen + 31) / 32);
+    if (Y > tiles_bound / 24) Y = (int)(tiles_bound / 24);
+    if (Y > a.plan_wcap - 1) Y = a.plan_wcap - 1;
+    if (Y < 1) Y = 1;
+    const size_t lds = (size_t)2 * R * (S3Q_SLOT + S3Q_RAW);
+    hipLaunchKernelGGL(s3q_split_q, dim3((nqp * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens, a.nq, nqp, a.q_hi, a.q_lo);
+    hipLaunchKernelGGL(s3_plan_kernel, dim3(a.nqueries), dim3(256), 0, st, a, ix->doc_offsets, ix->N, Y);
+    FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_qs_kernel<NBITS, NW, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((maxsim_qs_kernel<NBITS, NW, R>), dim3(a.nqueries, npass * Y), dim3(64 * NW), lds, st, a, ix->codes, ix->residuals,
+                       ix->centroids_f16, ix->wlut, ix->inv_norm, nqp, npass, per_pass);
+    hipLaunchKernelGGL(s3_colsum_kernel, dim3((a.max_count + 255) / 256, a.nqueries), dim3(256), 0, st, a, ix->doc_offsets, nqp);
+    return FLMR_OK;
+}
+
+template <int NBITS>
+static int launch_maxsim_qs_t(const flmr_maxsim_args& a, hipStream_t st, int nqp) {
+#ifdef S3Q_FORM4   // development probe: two 4-wave workgroups per CU, rounds of one tile (Nq = 832: 5.59 vs 5.03 ms per 256 queries)
+    return launch_maxsim_qs_nw<NBITS, 4, 1>(a, st, nqp);
+#else
+    return launch_maxsim_qs_nw<NBITS, 8, 3>(a, st, nqp);
+#endif
+}
+
 template <int NBITS>
 static int launch_maxsim_f16_t(const flmr_maxsim_args& a, hipStream_t st) {
     const flmr_index* ix = a.ix;
     const int nqp = (int)flmr_round_up(a.nq, 32);
     const size_t lds = (size_t)256 * (8 / NBITS) * sizeof(float) + (size_t)4 * nqp * sizeof(float);
     if (lds > 64 * 1024) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nq=%d too large for the MaxSim kernel's LDS column maxima", a.nq);
+    // long queries: the query-stationary kernel on planned tiles (below ~6 q-tiles most of a workgroup's waves would hold no query
+    // rows: the chunked kernel stays); it splits the query itself (other scaling)
+    const bool use_qs = (nqp >= S3Q_MIN_NQP || (nqp > 32 && flmr_opts().is(FLMR_OPT_S3_IMPL, "qs"))) && !flmr_opts().has(FLMR_OPT_S3_NO_MULTIQ) &&
+        ix->inv_norm && a.plan_desc && a.plan_wbeg && a.colmax_ws && a.colmax_cap >= (int64_t)a.nqueries * a.key_stride * nqp && ix->N >= 32 &&
+        ix->N < ((int64_t)1 << 32) && ((size_t)ix->K * 256 < ((size_t)1 << 32)) && a.max_count <= S3L_MAX_DOCS && a.plan_wcap >= 2 &&
+        a.plan_stride >= (int64_t)a.max_count * ((ix->max_doclen + 31) / 32) &&
+        (flmr_opts().is(FLMR_OPT_S3_IMPL, "qs") || !flmr_opts().has(FLMR_OPT_S3_IMPL));
+    if (use_qs) {
+        const int rc = launch_maxsim_qs_t<NBITS>(a, st, nqp);
+        if (rc) return rc;
+        FLMR_LAUNCH_CHECK();
+        return FLMR_OK;
+    }
     if (!a.q_split_done)
         hipLaunchKernelGGL(s3_split_q, dim3((nqp * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens, a.nq, nqp,
                            a.q_hi, a.q_lo);

@@ -10,7 +10,7 @@
 
 // RAII-less scratch helper: ops allocate small temporaries and free them after a stream sync.
 struct scratch {
-    void* p[8];
+    void* p[12];
     int n = 0;
     ~scratch() { for (int i = 0; i < n; i++) (void)hipFree(p[i]); }
     template <typename T>
@@ -215,13 +215,18 @@ extern "C" int flmr_score_pids(const flmr_index_t* ix, const float* Q, int32_t n
         RUN(sc.alloc(&ql, (size_t)flmr_round_up(nq, 32) * FLMR_DIM));
         m.q_hi = qh; m.q_lo = ql;
     }
-    if (ix->centroids_f16_exact && nq <= 32 && ix->max_doclen > 0) {   // workspace of the planned-tile kernel (optional)
+    if (ix->centroids_f16_exact && ix->max_doclen > 0) {   // workspace of the planned-tile kernels (optional)
         const int64_t stride = (int64_t)npids * ((ix->max_doclen + 31) / 32);
         uint2* desc = nullptr;
         int32_t* wbeg = nullptr;
         if (stride * (int64_t)sizeof(uint2) <= ((int64_t)1 << 30) && sc.alloc(&desc, (size_t)stride) == FLMR_OK &&
             sc.alloc(&wbeg, (size_t)npids + 8) == FLMR_OK) {
             m.plan_desc = desc; m.plan_stride = stride; m.plan_wbeg = wbeg; m.plan_wcap = npids + 8;
+            const int64_t cmf = (int64_t)npids * flmr_round_up(nq, 32);
+            float* cm = nullptr;
+            if (nq > 32 && cmf * (int64_t)sizeof(float) <= ((int64_t)2 << 30) && sc.alloc(&cm, (size_t)cmf) == FLMR_OK) {
+                m.colmax_ws = cm; m.colmax_cap = cmf;
+            }
         }
     }
     RUN(flmr_launch_maxsim(m, st));

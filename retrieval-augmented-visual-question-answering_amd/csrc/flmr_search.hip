@@ -40,6 +40,7 @@ struct flmr_searcher {
     float* s2_part;             // XCD-sliced stage 2: per (query, slice, survivor) column maxima (NULL when the index has no split table)
     _Float16* q3_hi; _Float16* q3_lo;
     uint2* s3_desc; int64_t s3_desc_stride; int32_t* s3_wbeg; int32_t s3_wcap;   // planned-tile S3 (NULL: the passage-walking kernel)
+    float* s3_colmax; int64_t s3_colmax_cap;   // long queries: per (query, finalist, column) maxima of the query-stationary S3 kernel
     int32_t* qual; int32_t* nqual; int32_t* chunk_cnt; uint8_t* cand_hit; int32_t qmax;
     // last call (for taps)
     int32_t last_nqueries, last_ncol, last_ndocs, last_full_table;
@@ -177,6 +178,16 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
             (void)hipFree(s->s3_desc); (void)hipFree(s->s3_wbeg);
             s->s3_desc = nullptr; s->s3_wbeg = nullptr;
         }
+        if (s->s3_desc && max_nq > 32) {
+            s->s3_colmax_cap = (int64_t)B * nd4 * flmr_round_up(max_nq, 32);
+            if (s->s3_colmax_cap * (int64_t)sizeof(float) <= ((int64_t)2 << 30) &&
+                hipMalloc(reinterpret_cast<void**>(&s->s3_colmax), (size_t)s->s3_colmax_cap * sizeof(float)) == hipSuccess) {
+                s->bytes += s->s3_colmax_cap * (int64_t)sizeof(float);
+            } else {
+                (void)hipGetLastError();
+                s->s3_colmax = nullptr; s->s3_colmax_cap = 0;
+            }
+        }
     }
     FLMR_HIP(hipMemset(s->overflow, 0, 4 * sizeof(int32_t)));
     FLMR_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->status_host), 4 * sizeof(int32_t), hipHostMallocDefault));
@@ -192,7 +203,7 @@ extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
     if (!s) return FLMR_OK;
     void* ptrs[] = {s->cs, s->rows, s->idx_prefix, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
                     s->keys1, s->s1_pids, s->s1_count, s->keys2, s->s2_pids, s->s2_count, s->keys3, s->doc_scores,
-                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->q_err, s->q_err_sum, s->s2_band, s->s2_band_count, s->s2_need, s->s2_def, s->keys2b, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->chunk_hits, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part, s->s3_desc, s->s3_wbeg};
+                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->q_err, s->q_err_sum, s->s2_band, s->s2_band_count, s->s2_need, s->s2_def, s->keys2b, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->chunk_hits, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part, s->s3_desc, s->s3_wbeg, s->s3_colmax};
     for (void* p : ptrs) (void)hipFree(p);
     if (s->status_host) (void)hipHostFree(s->status_host);
     if (s->status_ev) (void)hipEventDestroy(s->status_ev);
@@ -606,6 +617,7 @@ static int stage_s3(run_ctx& c, bool s0_images) {
     m.q_hi = s->q3_hi; m.q_lo = s->q3_lo;
     m.gpu_fp16 = c.f.f16_round;
     m.plan_desc = s->s3_desc; m.plan_stride = s->s3_desc_stride; m.plan_wbeg = s->s3_wbeg; m.plan_wcap = s->s3_wcap;
+    m.colmax_ws = s->s3_colmax; m.colmax_cap = s->s3_colmax_cap;
     // Stage 0's fp16 images ARE stage 3's when every query row is a candidate-generation column (nq <= 32 <= nq_cand): rows
     // below min(q_len, nq) real, the rest zero, one tile of 32 -- no second split launch
     if (s0_images && c.sparse && !c.f.f16_round && c.nq <= 32 && c.nqc == c.nq && c.ncol == 32) {

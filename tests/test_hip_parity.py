@@ -154,7 +154,8 @@ def test_score_pids_fused_vs_oracle(hip, scorers, name):
         pd = torch.from_numpy(pids).cuda()
         # cw: (c.q + w.q) / norm with table-decoded weights (the default for one query tile); regs: decompress-normalise-split
         # wave-per-document kernel (also what long queries take); f32: the fp32-MFMA kernel
-        for impl in ("lean", "cw", "cwregs", "regs", "f32"):
+        # qs: the query-stationary long-query kernel (the default for Nq > 32; falls to regs for one query tile)
+        for impl in ("qs", "lean", "cw", "cwregs", "regs", "f32"):
             with hip["native"].options(FLMR_S3_IMPL=impl):
                 out = torch.empty(len(pids), dtype=torch.float32, device="cuda")
                 hip["native"].check(scorer._lib.flmr_score_pids(scorer.device_index.handle, C.c_void_p(Qd.data_ptr()), Q.shape[0],
