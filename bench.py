@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--cpu-queries-8t", type=int, default=64, help="queries timed on the CPU baseline at 8 threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-built-index", action="store_true", help="skip the built-index sub-result (~25 s: 128 M tokens indexed on the device)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the k=5 / nbits=8 / ragged / Nq=832 sub-results")
+    ap.add_argument("--no-extras", action="store_true", help="skip the k=5 / nbits=8 / ragged / Nq=320 / Nq=832 sub-results")
     ap.add_argument("--replicate-stage0", action="store_true",
                     help="exact shard mode: every rank runs stage 0 for the whole batch instead of 1/N of the queries + an exchange")
     ap.add_argument("--shard-depth", type=int, default=0,
@@ -629,7 +629,8 @@ def main():
             qids = list(range(args.batch))
 
             def api_call(Qb):   # the host side of _search_all_Q after the policy: results -> Ranking -> todict() (FLMR_executor.py:792-794)
-                rows = _S.ranking_lists(*scorer.search_batch(Qb, k, ncells, thr, ndocs, 32), k)
+                # (pipelined, as _search_all_Q does it: the call returns with the kernels queued; a list waits for its sub-batch)
+                rows = _S.pending_lists(scorer.search_batch_pending(Qb, k, ncells, thr, ndocs, 32))
                 return _R(data=dict(zip(qids, rows))).todict()
 
             d_ = api_call(Qs[0])   # (warm-up: imports, allocator)
@@ -637,6 +638,7 @@ def main():
             t0_ = time.perf_counter()
             for i in range(4):
                 d_ = api_call(Qs[i % nb])
+                len(d_[qids[-1]])   # (the call returns before the device is done: the last list's length waits for the last sub-batch)
             dt_api = (time.perf_counter() - t0_) / 4
             t0_ = time.perf_counter()
             for i in range(4):   # + what the executor's loop then does with it: every (pid, rank, score) of every query unpacked
@@ -653,8 +655,9 @@ def main():
             out["api_layer"] = {"queries_per_sec": args.batch / dt_api, "ms_per_step": dt_api * 1e3, "results_per_query": len(d_[0]),
                                 "queries_per_sec_reading_every_tuple": args.batch / dt_all, "queries_per_sec_reading_top5": args.batch / dt_top5,
                                 "note": "search_batch + Searcher.ranking_lists + Ranking(data).todict(): what a caller of _search_all_Q holds per "
-                                        "1024 queries (bulk device->host copy; each query's list is a lazy sequence over its numpy rows, the "
-                                        "(pid, rank, score) tuples are built when read); the two other rates add the caller's own reads"}
+                                        "1024 queries (pipelined: every 256-query sub-batch's rows are copied to pinned host memory behind its kernels and a query's "
+                                        "list waits for its sub-batch when first read; tuples are built per sub-batch when a list is iterated); the two "
+                                        "other rates add the caller's own reads -- reading every tuple overlaps the device's later sub-batches"}
         except Exception as e:  # noqa: BLE001
             out["api_layer"] = {"failed": repr(e)}
         sub("k5", scorer, Qs, tgts, 5, "same index, k=5 (same pruning policy as k=100, searcher.py:92-107; 5 results returned)")
@@ -673,14 +676,18 @@ def main():
             del scf
         except Exception as e:
             subs.append({"name": "gpu_fp16_numerics", "value": None, "note": f"failed: {e!r}"})
-        try:
-            Q8, t8 = zip(*[synth.make_queries(corpus, args.batch, 832, seed=40 + j) for j in range(2)])
-            sc8 = IndexScorer(device_index=scorer.device_index, max_batch=min(256, args.sub_batch), streams=args.streams)
-            sub("nq832", sc8, list(Q8), list(t8), k, "same index, PreFLMR-sized queries (Nq=832, candidate generation on the first 32 tokens)")
-            sc8.close_searcher()
-            del Q8, t8, sc8
-        except Exception as e:
-            subs.append({"name": "nq832", "value": None, "note": f"failed: {e!r}"})
+        # the reference's flagship query shapes: FLMR = 32 text rows + 9 ROIs x 32 visual rows (Nq = 320, src/models/retriever/FLMR.py:73-99,
+        # README.md:115), PreFLMR up to 832 rows; candidate generation on the first 32 rows, stage 3 on all of them
+        for name_, nq_, note_ in (("nq320", 320, "same index, FLMR-sized queries (Nq=320: 32 text + 9 x 32 visual rows; candidate generation on the first 32 tokens)"),
+                                  ("nq832", 832, "same index, PreFLMR-sized queries (Nq=832, candidate generation on the first 32 tokens)")):
+            try:
+                Q8, t8 = zip(*[synth.make_queries(corpus, args.batch, nq_, seed=40 + j) for j in range(2)])
+                sc8 = IndexScorer(device_index=scorer.device_index, max_batch=min(256, args.sub_batch), streams=args.streams)
+                sub(name_, sc8, list(Q8), list(t8), k, note_)
+                sc8.close_searcher()
+                del Q8, t8, sc8
+            except Exception as e:
+                subs.append({"name": name_, "value": None, "note": f"failed: {e!r}"})
         scorer.close_searcher()
         del scorer, corpus, local
         torch.cuda.empty_cache()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FLMR_ABI_VERSION 3
+#define FLMR_ABI_VERSION 4
 
 typedef enum flmr_status {
     FLMR_OK = 0,
@@ -134,6 +134,13 @@ int flmr_searcher_workspace_bytes(const flmr_searcher_t* searcher, int64_t* byte
  * host asynchronously after the batch; the NEXT call on the searcher returns FLMR_ERR_CAPACITY / FLMR_ERR_INVALID and
  * clears it.  flmr_searcher_check waits for the searcher's last batch and reports at once (synchronous). */
 int flmr_searcher_check(flmr_searcher_t* searcher);
+/* The same flags for a caller that pipelines sub-batches (device batch i+1 beside the host's reading of batch i): enqueues, on
+ * `stream`, a copy of the searcher's four device status words -- [0] candidate bound exceeded, [1] q_lens outside [0, nq], [2] more
+ * surviving centroids than score rows, [3] reserved -- to `host_flags` (pinned host memory, 4 x int32).  Once an event recorded
+ * after this call has completed the words are those of every batch issued on the searcher up to here (they are sticky until
+ * flmr_searcher_check or a later call reports them and clears them).  Asynchronous; nothing is reported or cleared by this call.
+ * Reference counterpart: none (Searcher._search_all_Q is synchronous per query, TPC/searcher.py:73-89). */
+int flmr_searcher_status_async(flmr_searcher_t* searcher, int32_t* host_flags, flmr_stream_t stream);
 
 /* Q [nqueries, nq, dim] fp32.  q_lens (nullable) i32[nqueries]: number of valid leading rows per query
  * (rows removed by remove_zero_tensors, searcher.py:120-126, are compacted away by the host).

@@ -19,7 +19,7 @@ FLMR_MEM_HOST, FLMR_MEM_DEVICE = 0, 1
 (TAP_CENTROID_SCORES, TAP_IDX_BITS, TAP_CELLS, TAP_CANDIDATES, TAP_STAGE1, TAP_STAGE2, TAP_DOC_SCORES, TAP_Q_ERR,
  TAP_Q_ERR_SUM) = range(9)
 NUM_STAGES = 9
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class FlmrNativeError(RuntimeError):
@@ -116,6 +116,7 @@ _SIGS = {
     "flmr_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "flmr_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
     "flmr_searcher_check": (C.c_int, [C.c_void_p]),
+    "flmr_searcher_status_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "flmr_searcher_probe_supported": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(SearchParams), C.POINTER(C.c_int32)]),
     "flmr_index_open": (C.c_int, [C.POINTER(IndexDesc), C.POINTER(C.c_void_p)]),
     "flmr_index_close": (C.c_int, [C.c_void_p]),
@@ -181,11 +182,13 @@ def load(require_device=True):
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
                 "There is no CPU fallback for the search path.")
         lib = C.CDLL(LIB_PATH)
+        lib.flmr_abi_version.restype = C.c_int
+        if lib.flmr_abi_version() != ABI_VERSION:   # (checked before the symbols are bound: a stale library says so, not AttributeError)
+            raise FlmrNativeError(f"{LIB_PATH}: ABI version {lib.flmr_abi_version()}, this package expects {ABI_VERSION}: rebuild it "
+                                  "(python -c 'import __graft_entry__ as g; g.build()')")
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)  # AttributeError => ABI mismatch, surfaced loudly
             fn.restype, fn.argtypes = res, args
-        if lib.flmr_abi_version() != ABI_VERSION:
-            raise FlmrNativeError("libflmr_hip.so ABI version mismatch")
         _lib = lib
     if require_device:
         n = C.c_int(0)

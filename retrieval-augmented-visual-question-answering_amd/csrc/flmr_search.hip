@@ -368,6 +368,12 @@ static int push_status(run_ctx& c) {
     return FLMR_OK;
 }
 
+extern "C" int flmr_searcher_status_async(flmr_searcher_t* s, int32_t* host_flags, flmr_stream_t stream) {
+    if (!s || !host_flags) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    FLMR_HIP(hipMemcpyAsync(host_flags, s->overflow, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream)));
+    return FLMR_OK;
+}
+
 extern "C" int flmr_searcher_check(flmr_searcher_t* s) {
     if (!s) FLMR_FAIL(FLMR_ERR_INVALID, "NULL searcher");
     return poll_status(s, true);

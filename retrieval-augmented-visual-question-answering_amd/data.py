@@ -150,6 +150,81 @@ def ranked_lists(pids, scores, counts):
     return [RankedList(pids[i, :c], scores[i, :c]) for i, c in enumerate(counts)]
 
 
+class RankedChunk:
+    """The rows of ONE device sub-batch of a `_search_all_Q` pass (scorer.PendingBatch): they become readable when the sub-batch's
+    copy to pinned host memory has completed, which the first read of any of them waits for -- the device works on the later
+    sub-batches meanwhile.  A full read of a row (iteration, `tolist`, comparison) builds the tuples of the WHOLE sub-batch at once:
+    one `tolist()` per array and one `zip` with the cyclic collector paused (it otherwise runs a dozen times over 25 k new tuples
+    that cannot form cycles), 2-3 x cheaper per tuple than row by row -- a caller that iterates one row iterates them all
+    (FLMR_executor.py:852-858).  Prefix slices and single elements are served from the arrays without building anything."""
+    __slots__ = ("_wait", "_P", "_S", "_C", "_lists")
+
+    def __init__(self, wait, pids, scores, counts):
+        self._wait, self._P, self._S, self._C, self._lists = wait, pids, scores, counts, None
+
+    def arrays(self):
+        if self._wait is not None:
+            self._wait()           # blocks until this sub-batch's rows are in host memory (raises its deferred device errors)
+            self._wait = None
+            k = self._P.shape[1] if self._P.ndim == 2 else 0
+            self._C = [min(max(int(c), 0), k) for c in self._C.tolist()]
+        return self._P, self._S, self._C
+
+    def lists(self):
+        if self._lists is None:
+            import gc
+            P, S, C = self.arrays()
+            n, k = P.shape
+            was = gc.isenabled()
+            gc.disable()
+            try:
+                flat = list(zip(P.ravel().tolist(), list(range(1, k + 1)) * n, S.ravel().tolist()))
+                self._lists = [flat[i * k:i * k + c] for i, c in enumerate(C)]
+            finally:
+                if was:
+                    gc.enable()
+        return self._lists
+
+
+class ChunkRankedList(RankedList):
+    """RankedList whose numpy rows arrive with its sub-batch (RankedChunk)."""
+    __slots__ = ("_chunk", "_j")
+
+    def __init__(self, chunk, j):
+        self._p = self._s = self._rows = None
+        self._chunk, self._j = chunk, j
+
+    def _bind(self):
+        if self._p is None:
+            P, S, C = self._chunk.arrays()
+            c = C[self._j]
+            self._p, self._s = P[self._j, :c], S[self._j, :c]
+
+    def _all(self):
+        if self._rows is None:
+            self._rows = self._chunk.lists()[self._j]
+            self._bind()
+        return self._rows
+
+    def __len__(self):
+        self._bind()
+        return len(self._p)
+
+    def __getitem__(self, i):
+        self._bind()
+        return RankedList.__getitem__(self, i)
+
+    @property
+    def pids(self):
+        self._bind()
+        return self._p
+
+    @property
+    def scores(self):
+        self._bind()
+        return self._s
+
+
 def lazy_flat_ranking(base):
     """A subclass of a Ranking class (this package's or the reference's `colbert.data.Ranking`, ranking.py:25-55) whose
     `flat_ranking` -- [(qid, pid, rank, score)] over all queries, which the reference builds in its constructor -- is built on

@@ -19,8 +19,11 @@ def ranking_to_batch_result(ranking_dict: Dict, question_ids: Sequence, passage_
     with e.g. answers / gold_answer / pos_item_ids) is merged into the record."""
     out = []
     for qid, ranked in zip(question_ids, ranking_dict.values()):
-        idxs = [int(entry[0]) for entry in ranked]
-        scores = [float(entry[2]) for entry in ranked]
+        if hasattr(ranked, "pids"):   # data.RankedList: the numpy rows, no (pid, rank, score) tuples built
+            idxs, scores = ranked.pids.tolist(), ranked.scores.tolist()
+        else:
+            idxs = [int(entry[0]) for entry in ranked]
+            scores = [float(entry[2]) for entry in ranked]
         if idxs and len(idxs) < max_K:  # "simply replicate the last element to avoid crash" (:864-871)
             pad = max_K - len(idxs)
             idxs += [idxs[-1]] * pad

@@ -62,6 +62,57 @@ def _params(k, ncells, thr, ndocs, nq_cand):
     return _native.SearchParams(int(k), int(ncells), float(thr), int(ndocs), int(nq_cand))
 
 
+class PendingBatch:
+    """Results of one batched search on their way to pinned host memory (IndexScorer.search_batch_pending): numpy views `pids`
+    [n, k], `scores` [n, k], `counts` [n] whose rows [b0, b1) are valid once `wait(chunk)` has returned."""
+
+    def __init__(self, hp, hs, hc, marks, device_results, check, redo):
+        self._t = (hp, hs, hc)                      # the pinned tensors (kept alive with the views)
+        self.pids, self.scores, self.counts = hp.numpy(), hs.numpy(), hc.numpy()
+        self._marks, self._dev, self._check, self._redo = marks, device_results, check, redo
+        self._done = [False] * len(marks)
+
+    @classmethod
+    def resolved(cls, pids, scores, counts):
+        self = cls.__new__(cls)
+        self._t = (pids.cpu(), scores.cpu(), counts.cpu())
+        self.pids, self.scores, self.counts = (t.numpy() for t in self._t)
+        self._marks, self._dev, self._check, self._redo = [(0, self.pids.shape[0], None, None)], None, None, None
+        self._done = [True]
+        return self
+
+    def chunks(self):
+        return [(b0, b1) for b0, b1, _, _ in self._marks]
+
+    def wait(self, j):
+        if self._done[j]:
+            return
+        _, _, ev, flags = self._marks[j]
+        ev.synchronize()
+        if int(flags[0]) or int(flags[1]) or int(flags[2]):
+            # a deferred device-side error up to this sub-batch: report it exactly as search_batch_checked does (its recovery --
+            # the full score table -- repeats the WHOLE batch, synchronously)
+            try:
+                self._check()
+            except _native.FlmrNativeError as e:
+                if "FLMR_ROW_CAP" not in str(e):
+                    raise
+                import warnings
+                warnings.warn("ravqa_amd: a query has more centroids above centroid_score_threshold than the searcher keeps score rows "
+                              "for; repeating the batch with the full centroid-score table (slower; raise the threshold or set FLMR_ROW_CAP)",
+                              RuntimeWarning)
+            p, s, c = self._redo()
+            torch.cuda.synchronize()
+            self.pids[...], self.scores[...], self.counts[...] = p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy()
+            self._done = [True] * len(self._done)
+            return
+        self._done[j] = True
+
+    def wait_all(self):
+        for j in range(len(self._done)):
+            self.wait(j)
+
+
 class IndexScorer:
     # class attributes the reference installs from its JIT-built extensions (index_storage.py:29-60)
     filter_pids = _op("filter_pids")
@@ -187,7 +238,8 @@ class IndexScorer:
             pass
 
     # ---- batched fast path ---------------------------------------------------------------------------------
-    def search_batch(self, Q, k, ncells, centroid_score_threshold, ndocs, nq_cand=32, q_lens=None, profile=False, full_table=False):
+    def search_batch(self, Q, k, ncells, centroid_score_threshold, ndocs, nq_cand=32, q_lens=None, profile=False, full_table=False,
+                     _after_chunk=None):
         """Q: float32 [n, Nq, 128] (CPU or CUDA).  Returns CUDA tensors (pids i32 [n,k], scores f32 [n,k], counts i32 [n])."""
         if Q.dim() != 3 or Q.size(-1) != self.arrays.dim:
             raise ValueError(f"Q must be [n, Nq, {self.arrays.dim}], got {tuple(Q.shape)}")
@@ -221,6 +273,8 @@ class IndexScorer:
                 b1 - b0, nq, C.byref(p), C.c_void_p(out_p[b0:b1].data_ptr()), C.c_void_p(out_s[b0:b1].data_ptr()),
                 C.c_void_p(out_c[b0:b1].data_ptr()), C.c_void_p(st.cuda_stream)))
             self._tap_from = h
+            if _after_chunk is not None:
+                _after_chunk(i, b0, b1, out_p, out_s, out_c, h, st)
         for _, st in slots[1:]:
             cur.wait_event(st.record_event())
             for t in (Qd, ql, out_p, out_s, out_c):
@@ -229,6 +283,34 @@ class IndexScorer:
         if profile:   # every searcher profiled since the last stage_ms() read (the library sums per searcher until it is read)
             self._profiled = list({id(h): h for h in self._profiled + [h for h, _ in slots]}.values())
         return out_p, out_s, out_c
+
+    def search_batch_pending(self, Q, k, ncells, centroid_score_threshold, ndocs, nq_cand=32, q_lens=None):
+        """search_batch whose results go to pinned HOST memory sub-batch by sub-batch: returns a PendingBatch at once; each
+        sub-batch's rows (and the searcher's deferred status words, flmr_searcher_status_async) are copied behind its kernels on
+        the launch stream and an event marks them readable, so the host reads sub-batch i while the device computes i+1.  The
+        deferred errors of search_batch_checked surface when an affected sub-batch is first read; the recoverable one (score-row
+        capacity) repeats the whole batch synchronously with the full table."""
+        if self._nstreams > 1:   # sub-batches on several streams finish together: nothing to pipeline
+            return PendingBatch.resolved(*self.search_batch_checked(Q, k, ncells, centroid_score_threshold, ndocs, nq_cand, q_lens=q_lens))
+        n = Q.size(0)
+        hp = torch.empty((n, k), dtype=torch.int32, pin_memory=True)
+        hs = torch.empty((n, k), dtype=torch.float32, pin_memory=True)
+        hc = torch.empty((n,), dtype=torch.int32, pin_memory=True)
+        marks = []
+
+        def after_chunk(j, b0, b1, out_p, out_s, out_c, handle, stream):
+            hp[b0:b1].copy_(out_p[b0:b1], non_blocking=True)
+            hs[b0:b1].copy_(out_s[b0:b1], non_blocking=True)
+            hc[b0:b1].copy_(out_c[b0:b1], non_blocking=True)
+            flags = torch.zeros(4, dtype=torch.int32, pin_memory=True)
+            _native.check(self._lib.flmr_searcher_status_async(handle, C.c_void_p(flags.data_ptr()), C.c_void_p(stream.cuda_stream)))
+            marks.append((b0, b1, stream.record_event(), flags))
+
+        dev = self.search_batch(Q, k, ncells, centroid_score_threshold, ndocs, nq_cand, q_lens=q_lens, _after_chunk=after_chunk)
+
+        def redo():
+            return self.search_batch_checked(Q, k, ncells, centroid_score_threshold, ndocs, nq_cand, q_lens=q_lens)
+        return PendingBatch(hp, hs, hc, marks, dev, self.check, redo)
 
     def search_batch_checked(self, Q, k, ncells, centroid_score_threshold, ndocs, nq_cand=32, q_lens=None):
         """search_batch + check() (a host sync), with the one recoverable deferred error handled: a query with more centroids

@@ -50,7 +50,7 @@ class Searcher:
     Checkpoint = None   # the reference's colbert.modeling.checkpoint.Checkpoint when installed over the reference package
 
     def __init__(self, index, checkpoint=None, collection=None, config=None, disable_gpu=True, query_encoder=None,
-                 max_batch=256, numerics=None):
+                 max_batch=256, numerics=None, pipelined=None):
         cfg_cls = self.ColBERTConfig
         initial_config = cfg_cls.from_existing(config, self.Run().config)
         if config is not None:  # searcher.py:27 (the reference dereferences `config` unconditionally)
@@ -64,6 +64,9 @@ class Searcher:
         self.configure(checkpoint=self.checkpoint, collection=self.collection)
         self.query_encoder = query_encoder
         self._checkpoint_model = None
+        # _search_all_Q returns while the device still works and hands out lists that wait for their sub-batch (FLMR_PIPELINED=0 /
+        # pipelined=False: every result on the host, and every deferred device error raised, before it returns)
+        self.pipelined = (os.environ.get("FLMR_PIPELINED", "1") != "0") if pipelined is None else bool(pipelined)
         use_gpu = (self.config.total_visible_gpus or 0) > 0
         # searcher.py:42-45: total_visible_gpus > 0 selects the reference's CUDA branch.  Here that arithmetic is an opt-in
         # mode (module docstring): "reference" follows the reference's selection when the CALLER assigned the value (the
@@ -163,6 +166,17 @@ class Searcher:
         rows = rec.tolist()
         return [row if n >= len(row) else row[:n] for row, n in zip(rows, C)]
 
+    @staticmethod
+    def pending_lists(pend):
+        """scorer.PendingBatch -> the Ranking layout, one `data.ChunkRankedList` per query: rows become readable sub-batch by
+        sub-batch (FLMR_executor.py:852-858 reads every tuple of every query -- it reads sub-batch 0 while the device still works
+        on the others)."""
+        rows = []
+        for j, (b0, b1) in enumerate(pend.chunks()):
+            chunk = _data.RankedChunk((lambda j=j: pend.wait(j)), pend.pids[b0:b1], pend.scores[b0:b1], pend.counts[b0:b1])
+            rows += [_data.ChunkRankedList(chunk, i) for i in range(b1 - b0)]
+        return rows
+
     # ---- embedding entry points -----------------------------------------------------------------------------------
     def _search_all_Q(self, queries, Q, k, filter_fn=None, progress=True, remove_zero_tensors=False):
         qids = list(queries.keys())
@@ -173,11 +187,17 @@ class Searcher:
             self._apply_k_policy(k)
             c = self.config
             q_lens = None
+            all_scored = None
             Qb = Q
             if remove_zero_tensors:
                 Qb, q_lens = self._compact_nonzero_rows(Q)
             kk = min(k, max(c.ndocs // 4, 1))
-            if hasattr(self.ranker, "search_batch_checked"):   # + the deferred device-side errors (candidate bound, q_lens range;
+            if self.pipelined and hasattr(self.ranker, "search_batch_pending"):
+                # device sub-batch i+1 beside the host's reading of sub-batch i: the call returns when the kernels are queued, every
+                # sub-batch's rows land in pinned memory behind its kernels, and a list waits for ITS sub-batch when it is first read
+                pend = self.ranker.search_batch_pending(Qb, kk, c.ncells, c.centroid_score_threshold, c.ndocs, c.query_maxlen, q_lens=q_lens)
+                all_scored = self.pending_lists(pend)
+            elif hasattr(self.ranker, "search_batch_checked"):   # + the deferred device-side errors (candidate bound, q_lens range;
                 pids, scores, counts = self.ranker.search_batch_checked(Qb, kk, c.ncells, c.centroid_score_threshold, c.ndocs,   # score-row capacity: redone)
                                                                         c.query_maxlen, q_lens=q_lens)
             else:
@@ -185,7 +205,8 @@ class Searcher:
                                                                 c.query_maxlen, q_lens=q_lens)
                 if hasattr(self.ranker, "check"):
                     self.ranker.check()
-            all_scored = self.ranking_lists(pids, scores, counts, k)
+            if all_scored is None:
+                all_scored = self.ranking_lists(pids, scores, counts, k)
         data = dict(zip(qids, all_scored))
         provenance = self.Provenance()
         provenance.source = "Searcher::search_all"

@@ -283,6 +283,18 @@ def test_searcher_dropin_api(hip, tmp_path):
             tie_aware_equal(z[f"{r}.final_pids"][:100], z[f"{r}.final_scores"][:100], pids, scores, tol=SCORE_TOL)
         pids, ranks, scores = searcher.dense_search(Q[:1], k=10)
         assert pids == list(d["qa"][i][0] for i in range(10)) and ranks == list(range(1, 11))
+        # pipelined (default: lists that wait for their device sub-batch) == synchronous, over several sub-batches and every way of
+        # reading a list (prefix slice before anything is built, element, iteration, arrays)
+        Q9 = torch.cat([Q] * 5)[:9]
+        q9 = Queries(data={f"q{i}": "x" for i in range(9)})
+        sync = Searcher(index="temp_index.nbits=2", config=ColBERTConfig(total_visible_gpus=0), pipelined=False, max_batch=4)
+        pipe = Searcher(index="temp_index.nbits=2", config=ColBERTConfig(total_visible_gpus=0), pipelined=True, max_batch=4)
+        ds, dp = sync._search_all_Q(q9, Q9, k=100).todict(), pipe._search_all_Q(q9, Q9, k=100).todict()
+        assert dp["q8"][:3] == ds["q8"][:3] and dp["q5"][7] == ds["q5"][7] and len(dp["q4"]) == len(ds["q4"])
+        assert dp["q1"].pids.tolist() == ds["q1"].pids.tolist()
+        for qid in ds:
+            assert list(dp[qid]) == list(ds[qid]) and dp[qid] == ds[qid]
+        assert pipe._search_all_Q(q9, Q9, k=100).tolist() == sync._search_all_Q(q9, Q9, k=100).tolist()
         # filter_fn: keep even pids only -> every result even, and equals the oracle on the filtered candidate list
         pids_f, _, scores_f = searcher.dense_search(Q[:1], k=10, filter_fn=lambda p: p[p % 2 == 0])
         assert all(p % 2 == 0 for p in pids_f) and len(pids_f) == 10

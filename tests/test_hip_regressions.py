@@ -198,6 +198,12 @@ def test_many_surviving_centroids_code_scan_and_row_capacity(hip):
             pf, sf, cf = scorer.search_batch_checked(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=q_lens)
         assert np.array_equal(pf.cpu().numpy(), p) and np.array_equal(cf.cpu().numpy(), c)
         assert np.array_equal(sf.cpu().numpy().view(np.uint32), s.view(np.uint32))
+        # the pipelined form (results to pinned host memory sub-batch by sub-batch, what _search_all_Q hands out): the same error
+        # surfaces when the first affected sub-batch is READ, with the same recovery
+        pend = scorer.search_batch_pending(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=q_lens)
+        with pytest.warns(RuntimeWarning, match="FLMR_ROW_CAP"):
+            pend.wait(0)
+        assert np.array_equal(pend.pids, p) and np.array_equal(pend.counts, c) and np.array_equal(pend.scores.view(np.uint32), s.view(np.uint32))
         p2, s2, c2 = scorer.search_batch(Q, ndocs // 4, ncells, 0.6, ndocs, 32, q_lens=q_lens)   # few survivors: fine again
         scorer.check()
         p3, s3, c3 = IndexScorer(device_index=scorer.device_index, max_batch=16).search_batch(Q, ndocs // 4, ncells, 0.6, ndocs, 32, q_lens=q_lens)
