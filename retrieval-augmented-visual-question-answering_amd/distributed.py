@@ -101,8 +101,14 @@ class ShardedSearcher:
         shard = arrays.shard(rank, world)
         return cls(scorer=IndexScorer(arrays=shard, device_index=DeviceIndex(shard), max_batch=max_batch), group=group)
 
-    def _hip_local_search(self, Q, k, nq_cand=32, q_lens=None):
+    def _hip_local_search(self, Q, k, nq_cand=32, q_lens=None, checked=True):
+        """This shard's search.  checked (default): with the deferred device errors read after the batch and the recoverable one --
+        more surviving centroids than score rows, FLMR_ROW_CAP -- handled by one more pass through the full score table, as
+        Searcher._search_all_Q does it (a LOCAL recovery: no collective is involved, so the ranks cannot diverge); a throughput
+        loop passes checked=False and calls `check_all()` at its own sync points."""
         ncells, thr, ndocs = self.k_policy(k)
+        if checked and hasattr(self.scorer, "search_batch_checked"):
+            return self.scorer.search_batch_checked(Q, k, ncells, thr, ndocs, nq_cand, q_lens=q_lens)
         return self.scorer.search_batch(Q, k, ncells, thr, ndocs, nq_cand, q_lens=q_lens)
 
     # ---- the exact protocol as a coroutine: it YIELDS every exchange it has issued (a _Pending) and is resumed with the exchanged
@@ -248,7 +254,15 @@ class ShardedSearcher:
         except StopIteration as e:
             out = e.value
         if check:
-            self.check_all(gather)
+            if self.check_all(gather, recoverable=True) == "row_cap":
+                # a query on some shard has more centroids above the threshold than its searcher keeps score rows for: EVERY rank
+                # (the verdict is the gathered flag, identical everywhere) switches to the full centroid-score table and redoes the batch
+                import warnings
+                warnings.warn("ravqa_amd: a shard has a query with more centroids above centroid_score_threshold than its searcher keeps "
+                              "score rows for; all ranks repeat the batch with the full centroid-score table (and keep it)", RuntimeWarning)
+                self.enable_full_table()
+                return self.search_batch_exact(Q, k, nq_cand=nq_cand, q_lens=q_lens, gather=gather, split_stage0=split_stage0,
+                                               reduce_sum=reduce_sum, check=True, truncate_phase1=truncate_phase1)
             if cert and bool(cert[0]):   # (never on evenly sharded data) redo this batch with the full phase-1 exchange
                 return self.search_batch_exact(Q, k, nq_cand=nq_cand, q_lens=q_lens, gather=gather, split_stage0=split_stage0,
                                                reduce_sum=reduce_sum, check=True, truncate_phase1=False)
@@ -320,9 +334,20 @@ class ShardedSearcher:
             self.timings = {}
         return out
 
-    def check_all(self, gather=None):
+    def enable_full_table(self):
+        """Every scorer of this rank keeps the whole K x nq_cand centroid-score table from now on (the recovery from the score-row
+        capacity, FLMR_ROW_CAP; collective by convention: call it on every rank, e.g. after check_all() raised that error in a
+        pipelined loop, and redo the unchecked batches)."""
+        for sc in set(getattr(self, "_pipe", []) + [self.scorer]):
+            if sc is not None:
+                sc.force_full_table = True
+        self._split_ok = {}   # (the query-split capability depends on the table mode)
+
+    def check_all(self, gather=None, recoverable=False):
         """Collective: every rank reads its searcher's deferred status (waits for its last batch) and the ranks exchange one
-        flag; raises on ALL ranks if any shard failed (the failing rank re-raises its own error, the others name the rank)."""
+        flag; raises on ALL ranks if any shard failed (the failing rank re-raises its own error, the others name the rank).
+        recoverable=True: when the only failure anywhere is the score-row capacity (FLMR_ROW_CAP) nothing is raised and "row_cap"
+        is returned on every rank."""
         err = None
         try:
             for sc in getattr(self, "_pipe", [self.scorer]):
@@ -331,7 +356,7 @@ class ShardedSearcher:
         except Exception as e:  # noqa: BLE001 -- whatever the shard raised must reach the other ranks as a flag
             err = e
         dev = self.scorer.probe_device if hasattr(self.scorer, "probe_device") else "cuda"
-        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=dev)
+        flag = torch.tensor([0 if err is None else (2 if "FLMR_ROW_CAP" in str(err) else 1)], dtype=torch.int32, device=dev)
         if gather is not None:
             flags = gather(flag).reshape(-1)
         elif self.world > 1 or self.force_collectives:
@@ -340,6 +365,8 @@ class ShardedSearcher:
         else:
             flags = flag
         pending, self._cert = self._cert, []
+        if recoverable and int(flags.max()) == 2 and not bool((flags == 1).any()):
+            return "row_cap"
         if err is not None:
             raise err
         bad = torch.nonzero(flags).reshape(-1).tolist()

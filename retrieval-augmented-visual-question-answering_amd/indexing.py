@@ -46,6 +46,26 @@ class HipBackend:
         return ops.build_ivf(codes, doclens, K)
 
 
+def _require_unit_rows(x, what, n_check=4096):
+    """The build assigns by DOT PRODUCT (k-means and the final codes): that is the reference's L2 choice (faiss.Kmeans,
+    residual.py:206-220 `(centroids @ batch.T).max`) only for unit-norm rows -- what the encoders emit (colbert.py:207).  A cheap
+    check on a strided sample; anything else must be normalised by the caller (silently normalising here would index different
+    vectors than the ones handed in)."""
+    if x.numel() == 0:
+        return
+    step = max(1, x.size(0) // n_check)
+    nrm = x[::step][:n_check].float().norm(dim=-1)
+    if bool(((nrm - 1.0).abs() > 1e-2).any()):
+        raise ValueError(f"{what}: rows must be L2-normalised (norms in [{float(nrm.min()):.4f}, {float(nrm.max()):.4f}]); "
+                         "the build assigns by dot product, which equals the reference's L2 assignment only on unit vectors")
+
+
+def _require_device(x, backend, what):
+    if backend is HipBackend and not x.is_cuda:
+        raise ValueError(f"{what} must be on the GPU for the HIP build (there is no host path here; move the tensor once up "
+                         "front, or pass backend= a host implementation as the tests do)")
+
+
 def num_partitions_for(n_embeddings: int) -> int:
     return int(2 ** math.floor(math.log2(16 * math.sqrt(max(n_embeddings, 1)))))
 
@@ -57,6 +77,8 @@ def kmeans(sample, K, niters=4, seed=123, backend=HipBackend, chunk=1 << 20):
     (the index stores them as half anyway, residual.py:161; the MFMA argmax needs fp16-representable rows); empty clusters
     are re-seeded from random points.  The reference runs faiss.Kmeans (L2, its own RNG): same objective on the sphere,
     different arithmetic, hence validated by Recall, never bit-compared.  Returns fp32 centroids [K, dim] (unit rows)."""
+    _require_device(sample, backend, "the k-means sample")
+    _require_unit_rows(sample, "kmeans(sample)")
     g = torch.Generator(device=sample.device)
     g.manual_seed(seed)
     n = sample.size(0)
@@ -83,6 +105,8 @@ def build_index(embeddings, doclens, nbits=2, num_partitions=None, kmeans_niters
                 heldout_fraction=0.05, chunk=1 << 20, config=None, backend=HipBackend) -> IndexArrays:
     """embeddings: float tensor [N, 128] on the GPU, doclens: int tensor [P] with sum N.  Returns host IndexArrays
     (call `.save(path)` for the reference's directory layout)."""
+    _require_device(embeddings, backend, "embeddings")
+    _require_unit_rows(embeddings, "build_index(embeddings)")
     dev = embeddings.device
     N, dim = embeddings.shape
     doclens = torch.as_tensor(doclens, device=dev).long()

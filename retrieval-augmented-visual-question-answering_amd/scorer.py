@@ -208,10 +208,20 @@ class IndexScorer:
 
     def check(self):
         """Wait for the last batch and raise FlmrNativeError if it overflowed the candidate bound or was handed q_lens
-        outside [0, nq] (flmr_searcher_check); without this call the error surfaces on the next batch."""
+        outside [0, nq] (flmr_searcher_check); without this call the error surfaces on the next batch.  EVERY searcher is
+        polled (and its flags cleared) before the first error is raised -- with streams > 1 a side searcher's stale flag would
+        otherwise fail the recovery batch of search_batch_checked; an error other than the recoverable score-row capacity wins."""
+        first = None
         for h in [self._searcher] + [h for h, _ in self._side]:
-            if h is not None:
+            if h is None:
+                continue
+            try:
                 _native.check(self._lib.flmr_searcher_check(h))
+            except _native.FlmrNativeError as e:
+                if first is None or ("FLMR_ROW_CAP" in str(first) and "FLMR_ROW_CAP" not in str(e)):
+                    first = e
+        if first is not None:
+            raise first
 
     def supports_query_split(self, Q, k, ncells, thr, ndocs, nq_cand=32):
         """True iff the query-split stage 0 (probe / phase1_probed) runs for this batch shape; depends only on
@@ -257,6 +267,7 @@ class IndexScorer:
         slots = [(s, cur)]                          # slot 0 stays on the caller's stream
         if nchunks > 1 and self._nstreams > 1:
             slots += self._side_slots(min(nchunks, self._nstreams) - 1)
+        full_table = bool(full_table or getattr(self, "force_full_table", False))
         for h, _ in slots:
             self._lib.flmr_searcher_set_profiling(h, 1 if profile else 0)
             self._lib.flmr_searcher_set_full_table(h, 1 if full_table else 0)  # needed for the CENTROID_SCORES tap
@@ -339,6 +350,10 @@ class IndexScorer:
         if self._searcher_key is not None and self._searcher_key[3] != ndocs:
             self.close_searcher()  # key rows are exactly ndocs wide: the workspace must be created for this ndocs
         s = self._get_searcher(n, nq, p)
+        if getattr(self, "force_full_table", False) and not getattr(self, "full_table_state", False):
+            # (sharded recovery from the score-row capacity: every phase of every rank on the whole K x nq_cand table)
+            self._lib.flmr_searcher_set_full_table(s, 1)
+            self.full_table_state = True
         ql = None if q_lens is None else torch.as_tensor(q_lens).to(device="cuda", dtype=torch.int32).contiguous()
         return Qd, ql, n, nq, p, s
 

@@ -48,6 +48,7 @@ class Searcher:
     Provenance = _data.Provenance
     IndexScorer = _IndexScorer
     Checkpoint = None   # the reference's colbert.modeling.checkpoint.Checkpoint when installed over the reference package
+    _warned_cpu_numerics = False
 
     def __init__(self, index, checkpoint=None, collection=None, config=None, disable_gpu=True, query_encoder=None,
                  max_batch=256, numerics=None, pipelined=None):
@@ -82,6 +83,14 @@ class Searcher:
         self.numerics = getattr(self.ranker, "numerics", mode) or mode    # (the scorer falls back to "cpu" where fp16 is unsupported)
         logging.getLogger("ravqa_amd").info("Searcher(%s): numerics %s (requested %s, total_visible_gpus=%s)", self.index,
                                             self.numerics, requested, self.config.total_visible_gpus)
+        if use_gpu and explicit and self.numerics == "cpu" and not Searcher._warned_cpu_numerics:
+            # the caller asked for the reference's GPU branch (FLMR_executor.py:784 on one GPU): this build answers in the CPU-path
+            # arithmetic unless told otherwise -- near-ties can rank differently from a reference single-GPU run.  Said once.
+            Searcher._warned_cpu_numerics = True
+            warnings.warn("ravqa_amd.Searcher: config.total_visible_gpus > 0 was assigned, which selects the reference's CUDA-branch "
+                          "arithmetic (fp16 scores, -9999 padding); this build runs its default CPU-path arithmetic (fp32, the one its "
+                          "parity tests pin) -- pass numerics='reference' (or FLMR_NUMERICS=reference) to follow the reference's selection",
+                          RuntimeWarning, stacklevel=2)
 
     def _cast_collection(self, obj):
         """Collection.cast, but lazy: the search path never reads passage text, so a missing / unset collection is not

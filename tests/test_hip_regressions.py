@@ -204,6 +204,21 @@ def test_many_surviving_centroids_code_scan_and_row_capacity(hip):
         with pytest.warns(RuntimeWarning, match="FLMR_ROW_CAP"):
             pend.wait(0)
         assert np.array_equal(pend.pids, p) and np.array_equal(pend.counts, c) and np.array_equal(pend.scores.view(np.uint32), s.view(np.uint32))
+        # the sharded paths (one rank here; the exchanges are identities): the fast mode recovers locally, the exact protocol agrees
+        # on the verdict through its gathered status flag and repeats the batch with the full table on "every" rank
+        from ravqa_amd.distributed import ShardedSearcher
+        ss = ShardedSearcher(scorer=scorer, k_policy=lambda k_: (ncells, thr, ndocs))
+        with pytest.warns(RuntimeWarning, match="FLMR_ROW_CAP"):
+            pz, sz, cz = ss.search_batch(Q, ndocs // 4, q_lens=q_lens)
+        assert np.array_equal(pz.cpu().numpy(), p) and np.array_equal(sz.cpu().numpy().view(np.uint32), s.view(np.uint32))
+        import warnings
+        with warnings.catch_warnings(record=True) as seen:   # (a phase that keeps the whole table anyway never raises the flag)
+            warnings.simplefilter("always")
+            pe, se, ce = ss.search_batch_exact(Q, ndocs // 4, q_lens=q_lens, gather=lambda t: t.unsqueeze(0), reduce_sum=lambda t: t)
+        assert bool(getattr(scorer, "force_full_table", False)) == any("full centroid-score table" in str(w.message) for w in seen)
+        assert np.array_equal(pe.cpu().numpy(), p) and np.array_equal(ce.cpu().numpy(), c)
+        assert np.array_equal(se.cpu().numpy().view(np.uint32), s.view(np.uint32))
+        scorer.force_full_table = False
         p2, s2, c2 = scorer.search_batch(Q, ndocs // 4, ncells, 0.6, ndocs, 32, q_lens=q_lens)   # few survivors: fine again
         scorer.check()
         p3, s3, c3 = IndexScorer(device_index=scorer.device_index, max_batch=16).search_batch(Q, ndocs // 4, ncells, 0.6, ndocs, 32, q_lens=q_lens)
