@@ -728,9 +728,11 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(ROOT, "profiles"))
                 import built_index_probe
-                rec = built_index_probe.run(args.passages, 128, args.nbits, 4096, policies=((2, 0.45, 1024, 100),), phases=False)
+                rec = built_index_probe.run(args.passages, 128, args.nbits, 4096, policies=((2, 0.45, 1024, 100),), phases=False,
+                                            parity_queries=0 if args.no_cpu_baseline else 16)
                 sr = rec.pop("search_thr0.45")
                 subs.append({"name": "built_index_overlapping_clusters", "value": sr["queries_per_sec"], "unit": "queries/sec",
+                             "parity": sr.get("parity"),
                              "ms_per_step": sr["ms_per_step"], "recall_at_5": sr["recall_at_5"], "stage_ms_per_step": sr["stage_ms"],
                              "surviving_centroids_per_query": sr["surviving_centroids"], "candidates_per_query": sr["candidates"],
                              "index_build": rec,

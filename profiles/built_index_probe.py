@@ -14,27 +14,43 @@ import ravqa_amd
 from ravqa_amd import indexing, ops, synth
 from ravqa_amd.scorer import IndexScorer
 
-def run(P=1_000_000, L=128, nbits=2, NT=256, policies=((2, 0.45, 1024, 100), (2, 0.6, 1024, 100)), phases=True):
+def parity_vs_reference(arrays, scorer, Q, ncells, thr, ndocs):
+    """The checker's leg: every ranked list of `Q` against the reference's compiled CPU stages on the same index (oracle/_ref via
+    RefCpuScorer; the C restatement where they are absent) -- tie-aware ids, scores within 1e-4 (tests/conftest.py's bar)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(R, "tests"))
+    from conftest import tie_aware_equal
+    from oracle import oracle as orc
+    oi = orc.OracleIndex(arrays.dim, arrays.nbits, arrays.codes, arrays.residuals, arrays.doclens, arrays.ivf, arrays.ivf_lengths,
+                         arrays.centroids, arrays.bucket_weights)
+    ref = orc.RefCpuScorer(oi) if orc.ref_available() else None
+    p, s, c = scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32)
+    scorer.check()
+    p, s, c = p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy()
+    Qh = Q.cpu().numpy()
+    checked, worst = 0, 0.0
+    for i in range(Q.size(0)):
+        rp, rs, ncand = ref.rank(torch.from_numpy(Qh[i]), ncells, thr, ndocs) if ref is not None else oi.rank(Qh[i], ncells, thr, ndocs, 32)
+        if ncand < ndocs:
+            continue
+        m = int(c[i])
+        assert m == len(rp), (i, m, len(rp))
+        tie_aware_equal(rp, rs, p[i, :m], s[i, :m], gap=1e-5, tol=1e-4)
+        got = dict(zip(p[i, :m].tolist(), s[i, :m].tolist()))
+        worst = max(worst, max(abs(got[int(a)] - float(b)) for a, b in zip(rp, rs) if int(a) in got))
+        checked += 1
+    return {"queries_checked": checked, "of": int(Q.size(0)), "against": "reference" if ref is not None else "port", "ranked_ids": "equal (tie-aware)",
+            "max_abs_dscore": worst}
+
+
+def run(P=1_000_000, L=128, nbits=2, NT=256, policies=((2, 0.45, 1024, 100), (2, 0.6, 1024, 100)), phases=True, parity_queries=0):
     N = P * L
     dev = "cuda"
-    g = torch.Generator(device=dev).manual_seed(0)
-    NS = 65536   # (NT topics: fewer topics = more centroids per topic = more survivors per query)
-    T = torch.nn.functional.normalize(torch.randn(NT, 128, generator=g, device=dev), dim=-1)
-    S = torch.nn.functional.normalize(torch.randn(NS, 128, generator=g, device=dev), dim=-1)
-    ptop = torch.randint(0, NT, (P, 3), generator=g, device=dev)            # a passage's three topics
+    g = torch.Generator(device=dev).manual_seed(1)
     t0 = time.perf_counter()
-    embs = torch.empty((N, 128), dtype=torch.float16, device=dev)
-    CH = 1 << 22
-    for i in range(0, N, CH):
-        n = min(CH, N - i)
-        pid = (torch.arange(i, i + n, device=dev) // L)
-        top = ptop[pid, torch.randint(0, 3, (n,), generator=g, device=dev)]
-        sub = torch.randint(0, NS, (n,), generator=g, device=dev)
-        v = T[top] + 0.8 * S[sub] + 0.05 * torch.randn(n, 128, generator=g, device=dev)
-        embs[i:i + n] = torch.nn.functional.normalize(v, dim=-1).half()
+    embs, doclens, planted = synth.make_overlapping_embeddings(P, L, NT, seed=0, device=dev)
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
-    doclens = torch.full((P,), L, dtype=torch.int64, device=dev)
 
     # ---- build, phase by phase (the same calls indexing.build_index makes; timed apart) ----
     K = indexing.num_partitions_for(N)
@@ -65,13 +81,7 @@ def run(P=1_000_000, L=128, nbits=2, NT=256, policies=((2, 0.45, 1024, 100), (2,
     # ---- search planted queries ----
     scorer = IndexScorer(arrays=arrays, max_batch=256)
     nqr, nb = 1024, 2
-    Qs, tg = [], []
-    for j in range(nb):
-        tgt = torch.randint(0, P, (nqr,), generator=g, device=dev)
-        tok = tgt.unsqueeze(1) * L + (torch.arange(32, device=dev).unsqueeze(0) % L)
-        q = embs[tok.reshape(-1)].float().view(nqr, 32, 128)
-        Qs.append(torch.nn.functional.normalize(q + 0.02 * torch.randn(q.shape, generator=g, device=dev), dim=-1).contiguous())
-        tg.append(tgt)
+    Qs, tg = zip(*[planted(nqr) for _ in range(nb)])
     del embs
     out = {"passages": P, "tokens": N, "K": K, "topics": NT, "nbits": nbits, "generate_s": round(t_gen, 2), "build_index_s": round(t_build, 2),
            "ivf_entries": int(arrays.ivf.size)}
@@ -96,6 +106,8 @@ def run(P=1_000_000, L=128, nbits=2, NT=256, policies=((2, 0.45, 1024, 100), (2,
         ncand = [len(scorer.tap(ravqa_amd._native.TAP_CANDIDATES, q)) for q in range(0, 256, 64)]
         out[f"search_thr{thr}"] = {"queries_per_sec": round(nqr / dt), "ms_per_step": round(dt * 1e3, 2), "recall_at_5": hit, "recall_at_100": hit100,
                                    "surviving_centroids": surv, "candidates": ncand, "stage_ms": st}
+        if parity_queries:
+            out[f"search_thr{thr}"]["parity"] = parity_vs_reference(arrays, scorer, Qs[0][:parity_queries], ncells, thr, ndocs)
     del scorer, arrays
     torch.cuda.empty_cache()
     return out

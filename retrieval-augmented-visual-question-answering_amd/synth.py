@@ -194,3 +194,33 @@ def corpus_device_index(corpus, pid_base=None):
                "doc_offsets": corpus.doc_offsets.contiguous(), "ivf_pids": corpus.ivf.contiguous(),
                "ivf_offsets": corpus.ivf_offsets.contiguous(), "centroids": corpus.centroids.contiguous()}
     return DeviceIndex(meta, device_tensors=tensors)
+
+
+def make_overlapping_embeddings(n_passages, doclen, topics, seed=0, device="cuda", sub_directions=65536, chunk=1 << 22):
+    """Raw token embeddings whose clusters OVERLAP -- the regime the planted-centroid corpus above hides: a token = a topic
+    direction + 0.8 x a finer direction + noise (unit rows, fp16), a passage draws its tokens from three topics.  k-means has to
+    find the centroids, residuals are not iid noise, and a query token is close to MANY centroids (hundreds to thousands pass
+    centroid_score_threshold; fewer topics = more centroids per topic = more survivors).  Returns (embs fp16 [N, 128], doclens
+    int64 [P], planted(n, nq, sigma) -> (Q fp32 [n, nq, 128], target pids)); used by profiles/built_index_probe.py, bench.py's
+    built-index sub-result and tests/test_baseline_shapes.py."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    P, L, N = n_passages, doclen, n_passages * doclen
+    T = torch.nn.functional.normalize(torch.randn(topics, 128, generator=g, device=device), dim=-1)
+    S = torch.nn.functional.normalize(torch.randn(sub_directions, 128, generator=g, device=device), dim=-1)
+    ptop = torch.randint(0, topics, (P, 3), generator=g, device=device)
+    embs = torch.empty((N, 128), dtype=torch.float16, device=device)
+    for i in range(0, N, chunk):
+        n = min(chunk, N - i)
+        pid = torch.arange(i, i + n, device=device) // L
+        top = ptop[pid, torch.randint(0, 3, (n,), generator=g, device=device)]
+        sub = torch.randint(0, sub_directions, (n,), generator=g, device=device)
+        v = T[top] + 0.8 * S[sub] + 0.05 * torch.randn(n, 128, generator=g, device=device)
+        embs[i:i + n] = torch.nn.functional.normalize(v, dim=-1).half()
+    doclens = torch.full((P,), L, dtype=torch.int64, device=device)
+
+    def planted(n, nq=32, sigma=0.02):
+        tgt = torch.randint(0, P, (n,), generator=g, device=device)
+        tok = tgt.unsqueeze(1) * L + (torch.arange(nq, device=device).unsqueeze(0) % L)
+        q = embs[tok.reshape(-1)].float().view(n, nq, 128)
+        return torch.nn.functional.normalize(q + sigma * torch.randn(q.shape, generator=g, device=device), dim=-1).contiguous(), tgt
+    return embs, doclens, planted
