@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 F16_MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA peak (no sparsity)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04", "pmc_summary.csv")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05", "pmc_summary.csv")
 
 
 def parse():
@@ -358,7 +358,7 @@ def main():
                     pmc[row["kernel"]] = row
         except Exception:
             pass
-        kname = {"s0_centroid_scores": "s0_centroid_scores", "s3_maxsim": "maxsim_f16_dma_kernel",
+        kname = {"s0_centroid_scores": "s0_centroid_scores", "s3_maxsim": "maxsim_lean_kernel",
                  "s2_filter_sort": "filter_stage2", "s0_candidates": "cand_mark_score_kernel"}
 
         def roof_of(stage):
@@ -405,7 +405,7 @@ def main():
                 "frac": dom["mfma_frac"] if mfma_bound else dom["hbm_frac"], "traffic": dom.get("traffic"),
                 "peak_measured": {"hbm_copy_GBs": copy_gbs, "note": "device-to-device copy (read + write) measured in this run; the spec "
                                   "figure above is what `frac` is priced against"},
-                "traffic_source": ("static: profiles/r04/pmc_summary.csv (rocprofv3 --pmc of this workload, 2*FETCH_SIZE + "
+                "traffic_source": ("static: profiles/r05/pmc_summary.csv (rocprofv3 --pmc of this workload, 2*FETCH_SIZE + "
                                    "WRITE_SIZE, bytes per launch x launches per step; not measured in this run)") if dom.get("traffic") else None,
                 "launch_ms": dom["launch_ms"],
                 "note": ("achieved = the kernel's own compulsory bytes (or split-MFMA flops) per step / its HIP-event time per step "
@@ -416,7 +416,7 @@ def main():
                          "stage 2 is limited by neither roof: it moves one 256-byte fp16 centroid row per survivor token "
                          "(gathered_row_GBs) -- from the Infinity Cache in the gather form (measured ceiling 9.3-9.6 TB/s), "
                          "from an L2-resident table slice per XCD in the default sliced form (69 % L2 hits, ceiling 23-32 TB/s, "
-                         "profiles/microbench) whose time goes to per-wave set-up and instruction issue (DESIGN.md section 4)"),
+                         "profiles/microbench) whose time follows the bytes through the LDS-DMA path (DESIGN.md section 4.4)"),
                 "gathered_row_GBs": (2 * d * ns_tok * args.batch / (dom["launch_ms"] * 1e-3) / 1e9) if dom["kernel"] == "s2_filter_sort" else None,
                 "per_kernel": per_kernel,
                 "whole_path": {"compulsory_bytes_per_query": alg_build, "GBs": alg_build * qps / 1e9,
