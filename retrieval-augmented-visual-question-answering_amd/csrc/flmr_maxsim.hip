@@ -1675,11 +1675,13 @@ static int launch_maxsim_lean_t(const flmr_maxsim_args& a, hipStream_t st, int G
 // reads -- 39 % of the matrix pipe at Nq = 832 (profiles/r05/s3_multiq_ablation.txt).  Here the roles are swapped:
 //   * the QUERY sits in registers: each of a workgroup's 8 waves holds the hi / lo B fragments of up to two 32-row q-tiles
 //     (128 VGPRs), 16 q-tiles = 512 columns per workgroup "pass" (Nq = 320: one pass, 832: passes of 16 + 10 q-tiles);
-//   * the TOKEN TILES stream through LDS, gathered and decoded ONCE per pass, the work spread evenly: wave w issues DMA
-//     instruction w of every tile (rows {w, 8+w, 16+w, 24+w} -> a raw-row buffer, the planned-tile kernel's layout) and decodes
-//     k-step w of every tile (16 of the 128 dims of all 32 rows: one ds_read_b128 of the raw rows, NBITS table look-ups,
-//     (w + c) * 1/norm with the index's inv_norm, split into fp16 hi / lo, two ds_write_b128 into the tile's ring slot in
-//     fragment order); all 8 waves read every slot (16 ds_read_b128 per tile and wave feed 48 MFMAs);
+//   * the TOKEN TILES stream through LDS, gathered and decoded ONCE per pass: wave w issues DMA instruction w of every tile (rows
+//     {w, 8+w, 16+w, 24+w} -> a raw-row buffer, the planned-tile kernel's layout); waves 0-3 -- one per SIMD -- decode k-steps w
+//     and w + 4 of every tile (16 of the 128 dims of all 32 rows per k-step: one ds_read_b128 of the raw rows, NBITS table look-ups
+//     (all of a stage's in flight together), (w + c) * 1/norm with the index's inv_norm, split into fp16 hi / lo, two
+//     ds_write_b128 into the tile's ring slot in fragment order) BEFORE their MFMAs, while their SIMD partners (waves 4-7) only
+//     gather and consume: a SIMD's matrix pipe runs the partner's MFMAs during the decode and the decoder's afterwards; all 8
+//     waves read every slot (16 ds_read_b128 per tile and wave feed 48 MFMAs);
 //   * rounds of 3 tiles, ring and raw buffers double-buffered (96 + 48 KB).  Round r, every wave: decode its k-step of the
 //     tiles of round r+1 -> ring[(r + 1) & 1]; request rows / residual bytes / scales of the tiles of round r+2 (codes asked for
 //     a round earlier) and the codes of round r+3; consume ring[r & 1]; vmcnt(0) (everything it waits for is a round old); ONE
@@ -1718,22 +1720,26 @@ __global__ __launch_bounds__(256) void s3q_split_q(const float* Q, const int32_t
 }
 
 // 8 dims of one row (the lane's share of a k-step): weights by table, + centroid, * (64 / norm), split -> the hi / lo fragments
-// `bytes`: the NBITS residual bytes of those dims, low byte first
+// `bytes`: the NBITS residual bytes of those dims, low byte first.  In two parts so that a stage can issue the table look-ups of
+// ALL its units before the arithmetic of the first (one LDS round trip per stage instead of one per unit).
 template <int NBITS>
-__device__ __forceinline__ void s3q_decode_unit(const float* wlut, const uint32_t (&bytes)[2], const hf8& c, float inv64, hf8& ah, hf8& al) {
+__device__ __forceinline__ void s3q_unit_weights(const float* wlut, const uint32_t (&bytes)[2], float (&w)[8]) {
     constexpr int VPB = 8 / NBITS;
-    float x[8];
 #pragma unroll
     for (int bb = 0; bb < NBITS; bb++) {
         const uint32_t byte = (bytes[bb >> 2] >> (8 * (bb & 3))) & 255u;
         float wv[VPB];
         s3_lut<VPB>(wlut, byte, wv);
 #pragma unroll
-        for (int l = 0; l < VPB; l++) {
-            const int dd = bb * VPB + l;
-            const uint32_t cpk = __builtin_bit_cast(s3u4, c)[dd >> 1];
-            x[dd] = (dd & 1) ? s3_add_f16<1>(cpk, wv[l]) : s3_add_f16<0>(cpk, wv[l]);
-        }
+        for (int l = 0; l < VPB; l++) w[bb * VPB + l] = wv[l];
+    }
+}
+__device__ __forceinline__ void s3q_unit_split(const float (&w)[8], const hf8& c, float inv64, hf8& ah, hf8& al) {
+    float x[8];
+#pragma unroll
+    for (int dd = 0; dd < 8; dd++) {
+        const uint32_t cpk = __builtin_bit_cast(s3u4, c)[dd >> 1];
+        x[dd] = (dd & 1) ? s3_add_f16<1>(cpk, w[dd]) : s3_add_f16<0>(cpk, w[dd]);
     }
     const float m1 = -1.0f;
     s3u4 hpk, lpk;
@@ -1792,8 +1798,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void maxsim_qs_kernel(flm
                                                         const float* __restrict__ inv_norm, int nqp, int npass, int per_pass) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int VPB = 8 / NBITS, PACKED = FLMR_DIM * NBITS / 8, NB = 8 * NBITS;
-    constexpr int KS = 8 / NW;             // k-steps (and DMA instructions) of a tile this wave handles
-    constexpr int U = R * KS;              // decode units per round
+    constexpr int KS = 8 / NW;             // DMA instructions of a tile this wave issues
+    constexpr int U = R * KS;
+    constexpr int ND = 4;                  // decoding waves: 0 .. 3, one per SIMD -- in the 8-wave form each decodes beside a partner
+                                           // (wave + 4) that only consumes: the partner's MFMAs run while it decodes, its own afterwards
+    constexpr int KD = 8 / ND;             // k-steps of a tile a decoding wave handles: wave, wave + 4
+    constexpr int UD = R * KD;             // decode units per round and decoding wave
     __shared__ __attribute__((aligned(16))) float wlut_s[256 * VPB];
     char* const ring = smem;                                  // [2][R] decoded tiles: [k-step][hi | lo][lane] 16-byte fragments
     char* const raw = smem + 2 * R * S3Q_SLOT;                // [2][R] gathered centroid rows
@@ -1839,8 +1849,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void maxsim_qs_kernel(flm
     }
     // per-lane constants.  Gather: DMA instruction q of a tile moves rows {q, 8+q, 16+q, 24+q} (lane group j = lane >> 4: row 8j + q),
     // 16-byte pieces XOR-swizzled by (row & 15), row r in slot 4 (r & 7) + (r >> 3) of the 8 KB buffer (maxsim_lean_kernel's layout);
-    // this wave issues instructions q = wave + e NW and decodes k-steps s = wave + e NW (e < KS): the offsets below are for e = 0,
-    // the others follow by XOR / add of compile-time constants.
+    // this wave issues instructions q = wave + e NW (e < KS); a decoding wave (< ND) decodes k-steps s = wave + e ND (e < KD): the
+    // offsets below are for e = 0, the others follow by XOR / add of compile-time constants.
     const uint32_t code_voff = (uint32_t)(((lane >> 4) * 8 + wave) * 4);
     const uint32_t piece_off = (uint32_t)((((lane & 15) ^ (8 * ((lane >> 4) & 1))) << 4) ^ (wave << 4));
     const uint32_t res_voff = (uint32_t)(i * PACKED + h * NB + wave * NBITS), inv_voff = (uint32_t)(i * 4);
@@ -1848,19 +1858,23 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void maxsim_qs_kernel(flm
     const uint32_t wr_off = (uint32_t)(lane * 16 + 2 * wave * 1024);   // this lane's hi fragment of k-step `wave` inside a ring slot (lo: + 1024)
     const uint32_t frag_off = (uint32_t)(lane * 16);
 
-    // in-flight state of the pipeline; unit u = k KS + e: tile k of the round, e-th of my k-steps
+    // in-flight state of the pipeline; DMA unit u = k KS + e, decode unit u = k KD + e: tile k of the round, e-th of my instructions / k-steps
     uint32_t cdv[U];              // codes of my DMA rows, tiles of round r+3 (after stage C of round r)
-    uint32_t rsv[U][2];           // residual bytes of my k-steps, tiles of round r+1 (what stage D of round r decodes)
+    uint32_t rsv[UD][2];          // residual bytes of my k-steps, tiles of round r+1 (what stage D of round r decodes; decoding waves)
     float ivv[R];                 // 1 / norm of row i, same tiles
-    uint32_t rsn[U][2];           // the same for the tiles of round r+2: loaded by stage G of round r, moved to rsv / ivv at its end
+    uint32_t rsn[UD][2];          // the same for the tiles of round r+2: loaded by stage G of round r, moved to rsv / ivv at its end
     float ivn[R];
 #pragma unroll
-    for (int u = 0; u < U; u++) { cdv[u] = 0; rsv[u][0] = 0; rsv[u][1] = 0; rsn[u][0] = 0; rsn[u][1] = 0; }
+    for (int u = 0; u < U; u++) cdv[u] = 0;
+#pragma unroll
+    for (int u = 0; u < UD; u++) { rsv[u][0] = 0; rsv[u][1] = 0; rsn[u][0] = 0; rsn[u][1] = 0; }
 #pragma unroll
     for (int k = 0; k < R; k++) { ivv[k] = 0.0f; ivn[k] = 0.0f; }
     auto touch_state = [&]() {
 #pragma unroll
-        for (int u = 0; u < U; u++) asm volatile("" : "+v"(cdv[u]), "+v"(rsn[u][0]), "+v"(rsn[u][1])::"memory");
+        for (int u = 0; u < U; u++) asm volatile("" : "+v"(cdv[u])::"memory");
+#pragma unroll
+        for (int u = 0; u < UD; u++) asm volatile("" : "+v"(rsn[u][0]), "+v"(rsn[u][1])::"memory");
 #pragma unroll
         for (int k = 0; k < R; k++) asm volatile("" : "+v"(ivn[k])::"memory");
     };
@@ -1889,29 +1903,32 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void maxsim_qs_kernel(flm
             const int par = (r + 1) & 1;
             const char* rw = raw + par * (R * S3Q_RAW);
             char* wr = ring + par * (R * S3Q_SLOT) + wr_off;
-            hf8 c[U];
+            hf8 c[UD];
 #pragma unroll
-            for (int u = 0; u < U; u++)   // all raw-row reads first: one LDS round trip for the stage (k-step w + 4e: XOR, the bits are disjoint)
-                c[u] = *reinterpret_cast<const hf8*>(rw + (u / KS) * S3Q_RAW + (rd_off ^ (uint32_t)(((u % KS) * NW) << 4)));
+            for (int u = 0; u < UD; u++)   // all raw-row reads first: one LDS round trip for the stage (k-step w + 4e: XOR, the bits are disjoint)
+                c[u] = *reinterpret_cast<const hf8*>(rw + (u / KD) * S3Q_RAW + (rd_off ^ (uint32_t)(((u % KD) * ND) << 4)));
+            float wts[UD][8];
+#ifndef S3Q_NO_DECODE
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int k = u / KS, e = u % KS;
+            for (int u = 0; u < UD; u++) s3q_unit_weights<NBITS>(wlut_s, rsv[u], wts[u]);   // (all look-ups in flight together)
+#endif
+#pragma unroll
+            for (int u = 0; u < UD; u++) {
+                const int k = u / KD, e = u % KD;
                 const int lo = (int)(dD[k].y & 63u), hi = (int)((dD[k].y >> 6) & 63u);
                 const float inv64 = (i >= lo && i < hi) ? ivv[k] * S3Q_SCALE : 0.0f;     // rows outside the passage become exact zeros
                 hf8 fa, fl;
 #ifdef S3Q_NO_DECODE
-                fa = c[u]; fl = c[u]; asm volatile("" :: "v"(inv64), "v"(rsv[u][0]));
+                fa = c[u]; fl = c[u]; asm volatile("" :: "v"(inv64), "v"(rsv[u][0]), "v"(wts[u][0]));
 #else
-                s3q_decode_unit<NBITS>(wlut_s, rsv[u], c[u], inv64, fa, fl);
+                s3q_unit_split(wts[u], c[u], inv64, fa, fl);
 #endif
-                *reinterpret_cast<hf8*>(wr + k * S3Q_SLOT + e * NW * 2048) = fa;
-                *reinterpret_cast<hf8*>(wr + k * S3Q_SLOT + e * NW * 2048 + 1024) = fl;
+                *reinterpret_cast<hf8*>(wr + k * S3Q_SLOT + e * ND * 2048) = fa;
+                *reinterpret_cast<hf8*>(wr + k * S3Q_SLOT + e * ND * 2048 + 1024) = fl;
             }
         };
-        // <8, 3>: waves 0-3 decode, gather, consume; waves 4-7 gather, consume two tiles, decode, consume the third (the two waves of a
-        // SIMD decode at different times).  <4, 1>: decode, gather, consume.
-        bool decoded = false;
-        if (NW == 4 || wave < 4) { stage_d(); decoded = true; }
+        // decoding waves: decode, gather, consume; the others: gather, consume
+        if (wave < ND) stage_d();
         S3Q_STAMP(0);
         // ---- stage G: my rows, residual bytes and scales of the tiles of round r+2; stage C: my codes of round r+3 ----
         {
@@ -1920,16 +1937,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void maxsim_qs_kernel(flm
             for (int k = 0; k < R; k++) {
                 const uint32_t pos = dG[k].x;
                 const uint8_t* rbase = residuals + (size_t)pos * PACKED;
-                asm volatile("global_load_dword %0, %1, %2" : "=v"(ivn[k]) : "v"(inv_voff), "s"(inv_norm + pos) : "memory");
+                if (wave < ND) {   // (wave-uniform; every wave issues the same number of operations in a round or none of these)
+                    asm volatile("global_load_dword %0, %1, %2" : "=v"(ivn[k]) : "v"(inv_voff), "s"(inv_norm + pos) : "memory");
+#pragma unroll
+                    for (int e = 0; e < KD; e++) {
+                        const int u = k * KD + e;
+                        const uint8_t* rb2 = rbase + e * ND * NBITS;
+                        if constexpr (NBITS == 1) asm volatile("global_load_ubyte %0, %1, %2" : "=v"(rsn[u][0]) : "v"(res_voff), "s"(rb2) : "memory");
+                        else if constexpr (NBITS == 2) asm volatile("global_load_ushort %0, %1, %2" : "=v"(rsn[u][0]) : "v"(res_voff), "s"(rb2) : "memory");
+                        else if constexpr (NBITS == 4) asm volatile("global_load_dword %0, %1, %2" : "=v"(rsn[u][0]) : "v"(res_voff), "s"(rb2) : "memory");
+                        else asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(*reinterpret_cast<u32x2*>(&rsn[u][0])) : "v"(res_voff), "s"(rb2) : "memory");
+                    }
+                }
+#ifndef S3Q_NO_DMA
 #pragma unroll
                 for (int e = 0; e < KS; e++) {
                     const int u = k * KS + e;
-                    const uint8_t* rb2 = rbase + e * NW * NBITS;
-                    if constexpr (NBITS == 1) asm volatile("global_load_ubyte %0, %1, %2" : "=v"(rsn[u][0]) : "v"(res_voff), "s"(rb2) : "memory");
-                    else if constexpr (NBITS == 2) asm volatile("global_load_ushort %0, %1, %2" : "=v"(rsn[u][0]) : "v"(res_voff), "s"(rb2) : "memory");
-                    else if constexpr (NBITS == 4) asm volatile("global_load_dword %0, %1, %2" : "=v"(rsn[u][0]) : "v"(res_voff), "s"(rb2) : "memory");
-                    else asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(*reinterpret_cast<u32x2*>(&rsn[u][0])) : "v"(res_voff), "s"(rb2) : "memory");
-#ifndef S3Q_NO_DMA
                     const uint32_t dst = dst0 + k * S3Q_RAW + e * NW * 1024;
                     const uint32_t po = piece_off ^ (uint32_t)((e * NW) << 4);
                     uint32_t voff;
@@ -1937,8 +1960,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void maxsim_qs_kernel(flm
                                  : "=&v"(voff)
                                  : "s"(cen16), "s"(dst), "v"(cdv[u]), "v"(po)
                                  : "memory", "m0");
-#endif
                 }
+#endif
             }
 #pragma unroll
             for (int u = 0; u < U; u++)
@@ -2001,13 +2024,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void maxsim_qs_kernel(flm
             auto run = [&](auto ntc) {
                 tile(std::integral_constant<int, 0>{}, ntc);
                 if constexpr (R > 1) { if (nrt > 1) tile(std::integral_constant<int, 1>{}, ntc); }
-                if (!decoded) { stage_d(); decoded = true; }
                 if constexpr (R > 2) { if (nrt > 2) tile(std::integral_constant<int, 2>{}, ntc); }
             };
             if (nt == 2) run(std::integral_constant<int, 2>{});
             else run(std::integral_constant<int, 1>{});
         }
-        if (!decoded) stage_d();
         S3Q_STAMP(2);
         // everything this wave asked for in this round has landed (a consume phase ago) -- rows in LDS included -- before the
         // barrier lets the other waves read them
@@ -2021,7 +2042,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void maxsim_qs_kernel(flm
 #pragma unroll
         for (int k = 0; k < R; k++) { dM[k] = dD[k]; dD[k] = dG[k]; dG[k] = dC[k]; dC[k] = dN[k]; ivv[k] = ivn[k]; }
 #pragma unroll
-        for (int u = 0; u < U; u++) { rsv[u][0] = rsn[u][0]; rsv[u][1] = rsn[u][1]; }
+        for (int u = 0; u < UD; u++) { rsv[u][0] = rsn[u][0]; rsv[u][1] = rsn[u][1]; }
     }
 #ifdef S3Q_PROFILE
     if (lane == 0) {
