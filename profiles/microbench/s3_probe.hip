@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
         a.plan_stride = (int64_t)ND * ((L + 31) / 32); a.plan_wcap = ND + 8;
         CK(hipMalloc(&a.plan_desc, (size_t)NQ * a.plan_stride * sizeof(uint2)));
         CK(hipMalloc(&a.plan_wbeg, (size_t)NQ * a.plan_wcap * 4));
-        if (NQR > 32) { a.colmax_cap = (int64_t)NQ * ND * NQP; CK(hipMalloc(&a.colmax_ws, (size_t)a.colmax_cap * 4)); }
+        if (NQR > 32) { a.colmax_cap = (int64_t)NQ * ND * NQP + NQ; CK(hipMalloc(&a.colmax_ws, (size_t)a.colmax_cap * 4)); }
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<uint64_t> ref;

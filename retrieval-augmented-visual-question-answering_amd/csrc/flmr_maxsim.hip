@@ -1690,8 +1690,8 @@ static int launch_maxsim_lean_t(const flmr_maxsim_args& a, hipStream_t st, int G
 //     hi) -- not the 2048-fold residual the other kernels keep -- so hi.hi, hi.lo and lo.hi are products at ONE scale and add
 //     into the same registers (the lo products first, over all k-steps, then hi.hi: the small terms are summed before they meet
 //     the large ones).  No hi + lo / 2048 combine, half the accumulator registers, an epilogue of 8 v_max3 per q-tile; the
-//     column maximum is multiplied by 2^-12 once per passage.  |64 x| must stay below 65504: |Q| < 1000 (rows of an index are
-//     unit vectors).  lo is a normal fp16 number for |x| >= 2^-8 and loses nothing that matters below (absolute 2^-31 of x);
+//     column maximum is rescaled once per passage.  The query's scale is per query (s3q_scale_kernel: 64 unless an entry exceeds 256
+//     in magnitude), so its images never overflow; rows of an index are unit vectors.  lo is a normal fp16 number for |x| >= 2^-8 and loses nothing that matters below (absolute 2^-31 of x);
 //   * column maxima stay in registers until their passage ends (all waves see the same boundaries), then go to a
 //     [query][finalist][column] array; s3_colsum_kernel forms the k-ascending sums.
 // Scores differ from maxsim_f16_multiq_kernel's by fp32 roundoff (same decode up to the scaling, other accumulation order).
@@ -1705,14 +1705,42 @@ static int launch_maxsim_lean_t(const flmr_maxsim_args& a, hipStream_t st, int G
 #define S3Q_MIN_NQP 288
 #endif
 
-// the query images of this kernel: hi = fp16(64 q), lo = fp16(64 q - hi); rows >= q_len (and the padding to a multiple of 32) zero
-__global__ __launch_bounds__(256) void s3q_split_q(const float* Q, const int32_t* q_lens, int nq, int nqp, _Float16* q_hi, _Float16* q_lo) {
+// Per-query operand scale of this kernel's query images: L_b = 64 for queries whose entries stay below 256 in magnitude (every
+// normalised query), else the largest power of two with L_b * max|q| <= 16384 -- the fp16 images never overflow whatever the
+// caller hands in (FLMR's un-normalised visual rows included).  qscale[b] = 1 / (64 L_b): what a column maximum is multiplied by.
+__global__ __launch_bounds__(256) void s3q_scale_kernel(const float* Q, const int32_t* q_lens, int nq, float* qscale) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const int qlen = q_lens ? (q_lens[b] < nq ? q_lens[b] : nq) : nq;
+    float mx = 0.0f;
+    for (int e = threadIdx.x; e < qlen * FLMR_DIM; e += 256) mx = fmaxf(mx, fabsf(Q[(size_t)b * nq * FLMR_DIM + e]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float L = S3Q_SCALE;
+        if (!(mx * L <= 16384.0f)) {   // (also taken for inf / NaN input: the smallest scale)
+            L = 1.0f;
+            if (mx < 3.0e38f && mx > 16384.0f) { int ex; (void)frexpf(16384.0f / mx, &ex); L = ldexpf(1.0f, ex - 1); }
+            else if (mx <= 16384.0f) { int ex; (void)frexpf(16384.0f / mx, &ex); L = ldexpf(1.0f, ex - 1); }
+            else L = ldexpf(1.0f, -100);
+        }
+        qscale[b] = 1.0f / (S3Q_SCALE * L);
+    }
+}
+
+// the query images of this kernel: hi = fp16(L q), lo = fp16(L q - hi); rows >= q_len (and the padding to a multiple of 32) zero
+__global__ __launch_bounds__(256) void s3q_split_q(const float* Q, const int32_t* q_lens, int nq, int nqp, _Float16* q_hi, _Float16* q_lo,
+                                                   const float* qscale) {
     const int b = blockIdx.y;
     const int qlen = q_lens ? q_lens[b] : nq;
+    const float L = 1.0f / (qscale[b] * S3Q_SCALE);   // (powers of two: exact)
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nqp * FLMR_DIM; e += gridDim.x * blockDim.x) {
         const int row = e / FLMR_DIM;
         float v = 0.0f;
-        if (row < qlen && row < nq) v = Q[((size_t)b * nq + row) * FLMR_DIM + (e % FLMR_DIM)] * S3Q_SCALE;
+        if (row < qlen && row < nq) v = Q[((size_t)b * nq + row) * FLMR_DIM + (e % FLMR_DIM)] * L;
         const _Float16 hi = (_Float16)v;
         q_hi[(size_t)b * nqp * FLMR_DIM + e] = hi;
         q_lo[(size_t)b * nqp * FLMR_DIM + e] = (_Float16)(v - (float)hi);
@@ -1889,6 +1917,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void maxsim_qs_kernel(flm
     for (int k = 0; k < R; k++) { touch_desc(dM[k]); touch_desc(dD[k]); touch_desc(dG[k]); touch_desc(dC[k]); }
     float cmxA = 0.0f, cmxB = 0.0f;
     float* const cm_q = m.colmax_ws + (size_t)b * m.key_stride * (size_t)nqp + (size_t)(qt0 + wave) * 32 + i;
+    const float out_scale = (m.colmax_ws + (size_t)m.nqueries * m.key_stride * (size_t)nqp)[b];   // 1 / (64 L_b), s3q_scale_kernel
     __syncthreads();
 #ifdef S3Q_PROFILE
     long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -2011,11 +2040,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void maxsim_qs_kernel(flm
                 if constexpr (NT == 2) cmxB = s3q_tile_max(cmxB, accB[P]);
                 if ((dy >> 12) & 1u) {   // last tile of its passage: the column maxima leave the registers
                     float* row = cm_q + (size_t)(dy >> 13) * (size_t)nqp;
-                    const float va = flmr_xhalf_max(cmxA) * (1.0f / (S3Q_SCALE * S3Q_SCALE));
+                    const float va = flmr_xhalf_max(cmxA) * out_scale;
                     if (h == 0) row[0] = va;
                     cmxA = 0.0f;  // segmented_maxsim.cpp:58-59: the running max starts at zero
                     if constexpr (NT == 2) {
-                        const float vb = flmr_xhalf_max(cmxB) * (1.0f / (S3Q_SCALE * S3Q_SCALE));
+                        const float vb = flmr_xhalf_max(cmxB) * out_scale;
                         if (h == 0) row[NW * 32] = vb;
                         cmxB = 0.0f;
                     }
@@ -2086,7 +2115,9 @@ static int launch_maxsim_qs_nw(const flmr_maxsim_args& a, hipStream_t st, int nq
     if (Y > a.plan_wcap - 1) Y = a.plan_wcap - 1;
     if (Y < 1) Y = 1;
     const size_t lds = (size_t)2 * R * (S3Q_SLOT + S3Q_RAW);
-    hipLaunchKernelGGL(s3q_split_q, dim3((nqp * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens, a.nq, nqp, a.q_hi, a.q_lo);
+    float* qscale = a.colmax_ws + (size_t)a.nqueries * a.key_stride * (size_t)nqp;   // [nqueries], behind the column maxima
+    hipLaunchKernelGGL(s3q_scale_kernel, dim3(a.nqueries), dim3(256), 0, st, a.Q, a.q_lens, a.nq, qscale);
+    hipLaunchKernelGGL(s3q_split_q, dim3((nqp * FLMR_DIM + 255) / 256, a.nqueries), dim3(256), 0, st, a.Q, a.q_lens, a.nq, nqp, a.q_hi, a.q_lo, qscale);
     hipLaunchKernelGGL(s3_plan_kernel, dim3(a.nqueries), dim3(256), 0, st, a, ix->doc_offsets, ix->N, Y);
     FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_qs_kernel<NBITS, NW, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((maxsim_qs_kernel<NBITS, NW, R>), dim3(a.nqueries, npass * Y), dim3(64 * NW), lds, st, a, ix->codes, ix->residuals,
@@ -2113,7 +2144,7 @@ static int launch_maxsim_f16_t(const flmr_maxsim_args& a, hipStream_t st) {
     // long queries: the query-stationary kernel on planned tiles (below ~6 q-tiles most of a workgroup's waves would hold no query
     // rows: the chunked kernel stays); it splits the query itself (other scaling)
     const bool use_qs = (nqp >= S3Q_MIN_NQP || (nqp > 32 && flmr_opts().is(FLMR_OPT_S3_IMPL, "qs"))) && !flmr_opts().has(FLMR_OPT_S3_NO_MULTIQ) &&
-        ix->inv_norm && a.plan_desc && a.plan_wbeg && a.colmax_ws && a.colmax_cap >= (int64_t)a.nqueries * a.key_stride * nqp && ix->N >= 32 &&
+        ix->inv_norm && a.plan_desc && a.plan_wbeg && a.colmax_ws && a.colmax_cap >= (int64_t)a.nqueries * a.key_stride * nqp + a.nqueries && ix->N >= 32 &&
         ix->N < ((int64_t)1 << 32) && ((size_t)ix->K * 256 < ((size_t)1 << 32)) && a.max_count <= S3L_MAX_DOCS && a.plan_wcap >= 2 &&
         a.plan_stride >= (int64_t)a.max_count * ((ix->max_doclen + 31) / 32) &&
         (flmr_opts().is(FLMR_OPT_S3_IMPL, "qs") || !flmr_opts().has(FLMR_OPT_S3_IMPL));

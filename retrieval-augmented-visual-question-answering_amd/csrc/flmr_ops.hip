@@ -222,7 +222,7 @@ extern "C" int flmr_score_pids(const flmr_index_t* ix, const float* Q, int32_t n
         if (stride * (int64_t)sizeof(uint2) <= ((int64_t)1 << 30) && sc.alloc(&desc, (size_t)stride) == FLMR_OK &&
             sc.alloc(&wbeg, (size_t)npids + 8) == FLMR_OK) {
             m.plan_desc = desc; m.plan_stride = stride; m.plan_wbeg = wbeg; m.plan_wcap = npids + 8;
-            const int64_t cmf = (int64_t)npids * flmr_round_up(nq, 32);
+            const int64_t cmf = (int64_t)npids * flmr_round_up(nq, 32) + 1;
             float* cm = nullptr;
             if (nq > 32 && cmf * (int64_t)sizeof(float) <= ((int64_t)2 << 30) && sc.alloc(&cm, (size_t)cmf) == FLMR_OK) {
                 m.colmax_ws = cm; m.colmax_cap = cmf;

@@ -179,7 +179,7 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
             s->s3_desc = nullptr; s->s3_wbeg = nullptr;
         }
         if (s->s3_desc && max_nq > 32) {
-            s->s3_colmax_cap = (int64_t)B * nd4 * flmr_round_up(max_nq, 32);
+            s->s3_colmax_cap = (int64_t)B * nd4 * flmr_round_up(max_nq, 32) + (int64_t)B;   // (+ the per-query output scales of the query-stationary kernel)
             if (s->s3_colmax_cap * (int64_t)sizeof(float) <= ((int64_t)2 << 30) &&
                 hipMalloc(reinterpret_cast<void**>(&s->s3_colmax), (size_t)s->s3_colmax_cap * sizeof(float)) == hipSuccess) {
                 s->bytes += s->s3_colmax_cap * (int64_t)sizeof(float);

@@ -336,3 +336,30 @@ def test_fuzz_dense_survivor_sets_vs_oracle(hip, seed):
         checked += 1
     assert max(nsurv) >= 64, (seed, nsurv)
     scorer.close_searcher()
+
+
+def test_long_query_kernel_scales_per_query(hip):
+    """The query-stationary long-query S3 kernel (Nq >= 288) scales its fp16 operands per query: queries whose rows are far from
+    unit norm (FLMR's un-normalised visual tokens; here x 700 and x 1e-3) must score like the chunked kernel (FLMR_S3_IMPL=regs,
+    whose split has no such scale) -- relative to the scores' magnitude."""
+    import ctypes as C
+    nat, torch = hip["native"], hip["torch"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    corpus = synth.make_corpus(4000, (5, 150), 512, 2, seed=5, device="cuda")
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=4)
+    Q, _ = synth.make_queries(corpus, 1, 320, seed=4)
+    pids = torch.arange(0, 4000, 7, dtype=torch.int32, device="cuda")
+    for scale in (1.0, 700.0, 1e-3):
+        Qd = (Q[0] * scale).contiguous()
+        outs = {}
+        for impl in ("regs", "qs"):
+            with nat.options(FLMR_S3_IMPL=impl):
+                out = torch.empty(pids.numel(), dtype=torch.float32, device="cuda")
+                nat.check(scorer._lib.flmr_score_pids(scorer.device_index.handle, C.c_void_p(Qd.data_ptr()), 320, C.c_void_p(pids.data_ptr()),
+                                                      pids.numel(), C.c_void_p(out.data_ptr()), nat.stream_ptr()))
+                outs[impl] = out.cpu().numpy().astype(np.float64)
+        assert np.all(np.isfinite(outs["qs"])), scale
+        mag = float(np.max(np.abs(outs["regs"]))) + 1e-30
+        assert np.max(np.abs(outs["qs"] - outs["regs"])) <= 2e-6 * mag, (scale, np.max(np.abs(outs["qs"] - outs["regs"])), mag)
+    scorer.close_searcher()
