@@ -54,9 +54,11 @@ int flmr_device_count(int* count);
  * reads the environment.  (The reference has no counterpart: its extensions have one implementation each.)
  * Values with a measured use: FLMR_S2_IMPL = xcd | lds | ldsb | walk | regs (stage 2: one L2-resident table slice per XCD --
  * the default for whole batches when the fp16 centroid table exceeds an L2 -- / row gather with 4-wave or 16-wave blocks /
- * dense table walk / register gather); FLMR_S3_IMPL = regs | dma | f32 (fused MaxSim for Nq <= 32: register row gathers /
- * LDS-DMA two tiles ahead, the default for nbits = 8 / fp32-MFMA kernel).  Every variant is bit-identical to the default
- * (tests/test_hip_parity.py).
+ * dense table walk / register gather); FLMR_S3_IMPL = lean | cw | cwregs | regs | dma | f32 | qs (fused MaxSim.  Nq <= 32: lean, the
+ * default = the centroid + weight arithmetic on planned tiles; cw / cwregs = the same arithmetic walking the passages, rows by
+ * LDS-DMA / register gathers; regs / dma = decompress-normalise-split; f32 = fp32-MFMA kernel.  Longer queries: qs, the
+ * query-stationary kernel, the default from 288 rows; any other value = the chunked kernel).  Variants of one arithmetic are
+ * bit-identical to each other, the arithmetics agree to fp32 roundoff (tests/test_hip_parity.py).
  * One switch is a capacity, not a variant: FLMR_ROW_CAP = score rows a searcher keeps per query (64 .. 65535, default 16384,
  * never more than K).  The default path stores the centroid scores of a query only for the centroids that pass
  * centroid_score_threshold (the rows index_storage.py:116's `idx` selects; 128 bytes each) instead of the reference's
