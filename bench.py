@@ -309,6 +309,21 @@ def main():
             exchange_ms["ms_per_step_unpipelined"] = (time.perf_counter() - t0_) / args.steps * 1e3
             args.shard_depth = depth_keep
 
+    # ---- N > 1, exact mode: the FAST mode beside it (north_star's collective: every shard runs S0..S4, ONE all-gather of the
+    # per-shard top-k lists, merged) -- same steps, same queries, timed the same way ---------------------------------------
+    fast_line = None
+    if exact:
+        exact = False
+        try:
+            dt_f, _, recall_f, _ = timed(scorer, Qs, tgts, k, (ncells, thr, ndocs), args.steps, 2, collect_stages=False)
+            fast_line = {"queries_per_sec": args.batch * args.steps / dt_f, "ms_per_step": dt_f / args.steps * 1e3, "recall_at_5": recall_f,
+                         "note": "--shard-mode fast on the same shards and queries: every rank runs S0..S4 over its shard at the same ndocs, one "
+                                 "all-gather of the per-shard top-k (score, pid) lists, flmr_merge_topk -- exact scores over a superset of the "
+                                 "unsharded survivors (the exact mode's three exchanges reproduce the unsharded result bit for bit)"}
+        except Exception as e:  # noqa: BLE001
+            fast_line = {"failed": repr(e)}
+        exact = True
+
     out = None
     if rank == 0:
         # ---- workload statistics of the last batch (outside the timed region) ----------------------------------------
@@ -442,6 +457,8 @@ def main():
         }
         if shard_calibration is not None:
             out["shard_pipeline"] = shard_calibration
+        if fast_line is not None:
+            out["shard_mode_fast"] = fast_line
         if exchange_ms is not None:
             out["exchange_ms"] = exchange_ms
             out["exchange_ms_note"] = ("duration of each collective of one step between two events on the launch stream (separate "
