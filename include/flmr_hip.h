@@ -211,7 +211,9 @@ int flmr_unpack_keys(const uint64_t* keys, int32_t nqueries, int32_t n, int32_t 
  * IDX_BITS u32 [ceil(K/32)], CELLS i32, CANDIDATES i32 (ascending local pids), STAGE1 i32 (unordered),
  * STAGE2 i32 (descending (score,pid) order = filter_pids output), DOC_SCORES f32 (aligned with STAGE2),
  * Q_ERR f32 [32] / Q_ERR_SUM f32 [1]: the per-column and per-passage bounds the "hi first" stages 0 / 2 decide with
- * (0 elements when the last batch did not run that path). */
+ * (0 elements when the last batch did not run that path); STAGE1_FORM i32 [1]: which form of the list-scatter stage 1 produced
+ * the query's keys -- 0 the queue form, 1 the slot form (query not tried: too many surviving lists, or a searcher whose queries
+ * mostly overflow), 2 the slot form after the queue form gave the query up (0 elements: stage 1 ran in another mode). */
 typedef enum flmr_tap {
     FLMR_TAP_CENTROID_SCORES = 0,
     FLMR_TAP_IDX_BITS = 1,
@@ -221,7 +223,8 @@ typedef enum flmr_tap {
     FLMR_TAP_STAGE2 = 5,
     FLMR_TAP_DOC_SCORES = 6,
     FLMR_TAP_Q_ERR = 7,
-    FLMR_TAP_Q_ERR_SUM = 8
+    FLMR_TAP_Q_ERR_SUM = 8,
+    FLMR_TAP_STAGE1_FORM = 9
 } flmr_tap_t;
 int flmr_searcher_tap(flmr_searcher_t* searcher, int32_t what, int32_t query, void* host_out, int64_t capacity,
                       int64_t* count);

@@ -17,7 +17,7 @@ HEADERS = ["flmr_common.h", "flmr_device.h"]
 
 FLMR_MEM_HOST, FLMR_MEM_DEVICE = 0, 1
 (TAP_CENTROID_SCORES, TAP_IDX_BITS, TAP_CELLS, TAP_CANDIDATES, TAP_STAGE1, TAP_STAGE2, TAP_DOC_SCORES, TAP_Q_ERR,
- TAP_Q_ERR_SUM) = range(9)
+ TAP_Q_ERR_SUM, TAP_STAGE1_FORM) = range(10)
 NUM_STAGES = 9
 ABI_VERSION = 4
 

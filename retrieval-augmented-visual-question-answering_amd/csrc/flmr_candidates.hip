@@ -66,7 +66,7 @@ __global__ __launch_bounds__(1024) void qualifying_kernel(const uint32_t* idx_bi
                                                           int32_t* key_count, int ratio, uint32_t* idx_prefix,
                                                           float* rows_out, const _Float16* __restrict__ cen16,
                                                           const _Float16* __restrict__ q_hi, const _Float16* __restrict__ q_lo,
-                                                          int32_t* overflow) {
+                                                          int32_t* overflow, int32_t* fast_state) {
     __shared__ int scan_lds[17];
     __shared__ unsigned long long tot_q, tot_c;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(1024) void qualifying_kernel(const uint32_t* idx_bi
         nqual[b] = n;
         hit_valid[b] = (base <= smax) && (base <= qmax) && (tot_q <= (unsigned long long)ratio * tot_c);
         if (key_count) key_count[b] = 0;
+        if (fast_state) { fast_state[2 + b] = 0; fast_state[2 + gridDim.x + b] = 0; }   // (see cand_fast_kernel)
         if (rows_out && base > qmax && overflow) atomicExch(overflow + 2, 1);   // more surviving centroids than score rows (FLMR_ROW_CAP)
     }
     if (!rows_out || n == 0) return;   // (block-uniform)
@@ -297,6 +298,18 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     const int k = lane & 31;
     const int ch0 = blockIdx.y * cpb;
     const int ch_end = ch0 + cpb < a.nchunks ? ch0 + cpb : a.nchunks;
+    if (a.fast_state) {   // the queue form ran first: this kernel takes the queries it handed over (block-uniform)
+        const int r = a.fast_state[2 + b];
+        if (blockIdx.y == 0 && tid == 0) {
+            if (r == 0) a.key_count[b] = a.fast_state[2 + a.nqueries + b];
+            if (r != 1) {   // tried: the two cumulative counters that decide whether later batches try (halved now and then)
+                if (r == 2) atomicAdd(a.fast_state + 0, 1);
+                const int tried = atomicAdd(a.fast_state + 1, 1);
+                if (tried >= 16384) { atomicSub(a.fast_state + 1, tried / 2); atomicSub(a.fast_state + 0, a.fast_state[0] / 2); }
+            }
+        }
+        if (r == 0) return;
+    }
     const int nl = a.ncell[b];
     const bool scatter = a.hit_valid[b] != 0;
     const int nq = scatter ? a.nqual[b] : 0;
@@ -655,6 +668,372 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
 #endif
 }
 
+// ---- kernel A'': the QUEUE form of the scatter kernel -----------------------------------------------------------------------
+// Same outputs as cand_mark_score_kernel (bitmaps, per-chunk counts, one stage-1 key per candidate of the hit set) for the corpus
+// shape the index is built for -- nearly every hit passage holds ONE surviving centroid -- with a third of the instructions:
+// the slot kernel is VALU-issue bound (~1250 wave instructions per wave and chunk in seven barrier-separated phases).
+//   mark     the probed cells' slices set the candidate bitmap; a surviving list's pair sets its hit bit with a RETURNING
+//            ds_or: the pair that finds the bit set marks the passage in a third bitmap ("several surviving centroids").
+//   barrier  (the only one of a chunk)
+//   words    bitmaps out, candidate / hit counts by one LDS atomic per wave; the wave that arrives last owns the chunk's
+//            totals: it writes the counts and reserves the chunk's key range with the global atomic, whose result is first
+//            read a whole chunk later.  The next chunk's slices are requested here.
+//   pairs    every (list, passage) pair again, from the registers it was loaded into: candidate and single -> the list's
+//            constant (see the slot kernel) as a key into an LDS buffer; candidate and several -> (passage, list) on a queue.
+//   deferred (one chunk later, after that chunk's barrier, when the key range is known) the staged keys go out in one coalesced
+//            pass; the queue is folded by half-waves: the entry with the lowest index among those of its passage gathers the
+//            others' score rows (column maxima on the order-preserving int encoding, ascending-k sum: the slot kernel's
+//            arithmetic, bit for bit) and writes the key at the END of the chunk's range.
+// Bitmaps, queue and counters rotate over three sets and the key buffer over two, so that a wave may run ahead into the next
+// chunk's marking while others still read this chunk's: each set is cleared / reset in the period after its last reader.
+// Eight waves and 65 KB of LDS: two workgroups per CU hide each other's barrier and LDS round trips.
+// What it does not handle it hands over whole, per query (fast_state[2 + b] != 0 -> the slot kernel redoes the query): more
+// staged keys or queued pairs than fit (a corpus whose clusters overlap: the slot kernel's dense form), more than 512 lists.
+// Two cumulative counters (queries handed over after trying / tried) switch a searcher whose queries mostly overflow to trying
+// one query in sixteen.
+#define CF_WAVES 8
+#define CF_THREADS (64 * CF_WAVES)
+#define CF_FC 16          // probed-cell lists per wave whose slices are requested a chunk ahead (ncells = 4: 128 cells)
+#define CF_FQ 8           // surviving lists per wave requested a chunk ahead and kept in registers for the pair pass
+#define CF_KCAP 1536      // keys of a chunk staged in LDS
+#define CF_QCAP 256       // queued pairs per chunk
+#define CF_MAXLISTS (64 * CF_WAVES)
+
+struct cf_chunk_state { int qn, ks, km, nh, base, pad0, pad1, pad2; };
+struct cf_slices { int c; int64_t beg; uint32_t s, e; int n; };   // one list per lane: list wave + CF_WAVES * lane
+__device__ __forceinline__ cf_slices cf_load_slices(const int32_t* ids, int n_total, int wave, int lane, const int64_t* ivf_offsets,
+                                                    const uint32_t* tab, int nchunks, int ch) {
+    cf_slices m;
+    m.n = wave < n_total ? (n_total - wave + CF_WAVES - 1) / CF_WAVES : 0;
+    m.c = 0; m.beg = 0; m.s = 0; m.e = 0;
+    if (lane < m.n) {
+        m.c = ids[wave + CF_WAVES * lane];
+        m.beg = ivf_offsets[m.c];
+        m.s = tab[(size_t)m.c * (nchunks + 1) + ch];
+        m.e = tab[(size_t)m.c * (nchunks + 1) + ch + 1];
+    }
+    return m;
+}
+// sum over the wave: row sums by DPP (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), the four rows on the scalar unit
+__device__ __forceinline__ int cf_wave_sum(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false);
+    return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
+}
+
+template <bool F16>
+__global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args a, int cpb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* bm = reinterpret_cast<uint32_t*>(smem);                          // [3][candidate | hit | several][CAND_CHUNK_WORDS]
+    uint64_t* kbuf = reinterpret_cast<uint64_t*>(bm + 9 * CAND_CHUNK_WORDS);   // [2][CF_KCAP]
+    uint32_t* queue = reinterpret_cast<uint32_t*>(kbuf + 2 * CF_KCAP);         // [3][CF_QCAP] passage (inside the chunk) | list << 16
+    float* sumbuf = reinterpret_cast<float*>(queue + 3 * CF_QCAP);             // [2 * CF_WAVES][32]
+    __shared__ cf_chunk_state st[3];
+    __shared__ int s_tot, s_arr, s_abort[2];   // s_abort[round & 1]: set during a round, read after the NEXT round's barrier
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, k = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int32_t* const redo = a.fast_state + 2 + b;
+    int32_t* const kcount = a.fast_state + 2 + a.nqueries + b;
+    const int nl = a.ncell[b], nq = a.nqual[b];
+    {
+        const int lost = a.fast_state[0], tried = a.fast_state[1];
+        const bool mostly_lost = tried >= 64 && 2 * lost > tried;
+        const bool ok = a.hit_valid[b] != 0 && nl <= CF_MAXLISTS && nq <= CF_MAXLISTS && (!mostly_lost || (b & 15) == 0);
+        if (!ok) {   // (block-uniform) left to the slot kernel without trying
+            if (blockIdx.y == 0 && tid == 0) *redo = 1;
+            return;
+        }
+    }
+    const int ch0 = blockIdx.y * cpb;
+    const int ch_end = ch0 + cpb < a.nchunks ? ch0 + cpb : a.nchunks;
+    cf_slices mc = cf_load_slices(a.cells + (size_t)b * a.max_cells, nl, wave, lane, a.ivf_offsets, a.chunk_tab, a.nchunks, ch0);
+    cf_slices mq = cf_load_slices(a.qual + (size_t)b * a.qmax, nq, wave, lane, a.ivf_offsets, a.chunk_tab, a.nchunks, ch0);
+    const int init = s1s_enc(-9999.0f);
+    const int qlen = a.q_lens ? a.q_lens[b] : a.nq_cand;
+    const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;  // <= 32 on this path
+    const float* cs_b = a.cs + (size_t)b * a.cs_query_stride;
+    uint64_t* keys_b = a.keys + (size_t)b * a.cand_cap;
+
+    auto list_ptr = [&](const cf_slices& m, int u) { return a.ivf_pids + s1s_bcast64(m.beg, u); };
+    // the first 64 entries of list u's slice [ls, le) (bounds of list u in lane u); every lane loads (lanes past the end repeat the
+    // last entry: a load inside a divergent branch would be waited for before the branch ends)
+    auto issue1 = [&](const cf_slices& m, int u, uint32_t ls, uint32_t le) {
+        int r = 0;
+        if (u < m.n) {   // wave-uniform
+            const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)ls, u), ev = (uint32_t)__builtin_amdgcn_readlane((int)le, u);
+            if (sv < ev) {
+                const uint32_t x = sv + lane;
+                r = list_ptr(m, u)[x < ev ? x : ev - 1u];
+            }
+        }
+        return r;
+    };
+    int raw_c[CF_FC], raw_q[CF_FQ], raw_qn[CF_FQ];
+#pragma unroll
+    for (int u = 0; u < CF_FC; u++) raw_c[u] = issue1(mc, u, mc.s, mc.e);
+#pragma unroll
+    for (int u = 0; u < CF_FQ; u++) { raw_q[u] = issue1(mq, u, mq.s, mq.e); raw_qn[u] = 0; }
+    // the stage-1 score of a passage whose only surviving centroid is this lane's list (see the slot kernel)
+    float rconst = 0.0f;
+    if (lane < mq.n) {
+        const float4* r4 = reinterpret_cast<const float4*>(cs_b + (size_t)(a.cs_compact ? wave + CF_WAVES * lane : mq.c) * 32);
+        float sc = 0.0f;
+#pragma unroll
+        for (int q4 = 0; q4 < 8; q4++) {
+            const float4 v = r4[q4];
+            const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int e = s1s_enc(x[i]);
+                const float m = s1s_dec(e > init ? e : init);
+                sc += q4 * 4 + i < nqc ? (F16 ? flmr_round_f16(m) : m) : 0.0f;
+            }
+        }
+        rconst = F16 ? flmr_round_f16(sc) : sc;
+    }
+    for (int e = tid; e < 9 * CAND_CHUNK_WORDS; e += CF_THREADS) bm[e] = 0u;
+    if (tid < 3) { st[tid].qn = 0; st[tid].ks = 0; st[tid].km = 0; st[tid].nh = 0; st[tid].base = 0; }
+    if (tid == 0) { s_tot = 0; s_arr = 0; s_abort[0] = 0; s_abort[1] = 0; }
+    s1s_sync();
+
+    int my_base = 0;
+    bool issuer = false;          // this wave arrived last in the previous chunk's count and holds its key base (wave-uniform)
+    int r3 = 0;                   // the chunk's set of bitmaps / queue / counters
+    for (int ch = ch0; ch <= ch_end; ch++) {   // (the last round only drains the last chunk's deferred work)
+        const bool live = ch < ch_end, prev = ch > ch0;
+        const int rp = r3 == 0 ? 2 : r3 - 1, rn = r3 == 2 ? 0 : r3 + 1;
+        const int pid0 = ch * CAND_CHUNK_PIDS;
+        uint32_t* const cb = bm + (r3 * 3 + 0) * CAND_CHUNK_WORDS;
+        uint32_t* const hb = bm + (r3 * 3 + 1) * CAND_CHUNK_WORDS;
+        uint32_t* const mb = bm + (r3 * 3 + 2) * CAND_CHUNK_WORDS;
+        uint64_t* const kb = kbuf + (ch & 1) * CF_KCAP;
+        uint32_t* const qu = queue + r3 * CF_QCAP;
+        uint32_t mc_e2 = 0, mq_e2 = 0;
+        if (ch + 1 < ch_end) {   // the end of the NEXT chunk's slices
+            if (lane < mc.n) mc_e2 = a.chunk_tab[(size_t)mc.c * (a.nchunks + 1) + ch + 2];
+            if (lane < mq.n) mq_e2 = a.chunk_tab[(size_t)mq.c * (a.nchunks + 1) + ch + 2];
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this chunk's slices (requested a chunk ago) and the previous chunk's key base
+        if (issuer) {
+            if (lane == 0) st[rp].base = my_base;
+            issuer = false;
+        }
+        if (live) {
+            // ---- mark ----
+#pragma unroll
+            for (int u = 0; u < CF_FC; u++) {
+                if (u < mc.n) {
+                    const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)mc.s, u), ev = (uint32_t)__builtin_amdgcn_readlane((int)mc.e, u);
+                    if (sv + lane < ev) {
+                        const int p = raw_c[u] - pid0;
+                        atomicOr(&cb[p >> 5], 1u << (p & 31));
+                    }
+                    if (ev - sv > 64u && sv < ev) {   // rare: the slice's entries beyond the first 64
+                        const int32_t* ptr = list_ptr(mc, u);
+                        for (uint32_t x = sv + 64 + lane; x < ev; x += 64) {
+                            const int p = ptr[x] - pid0;
+                            atomicOr(&cb[p >> 5], 1u << (p & 31));
+                        }
+                        S1S_DRAIN();
+                    }
+                }
+            }
+            for (int u = CF_FC; u < mc.n; u++) {   // rare: more than CF_FC lists per wave
+                const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)mc.s, u), ev = (uint32_t)__builtin_amdgcn_readlane((int)mc.e, u);
+                const int32_t* ptr = list_ptr(mc, u);
+                for (uint32_t x = sv + lane; x < ev; x += 64) {
+                    const int p = ptr[x] - pid0;
+                    atomicOr(&cb[p >> 5], 1u << (p & 31));
+                }
+                S1S_DRAIN();
+            }
+            auto mark_hit = [&](int p) {
+                const uint32_t bit = 1u << (p & 31);
+                const uint32_t old = atomicOr(&hb[p >> 5], bit);
+                if (old & bit) atomicOr(&mb[p >> 5], bit);
+            };
+#pragma unroll
+            for (int u = 0; u < CF_FQ; u++) {
+                if (u < mq.n) {
+                    const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)mq.s, u), ev = (uint32_t)__builtin_amdgcn_readlane((int)mq.e, u);
+                    if (sv + lane < ev) mark_hit(raw_q[u] - pid0);
+                    if (ev - sv > 64u && sv < ev) {
+                        const int32_t* ptr = list_ptr(mq, u);
+                        for (uint32_t x = sv + 64 + lane; x < ev; x += 64) mark_hit(ptr[x] - pid0);
+                        S1S_DRAIN();
+                    }
+                }
+            }
+            for (int u = CF_FQ; u < mq.n; u++) {
+                const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)mq.s, u), ev = (uint32_t)__builtin_amdgcn_readlane((int)mq.e, u);
+                const int32_t* ptr = list_ptr(mq, u);
+                for (uint32_t x = sv + lane; x < ev; x += 64) mark_hit(ptr[x] - pid0);
+                S1S_DRAIN();
+            }
+        }
+        s1s_sync();
+        if (s_abort[(ch + 1) & 1]) return;   // (block-uniform: written only before the barrier, never cleared)
+        if (live) {
+            // ---- words: bitmaps out, counts, clear the previous chunk's set ----
+            int mine = 0;
+#pragma unroll
+            for (int h = 0; h < CAND_CHUNK_WORDS / CF_THREADS; h++) {
+                const int w = tid + h * CF_THREADS;
+                const int64_t gw = (int64_t)ch * CAND_CHUNK_WORDS + w;
+                uint32_t cw = cb[w];
+                const uint32_t hw = hb[w];
+                if (gw < a.words) {
+                    a.cand_bits[(size_t)b * a.words + gw] = cw;
+                    a.hit_bits[(size_t)b * a.words + gw] = hw;
+                } else {
+                    cw = 0u;
+                }
+                mine += __popc(cw) | (__popc(cw & hw) << 16);
+                bm[(rp * 3 + 0) * CAND_CHUNK_WORDS + w] = 0u;
+                bm[(rp * 3 + 1) * CAND_CHUNK_WORDS + w] = 0u;
+                bm[(rp * 3 + 2) * CAND_CHUNK_WORDS + w] = 0u;
+            }
+            const int wsum = cf_wave_sum(mine);   // candidates | hit candidates << 16 (each <= 32768)
+            int last = 0;
+            if (lane == 0) {
+                atomicAdd(&s_tot, wsum);
+                if (atomicAdd(&s_arr, 1) == CF_WAVES - 1) {   // every wave's total is in
+                    const uint32_t tot = (uint32_t)atomicExch(&s_tot, 0);
+                    s_arr = 0;
+                    const int cnt = (int)(tot & 0xffffu), nh = (int)(tot >> 16);
+                    a.chunk_cnt[(size_t)b * a.nchunks + ch] = cnt;
+                    a.chunk_hits[(size_t)b * a.nchunks + ch] = nh;
+                    st[r3].nh = nh;
+                    if (nh > CF_KCAP) { s_abort[ch & 1] = 1; *redo = 2; }
+                    int zero = 0;
+                    asm volatile("" : "+v"(zero));   // (see the slot kernel: keeps the compiler's atomic optimiser off this atomic)
+                    my_base = atomicAdd(kcount + zero, nh);
+                    last = 1;
+                }
+            }
+            issuer = __builtin_amdgcn_readfirstlane(last) != 0;
+            // ---- the next chunk's slices ----
+            if (ch + 1 < ch_end) {
+#pragma unroll
+                for (int u = 0; u < CF_FC; u++) raw_c[u] = issue1(mc, u, mc.e, mc_e2);
+#pragma unroll
+                for (int u = 0; u < CF_FQ; u++) raw_qn[u] = issue1(mq, u, mq.e, mq_e2);
+            }
+            // ---- pairs ----
+            auto emit = [&](int p, int u) {
+                bool single = false, several = false;
+                if (p >= 0) {
+                    const uint32_t bit = 1u << (p & 31);
+                    const bool cand = (cb[p >> 5] & bit) != 0u, sev = (mb[p >> 5] & bit) != 0u;
+                    single = cand && !sev;
+                    several = cand && sev;
+                }
+                const uint64_t ms = __builtin_amdgcn_ballot_w64(single);
+                if (ms) {   // wave-uniform
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&st[r3].ks, __popcll(ms));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0u));
+                    if (single && pos < CF_KCAP)
+                        kb[pos] = flmr_make_key(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(rconst), u)), pid0 + p);
+                }
+                if (__builtin_amdgcn_ballot_w64(several)) {
+                    if (several) {
+                        const int at = atomicAdd(&st[r3].qn, 1);
+                        if (at < CF_QCAP) qu[at] = (uint32_t)p | ((uint32_t)(wave + CF_WAVES * u) << 16);
+                        else { s_abort[ch & 1] = 1; *redo = 2; }
+                    }
+                }
+            };
+#pragma unroll
+            for (int u = 0; u < CF_FQ; u++) {
+                if (u < mq.n) {
+                    const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)mq.s, u), ev = (uint32_t)__builtin_amdgcn_readlane((int)mq.e, u);
+                    if (sv < ev) emit(sv + lane < ev ? raw_q[u] - pid0 : -1, u);
+                }
+            }
+            for (int u = 0; u < mq.n; u++) {   // rare: slices longer than 64 entries, lists beyond the first CF_FQ of a wave
+                const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)mq.s, u), ev = (uint32_t)__builtin_amdgcn_readlane((int)mq.e, u);
+                const uint32_t from = u < CF_FQ ? sv + 64u : sv;
+                if (from < ev) {
+                    const int32_t* ptr = list_ptr(mq, u);
+                    for (uint32_t x0 = from; x0 < ev; x0 += 64) {
+                        emit(x0 + lane < ev ? ptr[x0 + lane] - pid0 : -1, u);
+                        S1S_DRAIN();
+                    }
+                }
+            }
+        }
+        if (prev) {
+            // ---- deferred: the previous chunk's keys ----
+            const cf_chunk_state& S = st[rp];
+            const int base = S.base, nh = S.nh, qn = S.qn;
+            const int ns = S.ks < CF_KCAP ? S.ks : CF_KCAP;
+            const uint64_t* kp = kbuf + ((ch - 1) & 1) * CF_KCAP;
+            for (int t = tid; t < ns; t += CF_THREADS)
+                if ((int64_t)base + t < a.cand_cap) keys_b[(int64_t)base + t] = kp[t];
+            if (qn > 0) {   // block-uniform
+                const uint32_t* qp = queue + rp * CF_QCAP;
+                const int pid0p = (ch - 1) * CAND_CHUNK_PIDS;
+                const int hw = tid >> 5, hi = lane >> 5;
+                float* sb = sumbuf + hw * 32;
+                for (int e0 = 0; e0 < qn; e0 += 2 * CF_WAVES) {
+                    const int e = e0 + hw;
+                    const bool act = e < qn;
+                    const uint32_t pid = act ? (qp[e] & 0xffffu) : 0xffffffffu;
+                    // leader = the lowest entry of the passage; it folds the rows of all of them
+                    bool leader = act;
+                    int menc = init;
+                    for (int i0 = 0; i0 < qn; i0 += 32) {   // (block-uniform bounds)
+                        const int i = i0 + k;
+                        const uint32_t ent = i < qn ? qp[i] : 0xffffffffu;
+                        const bool same = (ent & 0xffffu) == pid && i < qn;
+                        const uint64_t bal = __builtin_amdgcn_ballot_w64(same);
+                        uint32_t hm = hi ? (uint32_t)(bal >> 32) : (uint32_t)bal;   // this half-wave's members in [i0, i0 + 32)
+                        if (hm && i0 + (int)__ffs(hm) - 1 < e) leader = false;
+                        if (!leader) hm = 0u;
+                        while (hm) {
+                            const int m = i0 + (int)__ffs(hm) - 1;
+                            hm &= hm - 1u;
+                            const int lj = (int)(qp[m] >> 16);
+                            const int c = a.cs_compact ? lj : a.qual[(size_t)b * a.qmax + lj];
+                            const int v = s1s_enc(cs_b[(size_t)c * 32 + k]);
+                            menc = v > menc ? v : menc;
+                        }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(leader)) {   // wave-uniform
+                        const float mv = s1s_dec(menc);
+                        sb[k] = k < nqc ? (F16 ? flmr_round_f16(mv) : mv) : 0.0f;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+                        if (leader && k == 0) {
+                            float sc = 0.0f;
+#pragma unroll
+                            for (int q = 0; q < 32; q++) sc += sb[q];   // ascending k (filter_pids.cpp:59-63)
+                            if (F16) sc = flmr_round_f16(sc);
+                            const int64_t pos = (int64_t)base + nh - 1 - atomicAdd(&st[rp].km, 1);
+                            if (pos >= base && pos < a.cand_cap) keys_b[pos] = flmr_make_key(sc, pid0p + (int)pid);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+        }
+        // the counters of the set the NEXT chunk uses: their last readers (the deferred pass of the previous round) are behind this
+        // round's barrier
+        if (tid == 0) { st[rn].qn = 0; st[rn].ks = 0; st[rn].km = 0; }
+        // next chunk
+        mc.s = mc.e; mc.e = mc_e2;
+        mq.s = mq.e; mq.e = mq_e2;
+#pragma unroll
+        for (int u = 0; u < CF_FQ; u++) raw_q[u] = raw_qn[u];
+        r3 = rn;
+    }
+}
+
 // ---- kernel B: bitmap chunk -> ascending pids at the chunk's global rank, one hit flag per candidate --------------------------
 __global__ __launch_bounds__(1024) void cand_emit_kernel(const uint32_t* cand_bits, const uint32_t* hit_bits, int64_t words,
                                                          const int32_t* chunk_cnt, int nchunks, int32_t* cand, int64_t cand_cap,
@@ -738,7 +1117,7 @@ __global__ __launch_bounds__(1024) void cand_emit_kernel(const uint32_t* cand_bi
 int flmr_launch_qualifying(const flmr_cand_args& a, hipStream_t st) {
     hipLaunchKernelGGL(qualifying_kernel, dim3(a.nqueries), dim3(1024), 0, st, a.idx_bits, a.idx_words, a.ivf_offsets, a.cells,
                        a.ncell, a.max_cells, a.qual, a.nqual, a.qmax, 1 << S1S_IDBITS, a.hit_valid, nullptr, 2, a.idx_prefix, a.rows_out,
-                       a.cen16, a.q_hi, a.q_lo, a.overflow);
+                       a.cen16, a.q_hi, a.q_lo, a.overflow, nullptr);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }
@@ -746,7 +1125,7 @@ int flmr_launch_qualifying(const flmr_cand_args& a, hipStream_t st) {
 int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
     hipLaunchKernelGGL(qualifying_kernel, dim3(a.nqueries), dim3(1024), 0, st, a.idx_bits, a.idx_words, a.ivf_offsets, a.cells,
                        a.ncell, a.max_cells, a.qual, a.nqual, a.qmax, 1 << S1S_IDBITS, a.hit_valid, a.scatter ? a.key_count : nullptr,
-                       a.scatter ? 8 : 2, a.idx_prefix, a.rows_out, a.cen16, a.q_hi, a.q_lo, a.overflow);
+                       a.scatter ? 8 : 2, a.idx_prefix, a.rows_out, a.cen16, a.q_hi, a.q_lo, a.overflow, a.scatter ? a.fast_state : nullptr);
     if (a.scatter) {
         const size_t lds = (size_t)CAND_CHUNK_WORDS * (2 * sizeof(uint32_t) + 2 * sizeof(uint16_t)) +
                            ((size_t)S1S_SLOTS * S1S_STRIDE + 96 + 1024 + S1S_QCAP) * sizeof(int) + S1S_QCAP * sizeof(uint16_t);   // + scratch words of slot-less lanes, list constants, queue (+ its passages)
@@ -757,6 +1136,18 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
         // chunk table, list constants -- costs about a third of a chunk; 8 vs 4 measured -3 % at 256 queries x 31 chunks)
         int cpb = 8;
         while (cpb > 1 && (int64_t)a.nqueries * ((a.nchunks + cpb - 1) / cpb) < 512) cpb >>= 1;
+        if (a.fast_state) {   // the queue form first; what it hands over (fast_state) is done by the slot kernel below
+            const size_t flds = (size_t)9 * CAND_CHUNK_WORDS * sizeof(uint32_t) + (size_t)2 * CF_KCAP * sizeof(uint64_t) +
+                                (size_t)3 * CF_QCAP * sizeof(uint32_t) + (size_t)2 * CF_WAVES * 32 * sizeof(float);
+            const void* ffn = a.f16_round ? reinterpret_cast<const void*>(cand_fast_kernel<true>) : reinterpret_cast<const void*>(cand_fast_kernel<false>);
+            FLMR_HIP(hipFuncSetAttribute(ffn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+            int fcpb = 8;   // two resident workgroups per CU: twice the slot kernel's workgroups
+            while (fcpb > 1 && (int64_t)a.nqueries * ((a.nchunks + fcpb - 1) / fcpb) < 1024) fcpb >>= 1;
+            if (a.f16_round)
+                hipLaunchKernelGGL(cand_fast_kernel<true>, dim3(a.nqueries, (a.nchunks + fcpb - 1) / fcpb), dim3(CF_THREADS), flds, st, a, fcpb);
+            else
+                hipLaunchKernelGGL(cand_fast_kernel<false>, dim3(a.nqueries, (a.nchunks + fcpb - 1) / fcpb), dim3(CF_THREADS), flds, st, a, fcpb);
+        }
         if (a.f16_round)
             hipLaunchKernelGGL(cand_mark_score_kernel<true>, dim3(a.nqueries, (a.nchunks + cpb - 1) / cpb), dim3(64 * S1S_WAVES), lds, st, a, cpb);
         else
@@ -771,6 +1162,14 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
                     (double)h[5] / h[10], (double)h[6] / h[10], (double)h[7] / h[10], (double)h[8] / h[10], (double)h[9] / h[10]);
             unsigned long long z[12] = {};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(s1s_prof), z, sizeof(z));
+            int nqh[1024], nch[1024];
+            const int nb = a.nqueries < 1024 ? a.nqueries : 1024;
+            (void)hipMemcpy(nqh, a.nqual, nb * sizeof(int), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(nch, a.ncell, nb * sizeof(int), hipMemcpyDeviceToHost);
+            long sq = 0, sc = 0; int mq = 0;
+            for (int i = 0; i < nb; i++) { sq += nqh[i]; sc += nch[i]; mq = nqh[i] > mq ? nqh[i] : mq; }
+            fprintf(stderr, "[s1s] queries %d cpb %d nchunks %d: surviving lists mean %.1f max %d, probed cells mean %.1f\n", a.nqueries, cpb, a.nchunks,
+                    (double)sq / nb, mq, (double)sc / nb);
         }
 #endif
     } else {

@@ -43,7 +43,7 @@ enum flmr_opt_id {
     FLMR_OPT_FULL_TABLE,     // set: keep the whole centroid-score table
     FLMR_OPT_CAND_IMPL,      // atomic: first candidate-generation implementation
     FLMR_OPT_S1_NO_HITMAP,   // set: no hit prefilter
-    FLMR_OPT_S1_IMPL,        // scan: code-scanning stage 1 for every query
+    FLMR_OPT_S1_IMPL,        // scan: code-scanning stage 1 for every query | slots: the slot form of the scatter kernel for every query (default: its queue form first)
     FLMR_OPT_S2_IMPL,        // xcda (approximate-then-refine on the sliced kernel: the default where the sliced kernel is) | xcd | walk | lds | ldsb | regs: force the XCD-sliced gather / the dense walk / the LDS-DMA gather (4-wave blocks; 16-wave blocks with the query operand in LDS) / the register gather (default: cost model)
     FLMR_OPT_S0_STAGED,      // set: staged epilogue for every tile
     FLMR_OPT_S3_NO_MULTIQ,   // set: single-tile MaxSim kernel for long queries too
@@ -223,6 +223,10 @@ struct flmr_cand_args {
     int32_t* chunk_hits;                  // [nqueries, nchunks] candidates of the chunk that are in the hit set (scatter mode)
     int32_t n_select;                     // how many keys the selection after stage 1 keeps (ndocs)
     int32_t f16_round;                    // see flmr_filter_args
+    // the queue form of the scatter kernel (cand_fast_kernel) and its hand-over to the slot form: [0, B) "this query is left to
+    // the slot kernel", [B, 2B) the queue kernel's own key counters, then two cumulative counters (queries handed over after
+    // trying / queries tried).  NULL: slot kernel only (FLMR_S1_IMPL=slots)
+    int32_t* fast_state;
 };
 int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st);
 int flmr_launch_qualifying(const flmr_cand_args& a, hipStream_t st);   // list + ranks + compact score rows only

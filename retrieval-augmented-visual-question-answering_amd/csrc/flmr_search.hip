@@ -42,6 +42,7 @@ struct flmr_searcher {
     uint2* s3_desc; int64_t s3_desc_stride; int32_t* s3_wbeg; int32_t s3_wcap;   // planned-tile S3 (NULL: the passage-walking kernel)
     float* s3_colmax; int64_t s3_colmax_cap;   // long queries: per (query, finalist, column) maxima of the query-stationary S3 kernel
     int32_t* qual; int32_t* nqual; int32_t* chunk_cnt; uint8_t* cand_hit; int32_t qmax;
+    int32_t* cand_fast;         // flmr_cand_args::fast_state ([2 * max_queries + 2]; the two counters at its end live as long as the searcher)
     // last call (for taps)
     int32_t last_nqueries, last_ncol, last_ndocs, last_full_table;
     flmr_cand_args last_ca{};   // candidate-stage arguments of the last batch (lazy FLMR_TAP_CANDIDATES in scatter mode)
@@ -189,6 +190,13 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
             }
         }
     }
+    {
+        int32_t* p = nullptr;
+        rc = ws_alloc(s, &p, 2 * B + 2);
+        if (rc) { flmr_searcher_destroy(s); return rc; }
+        s->cand_fast = p;
+        FLMR_HIP(hipMemset(s->cand_fast, 0, (2 * B + 2) * sizeof(int32_t)));
+    }
     FLMR_HIP(hipMemset(s->overflow, 0, 4 * sizeof(int32_t)));
     FLMR_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->status_host), 4 * sizeof(int32_t), hipHostMallocDefault));
     s->status_host[0] = s->status_host[1] = s->status_host[2] = s->status_host[3] = 0;
@@ -203,7 +211,7 @@ extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
     if (!s) return FLMR_OK;
     void* ptrs[] = {s->cs, s->rows, s->idx_prefix, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
                     s->keys1, s->s1_pids, s->s1_count, s->keys2, s->s2_pids, s->s2_count, s->keys3, s->doc_scores,
-                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->q_err, s->q_err_sum, s->s2_band, s->s2_band_count, s->s2_need, s->s2_def, s->keys2b, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->chunk_hits, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part, s->s3_desc, s->s3_wbeg, s->s3_colmax};
+                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->q_err, s->q_err_sum, s->s2_band, s->s2_band_count, s->s2_need, s->s2_def, s->keys2b, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->chunk_hits, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part, s->s3_desc, s->s3_wbeg, s->s3_colmax, s->cand_fast};
     for (void* p : ptrs) (void)hipFree(p);
     if (s->status_host) (void)hipHostFree(s->status_host);
     if (s->status_ev) (void)hipEventDestroy(s->status_ev);
@@ -527,6 +535,7 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
         ca.rows_out = c.sparse ? s->rows : nullptr; ca.cen16 = ix->centroids_f16; ca.q_hi = s->q_hi; ca.q_lo = s->q_lo;
         ca.keys = s->keys1; ca.key_count = s->key_count; ca.chunk_hits = s->chunk_hits; ca.n_select = c.p.ndocs;
         ca.f16_round = c.f.f16_round;
+        ca.fast_state = s->opt.is(FLMR_OPT_S1_IMPL, "slots") ? nullptr : s->cand_fast;
     }
     if (chunked) {
         RUN(flmr_launch_candidates_chunked(ca, st));
@@ -820,6 +829,8 @@ extern "C" int flmr_searcher_tap(flmr_searcher_t* s, int32_t what, int32_t q, vo
             n = s->last_hi_first ? 32 : 0; src = s->q_err + (size_t)q * s->ncol_max; break;
         case FLMR_TAP_Q_ERR_SUM:
             n = s->last_hi_first ? 1 : 0; src = s->q_err_sum + q; break;
+        case FLMR_TAP_STAGE1_FORM:
+            n = (s->last_ca.scatter && s->last_ca.fast_state) ? 1 : 0; src = s->cand_fast + 2 + q; break;
         default: FLMR_FAIL(FLMR_ERR_INVALID, "unknown tap %d", what);
     }
     *count = n;

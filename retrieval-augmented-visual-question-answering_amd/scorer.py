@@ -437,7 +437,7 @@ class IndexScorer:
         cap = {_native.TAP_CENTROID_SCORES: K * 128, _native.TAP_IDX_BITS: (K + 31) // 32,
                _native.TAP_CELLS: 1024, _native.TAP_CANDIDATES: self.arrays.num_passages,
                _native.TAP_STAGE1: 8192, _native.TAP_STAGE2: 2048, _native.TAP_DOC_SCORES: 2048,
-               _native.TAP_Q_ERR: 32, _native.TAP_Q_ERR_SUM: 1}[what]
+               _native.TAP_Q_ERR: 32, _native.TAP_Q_ERR_SUM: 1, _native.TAP_STAGE1_FORM: 1}[what]
         dt = {_native.TAP_CENTROID_SCORES: np.float32, _native.TAP_IDX_BITS: np.uint32, _native.TAP_DOC_SCORES: np.float32,
               _native.TAP_Q_ERR: np.float32, _native.TAP_Q_ERR_SUM: np.float32}.get(what, np.int32)
         buf = np.empty(max(cap, 1), dtype=dt)

@@ -207,7 +207,9 @@ def test_s0_query_stationary_equals_row_stationary(hip, K, npass, nq_list, thr):
                 p, s, c = scorer.search_batch(Q, 16, 2, thr, 64, 32, q_lens=q_lens)
                 torch.cuda.synchronize()
                 scorer.check()
-                taps = [[scorer.tap(t, q) for t in (nat.TAP_IDX_BITS, nat.TAP_CELLS, nat.TAP_CANDIDATES, nat.TAP_STAGE1)]
+                # (the stage-1 survivors are a SET: their order follows the key positions, which the queue form of the scatter
+                # kernel hands out with atomics)
+                taps = [[scorer.tap(t, q) for t in (nat.TAP_IDX_BITS, nat.TAP_CELLS, nat.TAP_CANDIDATES)] + [np.sort(scorer.tap(nat.TAP_STAGE1, q))]
                         for q in range(nb)]
                 outs[impl, nb] = (p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), taps)
         a, b = outs["f16rs", nb], outs[None, nb]
@@ -617,11 +619,17 @@ def test_query_split_stage0_equals_unsharded(hip, nshards):
             assert np.array_equal(bits[q].cpu().numpy(), ref_bits), q
             ref_cells = single.tap(pkg._native.TAP_CELLS, 0)
             assert np.array_equal(cells[q, :int(ncell[q])].cpu().numpy(), ref_cells), q
-        s1 = exchange([sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32, q_lens=q_lens) for sh in shards], ndocs)
-        s1_sorted = exchange([sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32, q_lens=q_lens) for sh in shards], ndocs, ordered=True)
+        keys1 = [sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32, q_lens=q_lens) for sh in shards]
+        s1 = exchange(keys1, ndocs)
+        s1_sorted = exchange(keys1, ndocs, ordered=True)
         # every rank derives this list on its own from the same gathered keys: the select must be reproducible
         for _ in range(3):
-            assert torch.equal(s1, exchange([sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32, q_lens=q_lens) for sh in shards], ndocs))
+            assert torch.equal(s1, exchange(keys1, ndocs))
+        # a rank's phase-1 keys are a SET (their order follows the key positions the scatter stage 1 hands out with atomics):
+        # running phase 1 again must give the same set
+        for _ in range(2):
+            again = [sh.phase1_probed(Q, k, ncells, thr, ndocs, bits, cells, ncell, 32, q_lens=q_lens) for sh in shards]
+            assert torch.equal(s1_sorted, exchange(again, ndocs, ordered=True))
         u = lambda t: t.cpu().numpy().view(np.uint64)                                   # keys are u64 bit patterns
         assert np.array_equal(np.sort(u(s1), axis=1)[:, ::-1], u(s1_sorted))             # same set as the bitonic top-n
         # phase-2/3 outputs are slot-aligned with the global list: one non-zero contributor per slot -> SUM "all-reduce"

@@ -363,3 +363,45 @@ def test_long_query_kernel_scales_per_query(hip):
         mag = float(np.max(np.abs(outs["regs"]))) + 1e-30
         assert np.max(np.abs(outs["qs"] - outs["regs"])) <= 2e-6 * mag, (scale, np.max(np.abs(outs["qs"] - outs["regs"])), mag)
     scorer.close_searcher()
+
+
+@pytest.mark.parametrize("policy", [(2, 0.45, 1024), (4, 0.4, 4096)])
+def test_stage1_queue_form_equals_slot_form_and_code_scan(hip, policy):
+    """The list-scatter stage 1 has two forms: the queue form (cand_fast_kernel: one barrier per chunk, single-centroid
+    passages scored by their list's constant, the pairs of the others queued) runs first and hands the queries it cannot
+    finish to the slot form (cand_mark_score_kernel).  On a corpus of the bench's shape (hundreds of thousands of passages,
+    K in the tens of thousands: ~30 entries per list and 32768-passage chunk) nearly every query must stay in the queue form, and
+    its survivors, their order after the selection, and the final ranking must be IDENTICAL to the slot form's and to the
+    code-scanning stage 1 (filter_pids.cpp:27-69).  Ragged lengths and an empty query included."""
+    torch, nat = hip["torch"], hip["native"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    ncells, thr, ndocs = policy
+    corpus = synth.make_corpus(300_000, (16, 112), 65536, 2, seed=21, device="cuda")
+    nqueries = 40
+    Q, _ = synth.make_queries(corpus, nqueries, 32, seed=22)
+    q_lens = torch.full((nqueries,), 32, dtype=torch.int32)
+    q_lens[3], q_lens[7], q_lens[11] = 9, 0, 31
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=64)
+    outs, forms = {}, None
+    for tag, env in (("queue", {}), ("slots", {"FLMR_S1_IMPL": "slots"}), ("scan", {"FLMR_S1_IMPL": "scan"})):
+        with nat.options(**env):
+            Qw, _ = synth.make_queries(corpus, 8, 32, seed=23)
+            scorer.search_batch(Qw, ndocs // 4, ncells, thr, ndocs, 32)   # (no form may live off the previous one's workspace)
+            p, s, c = scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=q_lens)
+            scorer.check()
+            if tag == "queue":
+                forms = [int(scorer.tap(nat.TAP_STAGE1_FORM, i)[0]) for i in range(nqueries)]
+            else:
+                assert scorer.tap(nat.TAP_STAGE1_FORM, 0).size == 0   # (the queue form did not run)
+            outs[tag] = ([np.sort(scorer.tap(nat.TAP_STAGE1, i)) for i in range(nqueries)],
+                         [scorer.tap(nat.TAP_STAGE2, i) for i in range(nqueries)], p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy())
+    print("stage-1 forms:", forms)
+    assert sum(1 for f in forms if f == 0) >= nqueries - 4, forms
+    for tag in ("slots", "scan"):
+        for i in range(nqueries):
+            assert np.array_equal(outs["queue"][0][i], outs[tag][0][i]), (tag, i)
+            assert np.array_equal(outs["queue"][1][i], outs[tag][1][i]), (tag, i)
+        for a, b in zip(outs["queue"][2:], outs[tag][2:]):
+            assert np.array_equal(a, b), tag
+    scorer.close_searcher()
