@@ -698,6 +698,7 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
 #define CF_KCAP 1536      // keys of a chunk staged in LDS
 #define CF_QCAP 256       // queued pairs per chunk
 #define CF_MAXLISTS (64 * CF_WAVES)
+#define CF_RC 64          // surviving lists whose score rows are kept in LDS for the queued pairs (the others are read from memory)
 
 struct cf_chunk_state { int qn, ks, km, nh, base, pad0, pad1, pad2; };
 struct cf_slices { int c; int64_t beg; uint32_t s, e; int n; };   // one list per lane: list wave + CF_WAVES * lane
@@ -723,13 +724,20 @@ __device__ __forceinline__ int cf_wave_sum(int x) {
     return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
 }
 
+#ifdef CF_PROFILE   // development only: per-phase clocks of wave 0, summed over the grid and printed by the launcher
+__device__ unsigned long long cf_prof[12];
+#define CF_STAMP(k) do { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); pt[k] += now_ - plast; plast = now_; } while (0)
+#else
+#define CF_STAMP(k) do { } while (0)
+#endif
+
 template <bool F16>
 __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args a, int cpb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* bm = reinterpret_cast<uint32_t*>(smem);                          // [3][candidate | hit | several][CAND_CHUNK_WORDS]
     uint64_t* kbuf = reinterpret_cast<uint64_t*>(bm + 9 * CAND_CHUNK_WORDS);   // [2][CF_KCAP]
     uint32_t* queue = reinterpret_cast<uint32_t*>(kbuf + 2 * CF_KCAP);         // [3][CF_QCAP] passage (inside the chunk) | list << 16
-    float* sumbuf = reinterpret_cast<float*>(queue + 3 * CF_QCAP);             // [2 * CF_WAVES][32]
+    int* rows = reinterpret_cast<int*>(queue + 3 * CF_QCAP);                   // [CF_RC][32] score rows of the query's first surviving lists (order-encoded, floored)
     __shared__ cf_chunk_state st[3];
     __shared__ int s_tot, s_arr, s_abort[2];   // s_abort[round & 1]: set during a round, read after the NEXT round's barrier
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, k = lane & 31;
@@ -759,9 +767,9 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
     auto list_ptr = [&](const cf_slices& m, int u) { return a.ivf_pids + s1s_bcast64(m.beg, u); };
     // the first 64 entries of list u's slice [ls, le) (bounds of list u in lane u); every lane loads (lanes past the end repeat the
     // last entry: a load inside a divergent branch would be waited for before the branch ends)
-    auto issue1 = [&](const cf_slices& m, int u, uint32_t ls, uint32_t le) {
+    auto issue1 = [&](const cf_slices& m, int n, int u, uint32_t ls, uint32_t le) {
         int r = 0;
-        if (u < m.n) {   // wave-uniform
+        if (u < n) {   // wave-uniform
             const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)ls, u), ev = (uint32_t)__builtin_amdgcn_readlane((int)le, u);
             if (sv < ev) {
                 const uint32_t x = sv + lane;
@@ -772,9 +780,9 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
     };
     int raw_c[CF_FC], raw_q[CF_FQ], raw_qn[CF_FQ];
 #pragma unroll
-    for (int u = 0; u < CF_FC; u++) raw_c[u] = issue1(mc, u, mc.s, mc.e);
+    for (int u = 0; u < CF_FC; u++) raw_c[u] = issue1(mc, mc.n, u, mc.s, mc.e);
 #pragma unroll
-    for (int u = 0; u < CF_FQ; u++) { raw_q[u] = issue1(mq, u, mq.s, mq.e); raw_qn[u] = 0; }
+    for (int u = 0; u < CF_FQ; u++) { raw_q[u] = issue1(mq, mq.n, u, mq.s, mq.e); raw_qn[u] = 0; }
     // the stage-1 score of a passage whose only surviving centroid is this lane's list (see the slot kernel)
     float rconst = 0.0f;
     if (lane < mq.n) {
@@ -793,11 +801,21 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
         }
         rconst = F16 ? flmr_round_f16(sc) : sc;
     }
+    const uint32_t rord = flmr_f2ord(rconst);   // the key's score half, once per list
+    for (int j = tid >> 5; j < nq && j < CF_RC; j += 2 * CF_WAVES) {
+        const int c = a.cs_compact ? j : a.qual[(size_t)b * a.qmax + j];
+        const int v = s1s_enc(cs_b[(size_t)c * 32 + k]);
+        rows[j * 32 + k] = v > init ? v : init;
+    }
     for (int e = tid; e < 9 * CAND_CHUNK_WORDS; e += CF_THREADS) bm[e] = 0u;
     if (tid < 3) { st[tid].qn = 0; st[tid].ks = 0; st[tid].km = 0; st[tid].nh = 0; st[tid].base = 0; }
     if (tid == 0) { s_tot = 0; s_arr = 0; s_abort[0] = 0; s_abort[1] = 0; }
     s1s_sync();
 
+#ifdef CF_PROFILE
+    long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long plast = (long long)__builtin_amdgcn_s_memtime();
+#endif
     int my_base = 0;
     bool issuer = false;          // this wave arrived last in the previous chunk's count and holds its key base (wave-uniform)
     int r3 = 0;                   // the chunk's set of bitmaps / queue / counters
@@ -815,16 +833,22 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
             if (lane < mc.n) mc_e2 = a.chunk_tab[(size_t)mc.c * (a.nchunks + 1) + ch + 2];
             if (lane < mq.n) mq_e2 = a.chunk_tab[(size_t)mq.c * (a.nchunks + 1) + ch + 2];
         }
+        CF_STAMP(0);
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this chunk's slices (requested a chunk ago) and the previous chunk's key base
+        CF_STAMP(1);
         if (issuer) {
             if (lane == 0) st[rp].base = my_base;
             issuer = false;
         }
         if (live) {
             // ---- mark ----
+            // (the list counts are made opaque once per phase: otherwise the 24 "u < n" tests of the unrolled loops are computed
+            // once before the chunk loop and kept in spilled scalar registers, two v_readlane per use)
+            int ncl = mc.n, nql = mq.n;
+            asm volatile("" : "+s"(ncl), "+s"(nql));
 #pragma unroll
             for (int u = 0; u < CF_FC; u++) {
-                if (u < mc.n) {
+                if (u < ncl) {
                     const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)mc.s, u), ev = (uint32_t)__builtin_amdgcn_readlane((int)mc.e, u);
                     if (sv + lane < ev) {
                         const int p = raw_c[u] - pid0;
@@ -856,7 +880,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
             };
 #pragma unroll
             for (int u = 0; u < CF_FQ; u++) {
-                if (u < mq.n) {
+                if (u < nql) {
                     const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)mq.s, u), ev = (uint32_t)__builtin_amdgcn_readlane((int)mq.e, u);
                     if (sv + lane < ev) mark_hit(raw_q[u] - pid0);
                     if (ev - sv > 64u && sv < ev) {
@@ -873,7 +897,9 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
                 S1S_DRAIN();
             }
         }
+        CF_STAMP(2);
         s1s_sync();
+        CF_STAMP(3);
         if (s_abort[(ch + 1) & 1]) return;   // (block-uniform: written only before the barrier, never cleared)
         if (live) {
             // ---- words: bitmaps out, counts, clear the previous chunk's set ----
@@ -914,13 +940,17 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
                 }
             }
             issuer = __builtin_amdgcn_readfirstlane(last) != 0;
+            CF_STAMP(4);
             // ---- the next chunk's slices ----
             if (ch + 1 < ch_end) {
+                int ncp = mc.n, nqp = mq.n;
+                asm volatile("" : "+s"(ncp), "+s"(nqp));
 #pragma unroll
-                for (int u = 0; u < CF_FC; u++) raw_c[u] = issue1(mc, u, mc.e, mc_e2);
+                for (int u = 0; u < CF_FC; u++) raw_c[u] = issue1(mc, ncp, u, mc.e, mc_e2);
 #pragma unroll
-                for (int u = 0; u < CF_FQ; u++) raw_qn[u] = issue1(mq, u, mq.e, mq_e2);
+                for (int u = 0; u < CF_FQ; u++) raw_qn[u] = issue1(mq, nqp, u, mq.e, mq_e2);
             }
+            CF_STAMP(5);
             // ---- pairs ----
             auto emit = [&](int p, int u) {
                 bool single = false, several = false;
@@ -937,7 +967,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
                     base = __builtin_amdgcn_readfirstlane(base);
                     const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0u));
                     if (single && pos < CF_KCAP)
-                        kb[pos] = flmr_make_key(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(rconst), u)), pid0 + p);
+                        kb[pos] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rord, u) << 32) | (uint32_t)(pid0 + p);
                 }
                 if (__builtin_amdgcn_ballot_w64(several)) {
                     if (several) {
@@ -947,11 +977,62 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
                     }
                 }
             };
+            {   // the first groups, from the registers they were loaded into: every list's LDS reads first, ONE position atomic per wave
+                int nqe = mq.n;
+                asm volatile("" : "+s"(nqe));
+                int pp[CF_FQ];
+                uint32_t cw_[CF_FQ], mw_[CF_FQ];
 #pragma unroll
-            for (int u = 0; u < CF_FQ; u++) {
-                if (u < mq.n) {
-                    const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)mq.s, u), ev = (uint32_t)__builtin_amdgcn_readlane((int)mq.e, u);
-                    if (sv < ev) emit(sv + lane < ev ? raw_q[u] - pid0 : -1, u);
+                for (int u = 0; u < CF_FQ; u++) {
+                    pp[u] = -1; cw_[u] = 0u; mw_[u] = 0u;
+                    if (u < nqe) {
+                        const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)mq.s, u), ev = (uint32_t)__builtin_amdgcn_readlane((int)mq.e, u);
+                        const int p = raw_q[u] - pid0;
+                        const bool ok = sv + lane < ev;
+                        pp[u] = ok ? p : -1;
+                        const int w = ok ? p >> 5 : 0;
+                        cw_[u] = cb[w]; mw_[u] = mb[w];
+                    }
+                }
+                uint64_t ms[CF_FQ];
+                int total = 0;
+                bool anysev = false;
+#pragma unroll
+                for (int u = 0; u < CF_FQ; u++) {
+                    ms[u] = 0ull;
+                    if (u < nqe) {
+                        const uint32_t bit = 1u << (pp[u] & 31);
+                        const bool cand = pp[u] >= 0 && (cw_[u] & bit) != 0u, sev = (mw_[u] & bit) != 0u;
+                        ms[u] = __builtin_amdgcn_ballot_w64(cand && !sev);
+                        total += __popcll(ms[u]);
+                        anysev |= cand && sev;
+                    }
+                }
+                if (total) {   // wave-uniform
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&st[r3].ks, total);
+                    base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+                    for (int u = 0; u < CF_FQ; u++) {
+                        if (u < nqe) {
+                            const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ms[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms[u], 0u));
+                            const bool single = (ms[u] >> lane) & 1ull;
+                            if (single && pos < CF_KCAP)
+                                kb[pos] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rord, u) << 32) | (uint32_t)(pid0 + pp[u]);
+                            base += __popcll(ms[u]);
+                        }
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(anysev)) {   // wave-uniform; rare per list
+#pragma unroll
+                    for (int u = 0; u < CF_FQ; u++) {
+                        const bool sev = u < nqe && pp[u] >= 0 && (cw_[u] & mw_[u] & (1u << (pp[u] & 31))) != 0u;
+                        if (sev) {
+                            const int at = atomicAdd(&st[r3].qn, 1);
+                            if (at < CF_QCAP) qu[at] = (uint32_t)pp[u] | ((uint32_t)(wave + CF_WAVES * u) << 16);
+                            else { s_abort[ch & 1] = 1; *redo = 2; }
+                        }
+                    }
                 }
             }
             for (int u = 0; u < mq.n; u++) {   // rare: slices longer than 64 entries, lists beyond the first CF_FQ of a wave
@@ -966,6 +1047,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
                 }
             }
         }
+        CF_STAMP(6);
         if (prev) {
             // ---- deferred: the previous chunk's keys ----
             const cf_chunk_state& S = st[rp];
@@ -978,7 +1060,6 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
                 const uint32_t* qp = queue + rp * CF_QCAP;
                 const int pid0p = (ch - 1) * CAND_CHUNK_PIDS;
                 const int hw = tid >> 5, hi = lane >> 5;
-                float* sb = sumbuf + hw * 32;
                 for (int e0 = 0; e0 < qn; e0 += 2 * CF_WAVES) {
                     const int e = e0 + hw;
                     const bool act = e < qn;
@@ -998,30 +1079,35 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
                             const int m = i0 + (int)__ffs(hm) - 1;
                             hm &= hm - 1u;
                             const int lj = (int)(qp[m] >> 16);
-                            const int c = a.cs_compact ? lj : a.qual[(size_t)b * a.qmax + lj];
-                            const int v = s1s_enc(cs_b[(size_t)c * 32 + k]);
+                            int v;
+                            if (lj < CF_RC) {
+                                v = rows[lj * 32 + k];
+                            } else {
+                                const int c = a.cs_compact ? lj : a.qual[(size_t)b * a.qmax + lj];
+                                v = s1s_enc(cs_b[(size_t)c * 32 + k]);
+                            }
                             menc = v > menc ? v : menc;
                         }
                     }
                     if (__builtin_amdgcn_ballot_w64(leader)) {   // wave-uniform
+                        // ascending-k sum (filter_pids.cpp:59-63) across the half-wave's 32 lanes: step t makes lane t's prefix from
+                        // lane t-1's (v_add_f32 with a wave_shr:1 operand); later steps overwrite it, only lane 31's total is kept
                         const float mv = s1s_dec(menc);
-                        sb[k] = k < nqc ? (F16 ? flmr_round_f16(mv) : mv) : 0.0f;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-                        if (leader && k == 0) {
-                            float sc = 0.0f;
+                        const float x = k < nqc ? (F16 ? flmr_round_f16(mv) : mv) : 0.0f;
+                        float acc = k == 0 ? 0.0f + x : x;
 #pragma unroll
-                            for (int q = 0; q < 32; q++) sc += sb[q];   // ascending k (filter_pids.cpp:59-63)
-                            if (F16) sc = flmr_round_f16(sc);
+                        for (int t = 1; t < 32; t++)
+                            acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x138, 0xF, 0xF, false)) + x;
+                        if (leader && k == 31) {
+                            const float sc = F16 ? flmr_round_f16(acc) : acc;
                             const int64_t pos = (int64_t)base + nh - 1 - atomicAdd(&st[rp].km, 1);
                             if (pos >= base && pos < a.cand_cap) keys_b[pos] = flmr_make_key(sc, pid0p + (int)pid);
                         }
-                        __builtin_amdgcn_wave_barrier();
                     }
                 }
             }
         }
+        CF_STAMP(7);
         // the counters of the set the NEXT chunk uses: their last readers (the deferred pass of the previous round) are behind this
         // round's barrier
         if (tid == 0) { st[rn].qn = 0; st[rn].ks = 0; st[rn].km = 0; }
@@ -1032,6 +1118,13 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
         for (int u = 0; u < CF_FQ; u++) raw_q[u] = raw_qn[u];
         r3 = rn;
     }
+#ifdef CF_PROFILE
+    if (tid == 0) {
+        for (int i = 0; i < 8; i++) atomicAdd(&cf_prof[i], (unsigned long long)pt[i]);
+        atomicAdd(&cf_prof[10], (unsigned long long)(ch_end - ch0));
+        atomicAdd(&cf_prof[11], 1ull);
+    }
+#endif
 }
 
 // ---- kernel B: bitmap chunk -> ascending pids at the chunk's global rank, one hit flag per candidate --------------------------
@@ -1138,7 +1231,7 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
         while (cpb > 1 && (int64_t)a.nqueries * ((a.nchunks + cpb - 1) / cpb) < 512) cpb >>= 1;
         if (a.fast_state) {   // the queue form first; what it hands over (fast_state) is done by the slot kernel below
             const size_t flds = (size_t)9 * CAND_CHUNK_WORDS * sizeof(uint32_t) + (size_t)2 * CF_KCAP * sizeof(uint64_t) +
-                                (size_t)3 * CF_QCAP * sizeof(uint32_t) + (size_t)2 * CF_WAVES * 32 * sizeof(float);
+                                (size_t)3 * CF_QCAP * sizeof(uint32_t) + (size_t)CF_RC * 32 * sizeof(int);
             const void* ffn = a.f16_round ? reinterpret_cast<const void*>(cand_fast_kernel<true>) : reinterpret_cast<const void*>(cand_fast_kernel<false>);
             FLMR_HIP(hipFuncSetAttribute(ffn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
             int fcpb = 8;   // two resident workgroups per CU: twice the slot kernel's workgroups
@@ -1147,6 +1240,18 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
                 hipLaunchKernelGGL(cand_fast_kernel<true>, dim3(a.nqueries, (a.nchunks + fcpb - 1) / fcpb), dim3(CF_THREADS), flds, st, a, fcpb);
             else
                 hipLaunchKernelGGL(cand_fast_kernel<false>, dim3(a.nqueries, (a.nchunks + fcpb - 1) / fcpb), dim3(CF_THREADS), flds, st, a, fcpb);
+#ifdef CF_PROFILE
+            {
+                unsigned long long h[12];
+                (void)hipDeviceSynchronize();
+                (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(cf_prof), sizeof(h));
+                fprintf(stderr, "[cf] blocks %llu chunks %llu; ticks per chunk: loop-top %.0f wait %.0f mark %.0f barrier %.0f words %.0f prefetch %.0f pairs %.0f deferred %.0f\n",
+                        h[11], h[10], (double)h[0] / h[10], (double)h[1] / h[10], (double)h[2] / h[10], (double)h[3] / h[10], (double)h[4] / h[10],
+                        (double)h[5] / h[10], (double)h[6] / h[10], (double)h[7] / h[10]);
+                unsigned long long z[12] = {};
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(cf_prof), z, sizeof(z));
+            }
+#endif
         }
         if (a.f16_round)
             hipLaunchKernelGGL(cand_mark_score_kernel<true>, dim3(a.nqueries, (a.nchunks + cpb - 1) / cpb), dim3(64 * S1S_WAVES), lds, st, a, cpb);
