@@ -25,7 +25,15 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> res((size_t)P * L * 32);
     for (auto& x : res) x = (uint8_t)rng();
     std::vector<int64_t> off(P + 1);
-    for (int p = 0; p <= P; p++) off[p] = (int64_t)p * L;
+    const bool ragged = getenv("S3P_RAGGED") != nullptr;   // S3P_RAGGED: passage lengths ~ U{32..224} (mean 128) inside the same token array
+    int maxlen = L;
+    off[0] = 0;
+    for (int p = 0; p < P; p++) {
+        int len = ragged ? 32 + (int)(rng() % 193) : L;
+        if (off[p] + len > (int64_t)P * L) len = (int)((int64_t)P * L - off[p]);
+        off[p + 1] = off[p] + len;
+        if (len > maxlen) maxlen = len;
+    }
     std::vector<int32_t> pids((size_t)NQ * ND), counts(NQ, ND);
     for (auto& x : pids) x = (int32_t)(rng() % P);
     std::vector<_Float16> cen((size_t)K * 128);
@@ -53,9 +61,9 @@ int main(int argc, char** argv) {
         std::vector<float> cen32(cen.size());
         for (size_t t = 0; t < cen.size(); t++) cen32[t] = (float)cen[t];
         CK(hipMalloc(&ix.centroids, cen32.size() * 4)); CK(hipMemcpy(ix.centroids, cen32.data(), cen32.size() * 4, hipMemcpyHostToDevice));
-        ix.max_doclen = L;
+        ix.max_doclen = maxlen;
         if (flmr_build_s3_tables(&ix) != 0 || !ix.inv_norm) { printf("no S3 tables\n"); return 1; }
-        a.plan_stride = (int64_t)ND * ((L + 31) / 32); a.plan_wcap = ND + 8;
+        a.plan_stride = (int64_t)ND * ((maxlen + 31) / 32); a.plan_wcap = ND + 8;
         CK(hipMalloc(&a.plan_desc, (size_t)NQ * a.plan_stride * sizeof(uint2)));
         CK(hipMalloc(&a.plan_wbeg, (size_t)NQ * a.plan_wcap * 4));
         if (NQR > 32) { a.colmax_cap = (int64_t)NQ * ND * NQP + NQ; CK(hipMalloc(&a.colmax_ws, (size_t)a.colmax_cap * 4)); }

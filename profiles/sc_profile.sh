@@ -1,4 +1,5 @@
-# per-phase clocks of s0_select_cells (library variant built with -DSC_PROFILE: python profiles/build_variant.py scprof -DSC_PROFILE)
+# per-phase clocks of the candidate / stage-1 scatter kernel (library variant built with -DS1S_PROFILE)
+# usage: bash profiles/s1s_profile.sh     (needs lib/libflmr_hip_scprof.so built beside the product library)
 L=retrieval-augmented-visual-question-answering_amd/lib
 cp $L/libflmr_hip.so /tmp/libflmr_hip.keep && cp $L/libflmr_hip_scprof.so $L/libflmr_hip.so
 BENCH_NO_EVENTS=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --sub-batch 256 2>&1 | grep "\[sc\]" | tail -3

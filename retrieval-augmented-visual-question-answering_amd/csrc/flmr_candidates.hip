@@ -686,16 +686,16 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
 //            arithmetic, bit for bit) and writes the key at the END of the chunk's range.
 // Bitmaps, queue and counters rotate over three sets and the key buffer over two, so that a wave may run ahead into the next
 // chunk's marking while others still read this chunk's: each set is cleared / reset in the period after its last reader.
-// Eight waves and 65 KB of LDS: two workgroups per CU hide each other's barrier and LDS round trips.
+// Eight waves and 77 KB of LDS: two workgroups per CU hide each other's barrier and LDS round trips.
 // What it does not handle it hands over whole, per query (fast_state[2 + b] != 0 -> the slot kernel redoes the query): more
 // staged keys or queued pairs than fit (a corpus whose clusters overlap: the slot kernel's dense form), more than 512 lists.
 // Two cumulative counters (queries handed over after trying / tried) switch a searcher whose queries mostly overflow to trying
-// one query in sixteen.
+// one query in 64.
 #define CF_WAVES 8
 #define CF_THREADS (64 * CF_WAVES)
 #define CF_FC 16          // probed-cell lists per wave whose slices are requested a chunk ahead (ncells = 4: 128 cells)
 #define CF_FQ 8           // surviving lists per wave requested a chunk ahead and kept in registers for the pair pass
-#define CF_KCAP 1536      // keys of a chunk staged in LDS
+#define CF_KCAP 3072      // keys of a chunk staged in LDS (as list << 15 | passage inside the chunk: 4 bytes each)
 #define CF_QCAP 256       // queued pairs per chunk
 #define CF_MAXLISTS (64 * CF_WAVES)
 #define CF_RC 64          // surviving lists whose score rows are kept in LDS for the queued pairs (the others are read from memory)
@@ -735,9 +735,10 @@ template <bool F16>
 __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args a, int cpb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* bm = reinterpret_cast<uint32_t*>(smem);                          // [3][candidate | hit | several][CAND_CHUNK_WORDS]
-    uint64_t* kbuf = reinterpret_cast<uint64_t*>(bm + 9 * CAND_CHUNK_WORDS);   // [2][CF_KCAP]
-    uint32_t* queue = reinterpret_cast<uint32_t*>(kbuf + 2 * CF_KCAP);         // [3][CF_QCAP] passage (inside the chunk) | list << 16
+    uint32_t* kbuf = bm + 9 * CAND_CHUNK_WORDS;                                // [2][CF_KCAP] list << 15 | passage inside the chunk
+    uint32_t* queue = kbuf + 2 * CF_KCAP;                                      // [3][CF_QCAP] passage (inside the chunk) | list << 16
     int* rows = reinterpret_cast<int*>(queue + 3 * CF_QCAP);                   // [CF_RC][32] score rows of the query's first surviving lists (order-encoded, floored)
+    uint32_t* rtab = reinterpret_cast<uint32_t*>(rows + CF_RC * 32);           // [CF_MAXLISTS] score half of the key of a passage whose only surviving centroid is list j
     __shared__ cf_chunk_state st[3];
     __shared__ int s_tot, s_arr, s_abort[2];   // s_abort[round & 1]: set during a round, read after the NEXT round's barrier
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, k = lane & 31;
@@ -748,7 +749,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
     {
         const int lost = a.fast_state[0], tried = a.fast_state[1];
         const bool mostly_lost = tried >= 64 && 2 * lost > tried;
-        const bool ok = a.hit_valid[b] != 0 && nl <= CF_MAXLISTS && nq <= CF_MAXLISTS && (!mostly_lost || (b & 15) == 0);
+        const bool ok = a.hit_valid[b] != 0 && nl <= CF_MAXLISTS && nq <= CF_MAXLISTS && (!mostly_lost || (b & 63) == 0);
         if (!ok) {   // (block-uniform) left to the slot kernel without trying
             if (blockIdx.y == 0 && tid == 0) *redo = 1;
             return;
@@ -801,7 +802,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
         }
         rconst = F16 ? flmr_round_f16(sc) : sc;
     }
-    const uint32_t rord = flmr_f2ord(rconst);   // the key's score half, once per list
+    if (lane < mq.n) rtab[wave + CF_WAVES * lane] = flmr_f2ord(rconst);   // (read after the first barrier)
     for (int j = tid >> 5; j < nq && j < CF_RC; j += 2 * CF_WAVES) {
         const int c = a.cs_compact ? j : a.qual[(size_t)b * a.qmax + j];
         const int v = s1s_enc(cs_b[(size_t)c * 32 + k]);
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
         uint32_t* const cb = bm + (r3 * 3 + 0) * CAND_CHUNK_WORDS;
         uint32_t* const hb = bm + (r3 * 3 + 1) * CAND_CHUNK_WORDS;
         uint32_t* const mb = bm + (r3 * 3 + 2) * CAND_CHUNK_WORDS;
-        uint64_t* const kb = kbuf + (ch & 1) * CF_KCAP;
+        uint32_t* const kb = kbuf + (ch & 1) * CF_KCAP;
         uint32_t* const qu = queue + r3 * CF_QCAP;
         uint32_t mc_e2 = 0, mq_e2 = 0;
         if (ch + 1 < ch_end) {   // the end of the NEXT chunk's slices
@@ -967,7 +968,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
                     base = __builtin_amdgcn_readfirstlane(base);
                     const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0u));
                     if (single && pos < CF_KCAP)
-                        kb[pos] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rord, u) << 32) | (uint32_t)(pid0 + p);
+                        kb[pos] = ((uint32_t)(wave + CF_WAVES * u) << 15) | (uint32_t)p;
                 }
                 if (__builtin_amdgcn_ballot_w64(several)) {
                     if (several) {
@@ -1018,7 +1019,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
                             const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ms[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms[u], 0u));
                             const bool single = (ms[u] >> lane) & 1ull;
                             if (single && pos < CF_KCAP)
-                                kb[pos] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rord, u) << 32) | (uint32_t)(pid0 + pp[u]);
+                                kb[pos] = ((uint32_t)(wave + CF_WAVES * u) << 15) | (uint32_t)pp[u];
                             base += __popcll(ms[u]);
                         }
                     }
@@ -1053,9 +1054,12 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
             const cf_chunk_state& S = st[rp];
             const int base = S.base, nh = S.nh, qn = S.qn;
             const int ns = S.ks < CF_KCAP ? S.ks : CF_KCAP;
-            const uint64_t* kp = kbuf + ((ch - 1) & 1) * CF_KCAP;
-            for (int t = tid; t < ns; t += CF_THREADS)
-                if ((int64_t)base + t < a.cand_cap) keys_b[(int64_t)base + t] = kp[t];
+            const uint32_t* kp = kbuf + ((ch - 1) & 1) * CF_KCAP;
+            const uint32_t pid0q = (uint32_t)(ch - 1) * CAND_CHUNK_PIDS;
+            for (int t = tid; t < ns; t += CF_THREADS) {
+                const uint32_t e = kp[t];
+                if ((int64_t)base + t < a.cand_cap) keys_b[(int64_t)base + t] = ((uint64_t)rtab[e >> 15] << 32) | (pid0q + (e & 0x7fffu));
+            }
             if (qn > 0) {   // block-uniform
                 const uint32_t* qp = queue + rp * CF_QCAP;
                 const int pid0p = (ch - 1) * CAND_CHUNK_PIDS;
@@ -1230,7 +1234,7 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
         int cpb = 8;
         while (cpb > 1 && (int64_t)a.nqueries * ((a.nchunks + cpb - 1) / cpb) < 512) cpb >>= 1;
         if (a.fast_state) {   // the queue form first; what it hands over (fast_state) is done by the slot kernel below
-            const size_t flds = (size_t)9 * CAND_CHUNK_WORDS * sizeof(uint32_t) + (size_t)2 * CF_KCAP * sizeof(uint64_t) +
+            const size_t flds = (size_t)9 * CAND_CHUNK_WORDS * sizeof(uint32_t) + (size_t)2 * CF_KCAP * sizeof(uint32_t) + (size_t)CF_MAXLISTS * sizeof(uint32_t) +
                                 (size_t)3 * CF_QCAP * sizeof(uint32_t) + (size_t)CF_RC * 32 * sizeof(int);
             const void* ffn = a.f16_round ? reinterpret_cast<const void*>(cand_fast_kernel<true>) : reinterpret_cast<const void*>(cand_fast_kernel<false>);
             FLMR_HIP(hipFuncSetAttribute(ffn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
