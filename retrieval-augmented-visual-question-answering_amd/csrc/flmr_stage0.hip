@@ -1554,6 +1554,11 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        SC_STAMP(5);
+        // (Measured, -DSC_PROFILE, 256 queries: block choice 50 k clocks, tasks 72 k, barrier skew 23 k, sort 10 k of 160 k.  The
+        // tasks move 64 blocks x 16 KB = 1 MB per query, 268 MB per launch in ~38 us: ~7 TB/s from beyond the L2 -- that phase is
+        // at the memory system's rate.  Fetching the rows in memory order (eight whole cache lines per instruction, transposed
+        // into fragments through LDS) and hand-counted waits that keep the next block in flight changed nothing: 0.367 vs 0.362 ms.)
         // ---- the tasks, software-pipelined: the next block's 64 rows (16 KB, 64 VGPRs per lane) are requested before the
         // current block is multiplied, so that after the first one no memory round trip (~4 us here: one workgroup per
         // CU, nothing else to switch to) is exposed.  Same MFMA sequence as s0_centroid_scores_f16 / _qs: bitwise the S0
@@ -1649,6 +1654,7 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
         }
 #endif
         finish();
+        SC_STAMP(6);
         // ---- parked columns: every block whose hi maximum + err reaches the current ncells-th best row is recomputed too (the
         // list can only improve, which only tightens the test: a block skipped earlier stays skippable) ----
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1851,7 +1857,7 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
     SC_STAMP(4);
 #ifdef SC_PROFILE
     if (tid == 0) {
-        for (int i = 0; i < 5; i++) atomicAdd(&sc_prof[i], (unsigned long long)pt[i]);
+        for (int i = 0; i < 7; i++) atomicAdd(&sc_prof[i], (unsigned long long)pt[i]);
         atomicAdd(&sc_prof[7], 1ull);
     }
 #endif
@@ -1870,8 +1876,8 @@ int flmr_launch_select_cells(const flmr_s0_args& a, hipStream_t st) {
         unsigned long long h[8];
         (void)hipDeviceSynchronize();
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(sc_prof), sizeof(h));
-        fprintf(stderr, "[sc] blocks %llu; clocks per block: scan %.0f columns %.0f barrier %.0f sort %.0f unique+write %.0f\n", h[7],
-                (double)h[0] / h[7], (double)h[1] / h[7], (double)h[2] / h[7], (double)h[3] / h[7], (double)h[4] / h[7]);
+        fprintf(stderr, "[sc] blocks %llu; clocks per block: scan %.0f columns %.0f (block choice %.0f, tasks %.0f, the rest = parked columns) barrier %.0f sort %.0f unique+write %.0f\n", h[7],
+                (double)(h[0]) / h[7], (double)(h[1] + h[5] + h[6]) / h[7], (double)h[5] / h[7], (double)h[6] / h[7], (double)h[2] / h[7], (double)h[3] / h[7], (double)h[4] / h[7]);
         unsigned long long z[8] = {};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(sc_prof), z, sizeof(z));
     }
