@@ -8,6 +8,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define FLMR_NEG_INF (-__builtin_huge_valf())
 
+// ---- wave reductions by DPP (row maxima / minima: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror; the four rows
+// through the scalar unit): ~10 instructions and no LDS round trip, against 6 x ds_bpermute for a shuffle butterfly ----------
+__device__ __forceinline__ float flmr_wave_max_f32(float x) {
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false)));
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, false)));
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, false)));
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, false)));
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ int flmr_wave_min_i32(int x) {
+    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false));
+    return min(min(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16)), min(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)));
+}
+
 // ---- top-NC list ordered by (value desc, index asc) --------------------------------------------
 // Used for the per-query-token probe of the `ncells` best centroids (candidate_generation.py:12-20).
 template <int NC>
@@ -37,6 +56,28 @@ struct flmr_toplist {
             v[t] = better ? x : v[t];
             id[t] = better ? i : id[t];
         }
+    }
+    // top-NC of the union of the wave's 64 lists (entries distinct across lanes; finite values or -inf), left in EVERY lane: NC
+    // rounds of (wave maximum of the heads, lowest index among the lanes holding it, pop) -- ~25 instructions a round against
+    // six butterfly merges of 2 NC shuffles + NC inserts each.  Same result as merge_xor(32) ... merge_xor(1).
+    __device__ __forceinline__ void merge_wave() {
+        float ov[NC]; int oi[NC];
+#pragma unroll
+        for (int t = 0; t < NC; t++) {
+            const float m = flmr_wave_max_f32(v[0]);
+            const unsigned long long tie = __ballot(v[0] == m);   // (m = -inf: every exhausted lane holds (-inf, INT_MAX); harmless)
+            int wid;
+            if (__popcll(tie) == 1) wid = __builtin_amdgcn_readlane(id[0], (int)__builtin_ctzll(tie));   // wave-uniform branch
+            else wid = flmr_wave_min_i32(v[0] == m ? id[0] : 0x7fffffff);
+            ov[t] = m; oi[t] = wid;
+            const bool win = v[0] == m && id[0] == wid;
+#pragma unroll
+            for (int u = 0; u + 1 < NC; u++) { v[u] = win ? v[u + 1] : v[u]; id[u] = win ? id[u + 1] : id[u]; }
+            v[NC - 1] = win ? FLMR_NEG_INF : v[NC - 1];
+            id[NC - 1] = win ? 0x7fffffff : id[NC - 1];
+        }
+#pragma unroll
+        for (int t = 0; t < NC; t++) { v[t] = ov[t]; id[t] = oi[t]; }
     }
     // merge with the list held by lane (lane ^ mask)
     __device__ __forceinline__ void merge_xor(int mask) {

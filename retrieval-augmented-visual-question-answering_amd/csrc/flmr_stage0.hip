@@ -1501,9 +1501,7 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
                     for (int u = 0; u < 4; u++) gt[k].insert_ascending(gv4[k][u], (g0 + 64 * u + lane < ngrp) ? g0 + 64 * u + lane : 0x7fffffff);
             }
 #pragma unroll
-            for (int k = 0; k < KW; k++)
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) gt[k].merge_xor(m);
+            for (int k = 0; k < KW; k++) gt[k].merge_wave();
             constexpr int SW = (NL + 7) / 8;   // sweeps of eight groups
             float bv[KW][SW];
             int bi[KW][SW];
@@ -1537,8 +1535,7 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
             } else {
                 for (int e = lane; e < SC_WAVES * NL; e += 64) bt.insert(pre_v[e / NL][col][e % NL], pre_i[e / NL][col][e % NL]);
             }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) bt.merge_xor(m);
+            bt.merge_wave();
             float gv = FLMR_NEG_INF;
 #pragma unroll
             for (int t = 0; t < NL; t++) {
@@ -1585,8 +1582,7 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
         };
         auto finish = [&]() __attribute__((always_inline)) {   // column done: exact top-NC over the wave, ids to the cell list
             if (cur_k < 0) return;
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) tl.merge_xor(m);
+            tl.merge_wave();
             const int col = wave + SC_WAVES * cur_k;
             bool safe = true;
             if (approx) {   // (wave-uniform: the merged list is the same in every lane)
@@ -1824,6 +1820,27 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
     constexpr int NT = 64 * SC_WAVES;
     int nsort = 64;
     while (nsort < nqc * a.ncells) nsort <<= 1;
+    if (nsort == 64) {   // (block-uniform) one value per lane: the first wave sorts in registers, no barriers (21 shuffle steps)
+        if (wave == 0) {
+            int x = raw[lane];
+#pragma unroll
+            for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    const int y = __shfl_xor(x, j, 64);
+                    const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+                    x = keep_min ? min(x, y) : max(x, y);
+                }
+            }
+            const int before = __shfl_up(x, 1, 64);
+            const bool first = x != 0x7fffffff && (lane == 0 || before != x);
+            const unsigned long long m = __ballot(first);
+            if (first) a.cells[(size_t)b * a.max_cells + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = x;
+            if (lane == 0) a.ncell[b] = __popcll(m);
+        }
+        SC_STAMP(3);
+        SC_STAMP(4);
+    } else {
     for (int k = 2; k <= nsort; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
 #pragma unroll
@@ -1855,6 +1872,7 @@ __global__ __launch_bounds__(64 * SC_WAVES) void s0_select_cells(flmr_s0_args a)
         if (flag[u]) a.cells[(size_t)b * a.max_cells + pos++] = vv[u];
     if (tid == 0) a.ncell[b] = total;
     SC_STAMP(4);
+    }
 #ifdef SC_PROFILE
     if (tid == 0) {
         for (int i = 0; i < 7; i++) atomicAdd(&sc_prof[i], (unsigned long long)pt[i]);
