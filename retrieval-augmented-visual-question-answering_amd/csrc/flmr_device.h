@@ -140,6 +140,42 @@ __device__ __forceinline__ void flmr_bitonic_sort_desc(T* s, int n) {
     }
 }
 
+// The same sort for 64 <= n <= blockDim.x keys with ONE key per thread in a register: the steps whose partner sits in the same
+// wave (j < 64: 21 + 6 per later level) are shuffles without a barrier; only the steps across waves go through LDS, one
+// barrier each (two buffers in turn: `s` must hold 2 n entries).  n = 1024: 10 barriers instead of 55.  Leaves s[0 .. n) sorted
+// and ends with a barrier, like the function above.
+__device__ __forceinline__ void flmr_bitonic_sort_desc_reg(unsigned long long* s, int n) {
+    const int t = threadIdx.x;
+    const bool live = t < n;
+    unsigned long long x = live ? s[t] : 0ull;
+    int buf = 1;   // (s[0 .. n) holds the input until every thread has read its key: the first exchange writes the upper half)
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            unsigned long long y;
+            if (j >= 64) {   // (block-uniform)
+                unsigned long long* e = s + buf * n;
+                if (live) e[t] = x;
+                __syncthreads();
+                y = live ? e[t ^ j] : 0ull;
+                buf ^= 1;
+            } else {
+                y = __shfl_xor(x, j, 64);
+            }
+            const bool keep_max = ((t & j) == 0) == ((t & k) == 0);
+            x = keep_max ? (x > y ? x : y) : (x < y ? x : y);
+        }
+    }
+    __syncthreads();   // (the last reads of either buffer are done)
+    if (live) s[t] = x;
+    __syncthreads();
+}
+// bytes of dynamic LDS a kernel sorting npow2 keys with the dispatch below needs
+static inline size_t flmr_sort_lds_bytes(int npow2) { return (size_t)(npow2 <= 1024 ? 2 * npow2 : npow2) * 8; }
+__device__ __forceinline__ void flmr_sort_keys_desc(unsigned long long* s, int n) {
+    if (n >= 64 && n <= (int)blockDim.x) flmr_bitonic_sort_desc_reg(s, n);
+    else flmr_bitonic_sort_desc<unsigned long long>(s, n);
+}
+
 // Both half-waves' values of a register (lanes L and L ^ 32) without an LDS round trip: v_permlane32_swap exchanges the upper
 // half of one copy with the lower half of another, leaving {v[L & 31], v[(L & 31) + 32]} in every lane (a VALU op; the
 // ds_bpermute form of __shfl_xor(v, 32) costs an LDS-crossbar round trip on the critical path of every tile).

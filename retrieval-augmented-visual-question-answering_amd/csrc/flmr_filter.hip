@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(1024) void sort_topn_kernel(const uint64_t* keys, i
     const int cnt = counts[b];
     for (int i = tid; i < npow2; i += blockDim.x) s[i] = (i < cnt) ? keys[(size_t)b * key_stride + i] : 0ull;
     __syncthreads();
-    flmr_bitonic_sort_desc<unsigned long long>(s, npow2);
+    flmr_sort_keys_desc(s, npow2);
     const int m = cnt < n ? cnt : n;
     for (int i = tid; i < n; i += blockDim.x) {
         if (i < m) {
@@ -1068,7 +1068,7 @@ int flmr_launch_sort_topn(const uint64_t* keys, int64_t key_stride, const int32_
     if (max_count > FLMR_MAX_NDOCS) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "sort_topn: %d keys > %d", max_count, FLMR_MAX_NDOCS);
     int npow2 = 2;
     while (npow2 < max_count) npow2 <<= 1;
-    hipLaunchKernelGGL(sort_topn_kernel, dim3(nqueries), dim3(1024), (size_t)npow2 * 8, st, keys, key_stride, counts,
+    hipLaunchKernelGGL(sort_topn_kernel, dim3(nqueries), dim3(1024), flmr_sort_lds_bytes(npow2), st, keys, key_stride, counts,
                        npow2, n, out_pids, out_scores, out_stride, n_out, pid_base, fill);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(1024) void s2_refine_plan_kernel(const uint64_t* ke
     const int cnt = counts[b];
     for (int i = tid; i < npow2; i += blockDim.x) s[i] = (i < cnt) ? keys[(size_t)b * key_stride + i] : 0ull;
     __syncthreads();
-    flmr_bitonic_sort_desc<unsigned long long>(s, npow2);
+    flmr_sort_keys_desc(s, npow2);
     if (cnt <= n) {   // nothing to select: every survivor goes on
         for (int i = tid; i < cnt; i += blockDim.x) out_pids[(size_t)b * out_stride + i] = flmr_key_pid(s[i]);
         if (tid == 0) { band_count[b] = 0; need[b] = 0; def_count[b] = cnt; }
@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(1024) void s2_refine_finish_kernel(const uint64_t* 
     if (np > npow2) np = npow2;
     for (int i = tid; i < np; i += blockDim.x) s[i] = (i < cnt) ? band_keys[(size_t)b * key_stride + i] : 0ull;
     __syncthreads();
-    flmr_bitonic_sort_desc<unsigned long long>(s, np);
+    flmr_sort_keys_desc(s, np);
     for (int i = tid; i < take; i += blockDim.x) out_pids[(size_t)b * out_stride + base + i] = flmr_key_pid(s[i]);
 }
 
@@ -1143,7 +1143,7 @@ int flmr_launch_s2_refine_plan(const uint64_t* keys, int64_t key_stride, const i
     if (max_count > FLMR_MAX_NDOCS) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "s2 refine: %d keys > %d", max_count, FLMR_MAX_NDOCS);
     int npow2 = 2;
     while (npow2 < max_count) npow2 <<= 1;
-    hipLaunchKernelGGL(s2_refine_plan_kernel, dim3(nqueries), dim3(1024), (size_t)npow2 * 8, st, keys, key_stride, counts, npow2, n,
+    hipLaunchKernelGGL(s2_refine_plan_kernel, dim3(nqueries), dim3(1024), flmr_sort_lds_bytes(npow2), st, keys, key_stride, counts, npow2, n,
                        err_sum, out_pids, out_stride, band_pids, band_stride, band_count, need, def_count);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
@@ -1154,7 +1154,7 @@ int flmr_launch_s2_refine_finish(const uint64_t* band_keys, int64_t key_stride, 
                                  int64_t out_stride, int32_t* n_out, hipStream_t st) {
     int npow2 = 2;
     while (npow2 < max_count) npow2 <<= 1;
-    hipLaunchKernelGGL(s2_refine_finish_kernel, dim3(nqueries), dim3(1024), (size_t)npow2 * 8, st, band_keys, key_stride, band_count,
+    hipLaunchKernelGGL(s2_refine_finish_kernel, dim3(nqueries), dim3(1024), flmr_sort_lds_bytes(npow2), st, band_keys, key_stride, band_count,
                        need, def_count, npow2, out_pids, out_stride, n_out);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
