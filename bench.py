@@ -374,7 +374,7 @@ def main():
         except Exception:
             pass
         kname = {"s0_centroid_scores": "s0_centroid_scores", "s3_maxsim": "maxsim_lean_kernel",
-                 "s2_filter_sort": "filter_stage2", "s0_candidates": "cand_mark_score_kernel"}
+                 "s2_filter_sort": "filter_stage2", "s0_candidates": "cand_fast_kernel"}
 
         def roof_of(stage):
             t_s = stage_ms[stage] * 1e-3
