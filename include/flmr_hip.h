@@ -57,8 +57,10 @@ int flmr_device_count(int* count);
  * dense table walk / register gather); FLMR_S3_IMPL = lean | cw | cwregs | regs | dma | f32 | qs (fused MaxSim.  Nq <= 32: lean, the
  * default = the centroid + weight arithmetic on planned tiles; cw / cwregs = the same arithmetic walking the passages, rows by
  * LDS-DMA / register gathers; regs / dma = decompress-normalise-split; f32 = fp32-MFMA kernel.  Longer queries: qs, the
- * query-stationary kernel, the default from 288 rows; any other value = the chunked kernel).  Variants of one arithmetic are
- * bit-identical to each other, the arithmetics agree to fp32 roundoff (tests/test_hip_parity.py).
+ * query-stationary kernel, the default from 288 rows; any other value = the chunked kernel); FLMR_S1_IMPL = scan | slots
+ * (stage 1: the code-scanning kernel for every query / the slot form of the list-scatter kernel for every query; default: its
+ * queue form first, the slot form for the queries that one hands over, the code scan beyond 1024 surviving centroids).
+ * Variants of one arithmetic are bit-identical to each other, the arithmetics agree to fp32 roundoff (tests/test_hip_parity.py).
  * One switch is a capacity, not a variant: FLMR_ROW_CAP = score rows a searcher keeps per query (64 .. 65535, default 16384,
  * never more than K).  The default path stores the centroid scores of a query only for the centroids that pass
  * centroid_score_threshold (the rows index_storage.py:116's `idx` selects; 128 bytes each) instead of the reference's
