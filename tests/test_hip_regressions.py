@@ -365,8 +365,9 @@ def test_long_query_kernel_scales_per_query(hip):
     scorer.close_searcher()
 
 
-@pytest.mark.parametrize("policy", [(2, 0.45, 1024), (4, 0.4, 4096), (8, 0.38, 1024), (8, 0.35, 1024), (8, 0.33, 1024)])
-def test_stage1_queue_form_equals_slot_form_and_code_scan(hip, policy):
+@pytest.mark.parametrize("policy,numerics", [((2, 0.45, 1024), "cpu"), ((4, 0.4, 4096), "cpu"), ((8, 0.38, 1024), "cpu"), ((8, 0.35, 1024), "cpu"),
+                                             ((8, 0.33, 1024), "cpu"), ((2, 0.45, 1024), "gpu-fp16"), ((8, 0.35, 1024), "gpu-fp16")])
+def test_stage1_queue_form_equals_slot_form_and_code_scan(hip, policy, numerics):
     """The list-scatter stage 1 has two forms: the queue form (cand_fast_kernel: one barrier per chunk, single-centroid
     passages scored by their list's constant, the pairs of the others queued) runs first and hands the queries it cannot
     finish to the slot form (cand_mark_score_kernel).  On a corpus of the bench's shape (hundreds of thousands of passages,
@@ -384,7 +385,8 @@ def test_stage1_queue_form_equals_slot_form_and_code_scan(hip, policy):
     Q, _ = synth.make_queries(corpus, nqueries, 32, seed=22)
     q_lens = torch.full((nqueries,), 32, dtype=torch.int32)
     q_lens[3], q_lens[7], q_lens[11] = 9, 0, 31
-    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=64)
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=64, numerics=numerics)   # (gpu-fp16: the kernels' F16 instantiations)
+    assert scorer.numerics == numerics
     outs, forms = {}, None
     for tag, env in (("queue", {}), ("slots", {"FLMR_S1_IMPL": "slots"}), ("scan", {"FLMR_S1_IMPL": "scan"})):
         with nat.options(**env):
