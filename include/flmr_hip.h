@@ -214,8 +214,9 @@ int flmr_unpack_keys(const uint64_t* keys, int32_t nqueries, int32_t n, int32_t 
  * STAGE2 i32 (descending (score,pid) order = filter_pids output), DOC_SCORES f32 (aligned with STAGE2),
  * Q_ERR f32 [32] / Q_ERR_SUM f32 [1]: the per-column and per-passage bounds the "hi first" stages 0 / 2 decide with
  * (0 elements when the last batch did not run that path); STAGE1_FORM i32 [1]: which form of the list-scatter stage 1 produced
- * the query's keys -- 0 the queue form, 1 the slot form (query not tried: too many surviving lists, or a searcher whose queries
- * mostly overflow), 2 the slot form after the queue form gave the query up (0 elements: stage 1 ran in another mode). */
+ * the query's keys -- 0 the queue form, 1 the slot form (query not tried by the others: too many surviving lists), 2 the slot form
+ * after the queue form gave the query up, 3 the small-dense form (a searcher whose queries mostly overflow the queue), 4 the slot
+ * form after the small-dense form gave the query up (0 elements: stage 1 ran in another mode). */
 typedef enum flmr_tap {
     FLMR_TAP_CENTROID_SCORES = 0,
     FLMR_TAP_IDX_BITS = 1,

@@ -103,9 +103,12 @@ def run(P=1_000_000, L=128, nbits=2, NT=256, policies=((2, 0.45, 1024, 100), (2,
             scorer.search_batch(Qs[i % nb], k, ncells, thr, ndocs, 32, profile=True)
         st = {a: round(b / 2, 3) for a, b in scorer.stage_ms().items()}
         surv = [sum(bin(int(x)).count("1") for x in scorer.tap(ravqa_amd._native.TAP_IDX_BITS, q)) for q in range(0, 256, 32)]
+        forms = [int(v[0]) if v.size else -1 for v in (scorer.tap(ravqa_amd._native.TAP_STAGE1_FORM, q) for q in range(256))]
         ncand = [len(scorer.tap(ravqa_amd._native.TAP_CANDIDATES, q)) for q in range(0, 256, 64)]
         out[f"search_thr{thr}"] = {"queries_per_sec": round(nqr / dt), "ms_per_step": round(dt * 1e3, 2), "recall_at_5": hit, "recall_at_100": hit100,
-                                   "surviving_centroids": surv, "candidates": ncand, "stage_ms": st}
+                                   "surviving_centroids": surv, "candidates": ncand, "stage_ms": st,
+                                   "stage1_forms_of_256": {"queue": forms.count(0), "slot_untried": forms.count(1), "slot_after_queue": forms.count(2),
+                                                           "small_dense": forms.count(3), "slot_after_small_dense": forms.count(4)}}
         if parity_queries:
             out[f"search_thr{thr}"]["parity"] = parity_vs_reference(arrays, scorer, Qs[0][:parity_queries], ncells, thr, ndocs)
     del scorer, arrays

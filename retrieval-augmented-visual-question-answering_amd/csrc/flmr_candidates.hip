@@ -102,7 +102,7 @@ __global__ __launch_bounds__(1024) void qualifying_kernel(const uint32_t* idx_bi
         nqual[b] = n;
         hit_valid[b] = (base <= smax) && (base <= qmax) && (tot_q <= (unsigned long long)ratio * tot_c);
         if (key_count) key_count[b] = 0;
-        if (fast_state) { fast_state[2 + b] = 0; fast_state[2 + gridDim.x + b] = 0; }   // (see cand_fast_kernel)
+        if (fast_state) { fast_state[FLMR_FAST_HDR + b] = 0; fast_state[FLMR_FAST_HDR + gridDim.x + b] = 0; }   // (see cand_fast_kernel)
         if (rows_out && base > qmax && overflow) atomicExch(overflow + 2, 1);   // more surviving centroids than score rows (FLMR_ROW_CAP)
     }
     if (!rows_out || n == 0) return;   // (block-uniform)
@@ -299,16 +299,17 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
     const int ch0 = blockIdx.y * cpb;
     const int ch_end = ch0 + cpb < a.nchunks ? ch0 + cpb : a.nchunks;
     if (a.fast_state) {   // the queue form ran first: this kernel takes the queries it handed over (block-uniform)
-        const int r = a.fast_state[2 + b];
+        const int r = a.fast_state[FLMR_FAST_HDR + b];
         if (blockIdx.y == 0 && tid == 0) {
-            if (r == 0) a.key_count[b] = a.fast_state[2 + a.nqueries + b];
-            if (r != 1) {   // tried: the two cumulative counters that decide whether later batches try (halved now and then)
+            if (r == 0 || r == 3) a.key_count[b] = a.fast_state[FLMR_FAST_HDR + a.nqueries + b];
+            if (b == 0) atomicAdd(a.fast_state + 2, 1);   // batches so far (the queue form probes a dense searcher in one batch of 16)
+            if (r == 0 || r == 2) {   // tried by the queue form: the two cumulative counters that decide whether later batches try (halved now and then)
                 if (r == 2) atomicAdd(a.fast_state + 0, 1);
                 const int tried = atomicAdd(a.fast_state + 1, 1);
                 if (tried >= 16384) { atomicSub(a.fast_state + 1, tried / 2); atomicSub(a.fast_state + 0, a.fast_state[0] / 2); }
             }
         }
-        if (r == 0) return;
+        if (r == 0 || r == 3) return;   // done by the queue form / by the small-dense form
     }
     const int nl = a.ncell[b];
     const bool scatter = a.hit_valid[b] != 0;
@@ -687,10 +688,10 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
 // Bitmaps, queue and counters rotate over three sets and the key buffer over two, so that a wave may run ahead into the next
 // chunk's marking while others still read this chunk's: each set is cleared / reset in the period after its last reader.
 // Eight waves and 77 KB of LDS: two workgroups per CU hide each other's barrier and LDS round trips.
-// What it does not handle it hands over whole, per query (fast_state[2 + b] != 0 -> the slot kernel redoes the query): more
+// What it does not handle it hands over whole, per query (fast_state[FLMR_FAST_HDR + b] != 0 -> the later kernels redo the query): more
 // staged keys or queued pairs than fit (a corpus whose clusters overlap: the slot kernel's dense form), more than 512 lists.
 // Two cumulative counters (queries handed over after trying / tried) switch a searcher whose queries mostly overflow to trying
-// one query in 64.
+// one query in 64 of one batch in 16.
 #define CF_WAVES 8
 #define CF_THREADS (64 * CF_WAVES)
 #define CF_FC 16          // probed-cell lists per wave whose slices are requested a chunk ahead (ncells = 4: 128 cells)
@@ -743,13 +744,15 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
     __shared__ int s_tot, s_arr, s_abort[2];   // s_abort[round & 1]: set during a round, read after the NEXT round's barrier
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, k = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int32_t* const redo = a.fast_state + 2 + b;
-    int32_t* const kcount = a.fast_state + 2 + a.nqueries + b;
+    int32_t* const redo = a.fast_state + FLMR_FAST_HDR + b;
+    int32_t* const kcount = a.fast_state + FLMR_FAST_HDR + a.nqueries + b;
     const int nl = a.ncell[b], nq = a.nqual[b];
     {
-        const int lost = a.fast_state[0], tried = a.fast_state[1];
+        const int lost = a.fast_state[0], tried = a.fast_state[1], batches = a.fast_state[2];
         const bool mostly_lost = tried >= 64 && 2 * lost > tried;
-        const bool ok = a.hit_valid[b] != 0 && nl <= CF_MAXLISTS && nq <= CF_MAXLISTS && (!mostly_lost || (b & 63) == 0);
+        // (a searcher whose queries mostly overflow the queue is probed with one query in 64 of one batch in 16: a query that goes
+        // through the slot kernel costs the whole launch that kernel's ~150 us, however few of them there are)
+        const bool ok = a.hit_valid[b] != 0 && nl <= CF_MAXLISTS && nq <= CF_MAXLISTS && (!mostly_lost || ((b & 63) == 0 && (batches & 15) == 0));
         if (!ok) {   // (block-uniform) left to the slot kernel without trying
             if (blockIdx.y == 0 && tid == 0) *redo = 1;
             return;
@@ -1131,6 +1134,296 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
 #endif
 }
 
+// ---- kernel A-3: the SMALL-DENSE form of the scatter kernel ------------------------------------------------------------------
+// The regime an index built from real embeddings is expected to be in (profiles/built_index_probe.py: ~95 surviving centroids
+// per query, ~19 of them in every hit passage, ~70 hit candidates and ~1.3 k (list, passage) pairs per chunk): every hit passage
+// folds several score rows, so the queue form gives the query up at once, and the slot form spends ~19 us per chunk in seven
+// barrier-separated phases on very little work.  This form is the queue form's frame -- eight waves, two workgroups per CU, the
+// slices of the next chunk requested a chunk ahead, counts by the wave that arrives last -- with the slot form's dense fold:
+//   mark / barrier / words: bitmaps out, counts, and a SLOT for every hit candidate (a wave scan of the words' popcounts + one
+//   LDS atomic per wave: slots are unique, not ordered) / barrier / pairs: every (list, passage) pair folds its list's row
+//   into the slot's 32 column maxima (ds_max on the order-preserving encoding) / barrier / sums: half a wave per slot, the
+//   ascending-k sum as a wave_shr DPP chain, the key straight to base + slot.
+// Three barriers a chunk.  It runs after the queue form, for the queries that one left untried because the searcher's counters
+// say its queries mostly overflow the queue (fast_state: 1 -> 3 "done here" / 4 "given up": more than CF_DSLOTS hit candidates
+// in a chunk); the slot kernel, launched last, takes what is left.
+#define CF_DSLOTS 256
+#define CF_DRC 128         // surviving lists whose score rows are kept in LDS
+#define CF_DFQ 16          // surviving lists per wave kept in registers from the marking to the pair pass
+
+template <bool F16>
+__global__ __launch_bounds__(CF_THREADS, 2) void cand_dense_small_kernel(flmr_cand_args a, int cpb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* bm = reinterpret_cast<uint32_t*>(smem);                          // [2][candidate | hit][CAND_CHUNK_WORDS]
+    int* acc = reinterpret_cast<int*>(bm + 4 * CAND_CHUNK_WORDS);              // [CF_DSLOTS][33] column maxima (+ 64 scratch words)
+    int* rows = acc + CF_DSLOTS * S1S_STRIDE + 64;                             // [CF_DRC][32]
+    uint16_t* wslot = reinterpret_cast<uint16_t*>(rows + CF_DRC * 32);         // [CAND_CHUNK_WORDS] slot of a word's first hit candidate
+    uint16_t* spid = wslot + CAND_CHUNK_WORDS;                                 // [CF_DSLOTS] the slot's passage (inside the chunk)
+    __shared__ int s_tot, s_arr, s_slots, s_nh, s_base, s_abort;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, k = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int32_t* const redo = a.fast_state + FLMR_FAST_HDR + b;
+    int32_t* const kcount = a.fast_state + FLMR_FAST_HDR + a.nqueries + b;
+    const int nl = a.ncell[b], nq = a.nqual[b];
+    {
+        const int lost = a.fast_state[0], tried = a.fast_state[1];
+        const bool mostly_lost = tried >= 64 && 2 * lost > tried;
+        const int r = *redo;   // 1: the queue form left the query untried; 3 / 4: another workgroup of this launch was here first
+        const bool ok = mostly_lost && (r == 1 || r == 3) && a.hit_valid[b] != 0 && nl <= CF_MAXLISTS && nq <= CF_MAXLISTS;
+        if (!ok) return;   // (block-uniform)
+        if (blockIdx.y == 0 && tid == 0) atomicMax(redo, 3);
+    }
+    const int ch0 = blockIdx.y * cpb;
+    const int ch_end = ch0 + cpb < a.nchunks ? ch0 + cpb : a.nchunks;
+    cf_slices mc = cf_load_slices(a.cells + (size_t)b * a.max_cells, nl, wave, lane, a.ivf_offsets, a.chunk_tab, a.nchunks, ch0);
+    cf_slices mq = cf_load_slices(a.qual + (size_t)b * a.qmax, nq, wave, lane, a.ivf_offsets, a.chunk_tab, a.nchunks, ch0);
+    const int init = s1s_enc(-9999.0f);
+    const int qlen = a.q_lens ? a.q_lens[b] : a.nq_cand;
+    const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;  // <= 32 on this path
+    const float* cs_b = a.cs + (size_t)b * a.cs_query_stride;
+    uint64_t* keys_b = a.keys + (size_t)b * a.cand_cap;
+    auto list_ptr = [&](const cf_slices& m, int u) { return a.ivf_pids + s1s_bcast64(m.beg, u); };
+    auto issue1 = [&](const cf_slices& m, int n, int u, uint32_t ls, uint32_t le) {
+        int r = 0;
+        if (u < n) {   // wave-uniform
+            const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)ls, u), ev = (uint32_t)__builtin_amdgcn_readlane((int)le, u);
+            if (sv < ev) {
+                const uint32_t x = sv + lane;
+                r = list_ptr(m, u)[x < ev ? x : ev - 1u];
+            }
+        }
+        return r;
+    };
+    auto row_of = [&](int j) {   // list j's score row, column k, order-encoded and floored
+        if (j < CF_DRC) return rows[j * 32 + k];
+        const int c = a.cs_compact ? j : a.qual[(size_t)b * a.qmax + j];
+        const int v = s1s_enc(cs_b[(size_t)c * 32 + k]);
+        return v > init ? v : init;
+    };
+    // (CF_DFQ surviving lists per wave stay in registers from the marking to the pair pass: ~100 surviving centroids are 12 per
+    // wave here, and a list that is reloaded costs a memory round trip in both passes.  Their next slices are requested behind
+    // the pair pass, the probed cells' -- dead after the marking -- a phase earlier.)
+    int raw_c[CF_FC], raw_q[CF_DFQ];
+#pragma unroll
+    for (int u = 0; u < CF_FC; u++) raw_c[u] = issue1(mc, mc.n, u, mc.s, mc.e);
+#pragma unroll
+    for (int u = 0; u < CF_DFQ; u++) raw_q[u] = issue1(mq, mq.n, u, mq.s, mq.e);
+    for (int j = tid >> 5; j < nq && j < CF_DRC; j += 2 * CF_WAVES) {
+        const int c = a.cs_compact ? j : a.qual[(size_t)b * a.qmax + j];
+        const int v = s1s_enc(cs_b[(size_t)c * 32 + k]);
+        rows[j * 32 + k] = v > init ? v : init;
+    }
+    for (int e = tid; e < 4 * CAND_CHUNK_WORDS; e += CF_THREADS) bm[e] = 0u;
+    for (int e = tid; e < CF_DSLOTS * S1S_STRIDE + 64; e += CF_THREADS) acc[e] = init;
+    if (tid == 0) { s_tot = 0; s_arr = 0; s_slots = 0; s_nh = 0; s_base = 0; s_abort = 0; }
+    s1s_sync();
+
+#ifdef CF_PROFILE
+    long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long plast = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    int my_base = 0;
+    bool issuer = false;   // this wave arrived last in the chunk's count and holds its key base (wave-uniform)
+    for (int ch = ch0; ch < ch_end; ch++) {
+        const int pid0 = ch * CAND_CHUNK_PIDS;
+        uint32_t* const cb = bm + ((ch & 1) * 2 + 0) * CAND_CHUNK_WORDS;
+        uint32_t* const hb = bm + ((ch & 1) * 2 + 1) * CAND_CHUNK_WORDS;
+        uint32_t mc_e2 = 0, mq_e2 = 0;
+        if (ch + 1 < ch_end) {   // the end of the NEXT chunk's slices
+            if (lane < mc.n) mc_e2 = a.chunk_tab[(size_t)mc.c * (a.nchunks + 1) + ch + 2];
+            if (lane < mq.n) mq_e2 = a.chunk_tab[(size_t)mq.c * (a.nchunks + 1) + ch + 2];
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this chunk's slices, requested a chunk ago
+        CF_STAMP(0);
+        // ---- mark ----
+        int ncl = mc.n, nql = mq.n;
+        asm volatile("" : "+s"(ncl), "+s"(nql));
+        auto mark_list = [&](const cf_slices& m, int u, int raw, bool first_group, uint32_t* dst) {
+            const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)m.s, u), ev = (uint32_t)__builtin_amdgcn_readlane((int)m.e, u);
+            uint32_t from = sv;
+            if (first_group) {
+                if (sv + lane < ev) { const int p = raw - pid0; atomicOr(&dst[p >> 5], 1u << (p & 31)); }
+                from = sv + 64u;
+            }
+            if (from < ev) {   // rare: entries beyond the first 64, lists beyond the first group
+                const int32_t* ptr = list_ptr(m, u);
+                for (uint32_t x = from + lane; x < ev; x += 64) { const int p = ptr[x] - pid0; atomicOr(&dst[p >> 5], 1u << (p & 31)); }
+                S1S_DRAIN();
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < CF_FC; u++)
+            if (u < ncl) mark_list(mc, u, raw_c[u], true, cb);
+        for (int u = CF_FC; u < mc.n; u++) mark_list(mc, u, 0, false, cb);
+#pragma unroll
+        for (int u = 0; u < CF_DFQ; u++)
+            if (u < nql) mark_list(mq, u, raw_q[u], true, hb);
+        for (int u = CF_DFQ; u < mq.n; u++) mark_list(mq, u, 0, false, hb);
+        CF_STAMP(1);
+        s1s_sync();
+        CF_STAMP(2);
+        // ---- words: bitmaps out, counts, a slot for every hit candidate ----
+        {
+            uint32_t hw_[CAND_CHUNK_WORDS / CF_THREADS];
+            int mine = 0, nslot = 0;
+#pragma unroll
+            for (int h = 0; h < CAND_CHUNK_WORDS / CF_THREADS; h++) {
+                const int w = tid + h * CF_THREADS;
+                const int64_t gw = (int64_t)ch * CAND_CHUNK_WORDS + w;
+                uint32_t cw = cb[w];
+                const uint32_t hw = hb[w];
+                if (gw < a.words) {
+                    a.cand_bits[(size_t)b * a.words + gw] = cw;
+                    a.hit_bits[(size_t)b * a.words + gw] = hw;
+                } else {
+                    cw = 0u;
+                }
+                hw_[h] = cw & hw;
+                mine += __popc(cw) | (__popc(cw & hw) << 16);
+                nslot += __popc(cw & hw);
+            }
+            const int incl = flmr_wave_inclusive_scan(nslot, lane);
+            int wbase = 0;
+            if (lane == 63) wbase = atomicAdd(&s_slots, incl);
+            wbase = __builtin_amdgcn_readlane(wbase, 63);
+            int slot = wbase + incl - nslot;
+#pragma unroll
+            for (int h = 0; h < CAND_CHUNK_WORDS / CF_THREADS; h++) {
+                const int w = tid + h * CF_THREADS;
+                wslot[w] = (uint16_t)slot;
+                uint32_t bits = hw_[h];
+                while (bits) {
+                    const int bit = __ffs(bits) - 1;
+                    bits &= bits - 1u;
+                    if (slot < CF_DSLOTS) spid[slot] = (uint16_t)(w * 32 + bit);
+                    slot++;
+                }
+            }
+            const int wsum = cf_wave_sum(mine);
+            int last = 0;
+            if (lane == 0) {
+                atomicAdd(&s_tot, wsum);
+                if (atomicAdd(&s_arr, 1) == CF_WAVES - 1) {   // every wave's total is in
+                    const uint32_t tot = (uint32_t)atomicExch(&s_tot, 0);
+                    s_arr = 0;
+                    const int cnt = (int)(tot & 0xffffu), nh = (int)(tot >> 16);
+                    a.chunk_cnt[(size_t)b * a.nchunks + ch] = cnt;
+                    a.chunk_hits[(size_t)b * a.nchunks + ch] = nh;
+                    s_nh = nh;
+                    if (nh > CF_DSLOTS) { s_abort = 1; atomicMax(redo, 4); }
+                    int zero = 0;
+                    asm volatile("" : "+v"(zero));
+                    my_base = atomicAdd(kcount + zero, nh);   // (first read behind the pair pass)
+                    last = 1;
+                }
+            }
+            issuer = __builtin_amdgcn_readfirstlane(last) != 0;
+        }
+        CF_STAMP(3);
+        // ---- the next chunk's slices ----
+        if (ch + 1 < ch_end) {
+            int ncp = mc.n;
+            asm volatile("" : "+s"(ncp));
+#pragma unroll
+            for (int u = 0; u < CF_FC; u++) raw_c[u] = issue1(mc, ncp, u, mc.e, mc_e2);
+        }
+        s1s_sync();
+        CF_STAMP(4);
+        if (s_abort) return;   // (block-uniform: written before this barrier only)
+        // ---- pairs: every (list, passage) pair of a hit candidate folds its list's row into the slot's column maxima ----
+        {
+            auto fold = [&](int p, int rowk) {
+                int slot = -1;
+                if (p >= 0) {
+                    const uint32_t hbits = cb[p >> 5] & hb[p >> 5], bit = 1u << (p & 31);
+                    if (hbits & bit) slot = (int)wslot[p >> 5] + __popc(hbits & (bit - 1u));
+                }
+                // Lane = COLUMN for the fold: one ds_max takes two pairs (a half-wave each, 32 consecutive words: no bank conflicts)
+                // and only pairs that have a slot are visited.  With lane = pair it was 32 ds_max per LIST whatever its ~14 entries:
+                // ~3 k LDS atomic instructions per chunk and workgroup, and the CU's LDS pipe -- not the VALUs -- set the pace
+                // (24 us per chunk, as in the slot kernel's dense path); this is ~650.
+                unsigned long long m = __builtin_amdgcn_ballot_w64(slot >= 0);
+                while (m) {   // (wave-uniform)
+                    const int e0 = (int)__builtin_ctzll(m);
+                    m &= m - 1ull;
+                    int e1 = e0;   // an odd pair out: the second half-wave repeats it (max is idempotent)
+                    if (m) { e1 = (int)__builtin_ctzll(m); m &= m - 1ull; }
+                    const int s0 = __builtin_amdgcn_readlane(slot, e0), s1 = __builtin_amdgcn_readlane(slot, e1);
+                    atomicMax(acc + (lane < 32 ? s0 : s1) * S1S_STRIDE + k, rowk);
+                }
+            };
+
+            int nqe = mq.n;
+            asm volatile("" : "+s"(nqe));
+#pragma unroll
+            for (int u = 0; u < CF_DFQ; u++) {
+                if (u < nqe) {
+                    const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)mq.s, u), ev = (uint32_t)__builtin_amdgcn_readlane((int)mq.e, u);
+                    if (sv < ev) fold(sv + lane < ev ? raw_q[u] - pid0 : -1, row_of(wave + CF_WAVES * u));
+                }
+            }
+            for (int u = 0; u < mq.n; u++) {   // slices longer than 64 entries, lists beyond the first CF_DFQ of a wave
+                const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)mq.s, u), ev = (uint32_t)__builtin_amdgcn_readlane((int)mq.e, u);
+                const uint32_t from = u < CF_DFQ ? sv + 64u : sv;
+                if (from < ev) {
+                    const int32_t* ptr = list_ptr(mq, u);
+                    const int rowk = row_of(wave + CF_WAVES * u);
+                    for (uint32_t x0 = from; x0 < ev; x0 += 64) {
+                        fold(x0 + lane < ev ? ptr[x0 + lane] - pid0 : -1, rowk);
+                        S1S_DRAIN();
+                    }
+                }
+            }
+        }
+        CF_STAMP(5);
+        if (ch + 1 < ch_end) {   // the surviving lists' next slices (their registers are free now)
+            int nqp = mq.n;
+            asm volatile("" : "+s"(nqp));
+#pragma unroll
+            for (int u = 0; u < CF_DFQ; u++) raw_q[u] = issue1(mq, nqp, u, mq.e, mq_e2);
+        }
+        if (issuer) {
+            if (lane == 0) s_base = my_base;
+            issuer = false;
+        }
+        s1s_sync();
+        CF_STAMP(6);
+        // ---- sums: half a wave per slot; the slot's row is left at its start value, this thread's bitmap words at zero ----
+        {
+            const int nh = s_nh, base = s_base;
+            for (int slot = tid >> 5; slot < nh; slot += 2 * CF_WAVES) {   // (nh <= CF_DSLOTS)
+                const int v = acc[slot * S1S_STRIDE + k];
+                acc[slot * S1S_STRIDE + k] = init;
+                const float mv = s1s_dec(v);
+                const float x = k < nqc ? (F16 ? flmr_round_f16(mv) : mv) : 0.0f;
+                float sum = k == 0 ? 0.0f + x : x;
+#pragma unroll
+                for (int t = 1; t < 32; t++)
+                    sum = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x138, 0xF, 0xF, false)) + x;
+                if (k == 31) {
+                    const float sc = F16 ? flmr_round_f16(sum) : sum;
+                    const int64_t pos = (int64_t)base + slot;
+                    if (pos < a.cand_cap) keys_b[pos] = flmr_make_key(sc, pid0 + (int)spid[slot]);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < CAND_CHUNK_WORDS / CF_THREADS; h++) { cb[tid + h * CF_THREADS] = 0u; hb[tid + h * CF_THREADS] = 0u; }
+            if (tid == 0) s_slots = 0;
+        }
+        CF_STAMP(7);
+        // next chunk (its marking uses the other pair of bitmaps; slots, counters and accumulators are next touched behind its first barrier)
+        mc.s = mc.e; mc.e = mc_e2;
+        mq.s = mq.e; mq.e = mq_e2;
+    }
+#ifdef CF_PROFILE
+    if (tid == 0) {
+        for (int i = 0; i < 8; i++) atomicAdd(&cf_prof[i], (unsigned long long)pt[i]);
+        atomicAdd(&cf_prof[10], (unsigned long long)(ch_end - ch0));
+        atomicAdd(&cf_prof[11], 1ull);
+    }
+#endif
+}
+
 // ---- kernel B: bitmap chunk -> ascending pids at the chunk's global rank, one hit flag per candidate --------------------------
 __global__ __launch_bounds__(1024) void cand_emit_kernel(const uint32_t* cand_bits, const uint32_t* hit_bits, int64_t words,
                                                          const int32_t* chunk_cnt, int nchunks, int32_t* cand, int64_t cand_cap,
@@ -1244,6 +1537,26 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
                 hipLaunchKernelGGL(cand_fast_kernel<true>, dim3(a.nqueries, (a.nchunks + fcpb - 1) / fcpb), dim3(CF_THREADS), flds, st, a, fcpb);
             else
                 hipLaunchKernelGGL(cand_fast_kernel<false>, dim3(a.nqueries, (a.nchunks + fcpb - 1) / fcpb), dim3(CF_THREADS), flds, st, a, fcpb);
+            {   // the small-dense form: returns at once unless the searcher's counters say its queries mostly overflow the queue
+                const size_t dlds = (size_t)4 * CAND_CHUNK_WORDS * sizeof(uint32_t) + ((size_t)CF_DSLOTS * S1S_STRIDE + 64) * sizeof(int) +
+                                    (size_t)CF_DRC * 32 * sizeof(int) + ((size_t)CAND_CHUNK_WORDS + CF_DSLOTS) * sizeof(uint16_t);
+                const void* dfn = a.f16_round ? reinterpret_cast<const void*>(cand_dense_small_kernel<true>) : reinterpret_cast<const void*>(cand_dense_small_kernel<false>);
+                FLMR_HIP(hipFuncSetAttribute(dfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
+                if (a.f16_round)
+                    hipLaunchKernelGGL(cand_dense_small_kernel<true>, dim3(a.nqueries, (a.nchunks + fcpb - 1) / fcpb), dim3(CF_THREADS), dlds, st, a, fcpb);
+                else
+                    hipLaunchKernelGGL(cand_dense_small_kernel<false>, dim3(a.nqueries, (a.nchunks + fcpb - 1) / fcpb), dim3(CF_THREADS), dlds, st, a, fcpb);
+#ifdef CF_PROFILE
+                {
+                    unsigned long long h[12];
+                    (void)hipDeviceSynchronize();
+                    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(cf_prof), sizeof(h));
+                    if (h[10]) fprintf(stderr, "[cfd] blocks %llu chunks %llu; ticks per chunk: top %.0f mark %.0f barrier1 %.0f words %.0f prefetch+barrier2 %.0f pairs %.0f prefetch+barrier3 %.0f sums %.0f\n",
+                            h[11], h[10], (double)h[0] / h[10], (double)h[1] / h[10], (double)h[2] / h[10], (double)h[3] / h[10], (double)h[4] / h[10],
+                            (double)h[5] / h[10], (double)h[6] / h[10], (double)h[7] / h[10]);
+                }
+#endif
+            }
 #ifdef CF_PROFILE
             {
                 unsigned long long h[12];

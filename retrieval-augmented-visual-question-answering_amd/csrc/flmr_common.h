@@ -203,6 +203,7 @@ int flmr_launch_filter_stage1(const flmr_filter_args& f, const uint32_t* idx_bit
                               const uint32_t* hit_bits, int64_t hit_words, const int32_t* hit_valid,
                               const uint8_t* hit_flags, hipStream_t st, const int32_t* skip = nullptr);
 // chunked candidate generation (flmr_candidates.hip): bitmaps in LDS per (query, 32768-passage chunk)
+#define FLMR_FAST_HDR 4
 struct flmr_cand_args {
     int32_t nqueries, idx_words, max_cells, qmax, nchunks;
     int64_t words, cand_cap;
@@ -223,9 +224,10 @@ struct flmr_cand_args {
     int32_t* chunk_hits;                  // [nqueries, nchunks] candidates of the chunk that are in the hit set (scatter mode)
     int32_t n_select;                     // how many keys the selection after stage 1 keeps (ndocs)
     int32_t f16_round;                    // see flmr_filter_args
-    // the queue form of the scatter kernel (cand_fast_kernel) and its hand-over to the slot form: [0, B) "this query is left to
-    // the slot kernel", [B, 2B) the queue kernel's own key counters, then two cumulative counters (queries handed over after
-    // trying / queries tried).  NULL: slot kernel only (FLMR_S1_IMPL=slots)
+    // the queue and small-dense forms of the scatter kernel and their hand-over to the slot form: FLMR_FAST_HDR words that live as
+    // long as the searcher ([0] queries the queue form gave up, [1] queries it tried, [2] batches so far), then per query of the
+    // batch [HDR + b] which form did / must do the query (FLMR_TAP_STAGE1_FORM) and [HDR + B + b] the fast forms' own key counter.
+    // NULL: slot kernel only (FLMR_S1_IMPL=slots)
     int32_t* fast_state;
 };
 int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st);

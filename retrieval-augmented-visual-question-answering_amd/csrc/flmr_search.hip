@@ -42,7 +42,7 @@ struct flmr_searcher {
     uint2* s3_desc; int64_t s3_desc_stride; int32_t* s3_wbeg; int32_t s3_wcap;   // planned-tile S3 (NULL: the passage-walking kernel)
     float* s3_colmax; int64_t s3_colmax_cap;   // long queries: per (query, finalist, column) maxima of the query-stationary S3 kernel
     int32_t* qual; int32_t* nqual; int32_t* chunk_cnt; uint8_t* cand_hit; int32_t qmax;
-    int32_t* cand_fast;         // flmr_cand_args::fast_state ([2 * max_queries + 2]; the two counters at its end live as long as the searcher)
+    int32_t* cand_fast;         // flmr_cand_args::fast_state ([FLMR_FAST_HDR + 2 * max_queries]; the header words live as long as the searcher)
     // last call (for taps)
     int32_t last_nqueries, last_ncol, last_ndocs, last_full_table;
     flmr_cand_args last_ca{};   // candidate-stage arguments of the last batch (lazy FLMR_TAP_CANDIDATES in scatter mode)
@@ -192,10 +192,10 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     }
     {
         int32_t* p = nullptr;
-        rc = ws_alloc(s, &p, 2 * B + 2);
+        rc = ws_alloc(s, &p, 2 * B + FLMR_FAST_HDR);
         if (rc) { flmr_searcher_destroy(s); return rc; }
         s->cand_fast = p;
-        FLMR_HIP(hipMemset(s->cand_fast, 0, (2 * B + 2) * sizeof(int32_t)));
+        FLMR_HIP(hipMemset(s->cand_fast, 0, (2 * B + FLMR_FAST_HDR) * sizeof(int32_t)));
     }
     FLMR_HIP(hipMemset(s->overflow, 0, 4 * sizeof(int32_t)));
     FLMR_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->status_host), 4 * sizeof(int32_t), hipHostMallocDefault));
@@ -830,7 +830,7 @@ extern "C" int flmr_searcher_tap(flmr_searcher_t* s, int32_t what, int32_t q, vo
         case FLMR_TAP_Q_ERR_SUM:
             n = s->last_hi_first ? 1 : 0; src = s->q_err_sum + q; break;
         case FLMR_TAP_STAGE1_FORM:
-            n = (s->last_ca.scatter && s->last_ca.fast_state) ? 1 : 0; src = s->cand_fast + 2 + q; break;
+            n = (s->last_ca.scatter && s->last_ca.fast_state) ? 1 : 0; src = s->cand_fast + FLMR_FAST_HDR + q; break;
         default: FLMR_FAIL(FLMR_ERR_INVALID, "unknown tap %d", what);
     }
     *count = n;

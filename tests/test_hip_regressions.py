@@ -415,3 +415,40 @@ def test_stage1_queue_form_equals_slot_form_and_code_scan(hip, policy, numerics)
         for a, b in zip(outs["queue"][2:], outs[tag][2:]):
             assert np.array_equal(a, b), tag
     scorer.close_searcher()
+
+
+def test_stage1_small_dense_form_on_a_built_index(hip):
+    """An index BUILT from overlapping clusters: every hit passage holds several surviving centroids, the queue form of the list
+    scatter gives its queries up, and after the searcher's counters have seen that for 64 queries the small-dense form
+    (cand_dense_small_kernel) takes them.  Its survivors, their stage-2 order and the final ranking must be IDENTICAL to the slot
+    form's; the tap says which form produced each query's keys."""
+    torch, nat = hip["torch"], hip["native"]
+    from ravqa_amd import indexing, synth
+    from ravqa_amd.scorer import IndexScorer
+    embs, doclens, planted = synth.make_overlapping_embeddings(300_000, 64, 2048, seed=5, device="cuda", sub_directions=8192)
+    arrays = indexing.build_index(embs, doclens, nbits=2, kmeans_niters=4)
+    ncells, thr, ndocs = 2, 0.45, 1024
+    Qs = [planted(64)[0] for _ in range(4)]
+    scorer = IndexScorer(arrays=arrays, max_batch=64)
+    for Q in Qs[:3]:   # the counters: queries tried by the queue form / given up by it
+        scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32)
+        scorer.check()
+        print("\nFORMS", [[int(scorer.tap(nat.TAP_STAGE1_FORM, i)[0]) for i in range(64)].count(v) for v in range(5)])
+    p, s, c = scorer.search_batch(Qs[3], ndocs // 4, ncells, thr, ndocs, 32)
+    scorer.check()
+    forms = [int(scorer.tap(nat.TAP_STAGE1_FORM, i)[0]) for i in range(64)]
+    nsurv = [int(np.unpackbits(scorer.tap(nat.TAP_IDX_BITS, i).view(np.uint8)).sum()) for i in range(0, 64, 8)]
+    print("FORMS", [forms.count(v) for v in range(5)], "surviving centroids", nsurv)
+    got = ([np.sort(scorer.tap(nat.TAP_STAGE1, i)) for i in range(64)], [scorer.tap(nat.TAP_STAGE2, i) for i in range(64)],
+           p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy())
+    assert forms.count(3) >= 40, forms
+    with nat.options(FLMR_S1_IMPL="slots"):
+        p2, s2, c2 = scorer.search_batch(Qs[3], ndocs // 4, ncells, thr, ndocs, 32)
+        scorer.check()
+        ref = ([np.sort(scorer.tap(nat.TAP_STAGE1, i)) for i in range(64)], [scorer.tap(nat.TAP_STAGE2, i) for i in range(64)],
+               p2.cpu().numpy(), s2.cpu().numpy(), c2.cpu().numpy())
+    for i in range(64):
+        assert np.array_equal(got[0][i], ref[0][i]) and np.array_equal(got[1][i], ref[1][i]), (i, forms[i])
+    for x, y in zip(got[2:], ref[2:]):
+        assert np.array_equal(x, y)
+    scorer.close_searcher()
