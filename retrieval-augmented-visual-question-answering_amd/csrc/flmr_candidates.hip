@@ -1160,6 +1160,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_dense_small_kernel(flmr_ca
     uint16_t* wslot = reinterpret_cast<uint16_t*>(rows + CF_DRC * 32);         // [CAND_CHUNK_WORDS] slot of a word's first hit candidate
     uint16_t* spid = wslot + CAND_CHUNK_WORDS;                                 // [CF_DSLOTS] the slot's passage (inside the chunk)
     __shared__ int s_tot, s_arr, s_slots, s_nh, s_base, s_abort;
+    __shared__ __attribute__((aligned(8))) int vs_all[CF_WAVES][66];           // a list's slots, packed, per wave (see the pair pass)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, k = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int32_t* const redo = a.fast_state + FLMR_FAST_HDR + b;
@@ -1194,6 +1195,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_dense_small_kernel(flmr_ca
         }
         return r;
     };
+    int* const vs = vs_all[wave];
     auto row_of = [&](int j) {   // list j's score row, column k, order-encoded and floored
         if (j < CF_DRC) return rows[j * 32 + k];
         const int c = a.cs_compact ? j : a.qual[(size_t)b * a.qmax + j];
@@ -1341,18 +1343,22 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_dense_small_kernel(flmr_ca
                 // Lane = COLUMN for the fold: one ds_max takes two pairs (a half-wave each, 32 consecutive words: no bank conflicts)
                 // and only pairs that have a slot are visited.  With lane = pair it was 32 ds_max per LIST whatever its ~14 entries:
                 // ~3 k LDS atomic instructions per chunk and workgroup, and the CU's LDS pipe -- not the VALUs -- set the pace
-                // (24 us per chunk, as in the slot kernel's dense path); this is ~650.
-                unsigned long long m = __builtin_amdgcn_ballot_w64(slot >= 0);
-                while (m) {   // (wave-uniform)
-                    const int e0 = (int)__builtin_ctzll(m);
-                    m &= m - 1ull;
-                    int e1 = e0;   // an odd pair out: the second half-wave repeats it (max is idempotent)
-                    if (m) { e1 = (int)__builtin_ctzll(m); m &= m - 1ull; }
-                    const int s0 = __builtin_amdgcn_readlane(slot, e0), s1 = __builtin_amdgcn_readlane(slot, e1);
-                    atomicMax(acc + (lane < 32 ? s0 : s1) * S1S_STRIDE + k, rowk);
+                // (24 us per chunk, as in the slot kernel's dense path); this is ~650.  The list's slots are first packed into a
+                // per-wave LDS array (ballot ranks), so that an iteration is one broadcast read of two slots, a select, an address
+                // and the ds_max (with v_readlane from the scattered lanes it was ~12 instructions per two pairs: 22 k of a
+                // chunk's 41 k clocks).
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(slot >= 0);
+                const int n = __popcll(m);
+                if (n) {   // (wave-uniform)
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (slot >= 0) vs[rank] = slot;
+                    if (slot >= 0 && rank == n - 1) vs[n] = slot;   // an odd pair out: the second half-wave repeats it (max is idempotent)
+                    for (int t = 0; t < n; t += 2) {
+                        const int2 s01 = *reinterpret_cast<const int2*>(vs + t);
+                        atomicMax(acc + (lane < 32 ? s01.x : s01.y) * S1S_STRIDE + k, rowk);
+                    }
                 }
             };
-
             int nqe = mq.n;
             asm volatile("" : "+s"(nqe));
 #pragma unroll
