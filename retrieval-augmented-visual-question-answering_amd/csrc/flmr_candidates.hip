@@ -303,6 +303,8 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
         if (blockIdx.y == 0 && tid == 0) {
             if (r == 0 || r == 3) a.key_count[b] = a.fast_state[FLMR_FAST_HDR + a.nqueries + b];
             if (b == 0) atomicAdd(a.fast_state + 2, 1);   // batches so far (the queue form probes a dense searcher in one batch of 16)
+            if (r == 4) { if (a.fast_state[3] < 1024) atomicAdd(a.fast_state + 3, 4); }   // the small-dense form's give-ups against its successes
+            else if (r == 3 && a.fast_state[3] > 0) atomicSub(a.fast_state + 3, 1);
             if (r == 0 || r == 2) {   // tried by the queue form: the two cumulative counters that decide whether later batches try (halved now and then)
                 if (r == 2) atomicAdd(a.fast_state + 0, 1);
                 const int tried = atomicAdd(a.fast_state + 1, 1);
@@ -1167,10 +1169,13 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_dense_small_kernel(flmr_ca
     int32_t* const kcount = a.fast_state + FLMR_FAST_HDR + a.nqueries + b;
     const int nl = a.ncell[b], nq = a.nqual[b];
     {
-        const int lost = a.fast_state[0], tried = a.fast_state[1];
+        const int lost = a.fast_state[0], tried = a.fast_state[1], batches = a.fast_state[2], given_up = a.fast_state[3];
         const bool mostly_lost = tried >= 64 && 2 * lost > tried;
         const int r = *redo;   // 1: the queue form left the query untried; 3 / 4: another workgroup of this launch was here first
-        const bool ok = mostly_lost && (r == 1 || r == 3) && a.hit_valid[b] != 0 && nl <= CF_MAXLISTS && nq <= CF_MAXLISTS;
+        // (fast_state[3]: + 4 for a query this form gave up, - 1 for one it finished, kept by the slot kernel: a searcher whose chunks
+        // mostly hold more hit candidates than this form has slots stops paying for the attempts, and is probed in one batch of 64)
+        const bool worth = given_up < 256 || (batches & 63) == 0;
+        const bool ok = mostly_lost && worth && (r == 1 || r == 3) && a.hit_valid[b] != 0 && nl <= CF_MAXLISTS && nq <= CF_MAXLISTS;
         if (!ok) return;   // (block-uniform)
         if (blockIdx.y == 0 && tid == 0) atomicMax(redo, 3);
     }

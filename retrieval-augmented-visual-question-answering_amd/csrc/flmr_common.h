@@ -225,7 +225,8 @@ struct flmr_cand_args {
     int32_t n_select;                     // how many keys the selection after stage 1 keeps (ndocs)
     int32_t f16_round;                    // see flmr_filter_args
     // the queue and small-dense forms of the scatter kernel and their hand-over to the slot form: FLMR_FAST_HDR words that live as
-    // long as the searcher ([0] queries the queue form gave up, [1] queries it tried, [2] batches so far), then per query of the
+    // long as the searcher ([0] queries the queue form gave up, [1] queries it tried, [2] batches so far, [3] the small-dense form's
+    // give-ups against its successes), then per query of the
     // batch [HDR + b] which form did / must do the query (FLMR_TAP_STAGE1_FORM) and [HDR + B + b] the fast forms' own key counter.
     // NULL: slot kernel only (FLMR_S1_IMPL=slots)
     int32_t* fast_state;
