@@ -24,6 +24,9 @@ def test_library_exports_every_declared_symbol():
     assert lib.flmr_abi_version() == _native.ABI_VERSION == int(re.search(r"#define FLMR_ABI_VERSION (\d+)", header).group(1))
     # the compiler the binary came from is recorded beside it (the hand-scheduled kernels are verified with that toolchain)
     assert "clang version" in _native.toolchain() and "gfx950" in _native.toolchain()
+    # the tap ids the host layer passes are the header's
+    taps = {name: int(v) for name, v in re.findall(r"FLMR_(TAP_[A-Z0-9_]+) = (\d+)", header)}
+    assert len(taps) == 10 and all(getattr(_native, name) == v for name, v in taps.items()), taps
 
 
 def test_product_path_fails_loudly_without_device():
