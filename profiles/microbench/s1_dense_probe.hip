@@ -1,0 +1,181 @@
+// Stand-alone harness of the dense stage-1 kernel (csrc/flmr_stage1_dense.hip): timing + a CPU check of both forms on synthetic
+// inputs shaped like the two dense regimes the bench measures:
+//   B (default)  index built from overlapping clusters: ~1.5 k surviving centroids, 31.5 k candidates per query, ~57 distinct
+//                codes per passage of which ~72 % survive  (S1D_N=1500 S1D_CAND=31500 S1D_ULEN=57 S1D_HIT=0.72 S1D_LPC=16)
+//   A            planted corpus at centroid_score_threshold 0.25: 8.7 k survivors, 60.6 k candidates, 128 distinct codes, 9 hits
+//                (S1D_N=8700 S1D_CAND=60600 S1D_ULEN=128 S1D_HIT=0.07 S1D_LPC=32)
+// Build (from the repo root):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Iretrieval-augmented-visual-question-answering_amd/csrc \
+//         -o profiles/microbench/s1_dense_probe profiles/microbench/s1_dense_probe.hip
+#include "../../retrieval-augmented-visual-question-answering_amd/csrc/flmr_stage1_dense.hip"
+
+#include <algorithm>
+#include <cmath>
+#include <random>
+#include <vector>
+
+thread_local char flmr_err_buf[512] = {0};
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+static double envd(const char* n, double d) { const char* e = getenv(n); return e ? atof(e) : d; }
+
+static float up16_host(float x) {
+    _Float16 h = (_Float16)x;
+    if ((float)h < x) {
+        uint16_t b; memcpy(&b, &h, 2);
+        if (b == 0x8000u) b = 1; else if (b & 0x8000u) b--; else b++;
+        memcpy(&h, &b, 2);
+    }
+    return (float)h;
+}
+
+int main() {
+    const int K = 131072, P = (int)envd("S1D_P", 1000000), L = 128, NQ = (int)envd("S1D_NQ", 256);
+    const int NS = (int)envd("S1D_N", 1500), NC = (int)envd("S1D_CAND", 31500), UL = (int)envd("S1D_ULEN", 57);
+    const double HIT = envd("S1D_HIT", 0.72);
+    const int LPC = (int)envd("S1D_LPC", 16), NDOCS = 1024, REPS = (int)envd("S1D_REPS", 4);
+    std::mt19937 rng(1);
+    // the surviving centroids (one set for every query: the kernel's cost does not depend on which)
+    std::vector<int> surv;
+    {
+        std::vector<char> in(K, 0);
+        while ((int)surv.size() < NS) { const int c = rng() % K; if (!in[c]) { in[c] = 1; surv.push_back(c); } }
+        std::sort(surv.begin(), surv.end());
+    }
+    const int idx_words = K / 32;
+    std::vector<uint32_t> bits(idx_words, 0), prefix(idx_words, 0);
+    for (int c : surv) bits[c >> 5] |= 1u << (c & 31);
+    { uint32_t run = 0; for (int w = 0; w < idx_words; w++) { prefix[w] = run; run += __builtin_popcount(bits[w]); } }
+    // passages: distinct ascending codes first, the rest of the 128-token run repeats the last
+    std::vector<int32_t> codes((size_t)P * L + 8, 0x7f7f7f7f);
+    std::vector<uint16_t> ulen(P);
+    std::vector<int64_t> off(P + 1);
+    for (int p = 0; p <= P; p++) off[p] = (int64_t)p * L;
+    {
+        std::vector<int> tmp;
+        for (int p = 0; p < P; p++) {
+            int want = UL >= L ? L : std::max(4, std::min(L, (int)(UL / 2 + rng() % (UL + 1))));
+            tmp.clear();
+            for (int t = 0; t < want; t++) {
+                const bool h = (rng() % 10000) < HIT * 10000;
+                tmp.push_back(h ? surv[rng() % NS] : (int)(rng() % K));
+            }
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            ulen[p] = (uint16_t)tmp.size();
+            for (int t = 0; t < L; t++) codes[(size_t)p * L + t] = tmp[std::min<size_t>(t, tmp.size() - 1)];
+        }
+    }
+    double mean_ul = 0; for (int p = 0; p < P; p++) mean_ul += ulen[p]; mean_ul /= P;
+    // candidates: ascending random pids
+    std::vector<int32_t> cand((size_t)NQ * NC), cand_count(NQ, NC), nqual(NQ, NS), mode(NQ);
+    for (int q = 0; q < NQ; q++) {
+        const double step = (double)P / NC;
+        for (int i = 0; i < NC; i++) cand[(size_t)q * NC + i] = std::min(P - 1, (int)(i * step + (rng() % 1000) / 1000.0 * step * 0.999));
+    }
+    const int row_cap = std::max(NS, 64);
+    std::vector<float> rows((size_t)NQ * row_cap * 32);
+    for (auto& x : rows) x = -0.2f + 1.1f * (float)(rng() % 1000000) / 1e6f;
+    std::vector<uint32_t> bits_all((size_t)NQ * idx_words), prefix_all((size_t)NQ * idx_words);
+    for (int q = 0; q < NQ; q++) { memcpy(&bits_all[(size_t)q * idx_words], bits.data(), idx_words * 4); memcpy(&prefix_all[(size_t)q * idx_words], prefix.data(), idx_words * 4); }
+
+    flmr_s1d_args a{};
+    int32_t *d_codes, *d_cand, *d_cc, *d_nqual, *d_mode, *d_band, *d_bc; int64_t* d_off; uint16_t* d_ulen; uint32_t *d_bits, *d_pre; float *d_rows, *d_err; uint64_t* d_keys;
+#define UP(dst, vec) CK(hipMalloc(reinterpret_cast<void**>(&dst), (vec).size() * sizeof((vec)[0]))); CK(hipMemcpy(dst, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice))
+    UP(d_codes, codes); UP(d_off, off); UP(d_ulen, ulen); UP(d_bits, bits_all); UP(d_pre, prefix_all); UP(d_rows, rows);
+    UP(d_cand, cand); UP(d_cc, cand_count); UP(d_nqual, nqual);
+    CK(hipMalloc(reinterpret_cast<void**>(&d_mode), NQ * 4)); CK(hipMalloc(reinterpret_cast<void**>(&d_err), NQ * 4));
+    CK(hipMalloc(reinterpret_cast<void**>(&d_keys), (size_t)NQ * NC * 8)); CK(hipMalloc(reinterpret_cast<void**>(&d_band), (size_t)NQ * NC * 4));
+    CK(hipMalloc(reinterpret_cast<void**>(&d_bc), NQ * 4));
+    a.codes = d_codes; a.offsets = d_off; a.ulen = d_ulen; a.idx_bits = d_bits; a.idx_prefix = d_pre; a.idx_words = idx_words;
+    a.rows = d_rows; a.row_cap = row_cap; a.nqual = d_nqual; a.q_lens = nullptr; a.nq_cand = 32; a.nqueries = NQ;
+    a.cand = d_cand; a.cand_stride = NC; a.cand_count = d_cc; a.band = d_band; a.band_count = d_bc; a.mode = d_mode; a.keys = d_keys; a.img_err = d_err;
+    a.parts = (int)envd("S1D_PARTS", 0);
+    a.codes_len = (int64_t)codes.size(); a.group = 64;
+    const int img_rows = flmr_s1_dense_image_rows(NQ, idx_words, LPC);
+    printf("P %d, survivors %d, candidates/query %d, distinct codes/passage %.1f, hit share %.2f, LPC %d, image rows that fit %d\n", P, NS, NC, mean_ul, HIT, LPC, img_rows);
+
+    auto time_it = [&](bool img, const char* what) {
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        if (flmr_launch_s1_dense(a, img, LPC, 0)) { printf("launch failed: %s\n", flmr_err_buf); exit(1); }
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < REPS; r++) if (flmr_launch_s1_dense(a, img, LPC, 0)) { printf("launch failed: %s\n", flmr_err_buf); exit(1); }
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-46s %8.3f ms per %d queries  (%.3f ms per 1024)\n", what, ms / REPS, NQ, ms / REPS * 1024.0 / NQ);
+    };
+    std::vector<uint64_t> ku((size_t)NQ * NC), ke((size_t)NQ * NC);
+    std::vector<float> err(NQ);
+    const bool img_ok = NS <= img_rows;
+    if (img_ok) {
+        std::fill(mode.begin(), mode.end(), FLMR_S1D_IMAGE);
+        CK(hipMemcpy(d_mode, mode.data(), NQ * 4, hipMemcpyHostToDevice));
+        CK(hipMemset(d_keys, 0, ku.size() * 8));
+        time_it(true, "IMG pass (fp16 images in LDS), all candidates");
+        CK(hipMemcpy(ku.data(), d_keys, ku.size() * 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(err.data(), d_err, NQ * 4, hipMemcpyDeviceToHost));
+    }
+    std::fill(mode.begin(), mode.end(), FLMR_S1D_EXACT);
+    CK(hipMemcpy(d_mode, mode.data(), NQ * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(d_keys, 0, ke.size() * 8));
+    time_it(false, "EXACT pass (fp32 rows through L2), all candidates");
+    CK(hipMemcpy(ke.data(), d_keys, ke.size() * 8, hipMemcpyDeviceToHost));
+
+    // ---- CPU check on a few queries ----
+    int bad_e = 0, bad_u = 0, bad_bound = 0;
+    double band_mean = 0;
+    const int checkq[3] = {0, NQ / 2, NQ - 1};
+    for (int qi = 0; qi < 3; qi++) {
+        const int q = checkq[qi];
+        std::vector<float> S(NC), U(NC);
+        for (int i = 0; i < NC; i++) {
+            const int pid = cand[(size_t)q * NC + i];
+            float mx[32]; for (int k = 0; k < 32; k++) mx[k] = -9999.0f;
+            int nh = 0;
+            for (int t = 0; t < ulen[pid]; t++) {
+                const int c = codes[(size_t)pid * L + t];
+                if (!((bits[c >> 5] >> (c & 31)) & 1u)) continue;
+                nh++;
+                const int rid = prefix[c >> 5] + __builtin_popcount(bits[c >> 5] & ((1u << (c & 31)) - 1u));
+                const float* r = &rows[((size_t)q * row_cap + rid) * 32];
+                for (int k = 0; k < 32; k++) mx[k] = std::max(mx[k], r[k]);
+            }
+            float s = 0; for (int k = 0; k < 32; k++) s += mx[k];
+            S[i] = s;
+            float part[4];
+            for (int pr = 0; pr < 4; pr++) { float t = 0; for (int e = 0; e < 8; e++) t += up16_host(mx[pr * 8 + e]); part[pr] = t; }
+            U[i] = nh ? (part[0] + part[1]) + (part[2] + part[3]) : s;
+            if (ke[(size_t)q * NC + i] != flmr_make_key(S[i], pid)) { if (bad_e++ < 5) printf("  EXACT mismatch q %d i %d pid %d: got %.7g want %.7g\n", q, i, pid, flmr_key_score(ke[(size_t)q * NC + i]), S[i]); }
+            if (img_ok) {
+                if (ku[(size_t)q * NC + i] != flmr_make_key(U[i], pid)) { if (bad_u++ < 5) printf("  IMG mismatch q %d i %d pid %d: got %.7g want %.7g (hits %d)\n", q, i, pid, flmr_key_score(ku[(size_t)q * NC + i]), U[i], nh); }
+                if (!(U[i] >= S[i] - err[q] && U[i] <= S[i] + err[q])) bad_bound++;
+            }
+        }
+        if (img_ok) {   // band rule: every member of the exact top NDOCS has U >= u* - err
+            std::vector<float> us(U); std::nth_element(us.begin(), us.begin() + NDOCS - 1, us.end(), std::greater<float>());
+            const float ustar = us[NDOCS - 1];
+            std::vector<int> order(NC); for (int i = 0; i < NC; i++) order[i] = i;
+            std::partial_sort(order.begin(), order.begin() + NDOCS, order.end(), [&](int x, int y) { return S[x] > S[y]; });
+            int band = 0, missing = 0;
+            for (int i = 0; i < NC; i++) band += U[i] >= ustar - err[q];
+            for (int r = 0; r < NDOCS; r++) missing += !(U[order[r]] >= ustar - err[q]);
+            band_mean += band / 3.0;
+            printf("  query %d: E %.5f, band %d of %d candidates for the top %d, members of the exact top outside the band: %d\n", q, err[q], band, NC, NDOCS, missing);
+        }
+    }
+    printf("CPU check (3 queries x %d candidates): EXACT mismatches %d, IMG mismatches %d, bound violations %d\n", NC, bad_e, bad_u, bad_bound);
+    if (img_ok) {   // the EXACT pass over a band-sized list (what follows the IMG pass)
+        std::fill(mode.begin(), mode.end(), FLMR_S1D_IMAGE);
+        CK(hipMemcpy(d_mode, mode.data(), NQ * 4, hipMemcpyHostToDevice));
+        const int bn = std::min(NC, (int)band_mean + 1);
+        std::vector<int32_t> bc(NQ, bn);
+        CK(hipMemcpy(d_bc, bc.data(), NQ * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_band, d_cand, (size_t)NQ * NC * 4, hipMemcpyDeviceToDevice));
+        char what[96]; snprintf(what, sizeof(what), "EXACT pass over a band of %d per query", bn);
+        time_it(false, what);
+        a.parts = 1; a.group = 16;
+        snprintf(what, sizeof(what), "  the same, one item per query, groups of 16");
+        time_it(false, what);
+    }
+    return (bad_e || bad_u || bad_bound) ? 1 : 0;
+}

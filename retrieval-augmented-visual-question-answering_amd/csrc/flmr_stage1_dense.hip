@@ -1,0 +1,523 @@
+// Stage 1 for DENSE survivor sets (more surviving centroids than the list-scatter forms of flmr_candidates.hip take): the
+// centroid-only MaxSim of every candidate restricted to the centroids above the threshold.
+//
+// Reference: TPC/search/filter_pids.cpp -- maxsim() :27-69 with the `idx` mask of TPC/search/index_storage.py:116,
+// filter_pids_helper() :71-124 (top-ndocs by (score, pid)).
+//   per candidate:  per_k = max over the DISTINCT surviving codes of the passage of centroid_scores[code][k]  (init -9999)
+//                   score = sum_k per_k, k ascending in fp32 (:59-63)
+//
+// What the round-5 scan (filter_stage1_kernel) cost on an index built from overlapping clusters (1 M passages, ~1.5 k surviving
+// centroids, 31.5 k candidates per query, 43 hits per candidate): 29 ms per 1024 queries, of which 15 ms "reading the
+// candidates' codes".  profiles/microbench/gather_probe shows that was never a memory floor: the chip delivers 6.3-7.4 TB/s
+// for saturated random 256/512-byte records (16 GB per step = 2.5 ms).  The time went into the scan's structure -- one
+// round of 8 passages per wave at a time behind a dependent pid -> offset -> codes chain, a fresh 128-byte fp32 score row from
+// L2 per hit, duplicates of a code scored again.  This file restates the scan around three facts:
+//   1. DISTINCT codes.  A maximum is idempotent (filter_pids.cpp:50-63 skips repeated codes for the same reason), and the
+//      index keeps a per-passage ascending copy of the codes whose distinct values come first (`codes_sorted` + `doc_ulen`,
+//      built at flmr_index_open): 57 instead of 128 codes per passage on that index.
+//   2. ROWS IN LDS.  A query's surviving rows are few (<= ~2 k) but 32 x fp32 = 128 bytes each: too big for LDS as they are.
+//      Their fp16 images ROUNDED UP fit (64 bytes a row, 2032 rows at K = 131072).  max commutes with a monotone rounding, so
+//      the column maxima of images are the images of the column maxima, and U(p) = sum_k up16(per_k) satisfies
+//      S(p) - eps <= U(p) <= S(p) + E for the exact score S, with E = 32 x (largest rounding step of the query's rows) + eps
+//      and eps a bound on the two summations' roundoff: both computed per query while the images are made.
+//   3. APPROXIMATE, THEN REFINE (as stage 2 does with its hi products, flmr_filter.hip): with u* = the ndocs-th largest U,
+//      at least ndocs passages have S >= u* - E, so the ndocs-th largest exact score is >= u* - E and every passage of the exact
+//      top ndocs has U >= u* - E - eps.  That BAND (ndocs + a few per cent) is rescored exactly -- fp32 rows, ascending-k sum --
+//      by the second form of this kernel, and the top ndocs of the band by exact (score, pid) key is, as a set with its keys,
+//      bit for bit what the full scan selects.
+//
+// Two instantiations of one kernel:
+//   IMG   = the approximate pass: rows' fp16 images in LDS, packed fp16 maxima, U keys for every candidate;
+//   EXACT = fp32 rows gathered through L2 (8 lanes x 16 bytes per row, a batch in flight), per-column maxima summed k-ascending
+//           along a DPP chain: the reference's arithmetic.  Runs over the band of an IMG query, or over the whole candidate
+//           list of a query whose rows do not fit LDS (mode 2: also what replaces the round-5 scan there).
+//
+// MI355X shape: one persistent 16-wave workgroup per CU (the images take the LDS), item = (query, part of its candidates),
+// items dealt XCD-aware (workgroup L runs on XCD L % 8: a query's parts share an L2 for its rows).  A wave takes 64
+// candidates at a time (lane = candidate for pid / offset / length, the next group's prefetched), and inside a group rounds
+// of 64 / LPC candidates, LPC lanes x 4 codes each (LPC = 16 or 32 by the index's mean number of distinct codes); the codes of
+// round r + 2 are requested when round r's have been listed.  Listing: one probe of the query's K-bit mask in LDS per code,
+// hits compacted by a DPP row scan into a per-wave list of row ids (rank = prefix[word] + popcount below).
+#include "flmr_device.h"
+
+#define D1_WAVES 16
+#ifdef D1_NT_CODES   // development switch: codes by non-temporal loads (gather_probe: plain loads are the faster ones)
+#define D1_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define D1_LOAD(p) (*(p))
+#endif
+#define D1_THREADS (64 * D1_WAVES)
+#define D1_XCDS 8
+
+typedef uint32_t d1u4 __attribute__((ext_vector_type(4)));
+typedef int d1i4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef _Float16 d1h2 __attribute__((ext_vector_type(2)));
+typedef float d1f4 __attribute__((ext_vector_type(4)));
+
+// DPP helpers (row = 16 lanes).  bound_ctrl = true: lanes without a source read 0.
+#define D1_DPP(x, ctrl) __builtin_amdgcn_update_dpp(0, (x), (ctrl), 0xF, 0xF, true)
+#define D1_ROW_SHR(n) (0x110 + (n))
+#define D1_ROW_ROR(n) (0x120 + (n))
+
+// smallest fp16 >= x (x finite, |x| <= 65504)
+__device__ __forceinline__ _Float16 d1_up16(float x) {
+    _Float16 h = (_Float16)x;   // RNE
+    if ((float)h < x) {         // step to the next value above
+        uint16_t b = __builtin_bit_cast(uint16_t, h);
+        if (b == 0x8000u) b = 0x0001u;             // -0 -> smallest positive subnormal
+        else if (b & 0x8000u) b--;                 // negative: smaller magnitude
+        else b++;                                  // positive: larger magnitude
+        h = __builtin_bit_cast(_Float16, b);
+    }
+    return h;
+}
+
+// (written as the instruction: the builtin maximum first canonicalises each operand -- three instructions instead of one)
+__device__ __forceinline__ uint32_t d1_pk_max(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// LDS byte address of the row whose id is the low (hi = 0) or high (hi = 1) half of q: 64 * id + base
+__device__ __forceinline__ uint32_t d1_row_addr(uint32_t q, int hi, uint32_t base) {
+    uint32_t r;
+    if (hi) asm("v_mad_u32_u16 %0, %1, 64, %2 op_sel:[1,0,0,0]" : "=v"(r) : "v"(q), "v"(base));
+    else asm("v_mad_u32_u16 %0, %1, 64, %2" : "=v"(r) : "v"(q), "v"(base));
+    return r;
+}
+
+struct flmr_s1d_args {
+    const int32_t* codes;        // per-passage code runs: `codes_sorted` (distinct values first) with `ulen`, or the plain codes
+    const int64_t* offsets;      // [num_passages + 1]
+    const uint16_t* ulen;        // [num_passages] distinct codes per passage (NULL: every token, offsets[p+1] - offsets[p])
+    const uint32_t* idx_bits;    // [nqueries, idx_words] surviving-centroid mask (index_storage.py:116)
+    const uint32_t* idx_prefix;  // [nqueries, idx_words] exclusive popcount per word (qualifying_kernel)
+    int32_t idx_words;
+    const float* rows;           // compact score rows [nqueries, row_cap, 32] (row = rank of the centroid among the survivors)
+    int32_t row_cap;
+    const int32_t* nqual;        // [nqueries] surviving centroids (clamped to row_cap by qualifying_kernel)
+    const int32_t* q_lens;       // nullable
+    int32_t nq_cand, nqueries;
+    const int32_t* cand;         // [nqueries, cand_stride] ascending candidate pids
+    int64_t cand_stride;
+    const int32_t* cand_count;
+    const int32_t* band;         // [nqueries, cand_stride] the band of an image query (EXACT pass)
+    const int32_t* band_count;
+    const int32_t* mode;         // [nqueries] FLMR_S1D_*: which queries this launch takes, from which list
+    uint64_t* keys;              // [nqueries, cand_stride] out
+    float* img_err;              // [nqueries] out (IMG pass): E + eps of the band rule (inf: the images cannot be used)
+    int32_t parts;               // items per query
+    int32_t group;               // candidates per wave and group: 64, or 16 for short lists
+    int64_t codes_len;           // ints readable at `codes` (the sorted copy carries 8 words of padding)
+    int32_t img_rows;            // rows of images the launch's LDS holds (IMG pass)
+};
+#define FLMR_S1D_SKIP 0    // stage 1 of the query was done elsewhere (list-scatter forms)
+#define FLMR_S1D_IMAGE 1   // IMG pass over the candidates, band, EXACT pass over the band
+#define FLMR_S1D_EXACT 2   // EXACT pass over the candidates
+
+template <bool IMG, int LPC>
+__global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
+    constexpr int R = 64 / LPC;            // candidates per round
+    constexpr int LISTCAP = LPC * 4;       // hits of one candidate chunk
+    constexpr int LPR = IMG ? 4 : 8;       // lanes per row read (16 bytes each)
+    constexpr int HPI = LPC / LPR;         // hits folded per iteration and candidate
+    constexpr int NIT = LISTCAP / HPI;     // list entries of one hit group (16 IMG, 32 EXACT)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int scan_lds[17];
+    __shared__ int s_nscan;
+    __shared__ float s_red[2 * D1_WAVES];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = lane / LPC, l = lane % LPC;
+    // LDS: [scan list: nqueries i32][bits: idx_words u32][prefix: idx_words u16 (padded to 16 B)][lists: D1_WAVES * R * LISTCAP u16][images]
+    int* scan_list = reinterpret_cast<int*>(smem);
+    uint32_t* lbits = reinterpret_cast<uint32_t*>(scan_list + ((a.nqueries + 3) & ~3));
+    uint16_t* lpre = reinterpret_cast<uint16_t*>(lbits + a.idx_words);
+    uint16_t* lists = lpre + ((a.idx_words + 7) & ~7);
+    uint16_t* my_list = lists + (size_t)wave * R * LISTCAP;
+    char* img = reinterpret_cast<char*>(lists + (size_t)D1_WAVES * R * LISTCAP);
+
+    // ---- the queries of this launch ----
+    if (tid == 0) s_nscan = 0;
+    __syncthreads();
+    {
+        int base = 0;
+        for (int q0 = 0; q0 < a.nqueries; q0 += D1_THREADS) {
+            const int q = q0 + tid;
+            const int m = q < a.nqueries ? a.mode[q] : FLMR_S1D_SKIP;
+            const int need = IMG ? (m == FLMR_S1D_IMAGE) : (m != FLMR_S1D_SKIP);
+            int total;
+            const int pos = base + flmr_block_exclusive_scan(need, scan_lds, &total);
+            if (need) scan_list[pos] = q;
+            base += total;
+        }
+        if (tid == 0) s_nscan = base;
+    }
+    __syncthreads();
+    const int nscan = s_nscan;
+    if (nscan == 0) return;
+    const int nscan8 = (nscan + D1_XCDS - 1) & ~(D1_XCDS - 1);
+    const int G = a.parts;
+    const int nitems = nscan8 * G;
+
+    for (int t = blockIdx.x; t < nitems; t += gridDim.x) {
+        const int sidx = ((t >> 3) / G) * D1_XCDS + (t & 7), part = (t >> 3) % G;
+        if (sidx >= nscan) continue;   // (block-uniform)
+        const int b = scan_list[sidx];
+        const int m = a.mode[b];
+        const bool from_band = !IMG && m == FLMR_S1D_IMAGE;
+        const int P = from_band ? a.band_count[b] : a.cand_count[b];
+        const int32_t* const src = (from_band ? a.band : a.cand) + (size_t)b * a.cand_stride;
+        uint64_t* const keys_b = a.keys + (size_t)b * a.cand_stride;
+        const int qlen = a.q_lens ? a.q_lens[b] : a.nq_cand;
+        const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;
+        const float miss = flmr_miss_score(nqc, 0);
+        const int n = a.nqual[b] < a.row_cap ? a.nqual[b] : a.row_cap;
+        const float* const rows_b = a.rows + (size_t)b * a.row_cap * 32;
+        __syncthreads();   // (the previous item's readers of the LDS tables are done)
+        // ---- the query's mask and ranks ----
+        {
+            const uint32_t* gb = a.idx_bits + (size_t)b * a.idx_words;
+            const uint32_t* gp = a.idx_prefix + (size_t)b * a.idx_words;
+            for (int w = tid; w < a.idx_words; w += D1_THREADS) {
+                lbits[w] = gb[w];
+                const uint32_t p = gp[w];
+                lpre[w] = (uint16_t)(p < 65535u ? p : 65535u);
+            }
+        }
+        bool usable = true;
+        if (IMG) {
+            // ---- images: row r, columns 2j / 2j+1 -> dword 16 r + j; row n = the padding row (-inf: never wins) ----
+            float dmax = 0.0f, amax = 0.0f;
+            bool bad = false;
+            if (tid == 0) s_bad = 0;
+            const bool fits = n <= a.img_rows;
+            if (fits) {
+                uint32_t* im = reinterpret_cast<uint32_t*>(img);
+                for (int e = tid; e < n * 16; e += D1_THREADS) {
+                    const float2 v = *reinterpret_cast<const float2*>(rows_b + (size_t)e * 2);
+                    bad |= !(fabsf(v.x) <= 60000.0f) || !(fabsf(v.y) <= 60000.0f);   // (also NaN)
+                    const _Float16 hx = d1_up16(bad ? 0.0f : v.x), hy = d1_up16(bad ? 0.0f : v.y);
+                    dmax = fmaxf(dmax, fmaxf((float)hx - v.x, (float)hy - v.y));
+                    amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
+                    d1h2 pk; pk.x = hx; pk.y = hy;
+                    im[e] = __builtin_bit_cast(uint32_t, pk);
+                }
+                if (tid < 16) im[n * 16 + tid] = 0xFC00FC00u;
+            }
+            dmax = flmr_wave_max_f32(dmax);
+            amax = flmr_wave_max_f32(amax);
+            if (lane == 0) { s_red[wave] = dmax; s_red[D1_WAVES + wave] = amax; }
+            __syncthreads();
+            if (bad) s_bad = 1;
+            __syncthreads();
+            usable = fits && !s_bad;
+            if (tid == 0 && part == 0) {
+                float d = 0.0f, am = 0.0f;
+                for (int w = 0; w < D1_WAVES; w++) { d = fmaxf(d, s_red[w]); am = fmaxf(am, s_red[D1_WAVES + w]); }
+                // E: 32 rounding steps; eps: two 32-term fp32 sums of terms <= am, each within 32 * 2^-24 * (32 am) -- taken 8 x larger
+                a.img_err[b] = usable ? 32.0f * d + 2.0f * 32.0f * 32.0f * am * 4.8e-7f : __builtin_huge_valf();
+            }
+        } else {
+            __syncthreads();
+        }
+
+        // ---- the item's groups of 64 candidates ----
+        const int gsz = a.group;   // candidates per wave and group (64; 16 for short lists: every wave gets work)
+        const uint32_t pad2 = (uint32_t)n | ((uint32_t)n << 16);
+        const int ngroups = (P + gsz - 1) / gsz;
+        const int per = (ngroups + G - 1) / G;
+        const int gbeg = part * per, gend = (gbeg + per) < ngroups ? (gbeg + per) : ngroups;
+        if (IMG && !usable) {   // no images for this query: every candidate joins the band (E = inf)
+            for (int i = gbeg * gsz + tid; i < gend * gsz && i < P; i += D1_THREADS) keys_b[i] = flmr_make_key(0.0f, src[i]);
+            continue;
+        }
+        // token offsets fit 32 bits (checked by the launcher): a passage's run starts at codes + off
+        auto meta = [&](int g, int& pid, uint32_t& off, int& len) {
+            pid = 0; off = 0; len = 0;
+            const int i = g * gsz + lane;
+            if (g < gend && lane < gsz && i < P) {
+                pid = src[i];
+                const int64_t o = a.offsets[pid];
+                off = (uint32_t)o;
+                len = a.ulen ? (int)a.ulen[pid] : (int)(a.offsets[pid + 1] - o);
+            }
+        };
+        int pid, len; uint32_t off;
+        meta(gbeg + wave, pid, off, len);
+        for (int g = gbeg + wave; g < gend; g += D1_WAVES) {
+            int npid, nlen; uint32_t noff;
+            meta(g + D1_WAVES, npid, noff, nlen);   // next group's, while this one is processed
+            const int ndoc = (P - g * gsz) < gsz ? (P - g * gsz) : gsz;
+            const int nrounds = (ndoc + R - 1) / R;
+            float ukeep = 0.0f;   // lane j: the score of candidate j of the group
+            // codes of (round r, chunk at token t0): this lane's 4 codes of its candidate.  ONE 16-byte load whenever the lane has
+            // a token at all: what it reads beyond the passage's end (the next passage's codes, the copy's padding) is masked by
+            // the listing.  Only at the very end of the code array are the tokens read one by one.
+            auto load_codes = [&](d1i4u& c_, int r, int t0, int& jlen) {
+                const int j = r * R + sub;
+                const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(j << 2, (int)off);
+                jlen = __builtin_amdgcn_ds_bpermute(j << 2, len);   // (lanes past the group's end hold 0)
+                const int first = t0 + 4 * l;
+                c_.x = c_.y = c_.z = c_.w = 0;
+                if (first < jlen) {
+                    const uint64_t at = (uint64_t)o + (uint32_t)first;
+                    if (at + 4 <= (uint64_t)a.codes_len) {
+                        c_ = D1_LOAD(reinterpret_cast<const d1i4u*>(a.codes + at));
+                    } else {
+                        if (at < (uint64_t)a.codes_len) c_.x = a.codes[at];
+                        if (at + 1 < (uint64_t)a.codes_len) c_.y = a.codes[at + 1];
+                        if (at + 2 < (uint64_t)a.codes_len) c_.z = a.codes[at + 2];
+                    }
+                }
+            };
+            d1i4u cdA, cdB;
+            int lenA = 0, lenB = 0;
+            load_codes(cdA, 0, 0, lenA);
+            if (nrounds > 1) load_codes(cdB, 1, 0, lenB);
+            auto round = [&](d1i4u& cd, int& jlen, int r) {
+                const int my_len = jlen;
+                uint32_t acc[4];     // IMG: 8 fp16 column maxima of this lane's 16 bytes of a row
+                d1f4 facc;           // EXACT: 4 fp32 column maxima
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[e] = 0xFC00FC00u;
+                facc.x = facc.y = facc.z = facc.w = -9999.0f;   // filter_pids.cpp:30-33
+                int nh_total = 0;
+                d1i4u cur = cd;
+                const int hg = l / LPR, pr = l % LPR;
+                for (int t0 = 0;; t0 += LISTCAP) {
+                    // ---- list the hits of this chunk ----
+                    const int c_[4] = {cur.x, cur.y, cur.z, cur.w};
+                    if (IMG) reinterpret_cast<uint2*>(my_list)[lane] = make_uint2(pad2, pad2);   // every entry = the padding row
+                    int nv = my_len - (t0 + 4 * l);
+                    nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+                    uint32_t wd[4], wi[4], hm = 0u;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        wi[e] = min((uint32_t)c_[e] >> 5, (uint32_t)(a.idx_words - 1));
+                        wd[e] = lbits[wi[e]];
+                        hm |= ((wd[e] >> (c_[e] & 31)) & 1u) << e;
+                    }
+                    hm &= (1u << nv) - 1u;
+                    const int cnt = __popc(hm);
+                    int incl = cnt;
+                    incl += D1_DPP(incl, D1_ROW_SHR(1));
+                    incl += D1_DPP(incl, D1_ROW_SHR(2));
+                    incl += D1_DPP(incl, D1_ROW_SHR(4));
+                    incl += D1_DPP(incl, D1_ROW_SHR(8));
+                    if (LPC == 32) incl += __builtin_amdgcn_update_dpp(0, incl, 0x142 /* row_bcast15 */, 0xA, 0xF, false);
+                    int nh_own = 0, nmax;
+                    if (LPC == 16) {
+                        const int n0 = __builtin_amdgcn_readlane(incl, 15), n1 = __builtin_amdgcn_readlane(incl, 31);
+                        const int n2 = __builtin_amdgcn_readlane(incl, 47), n3 = __builtin_amdgcn_readlane(incl, 63);
+                        if (!IMG) nh_own = sub == 0 ? n0 : sub == 1 ? n1 : sub == 2 ? n2 : n3;
+                        nmax = max(max(n0, n1), max(n2, n3));
+                    } else {
+                        const int n0 = __builtin_amdgcn_readlane(incl, 31), n1 = __builtin_amdgcn_readlane(incl, 63);
+                        if (!IMG) nh_own = sub == 0 ? n0 : n1;
+                        nmax = max(n0, n1);
+                    }
+                    if (!IMG) nh_total += nh_own;
+                    {   // entry o of a candidate's list sits at [o % HPI][o / HPI]: a lane's hit group reads its entries contiguously
+                        const int base = incl - cnt;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int c = c_[e];
+                            int rid = (int)lpre[wi[e]] + __popc(wd[e] & ((1u << (c & 31)) - 1u));
+                            rid = rid < n ? rid : (IMG ? n : n - 1);
+                            const int o = base + __popc(hm & ((1u << e) - 1u));
+                            const int pos = sub * LISTCAP + (o & (HPI - 1)) * NIT + (o / HPI);
+                            if ((hm >> e) & 1u) my_list[pos] = (uint16_t)rid;
+                        }
+                    }
+                    // the codes are dead: request the chunk-0 codes of round r + 2 into the same registers
+                    const bool more_chunks = __ballot(my_len > t0 + LISTCAP) != 0ull;   // wave-uniform
+                    if (t0 == 0 && r + 2 < nrounds) load_codes(cd, r + 2, 0, jlen);
+                    // ---- fold the listed rows ----
+                    if (nmax > 0) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        // a lane's hit group reads its list entries 16 at a time (32 bytes), then the rows they name
+                        const d1u4* lp = reinterpret_cast<const d1u4*>(my_list + sub * LISTCAP + hg * NIT);
+#pragma unroll 1
+                        for (int hb = 0; hb < NIT; hb += 16) {
+                            if (hb * HPI >= nmax) break;   // (wave-uniform)
+                            uint32_t q[8];
+                            {
+                                const d1u4 t0v = lp[hb / 8], t1v = lp[hb / 8 + 1];
+                                q[0] = t0v.x; q[1] = t0v.y; q[2] = t0v.z; q[3] = t0v.w;
+                                q[4] = t1v.x; q[5] = t1v.y; q[6] = t1v.z; q[7] = t1v.w;
+                            }
+                            // blocks of four entries, every index static: the four rows of a block are requested together (an entry
+                            // beyond a candidate's hits names the padding row / is skipped by its test)
+                            if (IMG) {
+                                const uint32_t pb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)img + pr * 16;
+#pragma unroll
+                                for (int it = 0; it < 16; it += 4) {
+                                    if ((hb + it) * HPI < nmax) {   // (wave-uniform)
+                                        d1u4 v[4];
+#pragma unroll
+                                        for (int u = 0; u < 4; u++) {
+                                            const uint32_t at = d1_row_addr(q[(it + u) >> 1], (it + u) & 1, pb);
+                                            v[u] = *reinterpret_cast<const __attribute__((address_space(3))) d1u4*>((uintptr_t)at);
+                                        }
+#pragma unroll
+                                        for (int u = 0; u < 4; u++) {
+                                            acc[0] = d1_pk_max(acc[0], v[u].x); acc[1] = d1_pk_max(acc[1], v[u].y);
+                                            acc[2] = d1_pk_max(acc[2], v[u].z); acc[3] = d1_pk_max(acc[3], v[u].w);
+                                        }
+                                    }
+                                }
+                            } else {
+                                const float* rb = rows_b + pr * 4;
+#pragma unroll
+                                for (int it = 0; it < 16; it += 4) {
+                                    if ((hb + it) * HPI < nmax) {   // (wave-uniform)
+                                        d1f4 v[4];
+#pragma unroll
+                                        for (int u = 0; u < 4; u++) {
+                                            const int i0 = (hb + it + u) * HPI + hg;
+                                            const uint32_t rid = ((it + u) & 1) ? (q[(it + u) >> 1] >> 16) : (q[(it + u) >> 1] & 0xffffu);
+                                            v[u].x = v[u].y = v[u].z = v[u].w = -9999.0f;
+                                            if (i0 < nh_own) v[u] = *reinterpret_cast<const d1f4*>(rb + (size_t)rid * 32);
+                                        }
+#pragma unroll
+                                        for (int u = 0; u < 4; u++) {
+                                            facc.x = fmaxf(facc.x, v[u].x); facc.y = fmaxf(facc.y, v[u].y);
+                                            facc.z = fmaxf(facc.z, v[u].z); facc.w = fmaxf(facc.w, v[u].w);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();   // (the list is rewritten by the next chunk / round)
+                    }
+                    if (!more_chunks) break;
+                    {   // further chunks of long passages: on demand
+                        int dl;
+                        load_codes(cur, r, t0 + LISTCAP, dl);
+                    }
+                }
+                // ---- this round's candidates: combine the hit groups, sum the columns, keep the score for lane j ----
+                float sc;
+                if (IMG) {
+                    if (HPI >= 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) acc[e] = d1_pk_max(acc[e], (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc[e], D1_ROW_ROR(4), 0xF, 0xF, false));
+                    }
+                    if (HPI >= 4) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) acc[e] = d1_pk_max(acc[e], (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc[e], D1_ROW_ROR(8), 0xF, 0xF, false));
+                    }
+                    if (HPI >= 8) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) acc[e] = d1_pk_max(acc[e], (uint32_t)__shfl_xor((int)acc[e], 16, 64));
+                    }
+                    const bool nohit = (acc[0] & 0xffffu) == 0xFC00u;   // a real row is finite: -inf = only padding rows were folded
+                    float s = 0.0f;
+                    if (nqc == 32) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const d1h2 h = __builtin_bit_cast(d1h2, acc[e]);
+                            s += (float)h.x;
+                            s += (float)h.y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const d1h2 h = __builtin_bit_cast(d1h2, acc[e]);
+                            const int k0 = pr * 8 + 2 * e;
+                            s += k0 < nqc ? (float)h.x : 0.0f;
+                            s += k0 + 1 < nqc ? (float)h.y : 0.0f;
+                        }
+                    }
+                    s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false));
+                    s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false));
+                    sc = nohit ? miss : s;
+                } else {
+                    if (HPI >= 2) {
+                        facc.x = fmaxf(facc.x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.x), D1_ROW_ROR(8), 0xF, 0xF, false)));
+                        facc.y = fmaxf(facc.y, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.y), D1_ROW_ROR(8), 0xF, 0xF, false)));
+                        facc.z = fmaxf(facc.z, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.z), D1_ROW_ROR(8), 0xF, 0xF, false)));
+                        facc.w = fmaxf(facc.w, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.w), D1_ROW_ROR(8), 0xF, 0xF, false)));
+                    }
+                    if (HPI >= 4) {
+                        facc.x = fmaxf(facc.x, __shfl_xor(facc.x, 16, 64)); facc.y = fmaxf(facc.y, __shfl_xor(facc.y, 16, 64));
+                        facc.z = fmaxf(facc.z, __shfl_xor(facc.z, 16, 64)); facc.w = fmaxf(facc.w, __shfl_xor(facc.w, 16, 64));
+                    }
+                    // k-ascending sum (filter_pids.cpp:59-63): lane pr of the candidate holds columns 4 pr .. 4 pr + 3; the running
+                    // sum travels lane 0 -> 7 along row_shr:1.  Columns >= nqc add +0.0f, which leaves the bits unchanged.
+                    const float m0 = 4 * pr < nqc ? facc.x : 0.0f, m1 = 4 * pr + 1 < nqc ? facc.y : 0.0f;
+                    const float m2 = 4 * pr + 2 < nqc ? facc.z : 0.0f, m3 = 4 * pr + 3 < nqc ? facc.w : 0.0f;
+                    float s = 0.0f;
+#pragma unroll
+                    for (int p = 0; p < 8; p++) {
+                        const float sp = p == 0 ? 0.0f : __int_as_float(D1_DPP(__float_as_int(s), D1_ROW_SHR(1)));
+                        if (pr == p) s = (((sp + m0) + m1) + m2) + m3;
+                    }
+                    sc = nh_total > 0 ? s : miss;
+                }
+                // the finished score sits in lane (IMG: 0, EXACT: 7) of each candidate's lanes: hand it to lane j of the group
+#pragma unroll
+                for (int u = 0; u < R; u++) {
+                    const int v = __builtin_amdgcn_readlane(__float_as_int(sc), u * LPC + (IMG ? 0 : 7));
+                    const int dst = __builtin_amdgcn_readfirstlane(r * R + u);
+                    // (no builtin for v_writelane in this toolchain; the s_nop covers the SGPR hazards the compiler cannot see)
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(ukeep) : "s"(v), "s"(dst) : "m0");
+                }
+            };
+            for (int r = 0; r < nrounds; r += 2) {
+                round(cdA, lenA, r);
+                if (r + 1 < nrounds) round(cdB, lenB, r + 1);
+            }
+            if (lane < ndoc) keys_b[g * gsz + lane] = flmr_make_key(ukeep, pid);
+            pid = npid; off = noff; len = nlen;
+        }
+    }
+}
+
+// LDS the launch needs besides the images; rows of images that fit beside it
+static size_t d1_fixed_lds(int nqueries, int idx_words, int lpc) {
+    return (size_t)((nqueries + 3) & ~3) * 4 + (size_t)idx_words * 4 + (size_t)((idx_words + 7) & ~7) * 2 +
+           (size_t)D1_WAVES * (64 / lpc) * (lpc * 4) * 2;
+}
+int flmr_s1_dense_image_rows(int nqueries, int idx_words, int lpc) {
+    const size_t budget = (size_t)160 * 1024 - 1024;   // static __shared__ of the kernel and alignment
+    const size_t fixed = d1_fixed_lds(nqueries, idx_words, lpc);
+    if (fixed + 64 * 65 > budget) return 0;
+    const size_t rows = (budget - fixed) / 64 - 1;   // (+ the padding row)
+    return (int)(rows > 65000 ? 65000 : rows);
+}
+
+// lpc: 16 or 32 lanes per candidate (the index's choice: 4 x lpc >= the usual number of distinct codes of a passage)
+int flmr_launch_s1_dense(const flmr_s1d_args& a_in, bool img_pass, int lpc, hipStream_t st) {
+    flmr_s1d_args a = a_in;
+    size_t lds = d1_fixed_lds(a.nqueries, a.idx_words, lpc);
+    if (img_pass) {
+        a.img_rows = flmr_s1_dense_image_rows(a.nqueries, a.idx_words, lpc);
+        if (a.img_rows < 1) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "dense stage 1: the centroid mask leaves no room for score-row images in LDS");
+        lds += (size_t)(a.img_rows + 1) * 64;
+    }
+    if (lds > (size_t)160 * 1024) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "dense stage 1: K = %d does not fit the LDS form", a.idx_words * 32);
+    const void* fn = img_pass ? (lpc == 16 ? reinterpret_cast<const void*>(s1_dense_kernel<true, 16>) : reinterpret_cast<const void*>(s1_dense_kernel<true, 32>))
+                              : (lpc == 16 ? reinterpret_cast<const void*>(s1_dense_kernel<false, 16>) : reinterpret_cast<const void*>(s1_dense_kernel<false, 32>));
+    if (lds > 48 * 1024) FLMR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (a.parts < 1) a.parts = img_pass ? 4 : 8;
+    if (a.group != 16) a.group = 64;
+    if (a.codes_len > 0xffffffffLL) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "dense stage 1: token offsets beyond 32 bits");
+    int64_t grid = 256;   // one persistent workgroup per CU; a multiple of 8 so that workgroup L and its items share L % 8
+    const int64_t max_items = (int64_t)((a.nqueries + D1_XCDS - 1) & ~(D1_XCDS - 1)) * a.parts;
+    if (grid > max_items) grid = max_items;
+    dim3 g((unsigned)grid), block(D1_THREADS);
+    if (img_pass) {
+        if (lpc == 16) hipLaunchKernelGGL((s1_dense_kernel<true, 16>), g, block, lds, st, a);
+        else hipLaunchKernelGGL((s1_dense_kernel<true, 32>), g, block, lds, st, a);
+    } else {
+        if (lpc == 16) hipLaunchKernelGGL((s1_dense_kernel<false, 16>), g, block, lds, st, a);
+        else hipLaunchKernelGGL((s1_dense_kernel<false, 32>), g, block, lds, st, a);
+    }
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
