@@ -107,7 +107,9 @@ typedef struct flmr_index_info {
     int32_t xcd_round_robin;      /* 1: probe at open saw 8 XCDs and workgroup L of a 1-D grid on XCD (L % 8) */
     int32_t stage2_sliced;        /* 1: whole-batch stage 2 takes the XCD-sliced kernel on this index */
     int32_t passage_chunks;       /* 32768-passage chunks of the candidate stage */
-    int32_t reserved;
+    int32_t duplicate_permille;   /* tokens that repeat a code of their own passage, per thousand: what the distinct-code runs built at
+                                   * open save stage 2 and the dense stage 1 (0 when the sorted code copy was not built; below 100 the
+                                   * runs are not kept) */
 } flmr_index_info_t;
 int flmr_index_info(const flmr_index_t* index, flmr_index_info_t* out_info);
 
@@ -216,7 +218,8 @@ int flmr_unpack_keys(const uint64_t* keys, int32_t nqueries, int32_t n, int32_t 
  * (0 elements when the last batch did not run that path); STAGE1_FORM i32 [1]: which form of the list-scatter stage 1 produced
  * the query's keys -- 0 the queue form, 1 the slot form (query not tried by the others: too many surviving lists), 2 the slot form
  * after the queue form gave the query up, 3 the small-dense form (a searcher whose queries mostly overflow the queue), 4 the slot
- * form after the small-dense form gave the query up (0 elements: stage 1 ran in another mode). */
+ * form after the small-dense form gave the query up, 5 the dense image form (fp16 images of the score rows in LDS, the band around the cut
+ * rescored exactly), 6 the dense exact form (0 elements: stage 1 ran in another mode). */
 typedef enum flmr_tap {
     FLMR_TAP_CENTROID_SCORES = 0,
     FLMR_TAP_IDX_BITS = 1,

@@ -46,7 +46,7 @@ int main() {
     for (int c : surv) bits[c >> 5] |= 1u << (c & 31);
     { uint32_t run = 0; for (int w = 0; w < idx_words; w++) { prefix[w] = run; run += __builtin_popcount(bits[w]); } }
     // passages: distinct ascending codes first, the rest of the 128-token run repeats the last
-    std::vector<int32_t> codes((size_t)P * L + 8, 0x7f7f7f7f);
+    std::vector<int32_t> codes((size_t)P * L + 256, 0x7f7f7f7f);
     std::vector<uint16_t> ulen(P);
     std::vector<int64_t> off(P + 1);
     for (int p = 0; p <= P; p++) off[p] = (int64_t)p * L;
@@ -90,7 +90,7 @@ int main() {
     a.rows = d_rows; a.row_cap = row_cap; a.nqual = d_nqual; a.q_lens = nullptr; a.nq_cand = 32; a.nqueries = NQ;
     a.cand = d_cand; a.cand_stride = NC; a.cand_count = d_cc; a.band = d_band; a.band_count = d_bc; a.mode = d_mode; a.keys = d_keys; a.img_err = d_err;
     a.parts = (int)envd("S1D_PARTS", 0);
-    a.codes_len = (int64_t)codes.size(); a.group = 64;
+    a.codes_len = (int64_t)P * L; a.group = 64;
     const int img_rows = flmr_s1_dense_image_rows(NQ, idx_words, LPC);
     printf("P %d, survivors %d, candidates/query %d, distinct codes/passage %.1f, hit share %.2f, LPC %d, image rows that fit %d\n", P, NS, NC, mean_ul, HIT, LPC, img_rows);
 

@@ -12,7 +12,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.environ.get("FLMR_HIP_LIB") or os.path.join(PKG_DIR, "lib", "libflmr_hip.so")  # override: A/B-ing kernel builds
 CSRC = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["flmr_index.hip", "flmr_stage0.hip", "flmr_candidates.hip", "flmr_filter.hip", "flmr_stage2_walk.hip", "flmr_stage2_xcd.hip", "flmr_maxsim.hip", "flmr_search.hip", "flmr_ops.hip", "flmr_build.hip", "flmr_ivf.hip", "flmr_collective.hip"]
+SOURCES = ["flmr_index.hip", "flmr_stage0.hip", "flmr_candidates.hip", "flmr_filter.hip", "flmr_stage1_dense.hip", "flmr_stage2_walk.hip", "flmr_stage2_xcd.hip", "flmr_maxsim.hip", "flmr_search.hip", "flmr_ops.hip", "flmr_build.hip", "flmr_ivf.hip", "flmr_collective.hip"]
 HEADERS = ["flmr_common.h", "flmr_device.h"]
 
 FLMR_MEM_HOST, FLMR_MEM_DEVICE = 0, 1
@@ -37,7 +37,7 @@ class IndexDesc(C.Structure):
 class IndexInfo(C.Structure):
     _fields_ = [("derived_bytes", C.c_int64), ("max_doclen", C.c_int64), ("centroids_f16_exact", C.c_int32),
                 ("stage2_slices", C.c_int32), ("xcd_round_robin", C.c_int32), ("stage2_sliced", C.c_int32),
-                ("passage_chunks", C.c_int32), ("reserved", C.c_int32)]
+                ("passage_chunks", C.c_int32), ("duplicate_permille", C.c_int32)]
 
 
 class SearchParams(C.Structure):

@@ -12,6 +12,7 @@
 #define FLMR_MAX_NCELLS 8
 #define FLMR_MAX_NQ_CAND 128    // candidate-generation width limit (4 column tiles of 32)
 #define FLMR_MAX_NDOCS 8192
+#define FLMR_CODE_PAD 256        // ints readable behind the sorted code copy (the dense stage 1 reads whole 16-byte pieces)
 
 extern thread_local char flmr_err_buf[512];
 
@@ -114,7 +115,12 @@ struct flmr_index {
     int32_t centroids_f16_exact;  // every centroid value is representable in fp16 (true for reference-format indexes)
     uint32_t* ivf_chunk_tab;      // [K][nchunks+1]: first entry of each IVF list with pid >= chunk*32768
     int32_t nchunks;
-    int32_t* codes_sorted;        // [N] per-passage ascending copy of `codes` (stage-2 walk); NULL when a passage is too long
+    int32_t* codes_sorted;        // [N + FLMR_CODE_PAD] per-passage ascending copy of `codes` with the DISTINCT values first (the rest of a
+                                  // passage's run repeats its largest code: still ascending, the same set); NULL when a passage is too long
+    uint16_t* doc_ulen;           // [num_passages] distinct codes per passage = the length of the distinct prefix in codes_sorted; NULL when
+                                  // fewer than a tenth of the tokens repeat a code of their passage (every token then counts)
+    double dup_share;             // share of the tokens that repeat a code of their passage (0 when codes_sorted was not built)
+    double mean_ulen;             // mean number of distinct codes per passage
     _Float16* centroids_f16_tiled;  // centroids_f16 in MFMA A-operand order, one contiguous 1 KB run per (tile, k-step) (stage-2 walk)
     uint16_t* doc_splits;         // [num_passages][nslices]: codes_sorted position of the first code >= s * slice_rows (XCD-sliced stage 2)
     float cen_norm_max;           // >= the largest centroid 2-norm (bound of the "hi first" stage 0)
@@ -196,6 +202,8 @@ struct flmr_filter_args {
     const int64_t* doclens;    // nullable -> offsets[p+1]-offsets[p]
     const int64_t* offsets;
     int32_t f16_round;         // FLMR_NUMERICS_GPU_FP16: column maxima rounded to fp16, fp32 sum rounded to fp16 (flmr_device.h)
+    const uint16_t* ulen_sorted;  // nullable: distinct codes per passage -- the part of a passage's run in `codes_sorted` the sliced stage 2
+                                  // reads (a maximum is idempotent: filter_pids.cpp:50-63)
 };
 // stage 1: candidates (cand[q*cand_stride + i], i < cand_count[q]) restricted to idx_bits -> keys
 int flmr_launch_filter_stage1(const flmr_filter_args& f, const uint32_t* idx_bits, int32_t idx_words,
@@ -323,6 +331,46 @@ struct flmr_maxsim_args {
     int64_t colmax_cap;       // floats
 };
 int flmr_launch_maxsim(const flmr_maxsim_args& a, hipStream_t st);
+
+// ---- stage 1 for dense survivor sets (flmr_stage1_dense.hip) ----
+struct flmr_s1d_args {
+    const int32_t* codes;        // `codes_sorted`: per-passage runs, distinct values first, FLMR_CODE_PAD ints readable behind the last
+    const int64_t* offsets;      // [num_passages + 1]
+    const uint16_t* ulen;        // [num_passages] distinct codes per passage (NULL: every token, offsets[p+1] - offsets[p])
+    const uint32_t* idx_bits;    // [nqueries, idx_words] surviving-centroid mask (index_storage.py:116)
+    const uint32_t* idx_prefix;  // [nqueries, idx_words] exclusive popcount per word (qualifying_kernel)
+    int32_t idx_words;
+    const float* rows;           // compact score rows [nqueries, row_cap, 32] (row = rank of the centroid among the survivors)
+    int32_t row_cap;
+    const int32_t* nqual;        // [nqueries] surviving centroids (clamped to row_cap by qualifying_kernel)
+    const int32_t* q_lens;       // nullable
+    int32_t nq_cand, nqueries;
+    const int32_t* cand;         // [nqueries, cand_stride] ascending candidate pids
+    int64_t cand_stride;
+    const int32_t* cand_count;
+    const int32_t* band;         // [nqueries, cand_stride] the band of an image query (EXACT pass)
+    const int32_t* band_count;
+    const int32_t* mode;         // [nqueries] FLMR_S1D_*: which queries this launch takes, from which list
+    uint64_t* keys;              // [nqueries, cand_stride] out
+    float* img_err;              // [nqueries] out (IMG pass): E + eps of the band rule (inf: the images cannot be used)
+    int32_t parts;               // items per query (0: the launcher's choice)
+    int32_t group;               // candidates per wave and group: 64, or 16 for short lists
+    int64_t codes_len;           // tokens at `codes`; FLMR_CODE_PAD more ints must be readable behind them
+    int32_t img_rows;            // rows of images the launch's LDS holds (IMG pass; set by the launcher)
+};
+#define FLMR_S1D_SKIP 0    // stage 1 of the query is done elsewhere (list-scatter forms, the round-5 scan)
+#define FLMR_S1D_IMAGE 1   // IMG pass over the candidates, band, EXACT pass over the band
+#define FLMR_S1D_EXACT 2   // EXACT pass over the candidates
+int flmr_s1_dense_image_rows(int nqueries, int idx_words, int lpc);   // score-row images the LDS form holds per query (0: K too large)
+int flmr_launch_s1_dense(const flmr_s1d_args& a, bool img_pass, int lpc, hipStream_t st);
+// which queries the dense forms take: mode[q] = SKIP where skip[q] (done by a list-scatter form), IMAGE where the query's rows fit
+// `img_rows` images, else EXACT (exact_too) or SKIP with scan[q] = 0 (the round-5 scan takes the query); scan[q] = 1 everywhere else
+int flmr_launch_s1_dense_modes(const int32_t* skip, const int32_t* nqual, int32_t nqueries, int32_t img_rows, int32_t exact_too,
+                               int32_t* mode, int32_t* scan_skip, hipStream_t st);
+// the band of every IMAGE query from its U keys (keys >= the n-th largest - err[q]) -> band pids / counts; in_count[q] = the number
+// of keys the top-n selection after stage 1 reads for query q (band_count for IMAGE queries, counts[q] for the others)
+int flmr_launch_s1_band(const uint64_t* keys, int64_t key_stride, const int32_t* counts, const int32_t* mode, const float* err,
+                        int32_t nqueries, int32_t n, int32_t* band, int32_t* band_count, int32_t* in_count, hipStream_t st);
 
 int flmr_launch_exclusive_scan_lengths(const int32_t* pids, const int64_t* doclens, const int64_t* offsets, int32_t n,
                                        int64_t* out_offsets /* [n+1] */, hipStream_t st);

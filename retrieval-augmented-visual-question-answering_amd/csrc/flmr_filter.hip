@@ -849,11 +849,16 @@ __device__ __forceinline__ void sel_pick_digit(const unsigned int* hist, int rem
 // a pass that re-reads global memory is pure exposed latency (30 dependent iterations x 9 passes before); only the tail
 // of longer lists streams from global memory in every pass.  The passes stop once the selected bucket is taken whole.
 // ------------------------------------------------------------------------------------------------
-template <int KPT>
+// BAND (the dense stage 1's approximate-then-refine, flmr_stage1_dense.hip): for the queries with band_mode[q] == FLMR_S1D_IMAGE the
+// keys carry upper-bound scores U; instead of the n largest, EVERY key whose score is >= (the n-th largest U) - band_err[q] is
+// emitted (no cap: out_stride >= count), and band_in[q] = how many -- the exact pass rescores them, the selection proper follows.
+// The other queries only copy their count to band_in.
+template <int KPT, bool BAND>
 __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys, int64_t key_stride,
                                                            const int32_t* counts, int32_t n, int32_t* out_pids,
                                                            int64_t out_stride, int32_t* n_out, uint64_t* out_keys,
-                                                           uint64_t key_add, int32_t fixed_count) {
+                                                           uint64_t key_add, int32_t fixed_count, const int32_t* band_mode,
+                                                           const float* band_err, int32_t* band_in) {
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long s_prefix;
     __shared__ int s_remaining;
@@ -864,7 +869,18 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys,
     const uint64_t* kb = keys + (size_t)b * key_stride;
     int32_t* ob = out_pids ? out_pids + (size_t)b * out_stride : nullptr;  // optional: the selected pids
     uint64_t* okb = out_keys ? out_keys + (size_t)b * out_stride : nullptr;  // optional: the selected keys (+ pid base), 0 padded
-    if (P <= n) {
+    if (BAND) {
+        if (band_mode[b] != FLMR_S1D_IMAGE) {   // (block-uniform)
+            if (tid == 0) band_in[b] = P;
+            return;
+        }
+        if (P <= n) {   // every candidate is selected: all of them are rescored
+            for (int i = tid; i < P; i += blockDim.x) ob[i] = flmr_key_pid(kb[i]);
+            if (tid == 0) { n_out[b] = P; band_in[b] = P; }
+            return;
+        }
+    }
+    if (!BAND && P <= n) {
         for (int i = tid; i < n; i += blockDim.x) {
             if (ob && i < P) ob[i] = flmr_key_pid(kb[i]);
             if (okb) okb[i] = i < P ? kb[i] + key_add : 0ull;
@@ -967,6 +983,25 @@ __global__ __launch_bounds__(1024) void select_topn_kernel(const uint64_t* keys,
     // real keys) only fill what is left -- otherwise a run of empty keys met first in scan order could displace real ones.
     const unsigned long long thr = s_prefix;
     __shared__ int sel_scan[17];
+    if (BAND) {
+        // thr <= the n-th largest key; every key whose score reaches (its score - err) belongs to the band
+        const unsigned long long cut = flmr_make_key(flmr_key_score(thr) - band_err[b], 0);
+        int mine = 0;
+#pragma unroll
+        for (int j = 0; j < KPT; j++) mine += (j * 1024 + tid < P && kreg[j] >= cut) ? 1 : 0;
+        for (int i0 = KPT * 1024 + tid; i0 < P; i0 += 1024) mine += kb[i0] >= cut ? 1 : 0;
+        int total;
+        int pos = flmr_block_exclusive_scan(mine, sel_scan, &total);
+#pragma unroll
+        for (int j = 0; j < KPT; j++)
+            if (j * 1024 + tid < P && kreg[j] >= cut) ob[pos++] = flmr_key_pid(kreg[j]);
+        for (int i0 = KPT * 1024 + tid; i0 < P; i0 += 1024) {
+            const uint64_t key = kb[i0];
+            if (key >= cut) ob[pos++] = flmr_key_pid(key);
+        }
+        if (tid == 0) { n_out[b] = total; band_in[b] = total; }
+        return;
+    }
     int mine_gt = 0, mine_eq = 0;
 #pragma unroll
     for (int j = 0; j < KPT; j++) {
@@ -1012,11 +1047,23 @@ int flmr_launch_select_topn(const uint64_t* keys, int64_t key_stride, const int3
                             uint64_t* out_keys, uint64_t key_add) {
     // keys per thread held in registers: sized from the candidate capacity (the tail of longer lists streams)
     if (key_stride <= 16 * 1024)
-        hipLaunchKernelGGL(select_topn_kernel<16>, dim3(nqueries), dim3(1024), 0, st, keys, key_stride, counts, n, out_pids,
-                           out_stride, n_out, out_keys, key_add, 0);
+        hipLaunchKernelGGL((select_topn_kernel<16, false>), dim3(nqueries), dim3(1024), 0, st, keys, key_stride, counts, n, out_pids,
+                           out_stride, n_out, out_keys, key_add, 0, nullptr, nullptr, nullptr);
     else
-        hipLaunchKernelGGL(select_topn_kernel<24>, dim3(nqueries), dim3(1024), 0, st, keys, key_stride, counts, n, out_pids,
-                           out_stride, n_out, out_keys, key_add, 0);
+        hipLaunchKernelGGL((select_topn_kernel<24, false>), dim3(nqueries), dim3(1024), 0, st, keys, key_stride, counts, n, out_pids,
+                           out_stride, n_out, out_keys, key_add, 0, nullptr, nullptr, nullptr);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
+int flmr_launch_s1_band(const uint64_t* keys, int64_t key_stride, const int32_t* counts, const int32_t* mode, const float* err,
+                        int32_t nqueries, int32_t n, int32_t* band, int32_t* band_count, int32_t* in_count, hipStream_t st) {
+    if (key_stride <= 16 * 1024)
+        hipLaunchKernelGGL((select_topn_kernel<16, true>), dim3(nqueries), dim3(1024), 0, st, keys, key_stride, counts, n, band,
+                           key_stride, band_count, nullptr, 0ull, 0, mode, err, in_count);
+    else
+        hipLaunchKernelGGL((select_topn_kernel<24, true>), dim3(nqueries), dim3(1024), 0, st, keys, key_stride, counts, n, band,
+                           key_stride, band_count, nullptr, 0ull, 0, mode, err, in_count);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }
@@ -1025,11 +1072,11 @@ int flmr_launch_select_topn(const uint64_t* keys, int64_t key_stride, const int3
 // whose consumers do not care about order: a radix select instead of a full bitonic sort of up to 8192 keys)
 int flmr_launch_select_keys(const uint64_t* keys, int32_t nqueries, int32_t m, int32_t n, uint64_t* out, hipStream_t st) {
     if (m <= 16 * 1024)
-        hipLaunchKernelGGL(select_topn_kernel<16>, dim3(nqueries), dim3(1024), 0, st, keys, (int64_t)m, nullptr, n, nullptr,
-                           (int64_t)n, nullptr, out, 0ull, m);
+        hipLaunchKernelGGL((select_topn_kernel<16, false>), dim3(nqueries), dim3(1024), 0, st, keys, (int64_t)m, nullptr, n, nullptr,
+                           (int64_t)n, nullptr, out, 0ull, m, nullptr, nullptr, nullptr);
     else
-        hipLaunchKernelGGL(select_topn_kernel<24>, dim3(nqueries), dim3(1024), 0, st, keys, (int64_t)m, nullptr, n, nullptr,
-                           (int64_t)n, nullptr, out, 0ull, m);
+        hipLaunchKernelGGL((select_topn_kernel<24, false>), dim3(nqueries), dim3(1024), 0, st, keys, (int64_t)m, nullptr, n, nullptr,
+                           (int64_t)n, nullptr, out, 0ull, m, nullptr, nullptr, nullptr);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }

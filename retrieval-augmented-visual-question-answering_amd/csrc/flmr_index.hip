@@ -199,7 +199,8 @@ extern "C" int flmr_index_info(const flmr_index_t* ix, flmr_index_info_t* out) {
     size_t b = 256 * (8 / ix->nbits) * sizeof(float);
     if (ix->centroids_f16) b += K * FLMR_DIM * sizeof(_Float16);
     if (ix->centroids_f16_tiled) b += K * FLMR_DIM * sizeof(_Float16);
-    if (ix->codes_sorted) b += ((size_t)ix->N + 8) * sizeof(int32_t);
+    if (ix->codes_sorted) b += ((size_t)ix->N + FLMR_CODE_PAD) * sizeof(int32_t);
+    if (ix->doc_ulen) b += (size_t)ix->num_passages * sizeof(uint16_t);
     if (ix->doc_splits) b += (size_t)ix->num_passages * ix->nslices * sizeof(uint16_t);
     if (ix->ivf_chunk_tab) b += K * ((size_t)ix->nchunks + 1) * sizeof(uint32_t);
     if (ix->inv_norm) b += ((size_t)ix->N + 64) * sizeof(float);
@@ -210,6 +211,7 @@ extern "C" int flmr_index_info(const flmr_index_t* ix, flmr_index_info_t* out) {
     out->xcd_round_robin = ix->xcd_round_robin;
     out->stage2_sliced = flmr_stage2_xcd_pays(ix) ? 1 : 0;
     out->passage_chunks = ix->nchunks;
+    out->duplicate_permille = (int32_t)(ix->dup_share * 1000.0 + 0.5);
     return FLMR_OK;
 }
 
@@ -225,6 +227,7 @@ extern "C" int flmr_index_close(flmr_index_t* ix) {
     (void)hipFree(ix->centroids_f16);
     (void)hipFree(ix->ivf_chunk_tab);
     (void)hipFree(ix->codes_sorted);
+    (void)hipFree(ix->doc_ulen);
     (void)hipFree(ix->centroids_f16_tiled);
     (void)hipFree(ix->doc_splits);
     delete[] ix->ivf_len_prefix;

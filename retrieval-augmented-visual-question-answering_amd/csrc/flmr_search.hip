@@ -42,11 +42,16 @@ struct flmr_searcher {
     uint2* s3_desc; int64_t s3_desc_stride; int32_t* s3_wbeg; int32_t s3_wcap;   // planned-tile S3 (NULL: the passage-walking kernel)
     float* s3_colmax; int64_t s3_colmax_cap;   // long queries: per (query, finalist, column) maxima of the query-stationary S3 kernel
     int32_t* qual; int32_t* nqual; int32_t* chunk_cnt; uint8_t* cand_hit; int32_t qmax;
+    // stage 1 for dense survivor sets (flmr_stage1_dense.hip): per query which form, the band of an image query, its error bound,
+    // how many keys the selection reads, and which queries are left to the round-5 scan
+    int32_t* s1d_mode; int32_t* s1d_band; int32_t* s1d_band_count; float* s1d_err; int32_t* s1d_in_count; int32_t* s1d_scan_skip;
+    int32_t s1d_lpc, s1d_img_rows;   // lanes per candidate (16 / 32 by the index's distinct codes per passage); images the LDS holds (0: no dense form)
     int32_t* cand_fast;         // flmr_cand_args::fast_state ([FLMR_FAST_HDR + 2 * max_queries]; the header words live as long as the searcher)
     // last call (for taps)
     int32_t last_nqueries, last_ncol, last_ndocs, last_full_table;
     flmr_cand_args last_ca{};   // candidate-stage arguments of the last batch (lazy FLMR_TAP_CANDIDATES in scatter mode)
     bool last_scatter = false;
+    bool last_dense = false;    // the last batch ran the dense stage-1 forms for the queries the list-scatter forms left
     bool last_hi_first = false; // the last batch's stage 0 wrote q_err / q_err_sum (FLMR_TAP_Q_ERR*)
     hipStream_t last_stream;
     bool profiling;
@@ -164,6 +169,13 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     WS(chunk_cnt, B * (size_t)ix->nchunks);
     WS(chunk_hits, B * (size_t)ix->nchunks);
     WS(cand_hit, B * (size_t)s->cand_cap);
+    // dense stage 1: needs the sorted code copy (whole 16-byte pieces are read: its padding) and 32-bit token offsets
+    s->s1d_lpc = ix->mean_ulen > 0.0 && ix->mean_ulen <= 72.0 ? 16 : 32;
+    s->s1d_img_rows = (ix->codes_sorted && s->ncol_max == 32 && !s->opt.is(FLMR_OPT_S1_IMPL, "scan")) ? flmr_s1_dense_image_rows(max_queries, s->idx_words, s->s1d_lpc) : 0;
+    if (s->s1d_img_rows > 0) {
+        WS(s1d_mode, B); WS(s1d_band_count, B); WS(s1d_err, B); WS(s1d_in_count, B); WS(s1d_scan_skip, B);
+        WS(s1d_band, B * (size_t)s->cand_cap);
+    }
     WS(q3_hi, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
     WS(q3_lo, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
 #undef WS
@@ -211,7 +223,7 @@ extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
     if (!s) return FLMR_OK;
     void* ptrs[] = {s->cs, s->rows, s->idx_prefix, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
                     s->keys1, s->s1_pids, s->s1_count, s->keys2, s->s2_pids, s->s2_count, s->keys3, s->doc_scores,
-                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->q_err, s->q_err_sum, s->s2_band, s->s2_band_count, s->s2_need, s->s2_def, s->keys2b, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->chunk_hits, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part, s->s3_desc, s->s3_wbeg, s->s3_colmax, s->cand_fast};
+                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->q_err, s->q_err_sum, s->s2_band, s->s2_band_count, s->s2_need, s->s2_def, s->keys2b, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->chunk_hits, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part, s->s3_desc, s->s3_wbeg, s->s3_colmax, s->cand_fast, s->s1d_mode, s->s1d_band, s->s1d_band_count, s->s1d_err, s->s1d_in_count, s->s1d_scan_skip};
     for (void* p : ptrs) (void)hipFree(p);
     if (s->status_host) (void)hipHostFree(s->status_host);
     if (s->status_ev) (void)hipEventDestroy(s->status_ev);
@@ -488,6 +500,7 @@ static int prepare_ctx(run_ctx& c, flmr_searcher* s, const float* Q, const int32
     f.K = ix->K; f.ncol = ncol; f.nq_cand = nqc;
     f.nqueries = nqueries; f.q_lens = q_lens; f.codes = ix->codes; f.doclens = nullptr; f.offsets = ix->doc_offsets;
     f.f16_round = f16num ? 1 : 0;
+    f.ulen_sorted = ix->doc_ulen;
     s->last_nqueries = nqueries; s->last_ncol = ncol; s->last_ndocs = p->ndocs; s->last_stream = c.st;
     s->last_full_table = a0.full_table;
     s->last_hi_first = c.sparse && a0.q_err_buf != nullptr && (int64_t)ix->K * 256 < (1ll << 32) && !s->opt.is(FLMR_OPT_S0_IMPL, "f16rs");
@@ -554,11 +567,39 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
                                        s->hit_bits, s->bitmap_words, s->hit_valid, st));
         RUN(mark(c));
     }
+    // Queries the list-scatter forms did not take (hit_valid == 0: more surviving centroids or longer lists than they handle):
+    // the dense forms of flmr_stage1_dense.hip -- fp16 images of the query's score rows in LDS, upper-bound keys for every
+    // candidate, the band around the cut rescored exactly -- where the rows fit (<= ~2 k survivors), the same kernel's exact form
+    // beyond; the round-5 scan keeps the cases those do not cover (several column tiles, the fp16 numerics mode, no sorted copy).
+    const bool dense = s->s1d_img_rows > 0 && chunked && c.sparse && c.ncol == 32 && !c.f.f16_round && !s->opt.is(FLMR_OPT_S1_IMPL, "scan");
+    const int32_t* scan_skip = scatter ? s->hit_valid : nullptr;
+    const int32_t* sel_counts = s->cand_count;
+    s->last_dense = dense;
+    if (dense) {
+        flmr_s1d_args d{};
+        d.codes = ix->codes_sorted; d.offsets = ix->doc_offsets; d.ulen = ix->doc_ulen; d.codes_len = ix->N;
+        d.idx_bits = s->idx_bits; d.idx_prefix = s->idx_prefix; d.idx_words = s->idx_words;
+        d.rows = s->rows; d.row_cap = s->row_cap; d.nqual = s->nqual; d.q_lens = c.q_lens; d.nq_cand = c.nqc; d.nqueries = c.nqueries;
+        d.cand = s->cand; d.cand_stride = s->cand_cap; d.cand_count = s->cand_count;
+        d.band = s->s1d_band; d.band_count = s->s1d_band_count; d.mode = s->s1d_mode; d.keys = s->keys1; d.img_err = s->s1d_err;
+        const bool exact_too = !s->opt.is(FLMR_OPT_S1_IMPL, "image");   // (development: "image" leaves the queries beyond the images to the scan)
+        RUN(flmr_launch_s1_dense_modes(scatter ? s->hit_valid : nullptr, s->nqual, c.nqueries, s->s1d_img_rows, exact_too ? 1 : 0,
+                                       s->s1d_mode, s->s1d_scan_skip, st));
+        d.parts = 0; d.group = 64;
+        RUN(flmr_launch_s1_dense(d, true, s->s1d_lpc, st));
+        RUN(flmr_launch_s1_band(s->keys1, s->cand_cap, s->cand_count, s->s1d_mode, s->s1d_err, c.nqueries, c.p.ndocs, s->s1d_band,
+                                s->s1d_band_count, s->s1d_in_count, st));
+        // the bands are short (ndocs + a few per cent): one item per query, groups of 16 so that every wave has some
+        d.parts = 1; d.group = 16;
+        RUN(flmr_launch_s1_dense(d, false, s->s1d_lpc, st));
+        scan_skip = s->s1d_scan_skip;
+        sel_counts = s->s1d_in_count;
+    }
     RUN(flmr_launch_filter_stage1(c.f, s->idx_bits, s->idx_words, s->cand, s->cand_cap, s->cand_count, s->keys1,
                                   (use_hits && !chunked) ? s->hit_bits : nullptr, s->bitmap_words, use_hits ? s->hit_valid : nullptr,
-                                  (use_hits && chunked) ? s->cand_hit : nullptr, st, scatter ? s->hit_valid : nullptr));
+                                  (use_hits && chunked) ? s->cand_hit : nullptr, st, scan_skip));
     RUN(mark(c));
-    RUN(flmr_launch_select_topn(s->keys1, s->cand_cap, s->cand_count, c.nqueries, c.p.ndocs, s->s1_pids, s->maxp.ndocs,
+    RUN(flmr_launch_select_topn(s->keys1, s->cand_cap, sel_counts, c.nqueries, c.p.ndocs, s->s1_pids, s->maxp.ndocs,
                                 s->s1_count, st, out_keys, (uint64_t)ix->pid_base));
     RUN(mark(c));
     return push_status(c);
@@ -830,6 +871,16 @@ extern "C" int flmr_searcher_tap(flmr_searcher_t* s, int32_t what, int32_t q, vo
         case FLMR_TAP_Q_ERR_SUM:
             n = s->last_hi_first ? 1 : 0; src = s->q_err_sum + q; break;
         case FLMR_TAP_STAGE1_FORM:
+            if (s->last_dense) {   // a query the dense forms took: 5 (images + band) / 6 (exact rows)
+                int32_t m = 0;
+                FLMR_HIP(hipMemcpy(&m, s->s1d_mode + q, 4, hipMemcpyDeviceToHost));
+                if (m != FLMR_S1D_SKIP) {
+                    *count = 1;
+                    if (capacity < 1) FLMR_FAIL(FLMR_ERR_CAPACITY, "tap needs 1 element");
+                    *static_cast<int32_t*>(host_out) = 4 + m;
+                    return FLMR_OK;
+                }
+            }
             n = (s->last_ca.scatter && s->last_ca.fast_state) ? 1 : 0; src = s->cand_fast + FLMR_FAST_HDR + q; break;
         default: FLMR_FAIL(FLMR_ERR_INVALID, "unknown tap %d", what);
     }

@@ -47,6 +47,7 @@
 #define D1_LOAD(p) (*(p))
 #endif
 #define D1_THREADS (64 * D1_WAVES)
+#define D1_CODE_PAD FLMR_CODE_PAD   // ints readable beyond the last passage's codes (flmr_build_sorted_codes pads the copy)
 #define D1_XCDS 8
 
 typedef uint32_t d1u4 __attribute__((ext_vector_type(4)));
@@ -86,34 +87,6 @@ __device__ __forceinline__ uint32_t d1_row_addr(uint32_t q, int hi, uint32_t bas
     return r;
 }
 
-struct flmr_s1d_args {
-    const int32_t* codes;        // per-passage code runs: `codes_sorted` (distinct values first) with `ulen`, or the plain codes
-    const int64_t* offsets;      // [num_passages + 1]
-    const uint16_t* ulen;        // [num_passages] distinct codes per passage (NULL: every token, offsets[p+1] - offsets[p])
-    const uint32_t* idx_bits;    // [nqueries, idx_words] surviving-centroid mask (index_storage.py:116)
-    const uint32_t* idx_prefix;  // [nqueries, idx_words] exclusive popcount per word (qualifying_kernel)
-    int32_t idx_words;
-    const float* rows;           // compact score rows [nqueries, row_cap, 32] (row = rank of the centroid among the survivors)
-    int32_t row_cap;
-    const int32_t* nqual;        // [nqueries] surviving centroids (clamped to row_cap by qualifying_kernel)
-    const int32_t* q_lens;       // nullable
-    int32_t nq_cand, nqueries;
-    const int32_t* cand;         // [nqueries, cand_stride] ascending candidate pids
-    int64_t cand_stride;
-    const int32_t* cand_count;
-    const int32_t* band;         // [nqueries, cand_stride] the band of an image query (EXACT pass)
-    const int32_t* band_count;
-    const int32_t* mode;         // [nqueries] FLMR_S1D_*: which queries this launch takes, from which list
-    uint64_t* keys;              // [nqueries, cand_stride] out
-    float* img_err;              // [nqueries] out (IMG pass): E + eps of the band rule (inf: the images cannot be used)
-    int32_t parts;               // items per query
-    int32_t group;               // candidates per wave and group: 64, or 16 for short lists
-    int64_t codes_len;           // ints readable at `codes` (the sorted copy carries 8 words of padding)
-    int32_t img_rows;            // rows of images the launch's LDS holds (IMG pass)
-};
-#define FLMR_S1D_SKIP 0    // stage 1 of the query was done elsewhere (list-scatter forms)
-#define FLMR_S1D_IMAGE 1   // IMG pass over the candidates, band, EXACT pass over the band
-#define FLMR_S1D_EXACT 2   // EXACT pass over the candidates
 
 template <bool IMG, int LPC>
 __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
@@ -135,8 +108,8 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
     uint32_t* lbits = reinterpret_cast<uint32_t*>(scan_list + ((a.nqueries + 3) & ~3));
     uint16_t* lpre = reinterpret_cast<uint16_t*>(lbits + a.idx_words);
     uint16_t* lists = lpre + ((a.idx_words + 7) & ~7);
-    uint16_t* my_list = lists + (size_t)wave * R * LISTCAP;
-    char* img = reinterpret_cast<char*>(lists + (size_t)D1_WAVES * R * LISTCAP);
+    uint16_t* my_list = lists + (size_t)wave * (R * LISTCAP + 64);   // (+ one scratch entry per lane)
+    char* img = reinterpret_cast<char*>(lists + (size_t)D1_WAVES * (R * LISTCAP + 64));
 
     // ---- the queries of this launch ----
     if (tid == 0) s_nscan = 0;
@@ -239,9 +212,11 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
             const int i = g * gsz + lane;
             if (g < gend && lane < gsz && i < P) {
                 pid = src[i];
-                const int64_t o = a.offsets[pid];
-                off = (uint32_t)o;
-                len = a.ulen ? (int)a.ulen[pid] : (int)(a.offsets[pid + 1] - o);
+                // (the LOW words only: a 64-bit load whose high half is unused leaves a register the compiler re-uses while the
+                // load is pending -- and waits for it with a vmcnt(0) inside the round loop)
+                const uint32_t* o32 = reinterpret_cast<const uint32_t*>(a.offsets) + 2 * (size_t)pid;
+                off = o32[0];
+                len = a.ulen ? (int)a.ulen[pid] : (int)(o32[2] - off);
             }
         };
         int pid, len; uint32_t off;
@@ -252,30 +227,32 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
             const int ndoc = (P - g * gsz) < gsz ? (P - g * gsz) : gsz;
             const int nrounds = (ndoc + R - 1) / R;
             float ukeep = 0.0f;   // lane j: the score of candidate j of the group
-            // codes of (round r, chunk at token t0): this lane's 4 codes of its candidate.  ONE 16-byte load whenever the lane has
-            // a token at all: what it reads beyond the passage's end (the next passage's codes, the copy's padding) is masked by
-            // the listing.  Only at the very end of the code array are the tokens read one by one.
-            auto load_codes = [&](d1i4u& c_, int r, int t0, int& jlen) {
+            // Codes of round r (first chunk): this lane's 4 codes of its candidate, ONE 16-byte load requested TWO ROUNDS AHEAD.
+            // The request is an asm statement and its wait is hand-counted (vmcnt(1) at the top of a round: only the other
+            // buffer's request is younger), as in the stage-2 / stage-3 kernels: left to the compiler, the two buffers' rounds are
+            // merged into one loop body that rotates the registers, and a register move of a pending load is a vmcnt(0) -- the
+            // rounds requested ahead were drained at every round (measured: 56 % of the wave cycles waiting).  So that the count
+            // holds, a request is ALWAYS issued: past the group's end it re-reads some candidate's codes, and what a lane reads
+            // beyond its passage's end (the next passage's codes, the sorted copy's D1_CODE_PAD words of padding) is masked by
+            // the listing.
+            auto request_codes = [&](d1i4u& c_, int r, int& jlen) {
                 const int j = r * R + sub;
                 const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(j << 2, (int)off);
-                jlen = __builtin_amdgcn_ds_bpermute(j << 2, len);   // (lanes past the group's end hold 0)
-                const int first = t0 + 4 * l;
-                c_.x = c_.y = c_.z = c_.w = 0;
-                if (first < jlen) {
-                    const uint64_t at = (uint64_t)o + (uint32_t)first;
-                    if (at + 4 <= (uint64_t)a.codes_len) {
-                        c_ = D1_LOAD(reinterpret_cast<const d1i4u*>(a.codes + at));
-                    } else {
-                        if (at < (uint64_t)a.codes_len) c_.x = a.codes[at];
-                        if (at + 1 < (uint64_t)a.codes_len) c_.y = a.codes[at + 1];
-                        if (at + 2 < (uint64_t)a.codes_len) c_.z = a.codes[at + 2];
-                    }
-                }
+                const int jl = __builtin_amdgcn_ds_bpermute(j << 2, len);
+                jlen = j < ndoc ? jl : 0;
+                const int32_t* at = a.codes + ((uint64_t)o + (uint32_t)(4 * l));
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(c_) : "v"(at) : "memory");
+            };
+            // further chunks of long passages: on demand, compiler-visible (its wait drains the requests ahead: rare)
+            auto load_chunk = [&](d1i4u& c_, int r, int t0) {
+                const int j = r * R + sub;
+                const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(j << 2, (int)off);
+                c_ = D1_LOAD(reinterpret_cast<const d1i4u*>(a.codes + ((uint64_t)o + (uint32_t)(t0 + 4 * l))));
             };
             d1i4u cdA, cdB;
             int lenA = 0, lenB = 0;
-            load_codes(cdA, 0, 0, lenA);
-            if (nrounds > 1) load_codes(cdB, 1, 0, lenB);
+            request_codes(cdA, 0, lenA);
+            request_codes(cdB, 1, lenB);
             auto round = [&](d1i4u& cd, int& jlen, int r) {
                 const int my_len = jlen;
                 uint32_t acc[4];     // IMG: 8 fp16 column maxima of this lane's 16 bytes of a row
@@ -284,6 +261,7 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
                 for (int e = 0; e < 4; e++) acc[e] = 0xFC00FC00u;
                 facc.x = facc.y = facc.z = facc.w = -9999.0f;   // filter_pids.cpp:30-33
                 int nh_total = 0;
+                asm volatile("s_waitcnt vmcnt(1)" : "+v"(cd) : : "memory");
                 d1i4u cur = cd;
                 const int hg = l / LPR, pr = l % LPR;
                 for (int t0 = 0;; t0 += LISTCAP) {
@@ -326,14 +304,14 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
                             const int c = c_[e];
                             int rid = (int)lpre[wi[e]] + __popc(wd[e] & ((1u << (c & 31)) - 1u));
                             rid = rid < n ? rid : (IMG ? n : n - 1);
-                            const int o = base + __popc(hm & ((1u << e) - 1u));
-                            const int pos = sub * LISTCAP + (o & (HPI - 1)) * NIT + (o / HPI);
-                            if ((hm >> e) & 1u) my_list[pos] = (uint16_t)rid;
+                            const uint32_t o = (uint32_t)base + __popc(hm & ((1u << e) - 1u));
+                            const uint32_t pos = sub * LISTCAP + (o & (HPI - 1)) * NIT + (o / HPI);
+                            my_list[((hm >> e) & 1u) ? pos : R * LISTCAP + lane] = (uint16_t)rid;   // (a miss: the lane's own scratch entry)
                         }
                     }
                     // the codes are dead: request the chunk-0 codes of round r + 2 into the same registers
                     const bool more_chunks = __ballot(my_len > t0 + LISTCAP) != 0ull;   // wave-uniform
-                    if (t0 == 0 && r + 2 < nrounds) load_codes(cd, r + 2, 0, jlen);
+                    if (t0 == 0) request_codes(cd, r + 2, jlen);
                     // ---- fold the listed rows ----
                     if (nmax > 0) {
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -395,10 +373,7 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
                         __builtin_amdgcn_wave_barrier();   // (the list is rewritten by the next chunk / round)
                     }
                     if (!more_chunks) break;
-                    {   // further chunks of long passages: on demand
-                        int dl;
-                        load_codes(cur, r, t0 + LISTCAP, dl);
-                    }
+                    load_chunk(cur, r, t0 + LISTCAP);
                 }
                 // ---- this round's candidates: combine the hit groups, sum the columns, keep the score for lane j ----
                 float sc;
@@ -472,6 +447,8 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
                 round(cdA, lenA, r);
                 if (r + 1 < nrounds) round(cdB, lenB, r + 1);
             }
+            // (the requests past the group's end must have landed before their registers mean anything else to the compiler)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cdA), "+v"(cdB) : : "memory");
             if (lane < ndoc) keys_b[g * gsz + lane] = flmr_make_key(ukeep, pid);
             pid = npid; off = noff; len = nlen;
         }
@@ -481,7 +458,7 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
 // LDS the launch needs besides the images; rows of images that fit beside it
 static size_t d1_fixed_lds(int nqueries, int idx_words, int lpc) {
     return (size_t)((nqueries + 3) & ~3) * 4 + (size_t)idx_words * 4 + (size_t)((idx_words + 7) & ~7) * 2 +
-           (size_t)D1_WAVES * (64 / lpc) * (lpc * 4) * 2;
+           (size_t)D1_WAVES * ((64 / lpc) * (lpc * 4) + 64) * 2;
 }
 int flmr_s1_dense_image_rows(int nqueries, int idx_words, int lpc) {
     const size_t budget = (size_t)160 * 1024 - 1024;   // static __shared__ of the kernel and alignment
@@ -518,6 +495,28 @@ int flmr_launch_s1_dense(const flmr_s1d_args& a_in, bool img_pass, int lpc, hipS
         if (lpc == 16) hipLaunchKernelGGL((s1_dense_kernel<false, 16>), g, block, lds, st, a);
         else hipLaunchKernelGGL((s1_dense_kernel<false, 32>), g, block, lds, st, a);
     }
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
+__global__ void s1_dense_modes_kernel(const int32_t* skip, const int32_t* nqual, int32_t nqueries, int32_t img_rows, int32_t exact_too,
+                                      int32_t* mode, int32_t* scan_skip) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nqueries) return;
+    int m = FLMR_S1D_SKIP, sk = 1;
+    if (!(skip && skip[q])) {
+        if (nqual[q] <= img_rows) m = FLMR_S1D_IMAGE;
+        else if (exact_too) m = FLMR_S1D_EXACT;
+        else sk = 0;   // the scan takes the query
+    }
+    mode[q] = m;
+    scan_skip[q] = sk;
+}
+
+int flmr_launch_s1_dense_modes(const int32_t* skip, const int32_t* nqual, int32_t nqueries, int32_t img_rows, int32_t exact_too,
+                               int32_t* mode, int32_t* scan_skip, hipStream_t st) {
+    hipLaunchKernelGGL(s1_dense_modes_kernel, dim3((nqueries + 255) / 256), dim3(256), 0, st, skip, nqual, nqueries, img_rows, exact_too,
+                       mode, scan_skip);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }

@@ -73,15 +73,23 @@ __device__ __forceinline__ float w2_dec(int e) { return __int_as_float(e ^ ((e >
 #define W2_MAX_DOCLEN 2048           // longest passage the in-LDS code sort handles
 
 // ------------------------------------------------------------------------------------------------
-// codes_sorted[off[p] .. off[p+1]) = ascending copy of codes[off[p] .. off[p+1]).  One wave per passage, bitonic in LDS.
+// codes_sorted[off[p] .. off[p+1]) = ascending copy of codes[off[p] .. off[p+1]) with the DISTINCT values first: the first
+// ulen[p] entries are the passage's distinct codes in ascending order, the rest repeat the largest (the run stays ascending
+// and holds the same set: every reader that takes all of it -- the walk -- computes the same maxima; the readers that take
+// only the distinct prefix -- the sliced stage 2, the dense stage 1 -- do less than half the work on a real index, where a
+// passage repeats its codes: 2.2 tokens per distinct (passage, centroid) pair on the built 1 M-passage index.  The
+// reference's own IVF is built from the same distinct pairs, indexing/utils.py:8-53, and filter_pids.cpp:50-63 skips repeats).
+// One wave per passage, bitonic in LDS.  `total_ulen`: sum of ulen over the passages.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void sort_doc_codes_kernel(const int32_t* __restrict__ codes, const int64_t* __restrict__ offsets,
-                                                            int64_t num_passages, int32_t* __restrict__ out) {
+                                                            int64_t num_passages, int32_t* __restrict__ out,
+                                                            uint16_t* __restrict__ ulen, unsigned long long* __restrict__ total_ulen) {
     __shared__ int32_t s[W2_MAX_DOCLEN];
+    unsigned long long mine = 0;
     for (int64_t p = blockIdx.x; p < num_passages; p += gridDim.x) {
         const int64_t off = offsets[p];
         const int len = (int)(offsets[p + 1] - off);
-        if (len <= 0) continue;
+        if (len <= 0) { if (threadIdx.x == 0) ulen[p] = 0; continue; }
         int n = 1;
         while (n < len) n <<= 1;
         for (int t = threadIdx.x; t < n; t += 64) s[t] = t < len ? codes[off + t] : W2_INF;
@@ -99,9 +107,21 @@ __global__ __launch_bounds__(64) void sort_doc_codes_kernel(const int32_t* __res
                 __syncthreads();
             }
         }
-        for (int t = threadIdx.x; t < len; t += 64) out[off + t] = s[t];
+        // distinct values to the front (positions by a running wave scan), the largest repeated behind them
+        int base = 0;
+        const int32_t last = s[len - 1];
+        for (int t0 = 0; t0 < len; t0 += 64) {
+            const int t = t0 + threadIdx.x;
+            const bool first = t < len && (t == 0 || s[t] != s[t - 1]);
+            const unsigned long long m = __ballot(first);
+            if (first) out[off + base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = s[t];
+            base += __popcll(m);
+        }
+        for (int t = base + threadIdx.x; t < len; t += 64) out[off + t] = last;
+        if (threadIdx.x == 0) { ulen[p] = (uint16_t)base; mine += (unsigned long long)base; }
         __syncthreads();
     }
+    if (threadIdx.x == 0 && mine) atomicAdd(total_ulen, mine);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -146,26 +166,39 @@ int flmr_build_tiled_centroids(flmr_index* ix) {
 }
 
 int flmr_build_sorted_codes(flmr_index* ix) {
-    ix->codes_sorted = nullptr;
+    ix->codes_sorted = nullptr; ix->doc_ulen = nullptr; ix->dup_share = 0.0; ix->mean_ulen = 0.0;
     if (ix->max_doclen > W2_MAX_DOCLEN || ix->N >= 0x7fffffffLL || ix->num_passages <= 0 || ix->N <= 0) return FLMR_OK;
-    // needed by the sliced / walking stage-2 forms only: where neither can be chosen (small K: the table fits an L2 and no walk
-    // was asked for) the gather form runs from `codes` and the copy (4 bytes per token) is not built; a failed allocation
-    // likewise only makes those forms unavailable
-    const double mean_len = (double)ix->N / (double)ix->num_passages;
-    const bool sliced = (size_t)ix->K * FLMR_DIM * sizeof(_Float16) > ((size_t)6 << 20);
-    const bool walk = ix->centroids_f16 && ix->K % 32 == 0 && ((double)ix->K <= 0.6 * W2_DOCS * mean_len);
-    if (!sliced && !walk && !flmr_process_options().has(FLMR_OPT_S2_IMPL)) return FLMR_OK;
-    if (hipMalloc(reinterpret_cast<void**>(&ix->codes_sorted), ((size_t)ix->N + 8) * sizeof(int32_t)) != hipSuccess) {  // + window padding
+    // Read by the sliced / walking stage-2 forms and by the dense stage 1 (flmr_stage1_dense.hip); a failed allocation only
+    // makes those forms unavailable (4 bytes per token + 2 per passage)
+    if (hipMalloc(reinterpret_cast<void**>(&ix->codes_sorted), ((size_t)ix->N + FLMR_CODE_PAD) * sizeof(int32_t)) != hipSuccess) {
         (void)hipGetLastError();
         ix->codes_sorted = nullptr;
         return FLMR_OK;
     }
-    FLMR_HIP(hipMemset(ix->codes_sorted + ix->N, 0x7f, 8 * sizeof(int32_t)));
+    unsigned long long* d_total = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&ix->doc_ulen), (size_t)ix->num_passages * sizeof(uint16_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d_total), sizeof(unsigned long long)) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(ix->codes_sorted); (void)hipFree(ix->doc_ulen); (void)hipFree(d_total);
+        ix->codes_sorted = nullptr; ix->doc_ulen = nullptr;
+        return FLMR_OK;
+    }
+    FLMR_HIP(hipMemset(ix->codes_sorted + ix->N, 0x7f, FLMR_CODE_PAD * sizeof(int32_t)));
+    FLMR_HIP(hipMemset(d_total, 0, sizeof(unsigned long long)));
     const int64_t grid = ix->num_passages < 262144 ? ix->num_passages : 262144;
     hipLaunchKernelGGL(sort_doc_codes_kernel, dim3((unsigned)grid), dim3(64), 0, 0, ix->codes, ix->doc_offsets, ix->num_passages,
-                       ix->codes_sorted);
+                       ix->codes_sorted, ix->doc_ulen, d_total);
     FLMR_LAUNCH_CHECK();
-    FLMR_HIP(hipDeviceSynchronize());
+    unsigned long long total = 0;
+    FLMR_HIP(hipMemcpy(&total, d_total, sizeof(total), hipMemcpyDeviceToHost));
+    (void)hipFree(d_total);
+    ix->dup_share = 1.0 - (double)total / (double)ix->N;
+    ix->mean_ulen = (double)total / (double)ix->num_passages;
+    if (ix->dup_share < 0.10) {   // nothing to gain: every token counts (the readers then take the whole run)
+        (void)hipFree(ix->doc_ulen);
+        ix->doc_ulen = nullptr;
+        ix->mean_ulen = (double)ix->N / (double)ix->num_passages;
+    }
     return FLMR_OK;
 }
 

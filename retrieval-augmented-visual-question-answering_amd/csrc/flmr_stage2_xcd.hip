@@ -46,13 +46,14 @@ typedef uint32_t x2u4 __attribute__((ext_vector_type(4)));
 // doc_splits[p * nsl + s] = number of codes of passage p below s * slice_rows (position in the sorted copy), s = 0..nsl-1
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void doc_splits_kernel(const int32_t* __restrict__ codes_sorted, const int64_t* __restrict__ offsets,
+                                                         const uint16_t* __restrict__ ulen,
                                                          int64_t npass, int slice_rows, int nsl, uint16_t* __restrict__ splits) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t p = t / nsl;
     const int s = (int)(t % nsl);
     if (p >= npass) return;
     const int64_t off = offsets[p];
-    const int len = (int)(offsets[p + 1] - off);
+    const int len = ulen ? (int)ulen[p] : (int)(offsets[p + 1] - off);   // (the distinct prefix of the run, when the index keeps its length)
     const int bound = s * slice_rows;
     int lo = 0, hi = len;
     while (lo < hi) {
@@ -131,7 +132,7 @@ int flmr_build_doc_splits(flmr_index* ix) {
     }
     const int64_t threads = ix->num_passages * ix->nslices;
     hipLaunchKernelGGL(doc_splits_kernel, dim3((unsigned)flmr_ceil_div(threads, 256)), dim3(256), 0, 0, ix->codes_sorted,
-                       ix->doc_offsets, ix->num_passages, ix->slice_rows, ix->nslices, ix->doc_splits);
+                       ix->doc_offsets, ix->doc_ulen, ix->num_passages, ix->slice_rows, ix->nslices, ix->doc_splits);
     FLMR_LAUNCH_CHECK();
     FLMR_HIP(hipDeviceSynchronize());
     return FLMR_OK;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
     if (lane < nd) {
         const int pid = pids[(size_t)b * pid_stride + slot0 + lane];
         const int64_t off = f.offsets[pid];
-        const int len = (int)(f.doclens ? f.doclens[pid] : (f.offsets[pid + 1] - off));
+        const int len = f.ulen_sorted ? (int)f.ulen_sorted[pid] : (int)(f.doclens ? f.doclens[pid] : (f.offsets[pid + 1] - off));
         const int start = splits[(size_t)pid * nsl + sl];
         const int end = sl < nsl - 1 ? (int)splits[(size_t)pid * nsl + sl + 1] : len;
         run_len = end - start;
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(256, X2_REG_MINW) void filter_stage2_xreg_kernel(fl
     if (lane < nd) {
         const int pid = pids[(size_t)b * pid_stride + slot0 + lane];
         const int64_t off = f.offsets[pid];
-        const int len = (int)(f.doclens ? f.doclens[pid] : (f.offsets[pid + 1] - off));
+        const int len = f.ulen_sorted ? (int)f.ulen_sorted[pid] : (int)(f.doclens ? f.doclens[pid] : (f.offsets[pid + 1] - off));
         const int start = splits[(size_t)pid * nsl + sl];
         const int end = sl < nsl - 1 ? (int)splits[(size_t)pid * nsl + sl + 1] : len;
         run_len = end - start;
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(256) void s2_combine_kernel(flmr_filter_args f, con
     if (live) {
         pid = pids[(size_t)b * pid_stride + d];
         const int64_t off = f.offsets[pid];
-        const int len = (int)(f.doclens ? f.doclens[pid] : (f.offsets[pid + 1] - off));
+        const int len = f.ulen_sorted ? (int)f.ulen_sorted[pid] : (int)(f.doclens ? f.doclens[pid] : (f.offsets[pid + 1] - off));
         uint32_t w[NSL / 2];
 #pragma unroll
         for (int q4 = 0; q4 < NSL / 8; q4++) {

@@ -452,3 +452,60 @@ def test_stage1_small_dense_form_on_a_built_index(hip):
     for x, y in zip(got[2:], ref[2:]):
         assert np.array_equal(x, y)
     scorer.close_searcher()
+
+
+def _dense_vs_scan(hip, corpus, policy, nqueries=24):
+    """one batch through the default path and through FLMR_S1_IMPL=scan: identical survivors, finalists, results; returns the forms"""
+    torch, nat = hip["torch"], hip["native"]
+    from ravqa_amd import synth
+    from ravqa_amd.scorer import IndexScorer
+    Q, _ = synth.make_queries(corpus, nqueries, 32, seed=78)
+    q_lens = torch.full((nqueries,), 32, dtype=torch.int32)
+    q_lens[2], q_lens[5], q_lens[9] = 11, 0, 1
+    scorer = IndexScorer(device_index=synth.corpus_device_index(corpus), max_batch=32)
+    ncells, thr, ndocs = policy
+    outs, forms = {}, None
+    for tag, env in (("dense", {}), ("scan", {"FLMR_S1_IMPL": "scan"})):
+        with nat.options(**env):
+            p, s, c = scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=q_lens)
+            scorer.check()
+            if tag == "dense":
+                forms = [int(scorer.tap(nat.TAP_STAGE1_FORM, i)[0]) if scorer.tap(nat.TAP_STAGE1_FORM, i).size else -1 for i in range(nqueries)]
+            outs[tag] = ([np.sort(scorer.tap(nat.TAP_STAGE1, i)) for i in range(nqueries)],
+                         [scorer.tap(nat.TAP_STAGE2, i) for i in range(nqueries)], p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy())
+    nsurv = [int(np.unpackbits(scorer.tap(nat.TAP_IDX_BITS, i).view(np.uint8)).sum()) for i in range(nqueries)]
+    print("\nPOLICY", policy, "FORMS", {v: forms.count(v) for v in sorted(set(forms))}, "surviving centroids min / median / max", min(nsurv), int(np.median(nsurv)), max(nsurv))
+    for i in range(nqueries):
+        assert np.array_equal(outs["dense"][0][i], outs["scan"][0][i]), ("stage-1 survivors", policy, i, forms[i], nsurv[i])
+        assert np.array_equal(outs["dense"][1][i], outs["scan"][1][i]), ("stage-2 finalists", policy, i, forms[i], nsurv[i])
+    assert np.array_equal(outs["dense"][4], outs["scan"][4]) and np.array_equal(outs["dense"][2], outs["scan"][2])
+    assert np.array_equal(outs["dense"][3].view(np.uint32), outs["scan"][3].view(np.uint32))
+    scorer.close_searcher()
+    return forms
+
+
+def test_stage1_dense_forms_equal_code_scan(hip):
+    """Queries with more surviving centroids than the list-scatter forms take run the dense forms of flmr_stage1_dense.hip: an
+    approximate pass on fp16 IMAGES of the score rows (rounded up, kept in LDS), the band of candidates within the images' error of
+    the cut, and an exact pass over the band -- or the exact pass over every candidate when the rows do not fit.  The survivors,
+    the stage-2 finalists and the final result must be bit for bit those of the code-scanning kernel (FLMR_S1_IMPL=scan:
+    filter_pids.cpp:27-124 on every candidate), ragged and empty queries included.  The threshold is lowered step by step so that
+    the batch passes from the list-scatter forms through the image form (5) to the exact form (6): both must have been seen."""
+    from ravqa_amd import synth
+    corpus = synth.make_corpus(30_000, (8, 100), 4096, 2, seed=77, device="cuda")
+    seen = set()
+    for thr in (0.30, 0.25, 0.20, 0.15, 0.10, 0.05, -0.05):
+        seen |= set(_dense_vs_scan(hip, corpus, (2, thr, 1024)))
+    assert 5 in seen and 6 in seen, seen
+
+
+@pytest.mark.parametrize("K,npass,doclen,policy", [
+    (8192, 60_000, 64, (2, 0.15, 4096)),             # more survivors wanted than a band would hold back
+    (2048, 6_000, (1, 300), (2, 0.15, 64)),          # passages longer than one 64 / 128-code chunk, tiny ndocs
+    (2048, 6_000, (1, 300), (4, -1.0, 8192)),        # every centroid survives, every candidate is selected
+])
+def test_stage1_dense_forms_shapes(hip, K, npass, doclen, policy):
+    from ravqa_amd import synth
+    corpus = synth.make_corpus(npass, doclen, K, 2, seed=79, device="cuda")
+    forms = _dense_vs_scan(hip, corpus, policy)
+    assert any(f in (5, 6) for f in forms), forms
