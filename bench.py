@@ -742,22 +742,26 @@ def main():
         # what the planted-centroid corpus above cannot show -- k-means + compression + IVF end to end, and a stage 1 whose hit
         # passages hold many surviving centroids (profiles/built_index_probe.py; --passages-sized, 4096 topics, k <= 100 policy)
         if not args.no_built_index and args.passages == 1_000_000:
-            try:
-                sys.path.insert(0, os.path.join(ROOT, "profiles"))
-                import built_index_probe
-                rec = built_index_probe.run(args.passages, 128, args.nbits, 4096, policies=((2, 0.45, 1024, 100),), phases=False,
-                                            parity_queries=0 if args.no_cpu_baseline else 16)
-                sr = rec.pop("search_thr0.45")
-                subs.append({"name": "built_index_overlapping_clusters", "value": sr["queries_per_sec"], "unit": "queries/sec",
-                             "parity": sr.get("parity"),
-                             "ms_per_step": sr["ms_per_step"], "recall_at_5": sr["recall_at_5"], "stage_ms_per_step": sr["stage_ms"],
-                             "surviving_centroids_per_query": sr["surviving_centroids"], "candidates_per_query": sr["candidates"],
-                             "index_build": rec,
-                             "note": "1 M passages x 128 raw token embeddings (a token = a topic direction + a finer direction + noise, three "
-                                     "topics per passage) indexed end to end on the device by indexing.build_index (k-means with the HIP "
-                                     "argmax as its assignment step, compression, IVF by flmr_build_ivf), then searched with planted queries"})
-            except Exception as e:  # noqa: BLE001
-                subs.append({"name": "built_index_overlapping_clusters", "value": None, "note": f"failed: {e!r}"})
+            sys.path.insert(0, os.path.join(ROOT, "profiles"))
+            # 4096 topics: ~95 surviving centroids per query (the list-scatter forms of stage 1); 256 topics: ~1.5 k (the dense forms:
+            # fp16 images of the score rows in LDS, the band around the cut rescored exactly -- flmr_stage1_dense.hip)
+            for topics, name in ((4096, "built_index_overlapping_clusters"), (256, "built_index_dense_survivors")):
+                try:
+                    import built_index_probe
+                    rec = built_index_probe.run(args.passages, 128, args.nbits, topics, policies=((2, 0.45, 1024, 100),), phases=False,
+                                                parity_queries=0 if args.no_cpu_baseline else 16)
+                    sr = rec.pop("search_thr0.45")
+                    subs.append({"name": name, "value": sr["queries_per_sec"], "unit": "queries/sec",
+                                 "parity": sr.get("parity"),
+                                 "ms_per_step": sr["ms_per_step"], "recall_at_5": sr["recall_at_5"], "stage_ms_per_step": sr["stage_ms"],
+                                 "surviving_centroids_per_query": sr["surviving_centroids"], "candidates_per_query": sr["candidates"],
+                                 "stage1_forms_of_256": sr.get("stage1_forms_of_256"), "index_info": sr.get("index_info"), "index_build": rec,
+                                 "note": f"1 M passages x 128 raw token embeddings ({topics} topics; a token = a topic direction + a finer direction + "
+                                         "noise, three topics per passage) indexed end to end on the device by indexing.build_index (k-means with "
+                                         "the HIP argmax as its assignment step, compression, IVF by flmr_build_ivf), then searched with planted queries"})
+                except Exception as e:  # noqa: BLE001
+                    subs.append({"name": name, "value": None, "note": f"failed: {e!r}"})
+                torch.cuda.empty_cache()
         out["sub_results"] = subs
 
     if rank == 0:

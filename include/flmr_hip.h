@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FLMR_ABI_VERSION 4
+#define FLMR_ABI_VERSION 5
 
 typedef enum flmr_status {
     FLMR_OK = 0,
@@ -59,13 +59,17 @@ int flmr_device_count(int* count);
  * LDS-DMA / register gathers; regs / dma = decompress-normalise-split; f32 = fp32-MFMA kernel.  Longer queries: qs, the
  * query-stationary kernel, the default from 288 rows; any other value = the chunked kernel); FLMR_S1_IMPL = scan | slots
  * (stage 1: the code-scanning kernel for every query / the slot form of the list-scatter kernel for every query; default: its
- * queue form first, the slot form for the queries that one hands over, the code scan beyond 1024 surviving centroids).
+ * queue form first, the slot form for the queries that one hands over, and beyond the list-scatter forms' limits -- more than 1024
+ * surviving centroids, lists far longer than the probed cells' -- the dense forms of flmr_stage1_dense.hip: fp16 images of the
+ * query's score rows in LDS, upper-bound keys for every candidate, the band around the cut rescored exactly; the exact form alone
+ * when the rows do not fit).
  * Variants of one arithmetic are bit-identical to each other, the arithmetics agree to fp32 roundoff (tests/test_hip_parity.py).
  * One switch is a capacity, not a variant: FLMR_ROW_CAP = score rows a searcher keeps per query (64 .. 65535, default 16384,
  * never more than K).  The default path stores the centroid scores of a query only for the centroids that pass
  * centroid_score_threshold (the rows index_storage.py:116's `idx` selects; 128 bytes each) instead of the reference's
- * K x nq_cand table per query (16.8 MB at K = 131072); a query with more surviving centroids than the capacity raises the
- * deferred FLMR_ERR_CAPACITY of flmr_searcher_check. */
+ * K x nq_cand table per query (16.8 MB at K = 131072).  A query with more surviving centroids than the capacity is NOT an error
+ * (the reference has no such limit): its stage 1 is recomputed from the fp16 centroids inside the same batch (slower for that
+ * query only; FLMR_TAP_STAGE1_FORM reads 7 for it). */
 int flmr_set_option(const char* name, const char* value);
 
 /* ------------------------------------------------------------------------------------------------
@@ -141,8 +145,8 @@ int flmr_searcher_workspace_bytes(const flmr_searcher_t* searcher, int64_t* byte
  * clears it.  flmr_searcher_check waits for the searcher's last batch and reports at once (synchronous). */
 int flmr_searcher_check(flmr_searcher_t* searcher);
 /* The same flags for a caller that pipelines sub-batches (device batch i+1 beside the host's reading of batch i): enqueues, on
- * `stream`, a copy of the searcher's four device status words -- [0] candidate bound exceeded, [1] q_lens outside [0, nq], [2] more
- * surviving centroids than score rows, [3] reserved -- to `host_flags` (pinned host memory, 4 x int32).  Once an event recorded
+ * `stream`, a copy of the searcher's four device status words -- [0] candidate bound exceeded, [1] q_lens outside [0, nq], [2], [3]
+ * reserved (always 0) -- to `host_flags` (pinned host memory, 4 x int32).  Once an event recorded
  * after this call has completed the words are those of every batch issued on the searcher up to here (they are sticky until
  * flmr_searcher_check or a later call reports them and clears them).  Asynchronous; nothing is reported or cleared by this call.
  * Reference counterpart: none (Searcher._search_all_Q is synchronous per query, TPC/searcher.py:73-89). */
@@ -219,7 +223,8 @@ int flmr_unpack_keys(const uint64_t* keys, int32_t nqueries, int32_t n, int32_t 
  * the query's keys -- 0 the queue form, 1 the slot form (query not tried by the others: too many surviving lists), 2 the slot form
  * after the queue form gave the query up, 3 the small-dense form (a searcher whose queries mostly overflow the queue), 4 the slot
  * form after the small-dense form gave the query up, 5 the dense image form (fp16 images of the score rows in LDS, the band around the cut
- * rescored exactly), 6 the dense exact form (0 elements: stage 1 ran in another mode). */
+ * rescored exactly), 6 the dense exact form, 7 the recompute form (a query with more surviving centroids than the searcher keeps score
+ * rows for: FLMR_ROW_CAP) (0 elements: stage 1 ran in another mode). */
 typedef enum flmr_tap {
     FLMR_TAP_CENTROID_SCORES = 0,
     FLMR_TAP_IDX_BITS = 1,
@@ -316,6 +321,11 @@ int flmr_score_pids(const flmr_index_t* index, const float* Q, int32_t nq, const
  * Padded tokens score -9999 (no zero clamp); forward only. */
 int flmr_colbert_score_padded(const float* Q, int32_t q_batch, int32_t nq, const float* D, const uint8_t* mask,
                               int32_t B, int32_t Ld, int32_t dim, float* out, flmr_stream_t stream);
+/* The cross form: Q f32[nqueries, nq, dim] holds independent queries and EVERY one is scored against every document:
+ * out f32[nqueries, B] = the rate matrix of the executor's exhaustive search (src/executors/FLMR_executor.py:799-847, which fills
+ * it four documents at a time through model.score) in one launch per document chunk.  nqueries <= 65535. */
+int flmr_colbert_score_cross(const float* Q, int32_t nqueries, int32_t nq, const float* D, const uint8_t* mask,
+                             int32_t B, int32_t Ld, int32_t dim, float* out, flmr_stream_t stream);
 /* The same kernel, stopped one step earlier: out_colmax f32 [B, nq] = the per-column maxima (-9999 padding) whose sum
  * flmr_colbert_score_padded returns -- what colbert_score_reduce's 'flipr' interaction reduces differently (the 32 largest of
  * the first 64 columns + the 8 largest of the rest, TPC/modeling/colbert.py:246-261). */

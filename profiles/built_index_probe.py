@@ -108,7 +108,9 @@ def run(P=1_000_000, L=128, nbits=2, NT=256, policies=((2, 0.45, 1024, 100), (2,
         out[f"search_thr{thr}"] = {"queries_per_sec": round(nqr / dt), "ms_per_step": round(dt * 1e3, 2), "recall_at_5": hit, "recall_at_100": hit100,
                                    "surviving_centroids": surv, "candidates": ncand, "stage_ms": st,
                                    "stage1_forms_of_256": {"queue": forms.count(0), "slot_untried": forms.count(1), "slot_after_queue": forms.count(2),
-                                                           "small_dense": forms.count(3), "slot_after_small_dense": forms.count(4)}}
+                                                           "small_dense": forms.count(3), "slot_after_small_dense": forms.count(4),
+                                                           "dense_image": forms.count(5), "dense_exact": forms.count(6), "recompute": forms.count(7)},
+                                   "index_info": scorer.device_index.info()}
         if parity_queries:
             out[f"search_thr{thr}"]["parity"] = parity_vs_reference(arrays, scorer, Qs[0][:parity_queries], ncells, thr, ndocs)
     del scorer, arrays

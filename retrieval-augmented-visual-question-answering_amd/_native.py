@@ -19,7 +19,7 @@ FLMR_MEM_HOST, FLMR_MEM_DEVICE = 0, 1
 (TAP_CENTROID_SCORES, TAP_IDX_BITS, TAP_CELLS, TAP_CANDIDATES, TAP_STAGE1, TAP_STAGE2, TAP_DOC_SCORES, TAP_Q_ERR,
  TAP_Q_ERR_SUM, TAP_STAGE1_FORM) = range(10)
 NUM_STAGES = 9
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class FlmrNativeError(RuntimeError):
@@ -160,6 +160,8 @@ _SIGS = {
     "flmr_score_pids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "flmr_colbert_score_padded": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                             C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "flmr_colbert_score_cross": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                           C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "flmr_colbert_colmax_padded": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                              C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "flmr_topk_allgather": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(1024) void qualifying_kernel(const uint32_t* idx_bi
                                                           int32_t* key_count, int ratio, uint32_t* idx_prefix,
                                                           float* rows_out, const _Float16* __restrict__ cen16,
                                                           const _Float16* __restrict__ q_hi, const _Float16* __restrict__ q_lo,
-                                                          int32_t* overflow, int32_t* fast_state) {
+                                                          int32_t* row_ovf, int32_t* fast_state) {
     __shared__ int scan_lds[17];
     __shared__ unsigned long long tot_q, tot_c;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(1024) void qualifying_kernel(const uint32_t* idx_bi
         hit_valid[b] = (base <= smax) && (base <= qmax) && (tot_q <= (unsigned long long)ratio * tot_c);
         if (key_count) key_count[b] = 0;
         if (fast_state) { fast_state[FLMR_FAST_HDR + b] = 0; fast_state[FLMR_FAST_HDR + gridDim.x + b] = 0; }   // (see cand_fast_kernel)
-        if (rows_out && base > qmax && overflow) atomicExch(overflow + 2, 1);   // more surviving centroids than score rows (FLMR_ROW_CAP)
+        if (row_ovf) row_ovf[b] = (rows_out && base > qmax) ? 1 : 0;   // more surviving centroids than score rows: stage 1 is recomputed
     }
     if (!rows_out || n == 0) return;   // (block-uniform)
     // ---- the listed centroids' score rows, one 32-row MFMA tile per wave at a time ---------------------------------------
@@ -1518,7 +1518,7 @@ __global__ __launch_bounds__(1024) void cand_emit_kernel(const uint32_t* cand_bi
 int flmr_launch_qualifying(const flmr_cand_args& a, hipStream_t st) {
     hipLaunchKernelGGL(qualifying_kernel, dim3(a.nqueries), dim3(1024), 0, st, a.idx_bits, a.idx_words, a.ivf_offsets, a.cells,
                        a.ncell, a.max_cells, a.qual, a.nqual, a.qmax, 1 << S1S_IDBITS, a.hit_valid, nullptr, 2, a.idx_prefix, a.rows_out,
-                       a.cen16, a.q_hi, a.q_lo, a.overflow, nullptr);
+                       a.cen16, a.q_hi, a.q_lo, a.row_ovf, nullptr);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }
@@ -1526,7 +1526,7 @@ int flmr_launch_qualifying(const flmr_cand_args& a, hipStream_t st) {
 int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
     hipLaunchKernelGGL(qualifying_kernel, dim3(a.nqueries), dim3(1024), 0, st, a.idx_bits, a.idx_words, a.ivf_offsets, a.cells,
                        a.ncell, a.max_cells, a.qual, a.nqual, a.qmax, 1 << S1S_IDBITS, a.hit_valid, a.scatter ? a.key_count : nullptr,
-                       a.scatter ? 8 : 2, a.idx_prefix, a.rows_out, a.cen16, a.q_hi, a.q_lo, a.overflow, a.scatter ? a.fast_state : nullptr);
+                       a.scatter ? 8 : 2, a.idx_prefix, a.rows_out, a.cen16, a.q_hi, a.q_lo, a.row_ovf, a.scatter ? a.fast_state : nullptr);
     if (a.scatter) {
         const size_t lds = (size_t)CAND_CHUNK_WORDS * (2 * sizeof(uint32_t) + 2 * sizeof(uint16_t)) +
                            ((size_t)S1S_SLOTS * S1S_STRIDE + 96 + 1024 + S1S_QCAP) * sizeof(int) + S1S_QCAP * sizeof(uint16_t);   // + scratch words of slot-less lanes, list constants, queue (+ its passages)

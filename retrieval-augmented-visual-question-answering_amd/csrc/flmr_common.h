@@ -238,6 +238,8 @@ struct flmr_cand_args {
     // batch [HDR + b] which form did / must do the query (FLMR_TAP_STAGE1_FORM) and [HDR + B + b] the fast forms' own key counter.
     // NULL: slot kernel only (FLMR_S1_IMPL=slots)
     int32_t* fast_state;
+    int32_t* row_ovf;   // [nqueries] out: 1 = the query has more surviving centroids than compact score rows (qmax): its stage 1 is
+                        // recomputed from the fp16 centroids (flmr_launch_filter_stage1_recompute); NULL on the full-table path
 };
 int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st);
 int flmr_launch_qualifying(const flmr_cand_args& a, hipStream_t st);   // list + ranks + compact score rows only
@@ -261,6 +263,10 @@ int flmr_launch_filter_stage2_walk(const flmr_filter_args& f, const int32_t* pid
                                    int32_t max_count, uint64_t* keys, int64_t key_stride, const _Float16* cen16,
                                    const _Float16* q_hi, const _Float16* q_lo, const int32_t* codes_sorted, hipStream_t st);
 bool flmr_stage2_walk_pays(const flmr_index* ix, int nqueries, int max_count);
+// stage 1 of the queries flagged in row_ovf (more surviving centroids than compact score rows) recomputed from the fp16 centroids
+int flmr_launch_filter_stage1_recompute(const flmr_filter_args& f, const uint32_t* idx_bits, int32_t idx_words, const int32_t* cand,
+                                        int64_t cand_stride, const int32_t* cand_count, const int32_t* row_ovf, uint64_t* keys,
+                                        const _Float16* cen16, const _Float16* q_hi, const _Float16* q_lo, hipStream_t st);
 // stage 2 with the centroid table cut into one L2-resident slice per XCD (flmr_stage2_xcd.hip): same keys, bit for bit;
 // `part`: workspace of flmr_stage2_xcd_part_floats(max_queries, part_stride) floats
 int flmr_launch_filter_stage2_xcd(const flmr_filter_args& f, const int32_t* pids, int64_t pid_stride, const int32_t* counts,
@@ -363,10 +369,11 @@ struct flmr_s1d_args {
 #define FLMR_S1D_EXACT 2   // EXACT pass over the candidates
 int flmr_s1_dense_image_rows(int nqueries, int idx_words, int lpc);   // score-row images the LDS form holds per query (0: K too large)
 int flmr_launch_s1_dense(const flmr_s1d_args& a, bool img_pass, int lpc, hipStream_t st);
-// which queries the dense forms take: mode[q] = SKIP where skip[q] (done by a list-scatter form), IMAGE where the query's rows fit
+// which queries the dense forms take: mode[q] = SKIP where skip[q] (done by a list-scatter form) or row_ovf[q] (no rows: the
+// recompute form), IMAGE where the query's rows fit
 // `img_rows` images, else EXACT (exact_too) or SKIP with scan[q] = 0 (the round-5 scan takes the query); scan[q] = 1 everywhere else
-int flmr_launch_s1_dense_modes(const int32_t* skip, const int32_t* nqual, int32_t nqueries, int32_t img_rows, int32_t exact_too,
-                               int32_t* mode, int32_t* scan_skip, hipStream_t st);
+int flmr_launch_s1_dense_modes(const int32_t* skip, const int32_t* nqual, const int32_t* row_ovf, int32_t nqueries, int32_t img_rows,
+                               int32_t exact_too, int32_t* mode, int32_t* scan_skip, hipStream_t st);
 // the band of every IMAGE query from its U keys (keys >= the n-th largest - err[q]) -> band pids / counts; in_count[q] = the number
 // of keys the top-n selection after stage 1 reads for query q (band_count for IMAGE queries, counts[q] for the others)
 int flmr_launch_s1_band(const uint64_t* keys, int64_t key_stride, const int32_t* counts, const int32_t* mode, const float* err,

@@ -616,6 +616,112 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_mfma_kernel(flmr_filter_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stage 1 WITHOUT score rows: the recovery form for a query with more surviving centroids than the searcher keeps compact rows
+// for (`row_ovf[q]`, raised by qualifying_kernel: more than FLMR_ROW_CAP / 65535 centroids above the threshold -- thresholds near
+// zero).  The reference has no such limit (index_storage.py:116), so neither may the library: instead of reporting the query, its
+// stage 1 is RECOMPUTED here exactly as stage 2 recomputes its scores -- the candidates' token rows of the fp16 centroid table
+// through the stage-0 MFMA sequence (bitwise the values stage 0 computes) -- with the idx mask applied per token
+// (filter_pids.cpp:36-47: a code outside idx contributes nothing).  Slow (every token of every candidate costs an MFMA row) and
+// rare; launched with every batch of the sparse path, its persistent workgroups leave at once when no query is flagged.
+// item = (flagged query, block of 256 candidates: 64 per wave).  grid <= 1024, block = 256.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void filter_stage1_recompute_kernel(flmr_filter_args f, const uint32_t* __restrict__ idx_bits, int idx_words,
+                                                                         const int32_t* __restrict__ cand, int64_t cand_stride,
+                                                                         const int32_t* __restrict__ cand_count, const int32_t* __restrict__ row_ovf,
+                                                                         uint64_t* keys, const _Float16* __restrict__ cen16,
+                                                                         const _Float16* __restrict__ q_hi, const _Float16* __restrict__ q_lo) {
+    __shared__ float tr_all[4 * 33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    {
+        int anyf = 0;
+        for (int q = threadIdx.x; q < f.nqueries; q += 256) anyf |= row_ovf[q];
+        if (!__syncthreads_or(anyf)) return;   // the usual case: no query of the batch is over the row capacity
+    }
+    float* tr = tr_all + wave * 33;
+    for (int b = 0; b < f.nqueries; b++) {
+        if (!row_ovf[b]) continue;   // (block-uniform)
+        const int cnt = cand_count[b];
+        const int qlen = f.q_lens ? f.q_lens[b] : f.nq_cand;
+        const int nqc = qlen < f.nq_cand ? qlen : f.nq_cand;
+        const uint32_t* gidx = idx_bits + (size_t)b * idx_words;
+        s2h8 bh[8], bl[8];
+        {
+            const s2h8* ph = reinterpret_cast<const s2h8*>(q_hi + ((size_t)b * f.ncol + i) * FLMR_DIM + 64 * h);
+            const s2h8* pl = reinterpret_cast<const s2h8*>(q_lo + ((size_t)b * f.ncol + i) * FLMR_DIM + 64 * h);
+#pragma unroll
+            for (int s = 0; s < 8; s++) { bh[s] = ph[s]; bl[s] = pl[s]; }
+        }
+        for (int blk = blockIdx.x; blk * 256 < cnt; blk += gridDim.x) {
+            const int d0 = blk * 256 + wave * 64;
+            const int ndw = cnt - d0 < 64 ? cnt - d0 : 64;
+            if (ndw <= 0) continue;   // (wave-uniform; no block-wide barrier below)
+            int my_pid = 0, my_len = 0;
+            int64_t my_off = 0;
+            if (lane < ndw) {
+                my_pid = cand[(size_t)b * cand_stride + d0 + lane];
+                my_off = f.offsets[my_pid];
+                my_len = (int)doc_len_of(f.doclens, f.offsets, my_pid);
+            }
+            for (int j = 0; j < ndw; j++) {
+                const int pid = __shfl(my_pid, j, 64);
+                const int len = __shfl(my_len, j, 64);
+                const int64_t off = shfl_i64(my_off, j);
+                const int ntiles = (len + 31) >> 5;
+                float cmax = -9999.0f;  // filter_pids.cpp:30-33
+                bool any = false;
+                for (int t = 0; t < ntiles; t++) {
+                    const int tok = t * 32 + i;
+                    const int code = tok < len ? f.codes[off + tok] : 0;
+                    const bool ok = tok < len && ((gidx[code >> 5] >> (code & 31)) & 1u);
+                    const uint32_t okmask = (uint32_t)__ballot(ok);   // bit r: token row r of the tile counts (lanes 0..31 = rows)
+                    if (okmask == 0u) continue;   // (wave-uniform)
+                    any = true;
+                    const s2h8* pc = reinterpret_cast<const s2h8*>(cen16 + (size_t)code * FLMR_DIM + 64 * h);
+                    s2h8 av[8];
+#pragma unroll
+                    for (int s = 0; s < 8; s++) av[s] = pc[s];
+                    f32x16 ah, al;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
+#pragma unroll
+                    for (int s = 0; s < 8; s++) {
+                        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[s], ah, 0, 0, 0);
+                        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[s], al, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const float v = fmaf(al[r], 1.0f / 2048.0f, ah[r]);
+                        cmax = fmaxf(cmax, ((okmask >> row) & 1u) ? v : -9999.0f);
+                    }
+                }
+                cmax = flmr_xhalf_max(cmax);
+                if (h == 0) tr[i] = cmax;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) {
+                    const float sc = any ? flmr_seq_sum(tr, nqc, f.f16_round) : flmr_miss_score(nqc, f.f16_round);
+                    keys[(size_t)b * cand_stride + d0 + j] = flmr_make_key(sc, pid);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+int flmr_launch_filter_stage1_recompute(const flmr_filter_args& f, const uint32_t* idx_bits, int32_t idx_words, const int32_t* cand,
+                                        int64_t cand_stride, const int32_t* cand_count, const int32_t* row_ovf, uint64_t* keys,
+                                        const _Float16* cen16, const _Float16* q_hi, const _Float16* q_lo, hipStream_t st) {
+    if (f.ncol != 32 || !cen16) FLMR_FAIL(FLMR_ERR_INVALID, "stage-1 recompute needs the sparse path (one column tile, fp16 centroids)");
+    hipLaunchKernelGGL(filter_stage1_recompute_kernel, dim3(1024), dim3(256), 0, st, f, idx_bits, idx_words, cand, cand_stride, cand_count,
+                       row_ovf, keys, cen16, q_hi, q_lo);
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
+}
+
 // WAVES = 4, B_LDS = false: the query's fp16 hi/lo operand (64 VGPRs) stays in registers -> 217 VGPRs, 2 waves per SIMD.
 // WAVES = 16, B_LDS = true: one 1024-thread block per CU shares the operand through LDS (16 KB, stored in the lane order of the
 // MFMA B operand: conflict-free ds_read_b128) -> <= 128 VGPRs, 4 waves per SIMD to hide the row-gather latency.

@@ -240,7 +240,9 @@ __global__ __launch_bounds__(256) void colbert_score_padded_kernel(const float* 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned int* colmax = reinterpret_cast<unsigned int*>(smem);  // order-preserving uint image of the fp32 max
     const int b = blockIdx.x;
-    const float* Qb = Q + (q_batch == 1 ? 0 : (size_t)b * nq * dim);
+    // gridDim.y > 1: the CROSS form -- every query (blockIdx.y) against every document, out [gridDim.y, B]
+    const size_t ob = (size_t)blockIdx.y * gridDim.x + b;
+    const float* Qb = Q + (gridDim.y > 1 ? (size_t)blockIdx.y * nq * dim : (q_batch == 1 ? 0 : (size_t)b * nq * dim));
     for (int k = threadIdx.x; k < nq; k += blockDim.x) colmax[k] = 0u;  // below every real value
     __syncthreads();
     for (int e = threadIdx.x; e < Ld * nq; e += blockDim.x) {
@@ -256,11 +258,11 @@ __global__ __launch_bounds__(256) void colbert_score_padded_kernel(const float* 
     }
     __syncthreads();
     if (colmax_out)   // the per-column maxima themselves ('flipr' sums the largest of them, colbert.py:246-261)
-        for (int k = threadIdx.x; k < nq; k += blockDim.x) colmax_out[(size_t)b * nq + k] = (Ld > 0) ? flmr_ord2f(colmax[k]) : FLMR_NEG_INF;
+        for (int k = threadIdx.x; k < nq; k += blockDim.x) colmax_out[ob * nq + k] = (Ld > 0) ? flmr_ord2f(colmax[k]) : FLMR_NEG_INF;
     if (threadIdx.x == 0 && out) {
         float s = 0.0f;
         for (int k = 0; k < nq; k++) s += (Ld > 0) ? flmr_ord2f(colmax[k]) : FLMR_NEG_INF;
-        out[b] = s;
+        out[ob] = s;
     }
 }
 
@@ -295,7 +297,9 @@ __global__ __launch_bounds__(256, 2) void colbert_score_padded_mfma_kernel(const
     unsigned int* colmax = reinterpret_cast<unsigned int*>(bq + PS_QC * 2 * 32 * PS_BROW);     // [nqp] order-preserving fp32 image
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const size_t qoff = (q_batch == 1 ? 0 : (size_t)b) * nqp * FLMR_DIM;
+    // gridDim.y > 1: the CROSS form -- every query (blockIdx.y) against every document, out [gridDim.y, B]
+    const size_t ob = (size_t)blockIdx.y * gridDim.x + b;
+    const size_t qoff = (gridDim.y > 1 ? (size_t)blockIdx.y : (q_batch == 1 ? 0 : (size_t)b)) * nqp * FLMR_DIM;
     for (int k = tid; k < nqp; k += 256) colmax[k] = 0u;  // below every real value
     const int ntiles = (Ld + 31) >> 5;
     for (int qc0 = 0; qc0 < nq; qc0 += 32 * PS_QC) {
@@ -359,19 +363,23 @@ __global__ __launch_bounds__(256, 2) void colbert_score_padded_mfma_kernel(const
     }
     __syncthreads();
     if (colmax_out)
-        for (int k = tid; k < nq; k += 256) colmax_out[(size_t)b * nq + k] = (Ld > 0) ? flmr_ord2f(colmax[k]) : FLMR_NEG_INF;
+        for (int k = tid; k < nq; k += 256) colmax_out[ob * nq + k] = (Ld > 0) ? flmr_ord2f(colmax[k]) : FLMR_NEG_INF;
     if (tid == 0 && out) {
         float sc = 0.0f;
         for (int k = 0; k < nq; k++) sc += (Ld > 0) ? flmr_ord2f(colmax[k]) : FLMR_NEG_INF;
-        out[b] = sc;
+        out[ob] = sc;
     }
 }
 
+// cross: Q holds q_batch independent queries and EVERY one of them is scored against every document (out [q_batch, B])
 static int score_padded(const float* Q, int32_t q_batch, int32_t nq, const float* D, const uint8_t* mask,
-                        int32_t B, int32_t Ld, int32_t dim, float* out, float* colmax_out, flmr_stream_t stream) {
+                        int32_t B, int32_t Ld, int32_t dim, float* out, float* colmax_out, flmr_stream_t stream, bool cross = false) {
     if (!Q || !D || !mask || (!out && !colmax_out)) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
-    if (q_batch != 1 && q_batch != B) FLMR_FAIL(FLMR_ERR_INVALID, "q_batch must be 1 or B");
+    if (!cross && q_batch != 1 && q_batch != B) FLMR_FAIL(FLMR_ERR_INVALID, "q_batch must be 1 or B");
+    if (cross && (q_batch < 1 || q_batch > 65535)) FLMR_FAIL(FLMR_ERR_INVALID, "cross scoring takes 1..65535 queries per call");
     if (B <= 0) return FLMR_OK;
+    const dim3 grid((unsigned)B, cross ? (unsigned)q_batch : 1u);
+    if (cross && q_batch == 1) cross = false;   // (the broadcast form)
     if ((size_t)nq * 4 > 48 * 1024) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "nq=%d too large", nq);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dim == FLMR_DIM && !flmr_opts().is(FLMR_OPT_SCORE_IMPL, "valu")) {
@@ -384,12 +392,12 @@ static int score_padded(const float* Q, int32_t q_batch, int32_t nq, const float
         const size_t lds = (size_t)PS_QC * 2 * 32 * PS_BROW * sizeof(_Float16) + (size_t)nqp * sizeof(unsigned int);
         FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(colbert_score_padded_mfma_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(colbert_score_padded_mfma_kernel, dim3(B), dim3(256), lds, st, qh, ql, q_batch, nq, nqp, D, mask, Ld, out, colmax_out);
+        hipLaunchKernelGGL(colbert_score_padded_mfma_kernel, grid, dim3(256), lds, st, qh, ql, q_batch, nq, nqp, D, mask, Ld, out, colmax_out);
         FLMR_LAUNCH_CHECK();
         FLMR_HIP(hipStreamSynchronize(st));  // the split buffers are released on return
         return FLMR_OK;
     }
-    hipLaunchKernelGGL(colbert_score_padded_kernel, dim3(B), dim3(256), (size_t)nq * 4, st, Q, q_batch, nq, D, mask, Ld, dim,
+    hipLaunchKernelGGL(colbert_score_padded_kernel, grid, dim3(256), (size_t)nq * 4, st, Q, q_batch, nq, D, mask, Ld, dim,
                        out, colmax_out);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
@@ -399,6 +407,14 @@ extern "C" int flmr_colbert_score_padded(const float* Q, int32_t q_batch, int32_
                                          int32_t B, int32_t Ld, int32_t dim, float* out, flmr_stream_t stream) {
     if (!out) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
     return score_padded(Q, q_batch, nq, D, mask, B, Ld, dim, out, nullptr, stream);
+}
+
+// every one of `nqueries` queries against every document: out f32 [nqueries, B] -- the rate matrix of the executor's exhaustive
+// search (src/executors/FLMR_executor.py:799-847 fills it four documents at a time through model.score)
+extern "C" int flmr_colbert_score_cross(const float* Q, int32_t nqueries, int32_t nq, const float* D, const uint8_t* mask,
+                                        int32_t B, int32_t Ld, int32_t dim, float* out, flmr_stream_t stream) {
+    if (!out) FLMR_FAIL(FLMR_ERR_INVALID, "NULL argument");
+    return score_padded(Q, nqueries, nq, D, mask, B, Ld, dim, out, nullptr, stream, true);
 }
 
 // the per-column maxima [B, nq] before their sum: what colbert_score_reduce's 'flipr' interaction reduces (colbert.py:246-261)

@@ -22,8 +22,9 @@ struct flmr_searcher {
     float* cs; uint32_t* idx_bits; float* part_val; int32_t* part_idx; int32_t* cells; int32_t* ncell;
     uint32_t* bitmap; int32_t* cand; int32_t* cand_count; uint64_t* keys1; int32_t* s1_pids; int32_t* s1_count;
     uint64_t* keys2; int32_t* s2_pids; int32_t* s2_count; uint64_t* keys3; float* doc_scores;
-    int32_t* overflow;          // = status: device flags [0] candidate capacity exceeded, [1] q_lens outside [0, nq], [2] more
-                                // surviving centroids than score rows (row_cap)
+    int32_t* overflow;          // = status: device flags [0] candidate capacity exceeded, [1] q_lens outside [0, nq] ([2], [3] unused)
+    int32_t* row_ovf;           // [max_queries] 1 = more surviving centroids than compact score rows (row_cap): the query's stage 1 is
+                                // recomputed from the fp16 centroids inside the same batch (no error, no host round trip)
     int32_t* status_host;       // pinned copy of the flags, refreshed asynchronously after every batch
     float* rows;                // compact score rows [max_queries, row_cap, 32]: the sparse path's whole "score table"
     uint32_t* idx_prefix;       // [max_queries, idx_words] ranks of the surviving centroids (qualifying_kernel)
@@ -172,10 +173,8 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     // dense stage 1: needs the sorted code copy (whole 16-byte pieces are read: its padding) and 32-bit token offsets
     s->s1d_lpc = ix->mean_ulen > 0.0 && ix->mean_ulen <= 72.0 ? 16 : 32;
     s->s1d_img_rows = (ix->codes_sorted && s->ncol_max == 32 && !s->opt.is(FLMR_OPT_S1_IMPL, "scan")) ? flmr_s1_dense_image_rows(max_queries, s->idx_words, s->s1d_lpc) : 0;
-    if (s->s1d_img_rows > 0) {
-        WS(s1d_mode, B); WS(s1d_band_count, B); WS(s1d_err, B); WS(s1d_in_count, B); WS(s1d_scan_skip, B);
-        WS(s1d_band, B * (size_t)s->cand_cap);
-    }
+    WS(s1d_mode, B); WS(s1d_band_count, B); WS(s1d_err, B); WS(s1d_in_count, B); WS(s1d_scan_skip, B); WS(row_ovf, B);
+    if (s->s1d_img_rows > 0) WS(s1d_band, B * (size_t)s->cand_cap);
     WS(q3_hi, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
     WS(q3_lo, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
 #undef WS
@@ -223,7 +222,7 @@ extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
     if (!s) return FLMR_OK;
     void* ptrs[] = {s->cs, s->rows, s->idx_prefix, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
                     s->keys1, s->s1_pids, s->s1_count, s->keys2, s->s2_pids, s->s2_count, s->keys3, s->doc_scores,
-                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->q_err, s->q_err_sum, s->s2_band, s->s2_band_count, s->s2_need, s->s2_def, s->keys2b, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->chunk_hits, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part, s->s3_desc, s->s3_wbeg, s->s3_colmax, s->cand_fast, s->s1d_mode, s->s1d_band, s->s1d_band_count, s->s1d_err, s->s1d_in_count, s->s1d_scan_skip};
+                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->q_err, s->q_err_sum, s->s2_band, s->s2_band_count, s->s2_need, s->s2_def, s->keys2b, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->chunk_hits, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part, s->s3_desc, s->s3_wbeg, s->s3_colmax, s->cand_fast, s->s1d_mode, s->s1d_band, s->s1d_band_count, s->s1d_err, s->s1d_in_count, s->s1d_scan_skip, s->row_ovf};
     for (void* p : ptrs) (void)hipFree(p);
     if (s->status_host) (void)hipHostFree(s->status_host);
     if (s->status_ev) (void)hipEventDestroy(s->status_ev);
@@ -361,16 +360,12 @@ static int poll_status(flmr_searcher* s, bool wait) {
         FLMR_HIP(e);
     }
     s->status_pending = false;
-    const int32_t ovf = s->status_host[0], bad = s->status_host[1], rows_ovf = s->status_host[2];
-    if (ovf || bad || rows_ovf) {
+    const int32_t ovf = s->status_host[0], bad = s->status_host[1];
+    if (ovf || bad) {
         s->status_host[0] = s->status_host[1] = s->status_host[2] = 0;
         // cleared IN ORDER on the searcher's stream: a synchronous memset on the null stream is not ordered against a later
         // batch already running on a non-blocking stream and could wipe that batch's flag
         FLMR_HIP(hipMemsetAsync(s->overflow, 0, 4 * sizeof(int32_t), s->last_stream));
-        if (rows_ovf)
-            FLMR_FAIL(FLMR_ERR_CAPACITY, "an earlier batch had a query with more than %d centroids above centroid_score_threshold: the searcher "
-                      "keeps that many score rows per query and that query's stage-1 scores are not reliable -- raise the threshold, or "
-                      "set the option FLMR_ROW_CAP (up to 65535) before creating the searcher", s->row_cap);
         if (ovf)
             FLMR_FAIL(FLMR_ERR_CAPACITY, "an earlier batch produced more candidates than the workspace bound (cand_cap=%lld): its "
                       "candidate lists were truncated and its results are not reliable (is the IVF consistent with the codes?)",
@@ -549,6 +544,7 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
         ca.keys = s->keys1; ca.key_count = s->key_count; ca.chunk_hits = s->chunk_hits; ca.n_select = c.p.ndocs;
         ca.f16_round = c.f.f16_round;
         ca.fast_state = s->opt.is(FLMR_OPT_S1_IMPL, "slots") ? nullptr : s->cand_fast;
+        ca.row_ovf = s->row_ovf;
     }
     if (chunked) {
         RUN(flmr_launch_candidates_chunked(ca, st));
@@ -572,9 +568,13 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
     // candidate, the band around the cut rescored exactly -- where the rows fit (<= ~2 k survivors), the same kernel's exact form
     // beyond; the round-5 scan keeps the cases those do not cover (several column tiles, the fp16 numerics mode, no sorted copy).
     const bool dense = s->s1d_img_rows > 0 && chunked && c.sparse && c.ncol == 32 && !c.f.f16_round && !s->opt.is(FLMR_OPT_S1_IMPL, "scan");
-    const int32_t* scan_skip = scatter ? s->hit_valid : nullptr;
     const int32_t* sel_counts = s->cand_count;
     s->last_dense = dense;
+    // who takes which query: the list-scatter forms (hit_valid), the dense forms, the recompute form (row_ovf), the scan (the rest)
+    const bool exact_too = dense && !s->opt.is(FLMR_OPT_S1_IMPL, "image");   // (development: "image" leaves the queries beyond the images to the scan)
+    RUN(flmr_launch_s1_dense_modes(scatter ? s->hit_valid : nullptr, s->nqual, s->row_ovf, c.nqueries, dense ? s->s1d_img_rows : 0,
+                                   exact_too ? 1 : 0, s->s1d_mode, s->s1d_scan_skip, st));
+    const int32_t* scan_skip = s->s1d_scan_skip;
     if (dense) {
         flmr_s1d_args d{};
         d.codes = ix->codes_sorted; d.offsets = ix->doc_offsets; d.ulen = ix->doc_ulen; d.codes_len = ix->N;
@@ -582,9 +582,6 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
         d.rows = s->rows; d.row_cap = s->row_cap; d.nqual = s->nqual; d.q_lens = c.q_lens; d.nq_cand = c.nqc; d.nqueries = c.nqueries;
         d.cand = s->cand; d.cand_stride = s->cand_cap; d.cand_count = s->cand_count;
         d.band = s->s1d_band; d.band_count = s->s1d_band_count; d.mode = s->s1d_mode; d.keys = s->keys1; d.img_err = s->s1d_err;
-        const bool exact_too = !s->opt.is(FLMR_OPT_S1_IMPL, "image");   // (development: "image" leaves the queries beyond the images to the scan)
-        RUN(flmr_launch_s1_dense_modes(scatter ? s->hit_valid : nullptr, s->nqual, c.nqueries, s->s1d_img_rows, exact_too ? 1 : 0,
-                                       s->s1d_mode, s->s1d_scan_skip, st));
         d.parts = 0; d.group = 64;
         RUN(flmr_launch_s1_dense(d, true, s->s1d_lpc, st));
         RUN(flmr_launch_s1_band(s->keys1, s->cand_cap, s->cand_count, s->s1d_mode, s->s1d_err, c.nqueries, c.p.ndocs, s->s1d_band,
@@ -592,9 +589,11 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
         // the bands are short (ndocs + a few per cent): one item per query, groups of 16 so that every wave has some
         d.parts = 1; d.group = 16;
         RUN(flmr_launch_s1_dense(d, false, s->s1d_lpc, st));
-        scan_skip = s->s1d_scan_skip;
         sel_counts = s->s1d_in_count;
     }
+    if (c.sparse)   // (a query over the score-row capacity; leaves at once when there is none)
+        RUN(flmr_launch_filter_stage1_recompute(c.f, s->idx_bits, s->idx_words, s->cand, s->cand_cap, s->cand_count, s->row_ovf, s->keys1,
+                                                ix->centroids_f16, s->q_hi, s->q_lo, st));
     RUN(flmr_launch_filter_stage1(c.f, s->idx_bits, s->idx_words, s->cand, s->cand_cap, s->cand_count, s->keys1,
                                   (use_hits && !chunked) ? s->hit_bits : nullptr, s->bitmap_words, use_hits ? s->hit_valid : nullptr,
                                   (use_hits && chunked) ? s->cand_hit : nullptr, st, scan_skip));
@@ -871,6 +870,16 @@ extern "C" int flmr_searcher_tap(flmr_searcher_t* s, int32_t what, int32_t q, vo
         case FLMR_TAP_Q_ERR_SUM:
             n = s->last_hi_first ? 1 : 0; src = s->q_err_sum + q; break;
         case FLMR_TAP_STAGE1_FORM:
+            {   // 7: a query over the score-row capacity (stage 1 recomputed from the centroids)
+                int32_t ro = 0;
+                FLMR_HIP(hipMemcpy(&ro, s->row_ovf + q, 4, hipMemcpyDeviceToHost));
+                if (ro) {
+                    *count = 1;
+                    if (capacity < 1) FLMR_FAIL(FLMR_ERR_CAPACITY, "tap needs 1 element");
+                    *static_cast<int32_t*>(host_out) = 7;
+                    return FLMR_OK;
+                }
+            }
             if (s->last_dense) {   // a query the dense forms took: 5 (images + band) / 6 (exact rows)
                 int32_t m = 0;
                 FLMR_HIP(hipMemcpy(&m, s->s1d_mode + q, 4, hipMemcpyDeviceToHost));

@@ -499,12 +499,12 @@ int flmr_launch_s1_dense(const flmr_s1d_args& a_in, bool img_pass, int lpc, hipS
     return FLMR_OK;
 }
 
-__global__ void s1_dense_modes_kernel(const int32_t* skip, const int32_t* nqual, int32_t nqueries, int32_t img_rows, int32_t exact_too,
-                                      int32_t* mode, int32_t* scan_skip) {
+__global__ void s1_dense_modes_kernel(const int32_t* skip, const int32_t* nqual, const int32_t* row_ovf, int32_t nqueries, int32_t img_rows,
+                                      int32_t exact_too, int32_t* mode, int32_t* scan_skip) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nqueries) return;
     int m = FLMR_S1D_SKIP, sk = 1;
-    if (!(skip && skip[q])) {
+    if (!(skip && skip[q]) && !(row_ovf && row_ovf[q])) {
         if (nqual[q] <= img_rows) m = FLMR_S1D_IMAGE;
         else if (exact_too) m = FLMR_S1D_EXACT;
         else sk = 0;   // the scan takes the query
@@ -513,10 +513,10 @@ __global__ void s1_dense_modes_kernel(const int32_t* skip, const int32_t* nqual,
     scan_skip[q] = sk;
 }
 
-int flmr_launch_s1_dense_modes(const int32_t* skip, const int32_t* nqual, int32_t nqueries, int32_t img_rows, int32_t exact_too,
-                               int32_t* mode, int32_t* scan_skip, hipStream_t st) {
-    hipLaunchKernelGGL(s1_dense_modes_kernel, dim3((nqueries + 255) / 256), dim3(256), 0, st, skip, nqual, nqueries, img_rows, exact_too,
-                       mode, scan_skip);
+int flmr_launch_s1_dense_modes(const int32_t* skip, const int32_t* nqual, const int32_t* row_ovf, int32_t nqueries, int32_t img_rows,
+                               int32_t exact_too, int32_t* mode, int32_t* scan_skip, hipStream_t st) {
+    hipLaunchKernelGGL(s1_dense_modes_kernel, dim3((nqueries + 255) / 256), dim3(256), 0, st, skip, nqual, row_ovf, nqueries, img_rows,
+                       exact_too, mode, scan_skip);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }

@@ -101,11 +101,11 @@ class ShardedSearcher:
         shard = arrays.shard(rank, world)
         return cls(scorer=IndexScorer(arrays=shard, device_index=DeviceIndex(shard), max_batch=max_batch), group=group)
 
-    def _hip_local_search(self, Q, k, nq_cand=32, q_lens=None, checked=True):
-        """This shard's search.  checked (default): with the deferred device errors read after the batch and the recoverable one --
-        more surviving centroids than score rows, FLMR_ROW_CAP -- handled by one more pass through the full score table, as
-        Searcher._search_all_Q does it (a LOCAL recovery: no collective is involved, so the ranks cannot diverge); a throughput
-        loop passes checked=False and calls `check_all()` at its own sync points."""
+    def _hip_local_search(self, Q, k, nq_cand=32, q_lens=None, checked=False):
+        """This shard's search, queued on the current stream (no host sync: the all-gather of the fast mode follows on the same
+        stream).  checked=True reads the deferred device status after the batch (a host sync: candidate overflow, q_lens out of
+        range -- nothing recoverable is left for the host to do: a query over the score-row capacity is handled inside the
+        library); a throughput loop leaves it off and calls `check_all()` at its own sync points."""
         ncells, thr, ndocs = self.k_policy(k)
         if checked and hasattr(self.scorer, "search_batch_checked"):
             return self.scorer.search_batch_checked(Q, k, ncells, thr, ndocs, nq_cand, q_lens=q_lens)
@@ -254,15 +254,7 @@ class ShardedSearcher:
         except StopIteration as e:
             out = e.value
         if check:
-            if self.check_all(gather, recoverable=True) == "row_cap":
-                # a query on some shard has more centroids above the threshold than its searcher keeps score rows for: EVERY rank
-                # (the verdict is the gathered flag, identical everywhere) switches to the full centroid-score table and redoes the batch
-                import warnings
-                warnings.warn("ravqa_amd: a shard has a query with more centroids above centroid_score_threshold than its searcher keeps "
-                              "score rows for; all ranks repeat the batch with the full centroid-score table (and keep it)", RuntimeWarning)
-                self.enable_full_table()
-                return self.search_batch_exact(Q, k, nq_cand=nq_cand, q_lens=q_lens, gather=gather, split_stage0=split_stage0,
-                                               reduce_sum=reduce_sum, check=True, truncate_phase1=truncate_phase1)
+            self.check_all(gather)
             if cert and bool(cert[0]):   # (never on evenly sharded data) redo this batch with the full phase-1 exchange
                 return self.search_batch_exact(Q, k, nq_cand=nq_cand, q_lens=q_lens, gather=gather, split_stage0=split_stage0,
                                                reduce_sum=reduce_sum, check=True, truncate_phase1=False)
@@ -334,29 +326,21 @@ class ShardedSearcher:
             self.timings = {}
         return out
 
-    def enable_full_table(self):
-        """Every scorer of this rank keeps the whole K x nq_cand centroid-score table from now on (the recovery from the score-row
-        capacity, FLMR_ROW_CAP; collective by convention: call it on every rank, e.g. after check_all() raised that error in a
-        pipelined loop, and redo the unchecked batches)."""
-        for sc in set(getattr(self, "_pipe", []) + [self.scorer]):
-            if sc is not None:
-                sc.force_full_table = True
-        self._split_ok = {}   # (the query-split capability depends on the table mode)
-
-    def check_all(self, gather=None, recoverable=False):
-        """Collective: every rank reads its searcher's deferred status (waits for its last batch) and the ranks exchange one
+    def check_all(self, gather=None):
+        """Collective: every rank reads its searchers' deferred status (waits for their last batches) and the ranks exchange one
         flag; raises on ALL ranks if any shard failed (the failing rank re-raises its own error, the others name the rank).
-        recoverable=True: when the only failure anywhere is the score-row capacity (FLMR_ROW_CAP) nothing is raised and "row_cap"
-        is returned on every rank."""
+        EVERY scorer of the pipeline is polled (and its flags cleared) before the first error is kept: a clone left with a stale
+        flag would fail its next phase call on this rank only, with the other ranks already inside the collective."""
         err = None
-        try:
-            for sc in getattr(self, "_pipe", [self.scorer]):
-                if hasattr(sc, "check"):
-                    sc.check()
-        except Exception as e:  # noqa: BLE001 -- whatever the shard raised must reach the other ranks as a flag
-            err = e
+        for sc in getattr(self, "_pipe", [self.scorer]):
+            if not hasattr(sc, "check"):
+                continue
+            try:
+                sc.check()
+            except Exception as e:  # noqa: BLE001 -- whatever the shard raised must reach the other ranks as a flag
+                err = err or e
         dev = self.scorer.probe_device if hasattr(self.scorer, "probe_device") else "cuda"
-        flag = torch.tensor([0 if err is None else (2 if "FLMR_ROW_CAP" in str(err) else 1)], dtype=torch.int32, device=dev)
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=dev)
         if gather is not None:
             flags = gather(flag).reshape(-1)
         elif self.world > 1 or self.force_collectives:
@@ -365,8 +349,6 @@ class ShardedSearcher:
         else:
             flags = flag
         pending, self._cert = self._cert, []
-        if recoverable and int(flags.max()) == 2 and not bool((flags == 1).any()):
-            return "row_cap"
         if err is not None:
             raise err
         bad = torch.nonzero(flags).reshape(-1).tolist()
@@ -383,7 +365,7 @@ class ShardedSearcher:
         issue different collectives) than the others."""
         from . import _native
         # the answer also depends on the kernel switches (flmr_set_option) and on whether the scorer keeps the full table
-        key = (int(Q.size(1)), int(k), int(nq_cand), _native.options_epoch, bool(getattr(scorer, "full_table_state", False)))
+        key = (int(Q.size(1)), int(k), int(nq_cand), _native.options_epoch, bool(getattr(scorer, "full_table_state", False)))   # (full table: set by taps / retrieve())
         if key not in self._split_ok:
             ok = bool(scorer.supports_query_split(Q, k, ncells, thr, ndocs, nq_cand))
             dev = scorer.probe_device if hasattr(scorer, "probe_device") else "cuda"

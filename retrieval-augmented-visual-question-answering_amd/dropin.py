@@ -111,13 +111,9 @@ def make_colbert_score_dispatch(reference_colbert_score):
                               "reference's torch expression (the HIP scorer takes them when a device is present)", RuntimeWarning)
             return reference(Q, D_padded, D_mask, config, use_gpu)
         Qr = Q.detach().to(dtype=D_padded.dtype)                                   # colbert.py:280
-        if interaction == "flipr":   # colbert.py:246-261: the column maxima from the HIP kernel, their top-k sums here
-            assert config.query_maxlen == 64, ("for now", config)
-            cm = ops.colbert_colmax_padded(Qr, D_padded.detach(), D_mask)           # [B, Nq] f32 on the device
-            qm, K2 = config.query_maxlen, 8
-            out = cm[:, :qm].topk(qm // 2, dim=-1).values.sum(-1)
-            if K2 <= cm.size(1) - qm:
-                out = out + cm[:, qm:].topk(K2, dim=-1).values.sum(1)
+        if interaction == "flipr":   # colbert.py:246-261: the column maxima from the HIP kernel, their top-k sums in scoring.reduce_colmax
+            from . import scoring
+            out = scoring.reduce_colmax(ops.colbert_colmax_padded(Qr, D_padded.detach(), D_mask), config)
         else:
             out = ops.colbert_score_padded(Qr, D_padded.detach(), D_mask)          # f32 on the device
         dev = torch.device("cuda") if use_gpu else D_padded.device

@@ -74,7 +74,9 @@ class FLMRModelForRetrieval:
     # ---- colbert.py:217-224 -------------------------------------------------------------------------------------------
     def score(self, Q, D_padded, D_mask):
         if self.colbert_config is not None and getattr(self.colbert_config, "similarity", "cosine") == "l2":
-            raise NotImplementedError("similarity='l2' is not part of the HIP scoring head (colbert.py:220-222)")
+            # colbert.py:220-222: the squared-distance variant is a plain torch expression upstream (no mask, no kernel): kept as it is
+            assert getattr(self.colbert_config, "interaction", "colbert") == "colbert"
+            return (-1.0 * ((Q.unsqueeze(2) - D_padded.unsqueeze(1)) ** 2).sum(-1)).max(-1).values.sum(-1)
         return scoring.colbert_score(Q, D_padded, D_mask, config=self.colbert_config)
 
     # ---- colbert.py:64-80 ---------------------------------------------------------------------------------------------

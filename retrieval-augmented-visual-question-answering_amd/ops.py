@@ -95,6 +95,19 @@ def colbert_score_padded(Q, D_padded, D_mask):
     return out
 
 
+def colbert_score_cross(Q, D_padded, D_mask):
+    """Every query against every document in ONE launch: Q [nqueries, Nq, d], D [B, Ld, d], mask [B, Ld(,1)] -> [nqueries, B]
+    (the rate matrix of the executor's exhaustive search, FLMR_executor.py:799-847)."""
+    lib = _native.load()
+    Qd, Dd = _d(Q, torch.float32), _d(D_padded, torch.float32)
+    B, Ld, dim = Dd.shape
+    md = _d(torch.as_tensor(D_mask).reshape(B, Ld), torch.bool).view(torch.uint8)
+    out = torch.empty((Qd.size(0), B), dtype=torch.float32, device="cuda")
+    _native.check(lib.flmr_colbert_score_cross(_p(Qd), Qd.size(0), Qd.size(1), _p(Dd), _p(md), B, Ld, dim, _p(out),
+                                               _native.stream_ptr()))
+    return out
+
+
 def colbert_colmax_padded(Q, D_padded, D_mask):
     """The per-column maxima [B, Nq] of the padded MaxSim (-9999 padding) before their sum: what `colbert_score_reduce`
     reduces -- by a plain sum for 'colbert', by top-k sums for 'flipr' (colbert.py:235-263)."""

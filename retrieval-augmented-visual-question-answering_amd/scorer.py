@@ -66,10 +66,10 @@ class PendingBatch:
     """Results of one batched search on their way to pinned host memory (IndexScorer.search_batch_pending): numpy views `pids`
     [n, k], `scores` [n, k], `counts` [n] whose rows [b0, b1) are valid once `wait(chunk)` has returned."""
 
-    def __init__(self, hp, hs, hc, marks, device_results, check, redo):
+    def __init__(self, hp, hs, hc, marks, device_results, check):
         self._t = (hp, hs, hc)                      # the pinned tensors (kept alive with the views)
         self.pids, self.scores, self.counts = hp.numpy(), hs.numpy(), hc.numpy()
-        self._marks, self._dev, self._check, self._redo = marks, device_results, check, redo
+        self._marks, self._dev, self._check = marks, device_results, check
         self._done = [False] * len(marks)
 
     @classmethod
@@ -77,7 +77,7 @@ class PendingBatch:
         self = cls.__new__(cls)
         self._t = (pids.cpu(), scores.cpu(), counts.cpu())
         self.pids, self.scores, self.counts = (t.numpy() for t in self._t)
-        self._marks, self._dev, self._check, self._redo = [(0, self.pids.shape[0], None, None)], None, None, None
+        self._marks, self._dev, self._check = [(0, self.pids.shape[0], None, None)], None, None
         self._done = [True]
         return self
 
@@ -89,23 +89,8 @@ class PendingBatch:
             return
         _, _, ev, flags = self._marks[j]
         ev.synchronize()
-        if int(flags[0]) or int(flags[1]) or int(flags[2]):
-            # a deferred device-side error up to this sub-batch: report it exactly as search_batch_checked does (its recovery --
-            # the full score table -- repeats the WHOLE batch, synchronously)
-            try:
-                self._check()
-            except _native.FlmrNativeError as e:
-                if "FLMR_ROW_CAP" not in str(e):
-                    raise
-                import warnings
-                warnings.warn("ravqa_amd: a query has more centroids above centroid_score_threshold than the searcher keeps score rows "
-                              "for; repeating the batch with the full centroid-score table (slower; raise the threshold or set FLMR_ROW_CAP)",
-                              RuntimeWarning)
-            p, s, c = self._redo()
-            torch.cuda.synchronize()
-            self.pids[...], self.scores[...], self.counts[...] = p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy()
-            self._done = [True] * len(self._done)
-            return
+        if int(flags[0]) or int(flags[1]):
+            self._check()   # a deferred device-side error up to this sub-batch (candidate bound, q_lens range): raises it
         self._done[j] = True
 
     def wait_all(self):
@@ -209,8 +194,8 @@ class IndexScorer:
     def check(self):
         """Wait for the last batch and raise FlmrNativeError if it overflowed the candidate bound or was handed q_lens
         outside [0, nq] (flmr_searcher_check); without this call the error surfaces on the next batch.  EVERY searcher is
-        polled (and its flags cleared) before the first error is raised -- with streams > 1 a side searcher's stale flag would
-        otherwise fail the recovery batch of search_batch_checked; an error other than the recoverable score-row capacity wins."""
+        polled (and its flags cleared) before the first error is raised: with streams > 1 a side searcher's stale flag would
+        otherwise fail a later batch."""
         first = None
         for h in [self._searcher] + [h for h, _ in self._side]:
             if h is None:
@@ -218,8 +203,7 @@ class IndexScorer:
             try:
                 _native.check(self._lib.flmr_searcher_check(h))
             except _native.FlmrNativeError as e:
-                if first is None or ("FLMR_ROW_CAP" in str(first) and "FLMR_ROW_CAP" not in str(e)):
-                    first = e
+                first = first or e
         if first is not None:
             raise first
 
@@ -267,7 +251,7 @@ class IndexScorer:
         slots = [(s, cur)]                          # slot 0 stays on the caller's stream
         if nchunks > 1 and self._nstreams > 1:
             slots += self._side_slots(min(nchunks, self._nstreams) - 1)
-        full_table = bool(full_table or getattr(self, "force_full_table", False))
+        full_table = bool(full_table)
         for h, _ in slots:
             self._lib.flmr_searcher_set_profiling(h, 1 if profile else 0)
             self._lib.flmr_searcher_set_full_table(h, 1 if full_table else 0)  # needed for the CENTROID_SCORES tap
@@ -299,8 +283,7 @@ class IndexScorer:
         """search_batch whose results go to pinned HOST memory sub-batch by sub-batch: returns a PendingBatch at once; each
         sub-batch's rows (and the searcher's deferred status words, flmr_searcher_status_async) are copied behind its kernels on
         the launch stream and an event marks them readable, so the host reads sub-batch i while the device computes i+1.  The
-        deferred errors of search_batch_checked surface when an affected sub-batch is first read; the recoverable one (score-row
-        capacity) repeats the whole batch synchronously with the full table."""
+        deferred errors of search_batch_checked surface when an affected sub-batch is first read."""
         if self._nstreams > 1:   # sub-batches on several streams finish together: nothing to pipeline
             return PendingBatch.resolved(*self.search_batch_checked(Q, k, ncells, centroid_score_threshold, ndocs, nq_cand, q_lens=q_lens))
         n = Q.size(0)
@@ -318,28 +301,15 @@ class IndexScorer:
             marks.append((b0, b1, stream.record_event(), flags))
 
         dev = self.search_batch(Q, k, ncells, centroid_score_threshold, ndocs, nq_cand, q_lens=q_lens, _after_chunk=after_chunk)
-
-        def redo():
-            return self.search_batch_checked(Q, k, ncells, centroid_score_threshold, ndocs, nq_cand, q_lens=q_lens)
-        return PendingBatch(hp, hs, hc, marks, dev, self.check, redo)
+        return PendingBatch(hp, hs, hc, marks, dev, self.check)
 
     def search_batch_checked(self, Q, k, ncells, centroid_score_threshold, ndocs, nq_cand=32, q_lens=None):
-        """search_batch + check() (a host sync), with the one recoverable deferred error handled: a query with more centroids
-        above the threshold than the searcher keeps score rows for (FLMR_ROW_CAP, default 16384 -- the reference has no such
-        limit) sends the call through the full K x nq_cand score table once more (allocated on first use, 16.8 MB per query at
-        K = 131072), with a warning.  What `Searcher._search_all_Q` calls."""
+        """search_batch + check() (a host sync): the deferred device errors of the batch (candidate bound, q_lens range) raise
+        here.  Nothing is left to recover on the host: a query with more centroids above the threshold than the searcher keeps
+        score rows for (FLMR_ROW_CAP; the reference has no such limit, index_storage.py:116) has its stage 1 recomputed from the
+        centroids inside the same batch by the library."""
         out = self.search_batch(Q, k, ncells, centroid_score_threshold, ndocs, nq_cand, q_lens=q_lens)
-        try:
-            self.check()
-        except _native.FlmrNativeError as e:
-            if "FLMR_ROW_CAP" not in str(e):
-                raise
-            import warnings
-            warnings.warn("ravqa_amd: a query has more centroids above centroid_score_threshold than the searcher keeps score rows "
-                          "for; repeating the batch with the full centroid-score table (slower; raise the threshold or set FLMR_ROW_CAP)",
-                          RuntimeWarning)
-            out = self.search_batch(Q, k, ncells, centroid_score_threshold, ndocs, nq_cand, q_lens=q_lens, full_table=True)
-            self.check()
+        self.check()
         return out
 
     # ---- exact sharded protocol (include/flmr_hip.h: flmr_search_phase1..3) -------------------------------------------
@@ -350,10 +320,6 @@ class IndexScorer:
         if self._searcher_key is not None and self._searcher_key[3] != ndocs:
             self.close_searcher()  # key rows are exactly ndocs wide: the workspace must be created for this ndocs
         s = self._get_searcher(n, nq, p)
-        if getattr(self, "force_full_table", False) and not getattr(self, "full_table_state", False):
-            # (sharded recovery from the score-row capacity: every phase of every rank on the whole K x nq_cand table)
-            self._lib.flmr_searcher_set_full_table(s, 1)
-            self.full_table_state = True
         ql = None if q_lens is None else torch.as_tensor(q_lens).to(device="cuda", dtype=torch.int32).contiguous()
         return Qd, ql, n, nq, p, s
 

@@ -15,21 +15,40 @@ def _no_grad_only(*tensors):
         raise RuntimeError("the HIP MaxSim scorer is forward-only; call it under torch.no_grad()/inference_mode()")
 
 
-def colbert_score_reduce(scores_padded, D_mask, config=None):
-    """[B, Ld, Nq] scores + mask -> [B] (colbert.py:235-263, 'colbert' interaction): tiny torch epilogue kept for
-    callers that already hold a padded score tensor on the device."""
+def _interaction(config):
     interaction = getattr(config, "interaction", "colbert") if config is not None else "colbert"
-    if interaction != "colbert":
-        raise NotImplementedError("only the 'colbert' interaction is implemented (flipr asserts query_maxlen==64 upstream)")
+    assert interaction in ("colbert", "flipr"), interaction   # colbert.py:244
+    return interaction
+
+
+def reduce_colmax(colmax, config=None):
+    """[B, Nq] per-column maxima -> [B] (the second half of colbert_score_reduce, colbert.py:244-263): their sum for
+    'colbert'; for 'flipr' the 32 largest of the first 64 columns plus, when there are that many, the 8 largest of the rest."""
+    if _interaction(config) == "flipr":
+        assert config.query_maxlen == 64, ("for now", config)
+        qm, K2 = config.query_maxlen, 8
+        out = colmax[:, :qm].topk(qm // 2, dim=-1).values.sum(-1)
+        if K2 <= colmax.size(1) - qm:
+            out = out + colmax[:, qm:].topk(K2, dim=-1).values.sum(1)
+        return out
+    return colmax.sum(-1)
+
+
+def colbert_score_reduce(scores_padded, D_mask, config=None):
+    """[B, Ld, Nq] scores + mask -> [B] (colbert.py:235-263, both interactions): tiny torch epilogue kept for callers that
+    already hold a padded score tensor on the device."""
     pad = ~D_mask.view(scores_padded.size(0), scores_padded.size(1)).bool()
     scores_padded = scores_padded.masked_fill(pad.unsqueeze(-1), -9999)
-    return scores_padded.max(1).values.sum(-1)
+    return reduce_colmax(scores_padded.max(1).values, config)
 
 
 def colbert_score(Q, D_padded, D_mask, config=None, use_gpu=False):
-    """Padded late-interaction score (colbert.py:268-286): Q [1|B, Nq, d] x D [B, Ld, d] -> [B] on the device."""
+    """Padded late-interaction score (colbert.py:268-286): Q [1|B, Nq, d] x D [B, Ld, d] -> [B] on the device; the 'flipr'
+    interaction takes the kernel's per-column maxima and reduces them as colbert.py:246-261 does."""
     _no_grad_only(Q, D_padded)
     assert Q.dim() == 3 and D_padded.dim() == 3 and Q.size(0) in (1, D_padded.size(0))
+    if _interaction(config) == "flipr":
+        return reduce_colmax(ops.colbert_colmax_padded(Q, D_padded, D_mask), config)
     return ops.colbert_score_padded(Q, D_padded, D_mask)
 
 
@@ -70,8 +89,8 @@ def exhaustive_search(query_embeddings, item_embeddings, item_embedding_mask, k,
 
     query_embeddings [nq, Nq, d]; item_embeddings [n_items, Ld, d]; item_embedding_mask [n_items, Ld(,1)] (1 = real token).
     Returns (indices int64 [nq, k'], scores f32 [nq, k'], rate_batch f32 [nq, n_items]) on the device, k' = min(k, n_items).
-    The items are uploaded once and stay resident; each query is one launch of the padded MaxSim kernel over all items
-    (q_batch == 1 broadcast), `item_chunk` bounds the items per launch for corpora larger than HBM headroom."""
+    One launch of the padded MaxSim kernel per item chunk scores EVERY query against the chunk's items (the cross form,
+    `flmr_colbert_score_cross`); `item_chunk` bounds the items resident per launch for corpora larger than HBM headroom."""
     _no_grad_only(query_embeddings, item_embeddings)
     Q = torch.as_tensor(query_embeddings).to("cuda", torch.float32)
     D = torch.as_tensor(item_embeddings)
@@ -83,8 +102,8 @@ def exhaustive_search(query_embeddings, item_embeddings, item_embedding_mask, k,
     for i0 in range(0, n_items, item_chunk):
         Dc = D[i0:i0 + item_chunk].to("cuda", torch.float32).contiguous()
         Mc = M[i0:i0 + item_chunk].to("cuda")
-        for q in range(Q.size(0)):
-            rate[q, i0:i0 + Dc.size(0)] = ops.colbert_score_padded(Q[q:q + 1], Dc, Mc)
+        for q0 in range(0, Q.size(0), 65535):   # (grid dimension limit of the cross form)
+            rate[q0:q0 + 65535, i0:i0 + Dc.size(0)] = ops.colbert_score_cross(Q[q0:q0 + 65535], Dc, Mc)
     scores, indices = torch.sort(rate, dim=-1, descending=True)
     kk = min(int(k), n_items)
     return indices[:, :kk], scores[:, :kk], rate

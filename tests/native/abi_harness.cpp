@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <cstring>
 #include <vector>
 #include "flmr_hip.h"
 
@@ -181,6 +182,39 @@ static void run_case(int K, int nbits, int64_t npass, unsigned seed) {
       float ms[16] = {};
       REQUIRE(flmr_searcher_stage_ms(s, ms) == FLMR_OK);
       HIPOK(hipFree(dP)); HIPOK(hipFree(dS)); HIPOK(hipFree(dC)); }
+    // A query with MORE surviving centroids than the searcher keeps score rows for is a legal query (the reference has no such
+    // limit, TPC/search/index_storage.py:116): a searcher created under FLMR_ROW_CAP=64 must return, through this same C ABI and
+    // without any error, exactly what the uncapped searcher returns (the library recomputes that query's stage 1 itself).
+    { flmr_search_params_t p = {32, 2, 0.2f, 256, 32};   // a low threshold: hundreds of centroids above it
+      int32_t *dP[2], *dC[2]; float* dS[2];
+      std::vector<int32_t> P[2], Cn[2]; std::vector<float> S[2];
+      int over = 0;
+      for (int capped = 0; capped < 2; capped++) {
+          REQUIRE(flmr_set_option("FLMR_ROW_CAP", capped ? "64" : nullptr) == FLMR_OK);
+          flmr_searcher_t* s2 = nullptr;
+          REQUIRE(flmr_searcher_create(ix, 32, nq, &maxp, &s2) == FLMR_OK && s2);
+          HIPOK(hipMalloc(reinterpret_cast<void**>(&dP[capped]), (size_t)nqueries * p.k * 4));
+          HIPOK(hipMalloc(reinterpret_cast<void**>(&dS[capped]), (size_t)nqueries * p.k * 4));
+          HIPOK(hipMalloc(reinterpret_cast<void**>(&dC[capped]), (size_t)nqueries * 4));
+          REQUIRE(flmr_search_batch(s2, dQ, dL, nqueries, nq, &p, dP[capped], dS[capped], dC[capped], nullptr) == FLMR_OK);
+          REQUIRE(flmr_searcher_check(s2) == FLMR_OK);   // no deferred capacity error either
+          P[capped].resize((size_t)nqueries * p.k); S[capped].resize((size_t)nqueries * p.k); Cn[capped].resize(nqueries);
+          HIPOK(hipMemcpy(P[capped].data(), dP[capped], P[capped].size() * 4, hipMemcpyDeviceToHost));
+          HIPOK(hipMemcpy(S[capped].data(), dS[capped], S[capped].size() * 4, hipMemcpyDeviceToHost));
+          HIPOK(hipMemcpy(Cn[capped].data(), dC[capped], Cn[capped].size() * 4, hipMemcpyDeviceToHost));
+          if (capped)
+              for (int q = 0; q < nqueries; q++) {
+                  int32_t form = -1; int64_t cnt = 0;
+                  REQUIRE(flmr_searcher_tap(s2, FLMR_TAP_STAGE1_FORM, q, &form, 1, &cnt) == FLMR_OK);
+                  over += (cnt == 1 && form == 7) ? 1 : 0;
+              }
+          REQUIRE(flmr_searcher_destroy(s2) == FLMR_OK);
+          HIPOK(hipFree(dP[capped])); HIPOK(hipFree(dS[capped])); HIPOK(hipFree(dC[capped]));
+      }
+      REQUIRE(flmr_set_option("FLMR_ROW_CAP", nullptr) == FLMR_OK);
+      REQUIRE(over >= nqueries / 2);   // the capped searcher really was over its capacity
+      REQUIRE(Cn[0] == Cn[1] && P[0] == P[1]);
+      REQUIRE(memcmp(S[0].data(), S[1].data(), S[0].size() * 4) == 0); }
     REQUIRE(flmr_set_option("FLMR_NO_SUCH_SWITCH", "x") != FLMR_OK);
     REQUIRE(flmr_set_option("FLMR_S2_IMPL", "lds") == FLMR_OK);
     REQUIRE(flmr_set_option("FLMR_S2_IMPL", nullptr) == FLMR_OK);

@@ -163,7 +163,7 @@ def test_many_surviving_centroids_code_scan_and_row_capacity(hip):
     """Thousands of centroids above the threshold per query (what a real corpus gives at the policy thresholds; the synthetic
     corpora have ~50): beyond the scatter stage 1's 1024 lists the code-scanning stage 1 runs, on the compact score rows
     (row = rank of the centroid among the survivors) -- ranked lists against the CPU oracle.  A searcher created with fewer
-    score rows than a query needs reports FLMR_ERR_CAPACITY at the next sync point and stays usable."""
+    score rows than a query needs gives the same results (the library recomputes that query's stage 1)."""
     torch, nat = hip["torch"], hip["native"]
     from ravqa_amd import synth
     from ravqa_amd.scorer import IndexScorer
@@ -189,37 +189,29 @@ def test_many_surviving_centroids_code_scan_and_row_capacity(hip):
         tie_aware_equal(rp, rs, p[i, :m], s[i, :m])
         checked += 1
     assert checked >= 8, checked
-    with nat.options(FLMR_ROW_CAP="256"):
-        scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=q_lens)
-        with pytest.raises(nat.FlmrNativeError, match="FLMR_ROW_CAP"):
-            scorer.check()
-        # what Searcher._search_all_Q calls: the same error handled by one more pass through the full score table
-        with pytest.warns(RuntimeWarning, match="FLMR_ROW_CAP"):
-            pf, sf, cf = scorer.search_batch_checked(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=q_lens)
+    # A searcher that keeps FEWER score rows than a query has surviving centroids: the reference has no such limit
+    # (index_storage.py:116), so the library recomputes that query's stage 1 from the centroids inside the same batch
+    # (filter_stage1_recompute_kernel) -- no error, no warning, bit for bit the same result, on every path above the C ABI.
+    import warnings
+    with nat.options(FLMR_ROW_CAP="256"), warnings.catch_warnings():
+        warnings.simplefilter("error")
+        pf, sf, cf = scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=q_lens)
+        scorer.check()
+        forms = [int(scorer.tap(nat.TAP_STAGE1_FORM, q)[0]) for q in range(Q.size(0)) if scorer.tap(nat.TAP_STAGE1_FORM, q).size]
+        assert forms.count(7) >= 8, forms       # the recompute form took the queries over the capacity
         assert np.array_equal(pf.cpu().numpy(), p) and np.array_equal(cf.cpu().numpy(), c)
         assert np.array_equal(sf.cpu().numpy().view(np.uint32), s.view(np.uint32))
-        # the pipelined form (results to pinned host memory sub-batch by sub-batch, what _search_all_Q hands out): the same error
-        # surfaces when the first affected sub-batch is READ, with the same recovery
         pend = scorer.search_batch_pending(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=q_lens)
-        with pytest.warns(RuntimeWarning, match="FLMR_ROW_CAP"):
-            pend.wait(0)
+        pend.wait_all()
         assert np.array_equal(pend.pids, p) and np.array_equal(pend.counts, c) and np.array_equal(pend.scores.view(np.uint32), s.view(np.uint32))
-        # the sharded paths (one rank here; the exchanges are identities): the fast mode recovers locally, the exact protocol agrees
-        # on the verdict through its gathered status flag and repeats the batch with the full table on "every" rank
         from ravqa_amd.distributed import ShardedSearcher
         ss = ShardedSearcher(scorer=scorer, k_policy=lambda k_: (ncells, thr, ndocs))
-        with pytest.warns(RuntimeWarning, match="FLMR_ROW_CAP"):
-            pz, sz, cz = ss.search_batch(Q, ndocs // 4, q_lens=q_lens)
+        pz, sz, cz = ss.search_batch(Q, ndocs // 4, q_lens=q_lens)
         assert np.array_equal(pz.cpu().numpy(), p) and np.array_equal(sz.cpu().numpy().view(np.uint32), s.view(np.uint32))
-        import warnings
-        with warnings.catch_warnings(record=True) as seen:   # (a phase that keeps the whole table anyway never raises the flag)
-            warnings.simplefilter("always")
-            pe, se, ce = ss.search_batch_exact(Q, ndocs // 4, q_lens=q_lens, gather=lambda t: t.unsqueeze(0), reduce_sum=lambda t: t)
-        assert bool(getattr(scorer, "force_full_table", False)) == any("full centroid-score table" in str(w.message) for w in seen)
+        pe, se, ce = ss.search_batch_exact(Q, ndocs // 4, q_lens=q_lens, gather=lambda t: t.unsqueeze(0), reduce_sum=lambda t: t)
         assert np.array_equal(pe.cpu().numpy(), p) and np.array_equal(ce.cpu().numpy(), c)
         assert np.array_equal(se.cpu().numpy().view(np.uint32), s.view(np.uint32))
-        scorer.force_full_table = False
-        p2, s2, c2 = scorer.search_batch(Q, ndocs // 4, ncells, 0.6, ndocs, 32, q_lens=q_lens)   # few survivors: fine again
+        p2, s2, c2 = scorer.search_batch(Q, ndocs // 4, ncells, 0.6, ndocs, 32, q_lens=q_lens)   # few survivors: the usual forms
         scorer.check()
         p3, s3, c3 = IndexScorer(device_index=scorer.device_index, max_batch=16).search_batch(Q, ndocs // 4, ncells, 0.6, ndocs, 32, q_lens=q_lens)
         assert torch.equal(p2, p3) and torch.equal(s2, s3) and torch.equal(c2, c3)
@@ -509,3 +501,47 @@ def test_stage1_dense_forms_shapes(hip, K, npass, doclen, policy):
     corpus = synth.make_corpus(npass, doclen, K, 2, seed=79, device="cuda")
     forms = _dense_vs_scan(hip, corpus, policy)
     assert any(f in (5, 6) for f in forms), forms
+
+
+def test_scoring_surface_flipr_l2_and_the_cross_form(hip):
+    """The scoring head's host surface: `scoring.colbert_score` / `colbert_score_reduce` serve the 'flipr' interaction as the patched
+    dispatch does (TPC/modeling/colbert.py:246-261), `FLMRModelForRetrieval.score` with similarity == 'l2' is the reference's
+    torch expression (colbert.py:220-222), and the cross form of the padded kernel (every query against every document in one
+    launch: the exhaustive search's rate matrix, FLMR_executor.py:799-847) equals one broadcast call per query, bit for bit, on
+    both kernels (dim 128: MFMA; dim 64: plain FMA)."""
+    torch = hip["torch"]
+    from types import SimpleNamespace
+    from ravqa_amd import ops, scoring
+    from ravqa_amd.flmr import FLMRModelForRetrieval
+    g = torch.Generator().manual_seed(9)
+    B, Ld, Nq = 29, 37, 80
+    Q = torch.nn.functional.normalize(torch.randn(1, Nq, 128, generator=g), dim=-1)
+    D = torch.nn.functional.normalize(torch.randn(B, Ld, 128, generator=g), dim=-1)
+    mask = torch.rand(B, Ld, generator=g) < 0.8
+    mask[:, 0] = True
+    cfg = SimpleNamespace(interaction="flipr", query_maxlen=64)
+    sc = D.double() @ Q.double().permute(0, 2, 1)
+    sc[~mask] = -9999
+    cm = sc.max(1).values
+    want = cm[:, :64].topk(32, dim=-1).values.sum(-1) + cm[:, 64:].topk(8, dim=-1).values.sum(1)
+    with torch.no_grad():
+        got = scoring.colbert_score(Q, D, mask, config=cfg).cpu().double()
+        got2 = scoring.colbert_score_reduce((D @ Q.permute(0, 2, 1)).cuda(), mask.cuda(), cfg).cpu().double()
+        plain = scoring.colbert_score(Q, D, mask, config=SimpleNamespace(interaction="colbert")).cpu().double()
+    assert float((got - want).abs().max()) <= 1e-4 and float((got2 - want).abs().max()) <= 1e-4
+    assert float((plain - cm.sum(-1)).abs().max()) <= 1e-4
+    # similarity 'l2' (no mask upstream either)
+    model = FLMRModelForRetrieval(text_encoder=None, colbert_config=SimpleNamespace(similarity="l2", interaction="colbert"))
+    Qb = Q.expand(B, -1, -1)
+    l2 = model.score(Qb, D, mask)
+    ref = (-1.0 * ((Qb.unsqueeze(2) - D.unsqueeze(1)) ** 2).sum(-1)).max(-1).values.sum(-1)
+    assert torch.equal(l2, ref)
+    # cross form == one broadcast call per query
+    for dim in (128, 64):
+        Qs = torch.nn.functional.normalize(torch.randn(7, 40, dim, generator=g), dim=-1)
+        Ds = torch.nn.functional.normalize(torch.randn(B, Ld, dim, generator=g), dim=-1)
+        cross = ops.colbert_score_cross(Qs, Ds, mask).cpu()
+        assert cross.shape == (7, B)
+        for q in range(7):
+            one = ops.colbert_score_padded(Qs[q:q + 1], Ds, mask).cpu()
+            assert torch.equal(cross[q].view(torch.int32), one.view(torch.int32)), (dim, q)
