@@ -681,8 +681,40 @@ def main():
         sub("k500", scorer, Qs, tgts, 500, "same index, k=500 policy (ncells=4, thr=0.4, ndocs=4096)")
         # a threshold so low that ~9 k centroids per query pass it (> the 1024 the scatter stage 1 is sized for): those queries take
         # the code-scanning stage 1 -- the cost of leaving the tuned path, which the headline number never shows
-        sub("thr0.25_code_scan", scorer, Qs[:2], tgts[:2], k, "same index, centroid_score_threshold=0.25: more surviving centroids than the scatter "
-            "stage 1 holds (1024), every query falls back to the code-scanning stage 1", pol=(2, 0.25, 1024))
+        sub("thr0.25_code_scan", scorer, Qs[:2], tgts[:2], k, "same index, centroid_score_threshold=0.25: ~8.7 k surviving centroids per query, more than the "
+            "list-scatter stage 1 takes (1024) and than fit LDS as images: the exact form of the dense stage 1 (flmr_stage1_dense.hip; until "
+            "round 5 the code-scanning kernel, hence the name)", pol=(2, 0.25, 1024))
+        # One searcher, the two regimes ALTERNATING step by step: the stage-1 form of a query is planned on the device from the query's own
+        # statistics (cand_plan_kernel, flmr_s1_dense_modes), so no step may pay for the searcher's history -- every step, and the first
+        # one after a switch in particular, within a few per cent of the same policy run homogeneously
+        try:
+            polA, polB = k_policy(k), (2, 0.25, 1024)
+
+            def step_ms(pol, i):
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                scorer.search_batch(Qs[i % nb], k, pol[0], pol[1], pol[2], 32)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0_) * 1e3
+            import statistics as _st
+            homo = {}
+            for tag_, pol_ in (("planted_policy", polA), ("thr0.25", polB)):
+                for i in range(3):
+                    step_ms(pol_, i)
+                homo[tag_] = _st.median([step_ms(pol_, i) for i in range(8)])
+            seq = []
+            for i in range(12):
+                tag_, pol_ = (("planted_policy", polA), ("thr0.25", polB))[i % 2]
+                seq.append((tag_, step_ms(pol_, i)))
+            dev_ = max(abs(ms_ / homo[tag_] - 1.0) for tag_, ms_ in seq)
+            subs.append({"name": "alternating_policies", "value": 2 * args.batch / (homo["planted_policy"] + homo["thr0.25"]) * 1e3, "unit": "queries/sec",
+                         "homogeneous_ms_per_step": homo, "alternating_ms_per_step": [[t_, round(m_, 3)] for t_, m_ in seq],
+                         "max_relative_deviation_from_homogeneous": dev_,
+                         "note": "the k=100 policy and centroid_score_threshold=0.25 alternating step by step on ONE searcher (every step a switch of "
+                                 "regime: list-scatter queue form <-> dense exact form), each step timed with a device sync, against the medians of "
+                                 "the same policies run homogeneously: the form of a query is planned from its own statistics, not from the searcher's history"})
+        except Exception as e:  # noqa: BLE001
+            subs.append({"name": "alternating_policies", "value": None, "note": f"failed: {e!r}"})
         try:   # what a config with total_visible_gpus = 1 (FLMR_executor.py:784) selects: the reference's CUDA-branch arithmetic
             scf = IndexScorer(device_index=scorer.device_index, max_batch=min(args.batch, args.sub_batch), streams=args.streams,
                               numerics="gpu-fp16")

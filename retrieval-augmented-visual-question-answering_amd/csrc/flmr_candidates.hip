@@ -18,6 +18,9 @@
 
 #define CAND_CHUNK_WORDS 1024                      // 32768 passages per chunk
 #define CAND_CHUNK_PIDS (CAND_CHUNK_WORDS * 32)
+#define CF_KCAP_LIMIT 3072     // = CF_KCAP, CF_QCAP, CF_DSLOTS below (static_assert there): what cand_plan_kernel plans against
+#define CF_QCAP_LIMIT 256
+#define CF_DSLOTS_LIMIT 256
 
 // ---- per-index chunk table: position of the first pid >= chunk*32768 inside every IVF list ----------------------
 __global__ void build_chunk_table_kernel(const int32_t* ivf_pids, const int64_t* ivf_offsets, int K, int nchunks,
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(1024) void qualifying_kernel(const uint32_t* idx_bi
         nqual[b] = n;
         hit_valid[b] = (base <= smax) && (base <= qmax) && (tot_q <= (unsigned long long)ratio * tot_c);
         if (key_count) key_count[b] = 0;
-        if (fast_state) { fast_state[FLMR_FAST_HDR + b] = 0; fast_state[FLMR_FAST_HDR + gridDim.x + b] = 0; }   // (see cand_fast_kernel)
+        if (fast_state) { fast_state[FLMR_FAST_HDR + b] = 1; fast_state[FLMR_FAST_HDR + gridDim.x + b] = 0; }   // (plan word: cand_plan_kernel; the fast forms' key counter)
         if (row_ovf) row_ovf[b] = (rows_out && base > qmax) ? 1 : 0;   // more surviving centroids than score rows: stage 1 is recomputed
     }
     if (!rows_out || n == 0) return;   // (block-uniform)
@@ -183,6 +186,78 @@ __global__ __launch_bounds__(256) void cand_mark_chunks_kernel(const int32_t* ce
     atomicAdd(&cnt_lds, cnt);
     __syncthreads();
     if (tid == 0) chunk_cnt[(size_t)b * nchunks + ch] = cnt_lds;
+}
+
+// ---- which form of the list scatter takes a query: decided from the query's own data, before any form runs ----------------------
+// The three forms (cand_fast_kernel's queue, cand_dense_small_kernel, cand_mark_score_kernel's slots) have hard per-chunk limits --
+// staged hit candidates, queued pairs of passages with several surviving centroids, slots -- and a form that runs into one hands
+// the whole query over after the work is done.  Which limits a query meets depends on how its surviving lists overlap inside the
+// candidates, which list LENGTHS do not say (1 k pairs per chunk are 15 collisions on the planted corpus and 1.2 k on an index built
+// from overlapping clusters); so the statistics are MEASURED on a sample: two of the query's 32768-passage chunks are marked exactly
+// as the forms mark them (candidate bitmap from the probed cells' slices, hit / several bitmaps from the surviving lists' slices)
+// and counted -- hit candidates H, pairs Q that belong to candidates with several surviving centroids.  The plan word
+// fast_state[b] = 0 queue form | FLMR_PLAN_SMALL small-dense form | 1 slot form is a function of the query and the index alone: no
+// searcher-lifetime counters, the first batch of a workload runs like the thousandth, and a batch may mix all forms.  (A form that
+// still overflows in a chunk the sample did not see hands over as before: results never depend on the plan.)
+// grid = nqueries, block = 256.
+#define FLMR_PLAN_SMALL 8
+__global__ __launch_bounds__(256) void cand_plan_kernel(flmr_cand_args a) {
+    __shared__ uint32_t cb[CAND_CHUNK_WORDS], hb[CAND_CHUNK_WORDS], sb[CAND_CHUNK_WORDS];
+    __shared__ int s_h, s_q;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nl = a.ncell[b], nq = a.nqual[b];
+    int32_t* const plan = a.fast_state + FLMR_FAST_HDR + b;
+    if (!a.hit_valid[b] || nl > 512 || nq > 512) {   // (block-uniform) not a list-scatter query / more lists than the fast forms index
+        if (tid == 0) *plan = 1;
+        return;
+    }
+    int hmax = 0, qmax = 0;
+    const int nsample = a.nchunks < 2 ? a.nchunks : 2;
+    for (int sidx = 0; sidx < nsample; sidx++) {
+        const int ch = (int)(((unsigned)b * 2654435761u >> 8) % (unsigned)a.nchunks + (unsigned)sidx * ((unsigned)a.nchunks / 2u)) % a.nchunks;
+        const int pid0 = ch * CAND_CHUNK_PIDS;
+        __syncthreads();
+        for (int w = tid; w < CAND_CHUNK_WORDS; w += 256) { cb[w] = 0u; hb[w] = 0u; sb[w] = 0u; }
+        if (tid == 0) { s_h = 0; s_q = 0; }
+        __syncthreads();
+        for (int l = wave; l < nl + nq; l += 4) {   // one list slice per wave at a time
+            const bool is_cell = l < nl;
+            const int c = is_cell ? a.cells[(size_t)b * a.max_cells + l] : a.qual[(size_t)b * a.qmax + (l - nl)];
+            const int64_t beg = a.ivf_offsets[c];
+            const uint32_t s0 = a.chunk_tab[(size_t)c * (a.nchunks + 1) + ch], e0 = a.chunk_tab[(size_t)c * (a.nchunks + 1) + ch + 1];
+            for (uint32_t x = s0 + lane; x < e0; x += 64) {
+                const int p = a.ivf_pids[beg + x] - pid0;
+                const uint32_t bit = 1u << (p & 31);
+                if (is_cell) atomicOr(&cb[p >> 5], bit);
+                else if (atomicOr(&hb[p >> 5], bit) & bit) atomicOr(&sb[p >> 5], bit);
+            }
+        }
+        __syncthreads();
+        int h = 0;
+        for (int w = tid; w < CAND_CHUNK_WORDS; w += 256) h += __popc(cb[w] & hb[w]);
+        int q = 0;
+        for (int l = wave; l < nq; l += 4) {   // the pairs the queue form would queue: (list, passage) with the passage a candidate with several lists
+            const int c = a.qual[(size_t)b * a.qmax + l];
+            const int64_t beg = a.ivf_offsets[c];
+            const uint32_t s0 = a.chunk_tab[(size_t)c * (a.nchunks + 1) + ch], e0 = a.chunk_tab[(size_t)c * (a.nchunks + 1) + ch + 1];
+            for (uint32_t x = s0 + lane; x < e0; x += 64) {
+                const int p = a.ivf_pids[beg + x] - pid0;
+                q += (int)((cb[p >> 5] & sb[p >> 5]) >> (p & 31)) & 1;
+            }
+        }
+        atomicAdd(&s_h, h);
+        atomicAdd(&s_q, q);
+        __syncthreads();
+        hmax = hmax > s_h ? hmax : s_h;
+        qmax = qmax > s_q ? qmax : s_q;
+    }
+    if (tid == 0) {
+        // margins under the forms' limits (CF_KCAP staged keys, CF_QCAP queued pairs, CF_DSLOTS slots): the chunks not sampled vary
+        int p = 1;
+        if (hmax <= (CF_KCAP_LIMIT * 7) / 10 && qmax <= (CF_QCAP_LIMIT * 5) / 8) p = 0;
+        else if (hmax <= (CF_DSLOTS_LIMIT * 7) / 10) p = FLMR_PLAN_SMALL;
+        *plan = p;
+    }
 }
 
 // ---- kernel A': mark + STAGE 1 BY SCATTER ---------------------------------------------------------------------------------
@@ -302,14 +377,6 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
         const int r = a.fast_state[FLMR_FAST_HDR + b];
         if (blockIdx.y == 0 && tid == 0) {
             if (r == 0 || r == 3) a.key_count[b] = a.fast_state[FLMR_FAST_HDR + a.nqueries + b];
-            if (b == 0) atomicAdd(a.fast_state + 2, 1);   // batches so far (the queue form probes a dense searcher in one batch of 16)
-            if (r == 4) { if (a.fast_state[3] < 1024) atomicAdd(a.fast_state + 3, 4); }   // the small-dense form's give-ups against its successes
-            else if (r == 3 && a.fast_state[3] > 0) atomicSub(a.fast_state + 3, 1);
-            if (r == 0 || r == 2) {   // tried by the queue form: the two cumulative counters that decide whether later batches try (halved now and then)
-                if (r == 2) atomicAdd(a.fast_state + 0, 1);
-                const int tried = atomicAdd(a.fast_state + 1, 1);
-                if (tried >= 16384) { atomicSub(a.fast_state + 1, tried / 2); atomicSub(a.fast_state + 0, a.fast_state[0] / 2); }
-            }
         }
         if (r == 0 || r == 3) return;   // done by the queue form / by the small-dense form
     }
@@ -701,6 +768,7 @@ __global__ __launch_bounds__(64 * S1S_WAVES) void cand_mark_score_kernel(flmr_ca
 #define CF_KCAP 3072      // keys of a chunk staged in LDS (as list << 15 | passage inside the chunk: 4 bytes each)
 #define CF_QCAP 256       // queued pairs per chunk
 #define CF_MAXLISTS (64 * CF_WAVES)
+static_assert(CF_KCAP == CF_KCAP_LIMIT && CF_QCAP == CF_QCAP_LIMIT && CF_MAXLISTS == 512, "cand_plan_kernel plans against these limits");
 #define CF_RC 64          // surviving lists whose score rows are kept in LDS for the queued pairs (the others are read from memory)
 
 struct cf_chunk_state { int qn, ks, km, nh, base, pad0, pad1, pad2; };
@@ -750,15 +818,9 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
     int32_t* const kcount = a.fast_state + FLMR_FAST_HDR + a.nqueries + b;
     const int nl = a.ncell[b], nq = a.nqual[b];
     {
-        const int lost = a.fast_state[0], tried = a.fast_state[1], batches = a.fast_state[2];
-        const bool mostly_lost = tried >= 64 && 2 * lost > tried;
-        // (a searcher whose queries mostly overflow the queue is probed with one query in 64 of one batch in 16: a query that goes
-        // through the slot kernel costs the whole launch that kernel's ~150 us, however few of them there are)
-        const bool ok = a.hit_valid[b] != 0 && nl <= CF_MAXLISTS && nq <= CF_MAXLISTS && (!mostly_lost || ((b & 63) == 0 && (batches & 15) == 0));
-        if (!ok) {   // (block-uniform) left to the slot kernel without trying
-            if (blockIdx.y == 0 && tid == 0) *redo = 1;
-            return;
-        }
+        // (the plan word, cand_plan_kernel: 0 = this form; anything else is another form's query)
+        const bool ok = *redo == 0 && a.hit_valid[b] != 0 && nl <= CF_MAXLISTS && nq <= CF_MAXLISTS;
+        if (!ok) return;   // (block-uniform; the word is 0 or 2 -- given up by another workgroup of this launch: its chunks are redone anyway)
     }
     const int ch0 = blockIdx.y * cpb;
     const int ch_end = ch0 + cpb < a.nchunks ? ch0 + cpb : a.nchunks;
@@ -1150,6 +1212,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_fast_kernel(flmr_cand_args
 // say its queries mostly overflow the queue (fast_state: 1 -> 3 "done here" / 4 "given up": more than CF_DSLOTS hit candidates
 // in a chunk); the slot kernel, launched last, takes what is left.
 #define CF_DSLOTS 256
+static_assert(CF_DSLOTS == CF_DSLOTS_LIMIT, "cand_plan_kernel plans against this limit");
 #define CF_DRC 128         // surviving lists whose score rows are kept in LDS
 #define CF_DFQ 16          // surviving lists per wave kept in registers from the marking to the pair pass
 
@@ -1169,15 +1232,10 @@ __global__ __launch_bounds__(CF_THREADS, 2) void cand_dense_small_kernel(flmr_ca
     int32_t* const kcount = a.fast_state + FLMR_FAST_HDR + a.nqueries + b;
     const int nl = a.ncell[b], nq = a.nqual[b];
     {
-        const int lost = a.fast_state[0], tried = a.fast_state[1], batches = a.fast_state[2], given_up = a.fast_state[3];
-        const bool mostly_lost = tried >= 64 && 2 * lost > tried;
-        const int r = *redo;   // 1: the queue form left the query untried; 3 / 4: another workgroup of this launch was here first
-        // (fast_state[3]: + 4 for a query this form gave up, - 1 for one it finished, kept by the slot kernel: a searcher whose chunks
-        // mostly hold more hit candidates than this form has slots stops paying for the attempts, and is probed in one batch of 64)
-        const bool worth = given_up < 256 || (batches & 63) == 0;
-        const bool ok = mostly_lost && worth && (r == 1 || r == 3) && a.hit_valid[b] != 0 && nl <= CF_MAXLISTS && nq <= CF_MAXLISTS;
+        const int r = *redo;   // FLMR_PLAN_SMALL: planned for this form (cand_plan_kernel); 3: another workgroup of this launch was here first
+        const bool ok = (r == FLMR_PLAN_SMALL || r == 3) && a.hit_valid[b] != 0 && nl <= CF_MAXLISTS && nq <= CF_MAXLISTS;
         if (!ok) return;   // (block-uniform)
-        if (blockIdx.y == 0 && tid == 0) atomicMax(redo, 3);
+        if (tid == 0) atomicCAS(redo, FLMR_PLAN_SMALL, 3);
     }
     const int ch0 = blockIdx.y * cpb;
     const int ch_end = ch0 + cpb < a.nchunks ? ch0 + cpb : a.nchunks;
@@ -1537,7 +1595,8 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
         // chunk table, list constants -- costs about a third of a chunk; 8 vs 4 measured -3 % at 256 queries x 31 chunks)
         int cpb = 8;
         while (cpb > 1 && (int64_t)a.nqueries * ((a.nchunks + cpb - 1) / cpb) < 512) cpb >>= 1;
-        if (a.fast_state) {   // the queue form first; what it hands over (fast_state) is done by the slot kernel below
+        if (a.fast_state) {   // the plan per query (measured on a sample of its chunks), then the queue form; what it hands over is done by the slot kernel below
+            hipLaunchKernelGGL(cand_plan_kernel, dim3(a.nqueries), dim3(256), 0, st, a);
             const size_t flds = (size_t)9 * CAND_CHUNK_WORDS * sizeof(uint32_t) + (size_t)2 * CF_KCAP * sizeof(uint32_t) + (size_t)CF_MAXLISTS * sizeof(uint32_t) +
                                 (size_t)3 * CF_QCAP * sizeof(uint32_t) + (size_t)CF_RC * 32 * sizeof(int);
             const void* ffn = a.f16_round ? reinterpret_cast<const void*>(cand_fast_kernel<true>) : reinterpret_cast<const void*>(cand_fast_kernel<false>);
@@ -1548,7 +1607,7 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
                 hipLaunchKernelGGL(cand_fast_kernel<true>, dim3(a.nqueries, (a.nchunks + fcpb - 1) / fcpb), dim3(CF_THREADS), flds, st, a, fcpb);
             else
                 hipLaunchKernelGGL(cand_fast_kernel<false>, dim3(a.nqueries, (a.nchunks + fcpb - 1) / fcpb), dim3(CF_THREADS), flds, st, a, fcpb);
-            {   // the small-dense form: returns at once unless the searcher's counters say its queries mostly overflow the queue
+            {   // the small-dense form: the queries planned for it
                 const size_t dlds = (size_t)4 * CAND_CHUNK_WORDS * sizeof(uint32_t) + ((size_t)CF_DSLOTS * S1S_STRIDE + 64) * sizeof(int) +
                                     (size_t)CF_DRC * 32 * sizeof(int) + ((size_t)CAND_CHUNK_WORDS + CF_DSLOTS) * sizeof(uint16_t);
                 const void* dfn = a.f16_round ? reinterpret_cast<const void*>(cand_dense_small_kernel<true>) : reinterpret_cast<const void*>(cand_dense_small_kernel<false>);

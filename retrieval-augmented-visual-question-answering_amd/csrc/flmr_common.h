@@ -211,7 +211,7 @@ int flmr_launch_filter_stage1(const flmr_filter_args& f, const uint32_t* idx_bit
                               const uint32_t* hit_bits, int64_t hit_words, const int32_t* hit_valid,
                               const uint8_t* hit_flags, hipStream_t st, const int32_t* skip = nullptr);
 // chunked candidate generation (flmr_candidates.hip): bitmaps in LDS per (query, 32768-passage chunk)
-#define FLMR_FAST_HDR 4
+#define FLMR_FAST_HDR 0
 struct flmr_cand_args {
     int32_t nqueries, idx_words, max_cells, qmax, nchunks;
     int64_t words, cand_cap;
@@ -232,11 +232,11 @@ struct flmr_cand_args {
     int32_t* chunk_hits;                  // [nqueries, nchunks] candidates of the chunk that are in the hit set (scatter mode)
     int32_t n_select;                     // how many keys the selection after stage 1 keeps (ndocs)
     int32_t f16_round;                    // see flmr_filter_args
-    // the queue and small-dense forms of the scatter kernel and their hand-over to the slot form: FLMR_FAST_HDR words that live as
-    // long as the searcher ([0] queries the queue form gave up, [1] queries it tried, [2] batches so far, [3] the small-dense form's
-    // give-ups against its successes), then per query of the
-    // batch [HDR + b] which form did / must do the query (FLMR_TAP_STAGE1_FORM) and [HDR + B + b] the fast forms' own key counter.
-    // NULL: slot kernel only (FLMR_S1_IMPL=slots)
+    // the queue and small-dense forms of the scatter kernel and their hand-over to the slot form: per query of the batch [b] the plan
+    // word written by cand_plan_kernel from statistics measured on a sample of the query's chunks (0 queue form, FLMR_PLAN_SMALL
+    // small-dense form, 1 slot form), overwritten by the forms with what happened (FLMR_TAP_STAGE1_FORM: 2 / 4 = handed over to the slot
+    // form after the queue / small-dense form ran into a limit, 3 = done by the small-dense form), and [B + b] the fast forms' own key
+    // counter.  Nothing in it outlives the batch.  NULL: slot kernel only (FLMR_S1_IMPL=slots)
     int32_t* fast_state;
     int32_t* row_ovf;   // [nqueries] out: 1 = the query has more surviving centroids than compact score rows (qmax): its stage 1 is
                         // recomputed from the fp16 centroids (flmr_launch_filter_stage1_recompute); NULL on the full-table path

@@ -409,40 +409,46 @@ def test_stage1_queue_form_equals_slot_form_and_code_scan(hip, policy, numerics)
     scorer.close_searcher()
 
 
-def test_stage1_small_dense_form_on_a_built_index(hip):
-    """An index BUILT from overlapping clusters: every hit passage holds several surviving centroids, the queue form of the list
-    scatter gives its queries up, and after the searcher's counters have seen that for 64 queries the small-dense form
-    (cand_dense_small_kernel) takes them.  Its survivors, their stage-2 order and the final ranking must be IDENTICAL to the slot
-    form's; the tap says which form produced each query's keys."""
+def test_stage1_forms_are_planned_per_query_on_a_built_index(hip):
+    """An index BUILT from overlapping clusters: every hit passage of a full query holds several surviving centroids -- the queue
+    form of the list scatter would overflow at once -- so cand_plan_kernel, which MEASURES hit candidates and queued pairs on a sample
+    of the query's chunks, plans the small-dense form (3) for them from the FIRST batch on (no searcher history: the plan is a
+    function of the query and the index), while the short queries of the same batch (few surviving lists, few pairs) go to the
+    queue form (0) or, where their surviving lists are far longer than their probed cells', to the dense image form (5).  One batch,
+    at least three forms, and survivors / finalists / results IDENTICAL to the slot form's and the code scan's."""
     torch, nat = hip["torch"], hip["native"]
     from ravqa_amd import indexing, synth
     from ravqa_amd.scorer import IndexScorer
     embs, doclens, planted = synth.make_overlapping_embeddings(300_000, 64, 2048, seed=5, device="cuda", sub_directions=8192)
     arrays = indexing.build_index(embs, doclens, nbits=2, kmeans_niters=4)
     ncells, thr, ndocs = 2, 0.45, 1024
-    Qs = [planted(64)[0] for _ in range(4)]
+    Q = planted(64)[0]
+    Q2 = planted(64)[0]
+    for j in range(48, 64):      # queries whose tokens come from 8 DIFFERENT planted queries: more topics, many more hit candidates per chunk
+        for t in range(32):
+            Q[j, t] = Q2[(j + 5 * (t // 4)) % 64, t]
+    q_lens = torch.full((64,), 32, dtype=torch.int32)
+    q_lens[32:48] = 1
     scorer = IndexScorer(arrays=arrays, max_batch=64)
-    for Q in Qs[:3]:   # the counters: queries tried by the queue form / given up by it
-        scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32)
-        scorer.check()
-        print("\nFORMS", [[int(scorer.tap(nat.TAP_STAGE1_FORM, i)[0]) for i in range(64)].count(v) for v in range(5)])
-    p, s, c = scorer.search_batch(Qs[3], ndocs // 4, ncells, thr, ndocs, 32)
-    scorer.check()
-    forms = [int(scorer.tap(nat.TAP_STAGE1_FORM, i)[0]) for i in range(64)]
+    outs, forms = {}, None
+    for tag, env in (("planned", {}), ("slots", {"FLMR_S1_IMPL": "slots"}), ("scan", {"FLMR_S1_IMPL": "scan"})):
+        with nat.options(**env):
+            p, s, c = scorer.search_batch(Q, ndocs // 4, ncells, thr, ndocs, 32, q_lens=q_lens)   # (the first batch of a fresh searcher)
+            scorer.check()
+            if tag == "planned":
+                forms = [int(scorer.tap(nat.TAP_STAGE1_FORM, i)[0]) for i in range(64)]
+            outs[tag] = ([np.sort(scorer.tap(nat.TAP_STAGE1, i)) for i in range(64)], [scorer.tap(nat.TAP_STAGE2, i) for i in range(64)],
+                         p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy())
     nsurv = [int(np.unpackbits(scorer.tap(nat.TAP_IDX_BITS, i).view(np.uint8)).sum()) for i in range(0, 64, 8)]
-    print("FORMS", [forms.count(v) for v in range(5)], "surviving centroids", nsurv)
-    got = ([np.sort(scorer.tap(nat.TAP_STAGE1, i)) for i in range(64)], [scorer.tap(nat.TAP_STAGE2, i) for i in range(64)],
-           p.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy())
-    assert forms.count(3) >= 40, forms
-    with nat.options(FLMR_S1_IMPL="slots"):
-        p2, s2, c2 = scorer.search_batch(Qs[3], ndocs // 4, ncells, thr, ndocs, 32)
-        scorer.check()
-        ref = ([np.sort(scorer.tap(nat.TAP_STAGE1, i)) for i in range(64)], [scorer.tap(nat.TAP_STAGE2, i) for i in range(64)],
-               p2.cpu().numpy(), s2.cpu().numpy(), c2.cpu().numpy())
-    for i in range(64):
-        assert np.array_equal(got[0][i], ref[0][i]) and np.array_equal(got[1][i], ref[1][i]), (i, forms[i])
-    for x, y in zip(got[2:], ref[2:]):
-        assert np.array_equal(x, y)
+    print("\nFORMS full", {v: forms[:32].count(v) for v in sorted(set(forms[:32]))}, "one token", {v: forms[32:48].count(v) for v in sorted(set(forms[32:48]))},
+          "8 topics", {v: forms[48:].count(v) for v in sorted(set(forms[48:]))}, "surviving centroids", nsurv)
+    assert forms[:32].count(3) >= 24, forms          # planned for the small-dense form, and finished by it
+    assert len(set(forms)) >= 3, forms               # one batch, three forms
+    for tag in ("slots", "scan"):
+        for i in range(64):
+            assert np.array_equal(outs["planned"][0][i], outs[tag][0][i]) and np.array_equal(outs["planned"][1][i], outs[tag][1][i]), (tag, i, forms[i])
+        for x, y in zip(outs["planned"][2:], outs[tag][2:]):
+            assert np.array_equal(x, y), tag
     scorer.close_searcher()
 
 
