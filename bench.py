@@ -324,6 +324,63 @@ def main():
             fast_line = {"failed": repr(e)}
         exact = True
 
+    # ---- N > 1: the REPLICA mode beside the two sharded ones -- every rank holds the WHOLE index and searches 1/N of the step's
+    # queries, no collective at all: what the reference's own structure implies (one Searcher per Lightning rank, each with the
+    # whole index: src/executors/FLMR_executor.py:774-798) and the throughput bound the sharded modes are to be read against
+    # whenever the index fits one HBM (a 1 M-passage index is 7 GB, the 6 M one 37 GB of 288 GB); sharding is for indexes
+    # larger than one HBM and for latency -------------------------------------------------------------
+    replica_line = None
+    if use_dist and world > 1:
+        try:
+            def build_whole():
+                return synth.make_corpus(args.passages, doclen, K, args.nbits, seed=0, device="cuda")
+            whole = None
+            if args.single_device_smoke:   # (one device for every rank: take turns building)
+                for r in range(world):
+                    if r == rank:
+                        whole = build_whole()
+                        torch.cuda.synchronize()
+                    dist.barrier()
+            else:
+                whole = build_whole()
+            per = -(-args.batch // world)
+            q_lo, q_hi = min(args.batch, rank * per), min(args.batch, (rank + 1) * per)
+            sc_rep = IndexScorer(device_index=synth.corpus_device_index(whole), max_batch=max(1, min(per, args.sub_batch)), streams=args.streams)
+            my_hits = []
+
+            def rep_step(j):
+                if q_hi > q_lo:
+                    return sc_rep.search_batch(Qs[j][q_lo:q_hi], k, ncells, thr, ndocs, 32)
+                return None
+            for i in range(2):
+                rep_step(i % nb)
+            barrier()
+            t0_ = time.perf_counter()
+            res_ = None
+            for i in range(args.steps):
+                res_ = rep_step(i % nb)
+            barrier()
+            dt_r = time.perf_counter() - t0_
+            tr_ = torch.tensor([dt_r], device="cpu" if args.single_device_smoke else "cuda", dtype=torch.float64)
+            dist.all_reduce(tr_, op=dist.ReduceOp.MAX)
+            dt_r = float(tr_.item())
+            sc_rep.check()
+            hit_ = torch.zeros(2, dtype=torch.float64, device="cpu" if args.single_device_smoke else "cuda")
+            if res_ is not None:
+                jl = (args.steps - 1) % nb
+                hit_[0] = float((res_[0][:, :5] == tgts[jl][q_lo:q_hi].unsqueeze(1).to(torch.int32)).any(dim=1).float().sum())
+                hit_[1] = q_hi - q_lo
+            dist.all_reduce(hit_)
+            replica_line = {"queries_per_sec": args.batch * args.steps / dt_r, "ms_per_step": dt_r / args.steps * 1e3,
+                            "recall_at_5": float(hit_[0] / max(1.0, float(hit_[1]))), "queries_per_rank": per,
+                            "note": "every rank holds the whole index and searches its 1/N of the step's queries: no collective in the step (the "
+                                    "barrier + MAX over ranks of the contract only); results are those of the unsharded index by construction"}
+            sc_rep.close_searcher()
+            del sc_rep, whole
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            replica_line = {"failed": repr(e)}
+
     out = None
     if rank == 0:
         # ---- workload statistics of the last batch (outside the timed region) ----------------------------------------
@@ -459,6 +516,8 @@ def main():
             out["shard_pipeline"] = shard_calibration
         if fast_line is not None:
             out["shard_mode_fast"] = fast_line
+        if replica_line is not None:
+            out["shard_mode_replica"] = replica_line
         if exchange_ms is not None:
             out["exchange_ms"] = exchange_ms
             out["exchange_ms_note"] = ("duration of each collective of one step between two events on the launch stream (separate "
