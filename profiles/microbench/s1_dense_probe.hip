@@ -94,12 +94,14 @@ int main() {
     const int img_rows = flmr_s1_dense_image_rows(NQ, idx_words, LPC);
     printf("P %d, survivors %d, candidates/query %d, distinct codes/passage %.1f, hit share %.2f, LPC %d, image rows that fit %d\n", P, NS, NC, mean_ul, HIT, LPC, img_rows);
 
+    const bool old_exact = envd("S1D_OLD_EXACT", 0) != 0;
+    auto launch = [&](bool img) { return (img || old_exact) ? flmr_launch_s1_dense(a, img, LPC, 0) : flmr_launch_s1_exact(a, mean_ul, 0); };
     auto time_it = [&](bool img, const char* what) {
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        if (flmr_launch_s1_dense(a, img, LPC, 0)) { printf("launch failed: %s\n", flmr_err_buf); exit(1); }
+        if (launch(img)) { printf("launch failed: %s\n", flmr_err_buf); exit(1); }
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
-        for (int r = 0; r < REPS; r++) if (flmr_launch_s1_dense(a, img, LPC, 0)) { printf("launch failed: %s\n", flmr_err_buf); exit(1); }
+        for (int r = 0; r < REPS; r++) if (launch(img)) { printf("launch failed: %s\n", flmr_err_buf); exit(1); }
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("%-46s %8.3f ms per %d queries  (%.3f ms per 1024)\n", what, ms / REPS, NQ, ms / REPS * 1024.0 / NQ);
@@ -175,6 +177,9 @@ int main() {
         time_it(false, what);
         a.parts = 1; a.group = 16;
         snprintf(what, sizeof(what), "  the same, one item per query, groups of 16");
+        time_it(false, what);
+        a.parts = 8; a.group = 0;
+        snprintf(what, sizeof(what), "  the same, 8 items per query, groups of 16 for bands (the library's launch)");
         time_it(false, what);
     }
     return (bad_e || bad_u || bad_bound) ? 1 : 0;

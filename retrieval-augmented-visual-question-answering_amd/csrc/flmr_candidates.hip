@@ -188,6 +188,15 @@ __global__ __launch_bounds__(256) void cand_mark_chunks_kernel(const int32_t* ce
     if (tid == 0) chunk_cnt[(size_t)b * nchunks + ch] = cnt_lds;
 }
 
+__device__ __forceinline__ int cf_wave_sum_early(int x) {   // (= cf_wave_sum below: row sums by DPP, the four rows on the scalar unit)
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false);
+    return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
+}
+__device__ __forceinline__ int64_t s1s_bcast64(int64_t v, int j);
+
 // ---- which form of the list scatter takes a query: decided from the query's own data, before any form runs ----------------------
 // The three forms (cand_fast_kernel's queue, cand_dense_small_kernel, cand_mark_score_kernel's slots) have hard per-chunk limits --
 // staged hit candidates, queued pairs of passages with several surviving centroids, slots -- and a form that runs into one hands
@@ -199,54 +208,89 @@ __global__ __launch_bounds__(256) void cand_mark_chunks_kernel(const int32_t* ce
 // fast_state[b] = 0 queue form | FLMR_PLAN_SMALL small-dense form | 1 slot form is a function of the query and the index alone: no
 // searcher-lifetime counters, the first batch of a workload runs like the thousandth, and a batch may mix all forms.  (A form that
 // still overflows in a chunk the sample did not see hands over as before: results never depend on the plan.)
-// grid = nqueries, block = 256.
+// grid = nqueries, block = 1024: a wave takes the lists wave, wave + 16, ...; their (offset, chunk-table) entries are fetched one list
+// per lane, and the slices' entries eight lists at a time into registers, where they stay from the marking to the count (a list a
+// wave takes beyond its first eight is re-read): the kernel is a handful of dependent memory round trips per query, ~15 us a launch.
 #define FLMR_PLAN_SMALL 8
-__global__ __launch_bounds__(256) void cand_plan_kernel(flmr_cand_args a) {
+#define PLAN_WAVES 16
+#define PLAN_REGS 8
+__global__ __launch_bounds__(64 * PLAN_WAVES) void cand_plan_kernel(flmr_cand_args a) {
     __shared__ uint32_t cb[CAND_CHUNK_WORDS], hb[CAND_CHUNK_WORDS], sb[CAND_CHUNK_WORDS];
     __shared__ int s_h, s_q;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nl = a.ncell[b], nq = a.nqual[b];
     int32_t* const plan = a.fast_state + FLMR_FAST_HDR + b;
     if (!a.hit_valid[b] || nl > 512 || nq > 512) {   // (block-uniform) not a list-scatter query / more lists than the fast forms index
         if (tid == 0) *plan = 1;
         return;
     }
+    const int ntot = nl + nq;
+    const int mine = wave < ntot ? (ntot - wave + PLAN_WAVES - 1) / PLAN_WAVES : 0;   // lists of this wave (<= 64)
+    // lane j: list wave + 16 j of the query (cells first, then the surviving lists)
+    int64_t beg = 0;
+    int is_cell = 0;
+    size_t trow = 0;
+    if (lane < mine) {
+        const int l = wave + PLAN_WAVES * lane;
+        is_cell = l < nl;
+        const int c = is_cell ? a.cells[(size_t)b * a.max_cells + l] : a.qual[(size_t)b * a.qmax + (l - nl)];
+        beg = a.ivf_offsets[c];
+        trow = (size_t)c * (a.nchunks + 1);
+    }
+    const unsigned long long cellmask = __ballot(is_cell != 0);
     int hmax = 0, qmax = 0;
     const int nsample = a.nchunks < 2 ? a.nchunks : 2;
     for (int sidx = 0; sidx < nsample; sidx++) {
         const int ch = (int)(((unsigned)b * 2654435761u >> 8) % (unsigned)a.nchunks + (unsigned)sidx * ((unsigned)a.nchunks / 2u)) % a.nchunks;
         const int pid0 = ch * CAND_CHUNK_PIDS;
+        uint32_t s0 = 0, e0 = 0;
+        if (lane < mine) { s0 = a.chunk_tab[trow + ch]; e0 = a.chunk_tab[trow + ch + 1]; }
         __syncthreads();
-        for (int w = tid; w < CAND_CHUNK_WORDS; w += 256) { cb[w] = 0u; hb[w] = 0u; sb[w] = 0u; }
+        for (int w = tid; w < CAND_CHUNK_WORDS; w += 64 * PLAN_WAVES) { cb[w] = 0u; hb[w] = 0u; sb[w] = 0u; }
         if (tid == 0) { s_h = 0; s_q = 0; }
         __syncthreads();
-        for (int l = wave; l < nl + nq; l += 4) {   // one list slice per wave at a time
-            const bool is_cell = l < nl;
-            const int c = is_cell ? a.cells[(size_t)b * a.max_cells + l] : a.qual[(size_t)b * a.qmax + (l - nl)];
-            const int64_t beg = a.ivf_offsets[c];
-            const uint32_t s0 = a.chunk_tab[(size_t)c * (a.nchunks + 1) + ch], e0 = a.chunk_tab[(size_t)c * (a.nchunks + 1) + ch + 1];
-            for (uint32_t x = s0 + lane; x < e0; x += 64) {
-                const int p = a.ivf_pids[beg + x] - pid0;
-                const uint32_t bit = 1u << (p & 31);
-                if (is_cell) atomicOr(&cb[p >> 5], bit);
-                else if (atomicOr(&hb[p >> 5], bit) & bit) atomicOr(&sb[p >> 5], bit);
+        // the first 64 entries of the slices of the wave's first PLAN_REGS lists (-1: no entry)
+        int r[PLAN_REGS];
+#pragma unroll
+        for (int u = 0; u < PLAN_REGS; u++) {
+            r[u] = -1;
+            if (u < mine) {   // (wave-uniform)
+                const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)s0, u), ev = (uint32_t)__builtin_amdgcn_readlane((int)e0, u);
+                if (sv + lane < ev) r[u] = a.ivf_pids[s1s_bcast64(beg, u) + sv + lane] - pid0;
             }
         }
+        auto mark = [&](int p, bool cell) {
+            const uint32_t bit = 1u << (p & 31);
+            if (cell) atomicOr(&cb[p >> 5], bit);
+            else if (atomicOr(&hb[p >> 5], bit) & bit) atomicOr(&sb[p >> 5], bit);
+        };
+        auto rest = [&](int u, bool count, int& q) {   // entries of list u not held in registers: beyond the first 64, or lists beyond PLAN_REGS
+            const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)s0, u), ev = (uint32_t)__builtin_amdgcn_readlane((int)e0, u);
+            const bool cell = (cellmask >> u) & 1ull;
+            const int64_t bg = s1s_bcast64(beg, u);
+            for (uint32_t x = sv + (u < PLAN_REGS ? 64u : 0u) + lane; x < ev; x += 64) {
+                const int p = a.ivf_pids[bg + x] - pid0;
+                if (!count) mark(p, cell);
+                else if (!cell) q += (int)((cb[p >> 5] & sb[p >> 5]) >> (p & 31)) & 1;
+            }
+        };
+        int q = 0;
+#pragma unroll
+        for (int u = 0; u < PLAN_REGS; u++)
+            if (r[u] >= 0) mark(r[u], (cellmask >> u) & 1ull);
+        for (int u = 0; u < mine; u++) rest(u, false, q);
         __syncthreads();
         int h = 0;
-        for (int w = tid; w < CAND_CHUNK_WORDS; w += 256) h += __popc(cb[w] & hb[w]);
-        int q = 0;
-        for (int l = wave; l < nq; l += 4) {   // the pairs the queue form would queue: (list, passage) with the passage a candidate with several lists
-            const int c = a.qual[(size_t)b * a.qmax + l];
-            const int64_t beg = a.ivf_offsets[c];
-            const uint32_t s0 = a.chunk_tab[(size_t)c * (a.nchunks + 1) + ch], e0 = a.chunk_tab[(size_t)c * (a.nchunks + 1) + ch + 1];
-            for (uint32_t x = s0 + lane; x < e0; x += 64) {
-                const int p = a.ivf_pids[beg + x] - pid0;
-                q += (int)((cb[p >> 5] & sb[p >> 5]) >> (p & 31)) & 1;
-            }
-        }
-        atomicAdd(&s_h, h);
-        atomicAdd(&s_q, q);
+        for (int w = tid; w < CAND_CHUNK_WORDS; w += 64 * PLAN_WAVES) h += __popc(cb[w] & hb[w]);
+        // the pairs the queue form would queue: (surviving list, passage) with the passage a candidate that holds several of them
+#pragma unroll
+        for (int u = 0; u < PLAN_REGS; u++)
+            if (r[u] >= 0 && !((cellmask >> u) & 1ull)) q += (int)((cb[r[u] >> 5] & sb[r[u] >> 5]) >> (r[u] & 31)) & 1;
+        for (int u = 0; u < mine; u++) rest(u, true, q);
+        h = cf_wave_sum_early(h);
+        q = cf_wave_sum_early(q);
+        if (lane == 0) { atomicAdd(&s_h, h); atomicAdd(&s_q, q); }
         __syncthreads();
         hmax = hmax > s_h ? hmax : s_h;
         qmax = qmax > s_q ? qmax : s_q;
@@ -1596,7 +1640,7 @@ int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
         int cpb = 8;
         while (cpb > 1 && (int64_t)a.nqueries * ((a.nchunks + cpb - 1) / cpb) < 512) cpb >>= 1;
         if (a.fast_state) {   // the plan per query (measured on a sample of its chunks), then the queue form; what it hands over is done by the slot kernel below
-            hipLaunchKernelGGL(cand_plan_kernel, dim3(a.nqueries), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(cand_plan_kernel, dim3(a.nqueries), dim3(64 * PLAN_WAVES), 0, st, a);
             const size_t flds = (size_t)9 * CAND_CHUNK_WORDS * sizeof(uint32_t) + (size_t)2 * CF_KCAP * sizeof(uint32_t) + (size_t)CF_MAXLISTS * sizeof(uint32_t) +
                                 (size_t)3 * CF_QCAP * sizeof(uint32_t) + (size_t)CF_RC * 32 * sizeof(int);
             const void* ffn = a.f16_round ? reinterpret_cast<const void*>(cand_fast_kernel<true>) : reinterpret_cast<const void*>(cand_fast_kernel<false>);

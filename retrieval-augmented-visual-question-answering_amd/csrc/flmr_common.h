@@ -363,17 +363,20 @@ struct flmr_s1d_args {
     int32_t group;               // candidates per wave and group: 64, or 16 for short lists
     int64_t codes_len;           // tokens at `codes`; FLMR_CODE_PAD more ints must be readable behind them
     int32_t img_rows;            // rows of images the launch's LDS holds (IMG pass; set by the launcher)
+    const int32_t* any;          // nullable: [0] some query takes the IMG pass, [1] some query takes the EXACT pass (flmr_launch_s1_dense_modes)
 };
 #define FLMR_S1D_SKIP 0    // stage 1 of the query is done elsewhere (list-scatter forms, the round-5 scan)
 #define FLMR_S1D_IMAGE 1   // IMG pass over the candidates, band, EXACT pass over the band
 #define FLMR_S1D_EXACT 2   // EXACT pass over the candidates
 int flmr_s1_dense_image_rows(int nqueries, int idx_words, int lpc);   // score-row images the LDS form holds per query (0: K too large)
 int flmr_launch_s1_dense(const flmr_s1d_args& a, bool img_pass, int lpc, hipStream_t st);
+// the exact pass as its own kernel: 16 or 32 lanes per candidate x 4 or 8 codes per lane by the index's mean number of distinct codes
+int flmr_launch_s1_exact(const flmr_s1d_args& a, double mean_codes, hipStream_t st);
 // which queries the dense forms take: mode[q] = SKIP where skip[q] (done by a list-scatter form) or row_ovf[q] (no rows: the
 // recompute form), IMAGE where the query's rows fit
 // `img_rows` images, else EXACT (exact_too) or SKIP with scan[q] = 0 (the round-5 scan takes the query); scan[q] = 1 everywhere else
 int flmr_launch_s1_dense_modes(const int32_t* skip, const int32_t* nqual, const int32_t* row_ovf, int32_t nqueries, int32_t img_rows,
-                               int32_t exact_too, int32_t* mode, int32_t* scan_skip, hipStream_t st);
+                               int32_t exact_too, int32_t* mode, int32_t* scan_skip, int32_t* any, hipStream_t st);
 // the band of every IMAGE query from its U keys (keys >= the n-th largest - err[q]) -> band pids / counts; in_count[q] = the number
 // of keys the top-n selection after stage 1 reads for query q (band_count for IMAGE queries, counts[q] for the others)
 int flmr_launch_s1_band(const uint64_t* keys, int64_t key_stride, const int32_t* counts, const int32_t* mode, const float* err,

@@ -45,7 +45,7 @@ struct flmr_searcher {
     int32_t* qual; int32_t* nqual; int32_t* chunk_cnt; uint8_t* cand_hit; int32_t qmax;
     // stage 1 for dense survivor sets (flmr_stage1_dense.hip): per query which form, the band of an image query, its error bound,
     // how many keys the selection reads, and which queries are left to the round-5 scan
-    int32_t* s1d_mode; int32_t* s1d_band; int32_t* s1d_band_count; float* s1d_err; int32_t* s1d_in_count; int32_t* s1d_scan_skip;
+    int32_t* s1d_any; int32_t* s1d_mode; int32_t* s1d_band; int32_t* s1d_band_count; float* s1d_err; int32_t* s1d_in_count; int32_t* s1d_scan_skip;
     int32_t s1d_lpc, s1d_img_rows;   // lanes per candidate (16 / 32 by the index's distinct codes per passage); images the LDS holds (0: no dense form)
     int32_t* cand_fast;         // flmr_cand_args::fast_state ([FLMR_FAST_HDR + 2 * max_queries]; the header words live as long as the searcher)
     // last call (for taps)
@@ -173,7 +173,7 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     // dense stage 1: needs the sorted code copy (whole 16-byte pieces are read: its padding) and 32-bit token offsets
     s->s1d_lpc = ix->mean_ulen > 0.0 && ix->mean_ulen <= 72.0 ? 16 : 32;
     s->s1d_img_rows = (ix->codes_sorted && s->ncol_max == 32 && !s->opt.is(FLMR_OPT_S1_IMPL, "scan")) ? flmr_s1_dense_image_rows(max_queries, s->idx_words, s->s1d_lpc) : 0;
-    WS(s1d_mode, B); WS(s1d_band_count, B); WS(s1d_err, B); WS(s1d_in_count, B); WS(s1d_scan_skip, B); WS(row_ovf, B);
+    WS(s1d_any, 2); WS(s1d_mode, B); WS(s1d_band_count, B); WS(s1d_err, B); WS(s1d_in_count, B); WS(s1d_scan_skip, B); WS(row_ovf, B);
     if (s->s1d_img_rows > 0) WS(s1d_band, B * (size_t)s->cand_cap);
     WS(q3_hi, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
     WS(q3_lo, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
@@ -222,7 +222,7 @@ extern "C" int flmr_searcher_destroy(flmr_searcher_t* s) {
     if (!s) return FLMR_OK;
     void* ptrs[] = {s->cs, s->rows, s->idx_prefix, s->idx_bits, s->part_val, s->part_idx, s->cells, s->ncell, s->bitmap, s->cand, s->cand_count,
                     s->keys1, s->s1_pids, s->s1_count, s->keys2, s->s2_pids, s->s2_count, s->keys3, s->doc_scores,
-                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->q_err, s->q_err_sum, s->s2_band, s->s2_band_count, s->s2_need, s->s2_def, s->keys2b, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->chunk_hits, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part, s->s3_desc, s->s3_wbeg, s->s3_colmax, s->cand_fast, s->s1d_mode, s->s1d_band, s->s1d_band_count, s->s1d_err, s->s1d_in_count, s->s1d_scan_skip, s->row_ovf};
+                    s->overflow, s->q_lens_ws, s->q_hi, s->q_lo, s->q_err, s->q_err_sum, s->s2_band, s->s2_band_count, s->s2_need, s->s2_def, s->keys2b, s->hit_bits, s->hit_valid, s->q3_hi, s->q3_lo, s->qual, s->nqual, s->chunk_cnt, s->chunk_hits, s->cand_hit, s->key_count, s->s1_slot, s->s2_slot, s->s2_part, s->s3_desc, s->s3_wbeg, s->s3_colmax, s->cand_fast, s->s1d_mode, s->s1d_band, s->s1d_band_count, s->s1d_err, s->s1d_in_count, s->s1d_scan_skip, s->row_ovf, s->s1d_any};
     for (void* p : ptrs) (void)hipFree(p);
     if (s->status_host) (void)hipHostFree(s->status_host);
     if (s->status_ev) (void)hipEventDestroy(s->status_ev);
@@ -573,7 +573,7 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
     // who takes which query: the list-scatter forms (hit_valid), the dense forms, the recompute form (row_ovf), the scan (the rest)
     const bool exact_too = dense && !s->opt.is(FLMR_OPT_S1_IMPL, "image");   // (development: "image" leaves the queries beyond the images to the scan)
     RUN(flmr_launch_s1_dense_modes(scatter ? s->hit_valid : nullptr, s->nqual, s->row_ovf, c.nqueries, dense ? s->s1d_img_rows : 0,
-                                   exact_too ? 1 : 0, s->s1d_mode, s->s1d_scan_skip, st));
+                                   exact_too ? 1 : 0, s->s1d_mode, s->s1d_scan_skip, s->s1d_any, st));
     const int32_t* scan_skip = s->s1d_scan_skip;
     if (dense) {
         flmr_s1d_args d{};
@@ -581,14 +581,13 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
         d.idx_bits = s->idx_bits; d.idx_prefix = s->idx_prefix; d.idx_words = s->idx_words;
         d.rows = s->rows; d.row_cap = s->row_cap; d.nqual = s->nqual; d.q_lens = c.q_lens; d.nq_cand = c.nqc; d.nqueries = c.nqueries;
         d.cand = s->cand; d.cand_stride = s->cand_cap; d.cand_count = s->cand_count;
-        d.band = s->s1d_band; d.band_count = s->s1d_band_count; d.mode = s->s1d_mode; d.keys = s->keys1; d.img_err = s->s1d_err;
+        d.band = s->s1d_band; d.band_count = s->s1d_band_count; d.mode = s->s1d_mode; d.keys = s->keys1; d.img_err = s->s1d_err; d.any = s->s1d_any;
         d.parts = 0; d.group = 64;
         RUN(flmr_launch_s1_dense(d, true, s->s1d_lpc, st));
         RUN(flmr_launch_s1_band(s->keys1, s->cand_cap, s->cand_count, s->s1d_mode, s->s1d_err, c.nqueries, c.p.ndocs, s->s1d_band,
                                 s->s1d_band_count, s->s1d_in_count, st));
-        // the bands are short (ndocs + a few per cent): one item per query, groups of 16 so that every wave has some
-        d.parts = 1; d.group = 16;
-        RUN(flmr_launch_s1_dense(d, false, s->s1d_lpc, st));
+        d.parts = 8; d.group = 0;   // (groups of 16 candidates for a band, 32 for a whole list: the kernel's choice per query)
+        RUN(flmr_launch_s1_exact(d, ix->mean_ulen, st));
         sel_counts = s->s1d_in_count;
     }
     if (c.sparse)   // (a query over the score-row capacity; leaves at once when there is none)

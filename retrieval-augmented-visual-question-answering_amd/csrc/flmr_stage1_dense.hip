@@ -111,6 +111,7 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
     uint16_t* my_list = lists + (size_t)wave * (R * LISTCAP + 64);   // (+ one scratch entry per lane)
     char* img = reinterpret_cast<char*>(lists + (size_t)D1_WAVES * (R * LISTCAP + 64));
 
+    if (a.any && a.any[IMG ? 0 : 1] == 0) return;   // (uniform: no query of the batch takes this pass)
     // ---- the queries of this launch ----
     if (tid == 0) s_nscan = 0;
     __syncthreads();
@@ -261,7 +262,8 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
                 for (int e = 0; e < 4; e++) acc[e] = 0xFC00FC00u;
                 facc.x = facc.y = facc.z = facc.w = -9999.0f;   // filter_pids.cpp:30-33
                 int nh_total = 0;
-                asm volatile("s_waitcnt vmcnt(1)" : "+v"(cd) : : "memory");
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // (no operand: see s1_exact_kernel)
+                asm volatile("" : "+v"(cd) : : "memory");
                 d1i4u cur = cd;
                 const int hg = l / LPR, pr = l % LPR;
                 for (int t0 = 0;; t0 += LISTCAP) {
@@ -448,11 +450,324 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
                 if (r + 1 < nrounds) round(cdB, lenB, r + 1);
             }
             // (the requests past the group's end must have landed before their registers mean anything else to the compiler)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cdA), "+v"(cdB) : : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(cdA), "+v"(cdB) : : "memory");
             if (lane < ndoc) keys_b[g * gsz + lane] = flmr_make_key(ukeep, pid);
             pid = npid; off = noff; len = nlen;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The EXACT form as its own kernel (round 6, second version).  The first one (s1_dense_kernel<false, .>) shares the image
+// form's skeleton, and on the regime it is for -- a planted corpus at centroid_score_threshold 0.25: 8.7 k surviving centroids
+// (no room for images), 60.6 k candidates of 128 distinct codes, 9 hits each -- it ran 17 ms per 1024 queries, VALU-bound: two
+// candidates per round (32 lanes x 4 codes), a row id computed for every code, a 48-instruction DPP chain per round for the
+// ascending-k sums, and the compiler's vmcnt(0) for every batch of row loads draining the codes requested ahead.  Here:
+//   * CPL codes per lane (4 or 8: one or two 16-byte requests): 16 lanes x 8 codes hold a 128-code passage, FOUR candidates a round;
+//   * hits are rare on this regime (7 % of the codes): a lane walks ITS hits (`while (hm)`), a row id is computed per hit;
+//   * every load of the round loop is UNCONDITIONAL (a load under a lane test makes the compiler's count of outstanding loads
+//     unknown and each of its waits a vmcnt(0)) and compiler-visible (asm requests into registers were tried: the compiler copies
+//     an asm statement's output registers where it likes -- also before the hand-written wait).  Loads return in order, so a
+//     request issued before the row loads would be waited for with them: the codes of round r + 2 are requested right AFTER the
+//     last block of row loads of round r, and the compiler's wait for that block is a vmcnt(CPL / 4) -- the codes stay in flight
+//     across the fold (checked in the generated code: profiles/r06/s1_exact_waits.txt);
+//   * the per-column maxima of a candidate (8 lanes x 4 columns) go to a per-wave LDS table, and at the end of a group lane j sums
+//     candidate j's 32 columns in ascending k (filter_pids.cpp:59-63): one 16-byte LDS store per round instead of the chain.
+// Same arithmetic, same keys, bit for bit (tests/test_hip_regressions.py::test_stage1_dense_forms_*).
+// ------------------------------------------------------------------------------------------------
+#define D1X_GROUP 32   // candidates per wave and group (the LDS table holds 32 x 36 floats per wave)
+#define D1X_TRS 36
+
+template <int LPC, int CPL>
+__global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
+    constexpr int R = 64 / LPC;            // candidates per round
+    constexpr int LISTCAP = LPC * CPL;     // codes (= most hits) of one candidate chunk
+    constexpr int NV = CPL / 4;            // 16-byte requests per lane and round
+    constexpr int LPR = 8;                 // lanes per fp32 row (16 bytes each)
+    constexpr int HPI = LPC / LPR;         // hits folded per iteration and candidate
+    constexpr int NIT = LISTCAP / HPI;     // list entries of one hit group
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int scan_lds[17];
+    __shared__ int s_nscan;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = lane / LPC, l = lane % LPC;
+    const int hg = l / LPR, pr = l % LPR;
+    // LDS: [scan list][bits u32][prefix u16][lists: per wave R * LISTCAP u16][tr: per wave D1X_GROUP x D1X_TRS f32]
+    int* scan_list = reinterpret_cast<int*>(smem);
+    uint32_t* lbits = reinterpret_cast<uint32_t*>(scan_list + ((a.nqueries + 3) & ~3));
+    uint16_t* lpre = reinterpret_cast<uint16_t*>(lbits + a.idx_words);
+    uint16_t* lists = lpre + ((a.idx_words + 7) & ~7);
+    uint16_t* my_list = lists + (size_t)wave * (R * LISTCAP);
+    float* tr = reinterpret_cast<float*>(lists + (size_t)D1_WAVES * (R * LISTCAP)) + (size_t)wave * D1X_GROUP * D1X_TRS;
+
+    if (a.any && a.any[1] == 0) return;   // (uniform: no query of the batch takes this pass)
+    if (tid == 0) s_nscan = 0;
+    __syncthreads();
+    {
+        int base = 0;
+        for (int q0 = 0; q0 < a.nqueries; q0 += D1_THREADS) {
+            const int q = q0 + tid;
+            const int need = (q < a.nqueries && a.mode[q] != FLMR_S1D_SKIP) ? 1 : 0;
+            int total;
+            const int pos = base + flmr_block_exclusive_scan(need, scan_lds, &total);
+            if (need) scan_list[pos] = q;
+            base += total;
+        }
+        if (tid == 0) s_nscan = base;
+    }
+    __syncthreads();
+    const int nscan = s_nscan;
+    if (nscan == 0) return;
+    const int nscan8 = (nscan + D1_XCDS - 1) & ~(D1_XCDS - 1);
+    const int G = a.parts;
+    const int nitems = nscan8 * G;
+
+    for (int t = blockIdx.x; t < nitems; t += gridDim.x) {
+        const int sidx = ((t >> 3) / G) * D1_XCDS + (t & 7), part = (t >> 3) % G;
+        if (sidx >= nscan) continue;   // (block-uniform)
+        const int b = scan_list[sidx];
+        const bool from_band = a.mode[b] == FLMR_S1D_IMAGE;
+        const int P = from_band ? a.band_count[b] : a.cand_count[b];
+        // a band is short (ndocs + a few per cent): groups of 16 so that every wave of the item has some; whole lists: 32
+        const int gsz = (from_band || a.group == 16) ? 16 : D1X_GROUP;
+        const int32_t* const src = (from_band ? a.band : a.cand) + (size_t)b * a.cand_stride;
+        uint64_t* const keys_b = a.keys + (size_t)b * a.cand_stride;
+        const int qlen = a.q_lens ? a.q_lens[b] : a.nq_cand;
+        const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;
+        const float miss = flmr_miss_score(nqc, 0);
+        const int n = a.nqual[b] < a.row_cap ? a.nqual[b] : a.row_cap;
+        const float* const rows_b = a.rows + (size_t)b * a.row_cap * 32;
+        const int ngroups = (P + gsz - 1) / gsz;
+        if (part * ((ngroups + G - 1) / G) >= ngroups) continue;   // (block-uniform: this part of a short list is empty -- no table load)
+        __syncthreads();   // (the previous item's readers of the LDS tables are done)
+        {
+            const uint32_t* gb = a.idx_bits + (size_t)b * a.idx_words;
+            const uint32_t* gp = a.idx_prefix + (size_t)b * a.idx_words;
+            for (int w = tid; w < a.idx_words; w += D1_THREADS) {
+                lbits[w] = gb[w];
+                const uint32_t p = gp[w];
+                lpre[w] = (uint16_t)(p < 65535u ? p : 65535u);
+            }
+        }
+        __syncthreads();
+        const int per = (ngroups + G - 1) / G;
+        const int gbeg = part * per, gend = (gbeg + per) < ngroups ? (gbeg + per) : ngroups;
+        auto meta = [&](int g, int& pid, uint32_t& off, int& len) {
+            pid = 0; off = 0; len = 0;
+            const int i = g * gsz + lane;
+            if (g < gend && lane < gsz && i < P) {
+                pid = src[i];
+                const uint32_t* o32 = reinterpret_cast<const uint32_t*>(a.offsets) + 2 * (size_t)pid;   // (low words: see s1_dense_kernel)
+                off = o32[0];
+                len = a.ulen ? (int)a.ulen[pid] : (int)(o32[2] - off);
+            }
+        };
+        int pid, len; uint32_t off;
+        meta(gbeg + wave, pid, off, len);
+        for (int g = gbeg + wave; g < gend; g += D1_WAVES) {
+            int npid, nlen; uint32_t noff;
+            meta(g + D1_WAVES, npid, noff, nlen);
+            const int ndoc = (P - g * gsz) < gsz ? (P - g * gsz) : gsz;
+            const int nrounds = (ndoc + R - 1) / R;
+            auto request_codes = [&](d1i4u (&c_)[NV], int r, int& jlen) {   // always issued (see s1_dense_kernel): NV requests
+                const int j = r * R + sub;
+                const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(j << 2, (int)off);
+                const int jl = __builtin_amdgcn_ds_bpermute(j << 2, len);
+                jlen = j < ndoc ? jl : 0;
+                const int32_t* at = a.codes + ((uint64_t)o + (uint32_t)(CPL * l));
+#pragma unroll
+                for (int v = 0; v < NV; v++) c_[v] = D1_LOAD(reinterpret_cast<const d1i4u*>(at) + v);
+            };
+            d1i4u cdA[NV], cdB[NV];
+            int lenA = 0, lenB = 0;
+            request_codes(cdA, 0, lenA);
+            request_codes(cdB, 1, lenB);
+            auto round = [&](d1i4u (&cd)[NV], int& jlen, int r) {
+                const int my_len = jlen;
+                d1f4 facc;
+                facc.x = facc.y = facc.z = facc.w = -9999.0f;   // filter_pids.cpp:30-33
+                int nh_total = 0;
+                int c_[CPL];
+#pragma unroll
+                for (int v = 0; v < NV; v++) { c_[4 * v] = cd[v].x; c_[4 * v + 1] = cd[v].y; c_[4 * v + 2] = cd[v].z; c_[4 * v + 3] = cd[v].w; }
+                for (int t0 = 0;; t0 += LISTCAP) {
+                    // ---- the hit mask of this lane's CPL codes ----
+                    int nv = my_len - (t0 + CPL * l);
+                    nv = nv < 0 ? 0 : (nv > CPL ? CPL : nv);
+                    uint32_t hm = 0u;
+#pragma unroll
+                    for (int e = 0; e < CPL; e++) {
+                        const uint32_t wi = min((uint32_t)c_[e] >> 5, (uint32_t)(a.idx_words - 1));
+                        hm |= ((lbits[wi] >> (c_[e] & 31)) & 1u) << e;
+                    }
+                    hm &= (1u << nv) - 1u;
+                    const int cnt = __popc(hm);
+                    int incl = cnt;
+                    incl += D1_DPP(incl, D1_ROW_SHR(1));
+                    incl += D1_DPP(incl, D1_ROW_SHR(2));
+                    incl += D1_DPP(incl, D1_ROW_SHR(4));
+                    incl += D1_DPP(incl, D1_ROW_SHR(8));
+                    if (LPC == 32) incl += __builtin_amdgcn_update_dpp(0, incl, 0x142 /* row_bcast15 */, 0xA, 0xF, false);
+                    int nh_own, nmax;
+                    if (LPC == 16) {
+                        const int n0 = __builtin_amdgcn_readlane(incl, 15), n1 = __builtin_amdgcn_readlane(incl, 31);
+                        const int n2 = __builtin_amdgcn_readlane(incl, 47), n3 = __builtin_amdgcn_readlane(incl, 63);
+                        nh_own = sub == 0 ? n0 : sub == 1 ? n1 : sub == 2 ? n2 : n3;
+                        nmax = max(max(n0, n1), max(n2, n3));
+                    } else {
+                        const int n0 = __builtin_amdgcn_readlane(incl, 31), n1 = __builtin_amdgcn_readlane(incl, 63);
+                        nh_own = sub == 0 ? n0 : n1;
+                        nmax = max(n0, n1);
+                    }
+                    nh_total += nh_own;
+                    // ---- a lane walks its hits: row id = rank of the centroid among the survivors; entry o of a candidate's list
+                    // sits at [o % HPI][o / HPI] ----
+                    {
+                        uint32_t o = (uint32_t)(incl - cnt);
+                        uint32_t left = hm;
+                        while (left) {
+                            const int e = __ffs(left) - 1;
+                            left &= left - 1u;
+                            int c = c_[0];
+#pragma unroll
+                            for (int x = 1; x < CPL; x++) c = e == x ? c_[x] : c;
+                            const uint32_t wi = (uint32_t)c >> 5;
+                            int rid = (int)lpre[wi] + __popc(lbits[wi] & ((1u << (c & 31)) - 1u));
+                            rid = rid < n ? rid : n - 1;
+                            my_list[sub * LISTCAP + (o & (HPI - 1)) * NIT + (o / HPI)] = (uint16_t)rid;
+                            o++;
+                        }
+                    }
+                    const bool more_chunks = __ballot(my_len > t0 + LISTCAP) != 0ull;   // wave-uniform
+                    // ---- fold the listed rows: blocks of four entries per lane.  The codes of round r + 2 are requested behind the LAST
+                    // block's row loads (in-order returns: a request issued before them would be waited for with them), and at ONE place
+                    // in the program: the last block is peeled off the loop, so that every path through the fold has issued the same
+                    // loads in the same order and the compiler's counted wait for the last rows leaves the codes in flight ----
+                    if (nmax > 0) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        // EIGHT entries (16 bytes of the list) per lane and block, their rows requested together: a block is one L2 round
+                        // trip (~1 us under this load) whatever it holds, and the rounds of this regime are a chain of such trips
+                        const d1u4* lp = reinterpret_cast<const d1u4*>(my_list + sub * LISTCAP + hg * NIT);
+                        const float* rb = rows_b + pr * 4;
+                        const int nblocks = (nmax + 8 * HPI - 1) / (8 * HPI);   // (wave-uniform, >= 1)
+                        auto rows_of = [&](int blk, d1f4 (&v)[8], bool (&ok)[8]) {
+                            const d1u4 e4 = lp[blk];
+                            const uint32_t rid[8] = {e4.x & 0xffffu, e4.x >> 16, e4.y & 0xffffu, e4.y >> 16, e4.z & 0xffffu, e4.z >> 16, e4.w & 0xffffu, e4.w >> 16};
+#pragma unroll
+                            for (int u = 0; u < 8; u++) {
+                                ok[u] = (8 * blk + u) * HPI + hg < nh_own;
+                                // (always issued: a load under a lane test makes the compiler's count unknown)
+                                v[u] = *reinterpret_cast<const d1f4*>(rb + (size_t)(ok[u] ? rid[u] : 0u) * 32);
+                            }
+                        };
+                        auto take = [&](const d1f4 (&v)[8], const bool (&ok)[8]) {
+#pragma unroll
+                            for (int u = 0; u < 8; u++) {
+                                facc.x = fmaxf(facc.x, ok[u] ? v[u].x : -9999.0f); facc.y = fmaxf(facc.y, ok[u] ? v[u].y : -9999.0f);
+                                facc.z = fmaxf(facc.z, ok[u] ? v[u].z : -9999.0f); facc.w = fmaxf(facc.w, ok[u] ? v[u].w : -9999.0f);
+                            }
+                        };
+#pragma unroll 1
+                        for (int blk = 0; blk + 1 < nblocks; blk++) {
+                            d1f4 v[8]; bool ok[8];
+                            rows_of(blk, v, ok);
+                            take(v, ok);
+                        }
+                        {
+                            d1f4 v[8]; bool ok[8];
+                            rows_of(nblocks - 1, v, ok);
+                            request_codes(cd, r + 2, jlen);   // (in a later chunk of long passages: the same request again -- unconditional, see above)
+                            take(v, ok);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();   // (the list is rewritten by the next chunk / round)
+                    } else {
+                        request_codes(cd, r + 2, jlen);   // (a round / chunk without a hit)
+                    }
+                    if (!more_chunks) break;
+                    {   // further chunks of long passages: on demand, compiler-visible (its wait drains the requests ahead: rare)
+                        const int j = r * R + sub;
+                        const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(j << 2, (int)off);
+                        const d1i4u* at = reinterpret_cast<const d1i4u*>(a.codes + ((uint64_t)o + (uint32_t)(t0 + LISTCAP + CPL * l)));
+#pragma unroll
+                        for (int v = 0; v < NV; v++) { const d1i4u x = D1_LOAD(at + v); c_[4 * v] = x.x; c_[4 * v + 1] = x.y; c_[4 * v + 2] = x.z; c_[4 * v + 3] = x.w; }
+                    }
+                }
+                // ---- this round's candidates: combine the hit groups; the 8 lanes of a candidate park their 4 columns in the table ----
+                if (HPI >= 2) {
+                    facc.x = fmaxf(facc.x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.x), D1_ROW_ROR(8), 0xF, 0xF, false)));
+                    facc.y = fmaxf(facc.y, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.y), D1_ROW_ROR(8), 0xF, 0xF, false)));
+                    facc.z = fmaxf(facc.z, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.z), D1_ROW_ROR(8), 0xF, 0xF, false)));
+                    facc.w = fmaxf(facc.w, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.w), D1_ROW_ROR(8), 0xF, 0xF, false)));
+                }
+                if (HPI >= 4) {
+                    facc.x = fmaxf(facc.x, __shfl_xor(facc.x, 16, 64)); facc.y = fmaxf(facc.y, __shfl_xor(facc.y, 16, 64));
+                    facc.z = fmaxf(facc.z, __shfl_xor(facc.z, 16, 64)); facc.w = fmaxf(facc.w, __shfl_xor(facc.w, 16, 64));
+                }
+                const int j = r * R + sub;
+                if (l < 8 && j < gsz) {
+                    if (nh_total == 0) facc.x = facc.y = facc.z = facc.w = __int_as_float(0x7fc00000);   // (NaN marks "no surviving centroid")
+                    *reinterpret_cast<d1f4*>(tr + j * D1X_TRS + 4 * l) = facc;
+                }
+            };
+            for (int r = 0; r < nrounds; r += 2) {
+                round(cdA, lenA, r);
+                if (r + 1 < nrounds) round(cdB, lenB, r + 1);
+            }
+            // (the requests past the group's end must have landed before their registers mean anything else to the compiler)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < ndoc) {
+                // ascending-k sum of the candidate's column maxima (filter_pids.cpp:59-63); columns >= nqc add +0.0f (bits unchanged)
+                const d1f4* row = reinterpret_cast<const d1f4*>(tr + lane * D1X_TRS);
+                d1f4 x[8];
+#pragma unroll
+                for (int w = 0; w < 8; w++) x[w] = row[w];
+                float sc = 0.0f;
+                const bool nohit = x[0].x != x[0].x;
+#pragma unroll
+                for (int w = 0; w < 8; w++) {
+                    sc += 4 * w < nqc ? x[w].x : 0.0f; sc += 4 * w + 1 < nqc ? x[w].y : 0.0f;
+                    sc += 4 * w + 2 < nqc ? x[w].z : 0.0f; sc += 4 * w + 3 < nqc ? x[w].w : 0.0f;
+                }
+                keys_b[g * gsz + lane] = flmr_make_key(nohit ? miss : sc, pid);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // (the table is rewritten by the next group)
+            pid = npid; off = noff; len = nlen;
+        }
+    }
+}
+
+static size_t d1x_lds(int nqueries, int idx_words, int lpc, int cpl) {
+    return (size_t)((nqueries + 3) & ~3) * 4 + (size_t)idx_words * 4 + (size_t)((idx_words + 7) & ~7) * 2 +
+           (size_t)D1_WAVES * (64 / lpc) * (lpc * cpl) * 2 + (size_t)D1_WAVES * D1X_GROUP * D1X_TRS * 4;
+}
+
+// the exact pass: (lanes per candidate, codes per lane) by the index's usual number of distinct codes per passage
+int flmr_launch_s1_exact(const flmr_s1d_args& a_in, double mean_codes, hipStream_t st) {
+    flmr_s1d_args a = a_in;
+    const int lpc = mean_codes <= 144.0 ? 16 : 32, cpl = mean_codes <= 72.0 ? 4 : 8;
+    const size_t lds = d1x_lds(a.nqueries, a.idx_words, lpc, cpl);
+    if (lds > (size_t)160 * 1024 - 1024) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "dense stage 1: K = %d does not fit the LDS form", a.idx_words * 32);
+    if (a.codes_len > 0xffffffffLL) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "dense stage 1: token offsets beyond 32 bits");
+    if (a.parts < 1) a.parts = 8;
+    int64_t grid = 256;
+    const int64_t max_items = (int64_t)((a.nqueries + D1_XCDS - 1) & ~(D1_XCDS - 1)) * a.parts;
+    if (grid > max_items) grid = max_items;
+    dim3 g((unsigned)grid), block(D1_THREADS);
+#define D1X_LAUNCH(L, C) do { \
+        if (lds > 48 * 1024) FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s1_exact_kernel<L, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((s1_exact_kernel<L, C>), g, block, lds, st, a); } while (0)
+    if (lpc == 16 && cpl == 4) D1X_LAUNCH(16, 4);
+    else if (lpc == 16) D1X_LAUNCH(16, 8);
+    else D1X_LAUNCH(32, 8);
+#undef D1X_LAUNCH
+    FLMR_LAUNCH_CHECK();
+    return FLMR_OK;
 }
 
 // LDS the launch needs besides the images; rows of images that fit beside it
@@ -499,24 +814,32 @@ int flmr_launch_s1_dense(const flmr_s1d_args& a_in, bool img_pass, int lpc, hipS
     return FLMR_OK;
 }
 
-__global__ void s1_dense_modes_kernel(const int32_t* skip, const int32_t* nqual, const int32_t* row_ovf, int32_t nqueries, int32_t img_rows,
-                                      int32_t exact_too, int32_t* mode, int32_t* scan_skip) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nqueries) return;
-    int m = FLMR_S1D_SKIP, sk = 1;
-    if (!(skip && skip[q]) && !(row_ovf && row_ovf[q])) {
-        if (nqual[q] <= img_rows) m = FLMR_S1D_IMAGE;
-        else if (exact_too) m = FLMR_S1D_EXACT;
-        else sk = 0;   // the scan takes the query
+// one block: mode / scan_skip per query, and any[0] = some query takes the image form, any[1] = some query takes the exact pass (a band
+// or a whole list): the dense kernels read their word first and leave at once when it is 0 (the usual case on the tuned path)
+__global__ __launch_bounds__(1024) void s1_dense_modes_kernel(const int32_t* skip, const int32_t* nqual, const int32_t* row_ovf, int32_t nqueries,
+                                                              int32_t img_rows, int32_t exact_too, int32_t* mode, int32_t* scan_skip, int32_t* any) {
+    int any_img = 0, any_exact = 0;
+    for (int q = threadIdx.x; q < nqueries; q += 1024) {
+        int m = FLMR_S1D_SKIP, sk = 1;
+        if (!(skip && skip[q]) && !(row_ovf && row_ovf[q])) {
+            if (nqual[q] <= img_rows) m = FLMR_S1D_IMAGE;
+            else if (exact_too) m = FLMR_S1D_EXACT;
+            else sk = 0;   // the scan takes the query
+        }
+        mode[q] = m;
+        scan_skip[q] = sk;
+        any_img |= m == FLMR_S1D_IMAGE;
+        any_exact |= m != FLMR_S1D_SKIP;
     }
-    mode[q] = m;
-    scan_skip[q] = sk;
+    any_img = __syncthreads_or(any_img);
+    any_exact = __syncthreads_or(any_exact);
+    if (threadIdx.x == 0) { any[0] = any_img; any[1] = any_exact; }
 }
 
 int flmr_launch_s1_dense_modes(const int32_t* skip, const int32_t* nqual, const int32_t* row_ovf, int32_t nqueries, int32_t img_rows,
-                               int32_t exact_too, int32_t* mode, int32_t* scan_skip, hipStream_t st) {
-    hipLaunchKernelGGL(s1_dense_modes_kernel, dim3((nqueries + 255) / 256), dim3(256), 0, st, skip, nqual, row_ovf, nqueries, img_rows,
-                       exact_too, mode, scan_skip);
+                               int32_t exact_too, int32_t* mode, int32_t* scan_skip, int32_t* any, hipStream_t st) {
+    hipLaunchKernelGGL(s1_dense_modes_kernel, dim3(1), dim3(1024), 0, st, skip, nqual, row_ovf, nqueries, img_rows, exact_too, mode,
+                       scan_skip, any);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }
