@@ -586,7 +586,7 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
         RUN(flmr_launch_s1_dense(d, true, s->s1d_lpc, st));
         RUN(flmr_launch_s1_band(s->keys1, s->cand_cap, s->cand_count, s->s1d_mode, s->s1d_err, c.nqueries, c.p.ndocs, s->s1d_band,
                                 s->s1d_band_count, s->s1d_in_count, st));
-        d.parts = 8; d.group = 0;   // (groups of 16 candidates for a band, 32 for a whole list: the kernel's choice per query)
+        d.parts = 4; d.group = 0;   // (groups of 16 candidates for a band, 32 for a whole list: the kernel's choice per query)
         RUN(flmr_launch_s1_exact(d, ix->mean_ulen, st));
         sel_counts = s->s1d_in_count;
     }

@@ -283,6 +283,9 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
             // SGPR base + 32-bit byte offset (the table is K * 256 bytes < 4 GB); the offset's VALU op is the wait state
             // between the write of M0 and the DMA that reads it.
             auto issue_rows = [&](int t) {
+#ifdef X2_NO_DMA   // development ablation (profiles/s2_ceiling.sh): no row gathers, everything else as it is
+                return;
+#endif
                 const int* cr = reinterpret_cast<const int*>(ring + (t & (X2_RING - 1)) * 256) + (lane >> 4);
                 int c[8];
 #pragma unroll
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
                 }
                 X2_STAMP(3);
                 X2_STAMP(4);
-#ifndef X2_LATE_DMA
+#if !defined(X2_LATE_DMA) && !defined(X2_NO_DMA)
 #pragma unroll
                 for (int gq = 0; gq < 8; gq++) {
                     const uint32_t dst = rowbuf_lds + (t & 1) * 8192 + gq * 1024;
@@ -366,11 +369,21 @@ __global__ __launch_bounds__(256, 2) void filter_stage2_xcd_kernel(flmr_filter_a
                 x2f16 ah, al;
 #pragma unroll
                 for (int r = 0; r < 16; r++) { ah[r] = 0.0f; al[r] = 0.0f; }
+#ifndef X2_NO_MFMA   // development ablation: no matrix products (the accumulators stay zero)
 #pragma unroll
                 for (int s = 0; s < 8; s++) {
                     ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bh[s], ah, 0, 0, 0);
                     if constexpr (!HI_ONLY) al = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bl[s], al, 0, 0, 0);
                 }
+#else
+#pragma unroll
+                for (int s = 0; s < 8; s++) asm volatile("" :: "v"(av[s]));   // (the LDS reads of the rows stay)
+#endif
+#ifdef X2_NO_FOLD   // development ablation: the products are made and dropped (no octet maxima, no per-passage fold, no flush)
+                asm volatile("" :: "v"(ah));
+                if constexpr (!HI_ONLY) asm volatile("" :: "v"(al));
+                continue;
+#endif
                 // rows 8k .. 8k+7 (octet k) live in registers 4k .. 4k+3 of the two half-waves: each lane keeps the maximum over
                 // ITS four rows; the two halves are only combined when a passage is flushed (one LDS-crossbar op per passage
                 // instead of four per tile)
