@@ -91,11 +91,11 @@ int main() {
     a.cand = d_cand; a.cand_stride = NC; a.cand_count = d_cc; a.band = d_band; a.band_count = d_bc; a.mode = d_mode; a.keys = d_keys; a.img_err = d_err;
     a.parts = (int)envd("S1D_PARTS", 0);
     a.codes_len = (int64_t)P * L; a.group = 64;
-    const int img_rows = flmr_s1_dense_image_rows(NQ, idx_words, LPC);
+    const int img_rows = flmr_s1_dense_image_rows(NQ, idx_words, envd("S1D_SHAPE_CODES", mean_ul));
     printf("P %d, survivors %d, candidates/query %d, distinct codes/passage %.1f, hit share %.2f, LPC %d, image rows that fit %d\n", P, NS, NC, mean_ul, HIT, LPC, img_rows);
 
-    const bool old_exact = envd("S1D_OLD_EXACT", 0) != 0;
-    auto launch = [&](bool img) { return (img || old_exact) ? flmr_launch_s1_dense(a, img, LPC, 0) : flmr_launch_s1_exact(a, mean_ul, 0); };
+    const double shape_codes = envd("S1D_SHAPE_CODES", mean_ul);   // (what picks lanes per candidate x codes per lane)
+    auto launch = [&](bool img) { return img ? flmr_launch_s1_image(a, shape_codes, 0) : flmr_launch_s1_exact(a, shape_codes, 0); };
     auto time_it = [&](bool img, const char* what) {
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         if (launch(img)) { printf("launch failed: %s\n", flmr_err_buf); exit(1); }

@@ -368,10 +368,10 @@ struct flmr_s1d_args {
 #define FLMR_S1D_SKIP 0    // stage 1 of the query is done elsewhere (list-scatter forms, the round-5 scan)
 #define FLMR_S1D_IMAGE 1   // IMG pass over the candidates, band, EXACT pass over the band
 #define FLMR_S1D_EXACT 2   // EXACT pass over the candidates
-int flmr_s1_dense_image_rows(int nqueries, int idx_words, int lpc);   // score-row images the LDS form holds per query (0: K too large)
-int flmr_launch_s1_dense(const flmr_s1d_args& a, bool img_pass, int lpc, hipStream_t st);
-// the exact pass as its own kernel: 16 or 32 lanes per candidate x 4 or 8 codes per lane by the index's mean number of distinct codes
-int flmr_launch_s1_exact(const flmr_s1d_args& a, double mean_codes, hipStream_t st);
+// `mean_codes` = the index's mean number of (distinct) codes per passage: 16 or 32 lanes per candidate x 4 or 8 codes per lane
+int flmr_s1_dense_image_rows(int nqueries, int idx_words, double mean_codes);   // score-row images the LDS form holds per query (0: K too large)
+int flmr_launch_s1_image(const flmr_s1d_args& a, double mean_codes, hipStream_t st);   // the approximate pass (U keys, img_err)
+int flmr_launch_s1_exact(const flmr_s1d_args& a, double mean_codes, hipStream_t st);   // the exact pass (bands, whole lists)
 // which queries the dense forms take: mode[q] = SKIP where skip[q] (done by a list-scatter form) or row_ovf[q] (no rows: the
 // recompute form), IMAGE where the query's rows fit
 // `img_rows` images, else EXACT (exact_too) or SKIP with scan[q] = 0 (the round-5 scan takes the query); scan[q] = 1 everywhere else

@@ -46,7 +46,7 @@ struct flmr_searcher {
     // stage 1 for dense survivor sets (flmr_stage1_dense.hip): per query which form, the band of an image query, its error bound,
     // how many keys the selection reads, and which queries are left to the round-5 scan
     int32_t* s1d_any; int32_t* s1d_mode; int32_t* s1d_band; int32_t* s1d_band_count; float* s1d_err; int32_t* s1d_in_count; int32_t* s1d_scan_skip;
-    int32_t s1d_lpc, s1d_img_rows;   // lanes per candidate (16 / 32 by the index's distinct codes per passage); images the LDS holds (0: no dense form)
+    int32_t s1d_img_rows;       // score-row images the LDS form holds (0: no dense form on this index)
     int32_t* cand_fast;         // flmr_cand_args::fast_state ([FLMR_FAST_HDR + 2 * max_queries]; the header words live as long as the searcher)
     // last call (for taps)
     int32_t last_nqueries, last_ncol, last_ndocs, last_full_table;
@@ -171,8 +171,7 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     WS(chunk_hits, B * (size_t)ix->nchunks);
     WS(cand_hit, B * (size_t)s->cand_cap);
     // dense stage 1: needs the sorted code copy (whole 16-byte pieces are read: its padding) and 32-bit token offsets
-    s->s1d_lpc = ix->mean_ulen > 0.0 && ix->mean_ulen <= 72.0 ? 16 : 32;
-    s->s1d_img_rows = (ix->codes_sorted && s->ncol_max == 32 && !s->opt.is(FLMR_OPT_S1_IMPL, "scan")) ? flmr_s1_dense_image_rows(max_queries, s->idx_words, s->s1d_lpc) : 0;
+    s->s1d_img_rows = (ix->codes_sorted && s->ncol_max == 32 && !s->opt.is(FLMR_OPT_S1_IMPL, "scan")) ? flmr_s1_dense_image_rows(max_queries, s->idx_words, ix->mean_ulen) : 0;
     WS(s1d_any, 2); WS(s1d_mode, B); WS(s1d_band_count, B); WS(s1d_err, B); WS(s1d_in_count, B); WS(s1d_scan_skip, B); WS(row_ovf, B);
     if (s->s1d_img_rows > 0) WS(s1d_band, B * (size_t)s->cand_cap);
     WS(q3_hi, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
@@ -583,7 +582,7 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
         d.cand = s->cand; d.cand_stride = s->cand_cap; d.cand_count = s->cand_count;
         d.band = s->s1d_band; d.band_count = s->s1d_band_count; d.mode = s->s1d_mode; d.keys = s->keys1; d.img_err = s->s1d_err; d.any = s->s1d_any;
         d.parts = 0; d.group = 64;
-        RUN(flmr_launch_s1_dense(d, true, s->s1d_lpc, st));
+        RUN(flmr_launch_s1_image(d, ix->mean_ulen, st));
         RUN(flmr_launch_s1_band(s->keys1, s->cand_cap, s->cand_count, s->s1d_mode, s->s1d_err, c.nqueries, c.p.ndocs, s->s1d_band,
                                 s->s1d_band_count, s->s1d_in_count, st));
         d.parts = 4; d.group = 0;   // (groups of 16 candidates for a band, 32 for a whole list: the kernel's choice per query)

@@ -26,7 +26,7 @@
 //      by the second form of this kernel, and the top ndocs of the band by exact (score, pid) key is, as a set with its keys,
 //      bit for bit what the full scan selects.
 //
-// Two instantiations of one kernel:
+// Two kernels (s1_image_kernel, s1_exact_kernel):
 //   IMG   = the approximate pass: rows' fp16 images in LDS, packed fp16 maxima, U keys for every candidate;
 //   EXACT = fp32 rows gathered through L2 (8 lanes x 16 bytes per row, a batch in flight), per-column maxima summed k-ascending
 //           along a DPP chain: the reference's arithmetic.  Runs over the band of an IMG query, or over the whole candidate
@@ -88,13 +88,18 @@ __device__ __forceinline__ uint32_t d1_row_addr(uint32_t q, int hi, uint32_t bas
 }
 
 
-template <bool IMG, int LPC>
-__global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
+// ---- the image form -----------------------------------------------------------------------------------------------------
+// LPC lanes per candidate x CPL codes per lane (16 x 4, 16 x 8 or 32 x 8 by the index's usual number of distinct codes per passage).
+// Every load of the round loop is compiler-visible and UNCONDITIONAL (s1_exact_kernel's header says why): the two code buffers'
+// requests are then the only vector-memory operations in flight and the compiler's wait at the top of a round is a vmcnt(CPL / 4).
+template <int LPC, int CPL>
+__global__ __launch_bounds__(D1_THREADS) void s1_image_kernel(flmr_s1d_args a) {
     constexpr int R = 64 / LPC;            // candidates per round
-    constexpr int LISTCAP = LPC * 4;       // hits of one candidate chunk
-    constexpr int LPR = IMG ? 4 : 8;       // lanes per row read (16 bytes each)
+    constexpr int LISTCAP = LPC * CPL;     // codes (= most hits) of one candidate chunk
+    constexpr int NV = CPL / 4;            // 16-byte requests per lane and round
+    constexpr int LPR = 4;                 // lanes per image row (16 bytes = 8 fp16 columns each)
     constexpr int HPI = LPC / LPR;         // hits folded per iteration and candidate
-    constexpr int NIT = LISTCAP / HPI;     // list entries of one hit group (16 IMG, 32 EXACT)
+    constexpr int NIT = LISTCAP / HPI;     // list entries of one hit group (16 or 32)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int scan_lds[17];
     __shared__ int s_nscan;
@@ -103,7 +108,8 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = lane / LPC, l = lane % LPC;
-    // LDS: [scan list: nqueries i32][bits: idx_words u32][prefix: idx_words u16 (padded to 16 B)][lists: D1_WAVES * R * LISTCAP u16][images]
+    const int hg = l / LPR, pr = l % LPR;
+    // LDS: [scan list: nqueries i32][bits: idx_words u32][prefix: idx_words u16 (padded to 16 B)][lists: per wave R * LISTCAP + 64 u16][images]
     int* scan_list = reinterpret_cast<int*>(smem);
     uint32_t* lbits = reinterpret_cast<uint32_t*>(scan_list + ((a.nqueries + 3) & ~3));
     uint16_t* lpre = reinterpret_cast<uint16_t*>(lbits + a.idx_words);
@@ -111,16 +117,14 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
     uint16_t* my_list = lists + (size_t)wave * (R * LISTCAP + 64);   // (+ one scratch entry per lane)
     char* img = reinterpret_cast<char*>(lists + (size_t)D1_WAVES * (R * LISTCAP + 64));
 
-    if (a.any && a.any[IMG ? 0 : 1] == 0) return;   // (uniform: no query of the batch takes this pass)
-    // ---- the queries of this launch ----
+    if (a.any && a.any[0] == 0) return;   // (uniform: no query of the batch takes this pass)
     if (tid == 0) s_nscan = 0;
     __syncthreads();
     {
         int base = 0;
         for (int q0 = 0; q0 < a.nqueries; q0 += D1_THREADS) {
             const int q = q0 + tid;
-            const int m = q < a.nqueries ? a.mode[q] : FLMR_S1D_SKIP;
-            const int need = IMG ? (m == FLMR_S1D_IMAGE) : (m != FLMR_S1D_SKIP);
+            const int need = (q < a.nqueries && a.mode[q] == FLMR_S1D_IMAGE) ? 1 : 0;
             int total;
             const int pos = base + flmr_block_exclusive_scan(need, scan_lds, &total);
             if (need) scan_list[pos] = q;
@@ -134,15 +138,14 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
     const int nscan8 = (nscan + D1_XCDS - 1) & ~(D1_XCDS - 1);
     const int G = a.parts;
     const int nitems = nscan8 * G;
+    const int gsz = 64;
 
     for (int t = blockIdx.x; t < nitems; t += gridDim.x) {
         const int sidx = ((t >> 3) / G) * D1_XCDS + (t & 7), part = (t >> 3) % G;
         if (sidx >= nscan) continue;   // (block-uniform)
         const int b = scan_list[sidx];
-        const int m = a.mode[b];
-        const bool from_band = !IMG && m == FLMR_S1D_IMAGE;
-        const int P = from_band ? a.band_count[b] : a.cand_count[b];
-        const int32_t* const src = (from_band ? a.band : a.cand) + (size_t)b * a.cand_stride;
+        const int P = a.cand_count[b];
+        const int32_t* const src = a.cand + (size_t)b * a.cand_stride;
         uint64_t* const keys_b = a.keys + (size_t)b * a.cand_stride;
         const int qlen = a.q_lens ? a.q_lens[b] : a.nq_cand;
         const int nqc = qlen < a.nq_cand ? qlen : a.nq_cand;
@@ -160,9 +163,9 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
                 lpre[w] = (uint16_t)(p < 65535u ? p : 65535u);
             }
         }
-        bool usable = true;
-        if (IMG) {
-            // ---- images: row r, columns 2j / 2j+1 -> dword 16 r + j; row n = the padding row (-inf: never wins) ----
+        // ---- images: row r, columns 2j / 2j+1 -> dword 16 r + j; row n = the padding row (-inf: never wins) ----
+        bool usable;
+        {
             float dmax = 0.0f, amax = 0.0f;
             bool bad = false;
             if (tid == 0) s_bad = 0;
@@ -193,17 +196,12 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
                 // E: 32 rounding steps; eps: two 32-term fp32 sums of terms <= am, each within 32 * 2^-24 * (32 am) -- taken 8 x larger
                 a.img_err[b] = usable ? 32.0f * d + 2.0f * 32.0f * 32.0f * am * 4.8e-7f : __builtin_huge_valf();
             }
-        } else {
-            __syncthreads();
         }
-
-        // ---- the item's groups of 64 candidates ----
-        const int gsz = a.group;   // candidates per wave and group (64; 16 for short lists: every wave gets work)
         const uint32_t pad2 = (uint32_t)n | ((uint32_t)n << 16);
         const int ngroups = (P + gsz - 1) / gsz;
         const int per = (ngroups + G - 1) / G;
         const int gbeg = part * per, gend = (gbeg + per) < ngroups ? (gbeg + per) : ngroups;
-        if (IMG && !usable) {   // no images for this query: every candidate joins the band (E = inf)
+        if (!usable) {   // no images for this query: every candidate joins the band (E = inf)
             for (int i = gbeg * gsz + tid; i < gend * gsz && i < P; i += D1_THREADS) keys_b[i] = flmr_make_key(0.0f, src[i]);
             continue;
         }
@@ -211,7 +209,7 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
         auto meta = [&](int g, int& pid, uint32_t& off, int& len) {
             pid = 0; off = 0; len = 0;
             const int i = g * gsz + lane;
-            if (g < gend && lane < gsz && i < P) {
+            if (g < gend && i < P) {
                 pid = src[i];
                 // (the LOW words only: a 64-bit load whose high half is unused leaves a register the compiler re-uses while the
                 // load is pending -- and waits for it with a vmcnt(0) inside the round loop)
@@ -228,53 +226,39 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
             const int ndoc = (P - g * gsz) < gsz ? (P - g * gsz) : gsz;
             const int nrounds = (ndoc + R - 1) / R;
             float ukeep = 0.0f;   // lane j: the score of candidate j of the group
-            // Codes of round r (first chunk): this lane's 4 codes of its candidate, ONE 16-byte load requested TWO ROUNDS AHEAD.
-            // The request is an asm statement and its wait is hand-counted (vmcnt(1) at the top of a round: only the other
-            // buffer's request is younger), as in the stage-2 / stage-3 kernels: left to the compiler, the two buffers' rounds are
-            // merged into one loop body that rotates the registers, and a register move of a pending load is a vmcnt(0) -- the
-            // rounds requested ahead were drained at every round (measured: 56 % of the wave cycles waiting).  So that the count
-            // holds, a request is ALWAYS issued: past the group's end it re-reads some candidate's codes, and what a lane reads
-            // beyond its passage's end (the next passage's codes, the sorted copy's D1_CODE_PAD words of padding) is masked by
-            // the listing.
-            auto request_codes = [&](d1i4u& c_, int r, int& jlen) {
+            // Codes of round r (first chunk): CPL codes of this lane's candidate, requested TWO ROUNDS AHEAD and ALWAYS (past the
+            // group's end some candidate's codes are read again): what a lane reads beyond its passage's end -- the next passage's
+            // codes, the sorted copy's FLMR_CODE_PAD words of padding -- is masked by the listing
+            auto request_codes = [&](d1i4u (&c_)[NV], int r, int t0, int& jlen) {
                 const int j = r * R + sub;
                 const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(j << 2, (int)off);
                 const int jl = __builtin_amdgcn_ds_bpermute(j << 2, len);
                 jlen = j < ndoc ? jl : 0;
-                const int32_t* at = a.codes + ((uint64_t)o + (uint32_t)(4 * l));
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(c_) : "v"(at) : "memory");
+                const d1i4u* at = reinterpret_cast<const d1i4u*>(a.codes + ((uint64_t)o + (uint32_t)(t0 + CPL * l)));
+#pragma unroll
+                for (int v = 0; v < NV; v++) c_[v] = D1_LOAD(at + v);
             };
-            // further chunks of long passages: on demand, compiler-visible (its wait drains the requests ahead: rare)
-            auto load_chunk = [&](d1i4u& c_, int r, int t0) {
-                const int j = r * R + sub;
-                const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(j << 2, (int)off);
-                c_ = D1_LOAD(reinterpret_cast<const d1i4u*>(a.codes + ((uint64_t)o + (uint32_t)(t0 + 4 * l))));
-            };
-            d1i4u cdA, cdB;
+            d1i4u cdA[NV], cdB[NV];
             int lenA = 0, lenB = 0;
-            request_codes(cdA, 0, lenA);
-            request_codes(cdB, 1, lenB);
-            auto round = [&](d1i4u& cd, int& jlen, int r) {
+            request_codes(cdA, 0, 0, lenA);
+            request_codes(cdB, 1, 0, lenB);
+            auto round = [&](d1i4u (&cd)[NV], int& jlen, int r) {
                 const int my_len = jlen;
-                uint32_t acc[4];     // IMG: 8 fp16 column maxima of this lane's 16 bytes of a row
-                d1f4 facc;           // EXACT: 4 fp32 column maxima
+                uint32_t acc[4];     // 8 fp16 column maxima of this lane's 16 bytes of a row
 #pragma unroll
                 for (int e = 0; e < 4; e++) acc[e] = 0xFC00FC00u;
-                facc.x = facc.y = facc.z = facc.w = -9999.0f;   // filter_pids.cpp:30-33
-                int nh_total = 0;
-                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // (no operand: see s1_exact_kernel)
-                asm volatile("" : "+v"(cd) : : "memory");
-                d1i4u cur = cd;
-                const int hg = l / LPR, pr = l % LPR;
+                int c_[CPL];
+#pragma unroll
+                for (int v = 0; v < NV; v++) { c_[4 * v] = cd[v].x; c_[4 * v + 1] = cd[v].y; c_[4 * v + 2] = cd[v].z; c_[4 * v + 3] = cd[v].w; }
                 for (int t0 = 0;; t0 += LISTCAP) {
                     // ---- list the hits of this chunk ----
-                    const int c_[4] = {cur.x, cur.y, cur.z, cur.w};
-                    if (IMG) reinterpret_cast<uint2*>(my_list)[lane] = make_uint2(pad2, pad2);   // every entry = the padding row
-                    int nv = my_len - (t0 + 4 * l);
-                    nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
-                    uint32_t wd[4], wi[4], hm = 0u;
+                    reinterpret_cast<uint2*>(my_list)[lane] = make_uint2(pad2, pad2);   // (first 256 entries = the padding row)
+                    if (R * LISTCAP > 256) reinterpret_cast<uint2*>(my_list)[64 + lane] = make_uint2(pad2, pad2);
+                    int nv = my_len - (t0 + CPL * l);
+                    nv = nv < 0 ? 0 : (nv > CPL ? CPL : nv);
+                    uint32_t wd[CPL], wi[CPL], hm = 0u;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
+                    for (int e = 0; e < CPL; e++) {
                         wi[e] = min((uint32_t)c_[e] >> 5, (uint32_t)(a.idx_words - 1));
                         wd[e] = lbits[wi[e]];
                         hm |= ((wd[e] >> (c_[e] & 31)) & 1u) << e;
@@ -287,25 +271,22 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
                     incl += D1_DPP(incl, D1_ROW_SHR(4));
                     incl += D1_DPP(incl, D1_ROW_SHR(8));
                     if (LPC == 32) incl += __builtin_amdgcn_update_dpp(0, incl, 0x142 /* row_bcast15 */, 0xA, 0xF, false);
-                    int nh_own = 0, nmax;
+                    int nmax;
                     if (LPC == 16) {
                         const int n0 = __builtin_amdgcn_readlane(incl, 15), n1 = __builtin_amdgcn_readlane(incl, 31);
                         const int n2 = __builtin_amdgcn_readlane(incl, 47), n3 = __builtin_amdgcn_readlane(incl, 63);
-                        if (!IMG) nh_own = sub == 0 ? n0 : sub == 1 ? n1 : sub == 2 ? n2 : n3;
                         nmax = max(max(n0, n1), max(n2, n3));
                     } else {
                         const int n0 = __builtin_amdgcn_readlane(incl, 31), n1 = __builtin_amdgcn_readlane(incl, 63);
-                        if (!IMG) nh_own = sub == 0 ? n0 : n1;
                         nmax = max(n0, n1);
                     }
-                    if (!IMG) nh_total += nh_own;
                     {   // entry o of a candidate's list sits at [o % HPI][o / HPI]: a lane's hit group reads its entries contiguously
                         const int base = incl - cnt;
 #pragma unroll
-                        for (int e = 0; e < 4; e++) {
+                        for (int e = 0; e < CPL; e++) {
                             const int c = c_[e];
                             int rid = (int)lpre[wi[e]] + __popc(wd[e] & ((1u << (c & 31)) - 1u));
-                            rid = rid < n ? rid : (IMG ? n : n - 1);
+                            rid = rid < n ? rid : n;
                             const uint32_t o = (uint32_t)base + __popc(hm & ((1u << e) - 1u));
                             const uint32_t pos = sub * LISTCAP + (o & (HPI - 1)) * NIT + (o / HPI);
                             my_list[((hm >> e) & 1u) ? pos : R * LISTCAP + lane] = (uint16_t)rid;   // (a miss: the lane's own scratch entry)
@@ -313,13 +294,16 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
                     }
                     // the codes are dead: request the chunk-0 codes of round r + 2 into the same registers
                     const bool more_chunks = __ballot(my_len > t0 + LISTCAP) != 0ull;   // wave-uniform
-                    if (t0 == 0) request_codes(cd, r + 2, jlen);
+                    if (t0 == 0) request_codes(cd, r + 2, 0, jlen);
                     // ---- fold the listed rows ----
                     if (nmax > 0) {
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
-                        // a lane's hit group reads its list entries 16 at a time (32 bytes), then the rows they name
+                        // a lane's hit group reads its list entries 16 at a time (32 bytes), then the rows they name: blocks of four
+                        // entries, every index static, the four rows of a block requested together (an entry beyond a candidate's hits
+                        // names the padding row)
                         const d1u4* lp = reinterpret_cast<const d1u4*>(my_list + sub * LISTCAP + hg * NIT);
+                        const uint32_t pb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)img + pr * 16;
 #pragma unroll 1
                         for (int hb = 0; hb < NIT; hb += 16) {
                             if (hb * HPI >= nmax) break;   // (wave-uniform)
@@ -329,44 +313,19 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
                                 q[0] = t0v.x; q[1] = t0v.y; q[2] = t0v.z; q[3] = t0v.w;
                                 q[4] = t1v.x; q[5] = t1v.y; q[6] = t1v.z; q[7] = t1v.w;
                             }
-                            // blocks of four entries, every index static: the four rows of a block are requested together (an entry
-                            // beyond a candidate's hits names the padding row / is skipped by its test)
-                            if (IMG) {
-                                const uint32_t pb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)img + pr * 16;
 #pragma unroll
-                                for (int it = 0; it < 16; it += 4) {
-                                    if ((hb + it) * HPI < nmax) {   // (wave-uniform)
-                                        d1u4 v[4];
+                            for (int it = 0; it < 16; it += 4) {
+                                if ((hb + it) * HPI < nmax) {   // (wave-uniform)
+                                    d1u4 v[4];
 #pragma unroll
-                                        for (int u = 0; u < 4; u++) {
-                                            const uint32_t at = d1_row_addr(q[(it + u) >> 1], (it + u) & 1, pb);
-                                            v[u] = *reinterpret_cast<const __attribute__((address_space(3))) d1u4*>((uintptr_t)at);
-                                        }
-#pragma unroll
-                                        for (int u = 0; u < 4; u++) {
-                                            acc[0] = d1_pk_max(acc[0], v[u].x); acc[1] = d1_pk_max(acc[1], v[u].y);
-                                            acc[2] = d1_pk_max(acc[2], v[u].z); acc[3] = d1_pk_max(acc[3], v[u].w);
-                                        }
+                                    for (int u = 0; u < 4; u++) {
+                                        const uint32_t at = d1_row_addr(q[(it + u) >> 1], (it + u) & 1, pb);
+                                        v[u] = *reinterpret_cast<const __attribute__((address_space(3))) d1u4*>((uintptr_t)at);
                                     }
-                                }
-                            } else {
-                                const float* rb = rows_b + pr * 4;
 #pragma unroll
-                                for (int it = 0; it < 16; it += 4) {
-                                    if ((hb + it) * HPI < nmax) {   // (wave-uniform)
-                                        d1f4 v[4];
-#pragma unroll
-                                        for (int u = 0; u < 4; u++) {
-                                            const int i0 = (hb + it + u) * HPI + hg;
-                                            const uint32_t rid = ((it + u) & 1) ? (q[(it + u) >> 1] >> 16) : (q[(it + u) >> 1] & 0xffffu);
-                                            v[u].x = v[u].y = v[u].z = v[u].w = -9999.0f;
-                                            if (i0 < nh_own) v[u] = *reinterpret_cast<const d1f4*>(rb + (size_t)rid * 32);
-                                        }
-#pragma unroll
-                                        for (int u = 0; u < 4; u++) {
-                                            facc.x = fmaxf(facc.x, v[u].x); facc.y = fmaxf(facc.y, v[u].y);
-                                            facc.z = fmaxf(facc.z, v[u].z); facc.w = fmaxf(facc.w, v[u].w);
-                                        }
+                                    for (int u = 0; u < 4; u++) {
+                                        acc[0] = d1_pk_max(acc[0], v[u].x); acc[1] = d1_pk_max(acc[1], v[u].y);
+                                        acc[2] = d1_pk_max(acc[2], v[u].z); acc[3] = d1_pk_max(acc[3], v[u].w);
                                     }
                                 }
                             }
@@ -375,71 +334,52 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
                         __builtin_amdgcn_wave_barrier();   // (the list is rewritten by the next chunk / round)
                     }
                     if (!more_chunks) break;
-                    load_chunk(cur, r, t0 + LISTCAP);
+                    {   // further chunks of long passages: on demand (their wait drains the requests ahead: rare)
+                        d1i4u cx[NV];
+                        int dl;
+                        request_codes(cx, r, t0 + LISTCAP, dl);
+#pragma unroll
+                        for (int v = 0; v < NV; v++) { c_[4 * v] = cx[v].x; c_[4 * v + 1] = cx[v].y; c_[4 * v + 2] = cx[v].z; c_[4 * v + 3] = cx[v].w; }
+                    }
                 }
                 // ---- this round's candidates: combine the hit groups, sum the columns, keep the score for lane j ----
-                float sc;
-                if (IMG) {
-                    if (HPI >= 2) {
+                if (HPI >= 2) {
 #pragma unroll
-                        for (int e = 0; e < 4; e++) acc[e] = d1_pk_max(acc[e], (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc[e], D1_ROW_ROR(4), 0xF, 0xF, false));
-                    }
-                    if (HPI >= 4) {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) acc[e] = d1_pk_max(acc[e], (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc[e], D1_ROW_ROR(8), 0xF, 0xF, false));
-                    }
-                    if (HPI >= 8) {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) acc[e] = d1_pk_max(acc[e], (uint32_t)__shfl_xor((int)acc[e], 16, 64));
-                    }
-                    const bool nohit = (acc[0] & 0xffffu) == 0xFC00u;   // a real row is finite: -inf = only padding rows were folded
-                    float s = 0.0f;
-                    if (nqc == 32) {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const d1h2 h = __builtin_bit_cast(d1h2, acc[e]);
-                            s += (float)h.x;
-                            s += (float)h.y;
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const d1h2 h = __builtin_bit_cast(d1h2, acc[e]);
-                            const int k0 = pr * 8 + 2 * e;
-                            s += k0 < nqc ? (float)h.x : 0.0f;
-                            s += k0 + 1 < nqc ? (float)h.y : 0.0f;
-                        }
-                    }
-                    s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false));
-                    s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false));
-                    sc = nohit ? miss : s;
-                } else {
-                    if (HPI >= 2) {
-                        facc.x = fmaxf(facc.x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.x), D1_ROW_ROR(8), 0xF, 0xF, false)));
-                        facc.y = fmaxf(facc.y, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.y), D1_ROW_ROR(8), 0xF, 0xF, false)));
-                        facc.z = fmaxf(facc.z, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.z), D1_ROW_ROR(8), 0xF, 0xF, false)));
-                        facc.w = fmaxf(facc.w, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.w), D1_ROW_ROR(8), 0xF, 0xF, false)));
-                    }
-                    if (HPI >= 4) {
-                        facc.x = fmaxf(facc.x, __shfl_xor(facc.x, 16, 64)); facc.y = fmaxf(facc.y, __shfl_xor(facc.y, 16, 64));
-                        facc.z = fmaxf(facc.z, __shfl_xor(facc.z, 16, 64)); facc.w = fmaxf(facc.w, __shfl_xor(facc.w, 16, 64));
-                    }
-                    // k-ascending sum (filter_pids.cpp:59-63): lane pr of the candidate holds columns 4 pr .. 4 pr + 3; the running
-                    // sum travels lane 0 -> 7 along row_shr:1.  Columns >= nqc add +0.0f, which leaves the bits unchanged.
-                    const float m0 = 4 * pr < nqc ? facc.x : 0.0f, m1 = 4 * pr + 1 < nqc ? facc.y : 0.0f;
-                    const float m2 = 4 * pr + 2 < nqc ? facc.z : 0.0f, m3 = 4 * pr + 3 < nqc ? facc.w : 0.0f;
-                    float s = 0.0f;
-#pragma unroll
-                    for (int p = 0; p < 8; p++) {
-                        const float sp = p == 0 ? 0.0f : __int_as_float(D1_DPP(__float_as_int(s), D1_ROW_SHR(1)));
-                        if (pr == p) s = (((sp + m0) + m1) + m2) + m3;
-                    }
-                    sc = nh_total > 0 ? s : miss;
+                    for (int e = 0; e < 4; e++) acc[e] = d1_pk_max(acc[e], (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc[e], D1_ROW_ROR(4), 0xF, 0xF, false));
                 }
-                // the finished score sits in lane (IMG: 0, EXACT: 7) of each candidate's lanes: hand it to lane j of the group
+                if (HPI >= 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[e] = d1_pk_max(acc[e], (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc[e], D1_ROW_ROR(8), 0xF, 0xF, false));
+                }
+                if (HPI >= 8) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[e] = d1_pk_max(acc[e], (uint32_t)__shfl_xor((int)acc[e], 16, 64));
+                }
+                const bool nohit = (acc[0] & 0xffffu) == 0xFC00u;   // a real row is finite: -inf = only padding rows were folded
+                float s = 0.0f;
+                if (nqc == 32) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const d1h2 h = __builtin_bit_cast(d1h2, acc[e]);
+                        s += (float)h.x;
+                        s += (float)h.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const d1h2 h = __builtin_bit_cast(d1h2, acc[e]);
+                        const int k0 = pr * 8 + 2 * e;
+                        s += k0 < nqc ? (float)h.x : 0.0f;
+                        s += k0 + 1 < nqc ? (float)h.y : 0.0f;
+                    }
+                }
+                s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false));
+                s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false));
+                const float sc = nohit ? miss : s;
+                // the finished score sits in lane 0 of each candidate's lanes: hand it to lane j of the group
 #pragma unroll
                 for (int u = 0; u < R; u++) {
-                    const int v = __builtin_amdgcn_readlane(__float_as_int(sc), u * LPC + (IMG ? 0 : 7));
+                    const int v = __builtin_amdgcn_readlane(__float_as_int(sc), u * LPC);
                     const int dst = __builtin_amdgcn_readfirstlane(r * R + u);
                     // (no builtin for v_writelane in this toolchain; the s_nop covers the SGPR hazards the compiler cannot see)
                     asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(ukeep) : "s"(v), "s"(dst) : "m0");
@@ -449,9 +389,6 @@ __global__ __launch_bounds__(D1_THREADS) void s1_dense_kernel(flmr_s1d_args a) {
                 round(cdA, lenA, r);
                 if (r + 1 < nrounds) round(cdB, lenB, r + 1);
             }
-            // (the requests past the group's end must have landed before their registers mean anything else to the compiler)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("" : "+v"(cdA), "+v"(cdB) : : "memory");
             if (lane < ndoc) keys_b[g * gsz + lane] = flmr_make_key(ukeep, pid);
             pid = npid; off = noff; len = nlen;
         }
@@ -742,6 +679,11 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
     }
 }
 
+// (lanes per candidate, codes per lane) by the index's usual number of distinct codes per passage
+static void d1_shape(double mean_codes, int* lpc, int* cpl) {
+    *lpc = mean_codes > 144.0 ? 32 : 16;
+    *cpl = mean_codes > 72.0 ? 8 : 4;
+}
 static size_t d1x_lds(int nqueries, int idx_words, int lpc, int cpl) {
     return (size_t)((nqueries + 3) & ~3) * 4 + (size_t)idx_words * 4 + (size_t)((idx_words + 7) & ~7) * 2 +
            (size_t)D1_WAVES * (64 / lpc) * (lpc * cpl) * 2 + (size_t)D1_WAVES * D1X_GROUP * D1X_TRS * 4;
@@ -750,7 +692,8 @@ static size_t d1x_lds(int nqueries, int idx_words, int lpc, int cpl) {
 // the exact pass: (lanes per candidate, codes per lane) by the index's usual number of distinct codes per passage
 int flmr_launch_s1_exact(const flmr_s1d_args& a_in, double mean_codes, hipStream_t st) {
     flmr_s1d_args a = a_in;
-    const int lpc = mean_codes <= 144.0 ? 16 : 32, cpl = mean_codes <= 72.0 ? 4 : 8;
+    int lpc, cpl;
+    d1_shape(mean_codes, &lpc, &cpl);
     const size_t lds = d1x_lds(a.nqueries, a.idx_words, lpc, cpl);
     if (lds > (size_t)160 * 1024 - 1024) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "dense stage 1: K = %d does not fit the LDS form", a.idx_words * 32);
     if (a.codes_len > 0xffffffffLL) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "dense stage 1: token offsets beyond 32 bits");
@@ -770,46 +713,41 @@ int flmr_launch_s1_exact(const flmr_s1d_args& a_in, double mean_codes, hipStream
     return FLMR_OK;
 }
 
-// LDS the launch needs besides the images; rows of images that fit beside it
-static size_t d1_fixed_lds(int nqueries, int idx_words, int lpc) {
+// LDS the image launch needs besides the images; rows of images that fit beside it
+static size_t d1_fixed_lds(int nqueries, int idx_words, int lpc, int cpl) {
     return (size_t)((nqueries + 3) & ~3) * 4 + (size_t)idx_words * 4 + (size_t)((idx_words + 7) & ~7) * 2 +
-           (size_t)D1_WAVES * ((64 / lpc) * (lpc * 4) + 64) * 2;
+           (size_t)D1_WAVES * ((64 / lpc) * (lpc * cpl) + 64) * 2;
 }
-int flmr_s1_dense_image_rows(int nqueries, int idx_words, int lpc) {
+int flmr_s1_dense_image_rows(int nqueries, int idx_words, double mean_codes) {
+    int lpc, cpl;
+    d1_shape(mean_codes, &lpc, &cpl);
     const size_t budget = (size_t)160 * 1024 - 1024;   // static __shared__ of the kernel and alignment
-    const size_t fixed = d1_fixed_lds(nqueries, idx_words, lpc);
-    if (fixed + 64 * 65 > budget) return 0;
+    const size_t fixed = d1_fixed_lds(nqueries, idx_words, lpc, cpl);
+    if (fixed + 64 * 65 > budget || d1x_lds(nqueries, idx_words, lpc, cpl) > budget) return 0;
     const size_t rows = (budget - fixed) / 64 - 1;   // (+ the padding row)
     return (int)(rows > 65000 ? 65000 : rows);
 }
 
-// lpc: 16 or 32 lanes per candidate (the index's choice: 4 x lpc >= the usual number of distinct codes of a passage)
-int flmr_launch_s1_dense(const flmr_s1d_args& a_in, bool img_pass, int lpc, hipStream_t st) {
+int flmr_launch_s1_image(const flmr_s1d_args& a_in, double mean_codes, hipStream_t st) {
     flmr_s1d_args a = a_in;
-    size_t lds = d1_fixed_lds(a.nqueries, a.idx_words, lpc);
-    if (img_pass) {
-        a.img_rows = flmr_s1_dense_image_rows(a.nqueries, a.idx_words, lpc);
-        if (a.img_rows < 1) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "dense stage 1: the centroid mask leaves no room for score-row images in LDS");
-        lds += (size_t)(a.img_rows + 1) * 64;
-    }
-    if (lds > (size_t)160 * 1024) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "dense stage 1: K = %d does not fit the LDS form", a.idx_words * 32);
-    const void* fn = img_pass ? (lpc == 16 ? reinterpret_cast<const void*>(s1_dense_kernel<true, 16>) : reinterpret_cast<const void*>(s1_dense_kernel<true, 32>))
-                              : (lpc == 16 ? reinterpret_cast<const void*>(s1_dense_kernel<false, 16>) : reinterpret_cast<const void*>(s1_dense_kernel<false, 32>));
-    if (lds > 48 * 1024) FLMR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (a.parts < 1) a.parts = img_pass ? 4 : 8;
-    if (a.group != 16) a.group = 64;
+    int lpc, cpl;
+    d1_shape(mean_codes, &lpc, &cpl);
+    a.img_rows = flmr_s1_dense_image_rows(a.nqueries, a.idx_words, mean_codes);
+    if (a.img_rows < 1) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "dense stage 1: the centroid mask leaves no room for score-row images in LDS");
+    const size_t lds = d1_fixed_lds(a.nqueries, a.idx_words, lpc, cpl) + (size_t)(a.img_rows + 1) * 64;
     if (a.codes_len > 0xffffffffLL) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "dense stage 1: token offsets beyond 32 bits");
+    if (a.parts < 1) a.parts = 4;
     int64_t grid = 256;   // one persistent workgroup per CU; a multiple of 8 so that workgroup L and its items share L % 8
     const int64_t max_items = (int64_t)((a.nqueries + D1_XCDS - 1) & ~(D1_XCDS - 1)) * a.parts;
     if (grid > max_items) grid = max_items;
     dim3 g((unsigned)grid), block(D1_THREADS);
-    if (img_pass) {
-        if (lpc == 16) hipLaunchKernelGGL((s1_dense_kernel<true, 16>), g, block, lds, st, a);
-        else hipLaunchKernelGGL((s1_dense_kernel<true, 32>), g, block, lds, st, a);
-    } else {
-        if (lpc == 16) hipLaunchKernelGGL((s1_dense_kernel<false, 16>), g, block, lds, st, a);
-        else hipLaunchKernelGGL((s1_dense_kernel<false, 32>), g, block, lds, st, a);
-    }
+#define D1I_LAUNCH(L, C) do { \
+        if (lds > 48 * 1024) FLMR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s1_image_kernel<L, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((s1_image_kernel<L, C>), g, block, lds, st, a); } while (0)
+    if (lpc == 16 && cpl == 4) D1I_LAUNCH(16, 4);
+    else if (lpc == 16) D1I_LAUNCH(16, 8);
+    else D1I_LAUNCH(32, 8);
+#undef D1I_LAUNCH
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }
