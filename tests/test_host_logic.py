@@ -414,3 +414,56 @@ def test_ranking_lists_layout():
         assert list(d) == qids and d["q0"] is rows[0] and d["q0"] == want[0]
         assert r.tolist() == [(q, *t) for q, w in zip(qids, want) for t in w]
         assert isinstance(r, Ranking) and cls.__name__ == "Ranking"
+
+
+def test_score_reduce_interactions_and_l2_on_the_host():
+    """`scoring.colbert_score_reduce` over an already computed [B, Ld, Nq] score tensor is plain torch (no device needed): the 'colbert'
+    sum and the 'flipr' top-k sums of TPC/modeling/colbert.py:235-263 -- against the reference's own function when the checkout is here
+    (build container), else against its restated expression -- and FLMRModelForRetrieval.score with similarity == 'l2' (colbert.py:220-222)."""
+    import sys
+    from types import SimpleNamespace
+    from ravqa_amd import scoring
+    from ravqa_amd.flmr import FLMRModelForRetrieval
+    g = torch.Generator().manual_seed(3)
+    B, Ld, Nq = 11, 19, 80
+    scores = torch.randn(B, Ld, Nq, generator=g)
+    mask = torch.rand(B, Ld, generator=g) < 0.8
+    mask[:, 0] = True
+
+    def restated(sc, m, cfg):
+        sc = sc.clone()
+        sc[~m] = -9999
+        cm = sc.max(1).values
+        if cfg.interaction == "flipr":
+            out = cm[:, :64].topk(32, dim=-1).values.sum(-1)
+            if 8 <= cm.size(1) - 64:
+                out = out + cm[:, 64:].topk(8, dim=-1).values.sum(1)
+            return out
+        return cm.sum(-1)
+
+    ref_fn = None
+    ref_root = os.path.join(os.environ.get("FLMR_REFERENCE_ROOT", "/root/reference"), "third_party", "ColBERT")
+    if os.path.isdir(ref_root):
+        try:   # the reference's own function (imports its package: build container only; any failure leaves the restated expression)
+            sys.path.insert(0, os.path.join(ROOT, "tests", "golden", "_shims"))
+            sys.path.insert(0, ref_root)
+            import transformers
+            if not hasattr(transformers, "AdamW"):
+                transformers.AdamW = torch.optim.AdamW
+            from colbert.modeling.colbert import colbert_score_reduce as ref_fn   # noqa: F811
+        except Exception:  # noqa: BLE001
+            ref_fn = None
+        finally:
+            sys.path[:] = [p for p in sys.path if p not in (ref_root, os.path.join(ROOT, "tests", "golden", "_shims"))]
+    for nq in (80, 64, 70):
+        for cfg in (SimpleNamespace(interaction="flipr", query_maxlen=64), SimpleNamespace(interaction="colbert", query_maxlen=64)):
+            got = scoring.colbert_score_reduce(scores[:, :, :nq].clone(), mask.unsqueeze(-1), cfg)
+            assert torch.equal(got, restated(scores[:, :, :nq], mask, cfg)), (nq, cfg.interaction)
+            if ref_fn is not None:
+                assert torch.equal(got, ref_fn(scores[:, :, :nq].clone(), mask.unsqueeze(-1), cfg)), (nq, cfg.interaction)
+    # l2 similarity: the reference's torch expression, no kernel
+    model = FLMRModelForRetrieval(text_encoder=None, colbert_config=SimpleNamespace(similarity="l2", interaction="colbert"), device="cpu")
+    Q = torch.randn(B, 7, 16, generator=g)
+    D = torch.randn(B, Ld, 16, generator=g)
+    want = (-1.0 * ((Q.unsqueeze(2) - D.unsqueeze(1)) ** 2).sum(-1)).max(-1).values.sum(-1)
+    assert torch.equal(model.score(Q, D, mask), want)
