@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 F16_MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA peak (no sparsity)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05", "pmc_summary.csv")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r06", "pmc_summary.csv")
 
 
 def parse():
@@ -477,7 +477,7 @@ def main():
                 "frac": dom["mfma_frac"] if mfma_bound else dom["hbm_frac"], "traffic": dom.get("traffic"),
                 "peak_measured": {"hbm_copy_GBs": copy_gbs, "note": "device-to-device copy (read + write) measured in this run; the spec "
                                   "figure above is what `frac` is priced against"},
-                "traffic_source": ("static: profiles/r05/pmc_summary.csv (rocprofv3 --pmc of this workload, 2*FETCH_SIZE + "
+                "traffic_source": ("static: profiles/r06/pmc_summary.csv (rocprofv3 --pmc of this workload, 2*FETCH_SIZE + "
                                    "WRITE_SIZE, bytes per launch x launches per step; not measured in this run)") if dom.get("traffic") else None,
                 "launch_ms": dom["launch_ms"],
                 "note": ("achieved = the kernel's own compulsory bytes (or split-MFMA flops) per step / its HIP-event time per step "
@@ -640,7 +640,49 @@ def main():
     if rank == 0 and not use_dist and not args.no_extras:
         subs = []
 
-        def sub(name, sc, batches, targets, kk, note, pol=None):
+        def sub_roofline(sc, st_, pol, nq_full, nbits_, queries_per_step):
+            """The dominant stage of a sub-result against its roof, from ITS workload: candidates / surviving centroids read off the
+            searcher's taps after the run, the same per-stage models as the headline's (compulsory bytes, executed fp16 products)."""
+            try:
+                if not st_:
+                    return None
+                stage = max(st_, key=st_.get)
+                t_s = st_[stage] * 1e-3
+                info = sc.device_index.info()
+                mean_len_ = sc.arrays.num_embeddings / max(1, sc.arrays.num_passages)
+                K_ = sc.arrays.num_centroids
+                codes_pp = mean_len_ * (1.0 - info.get("duplicate_permille", 0) / 1000.0 if info.get("duplicate_permille", 0) >= 100 else 1.0)
+                P_ = [len(sc.tap(_native.TAP_CANDIDATES, q)) for q in range(0, 32, 8)]
+                ns_ = [sum(bin(int(x)).count("1") for x in sc.tap(_native.TAP_IDX_BITS, q)) for q in range(0, 32, 8)]
+                P_m, ns_m = sum(P_) / len(P_), sum(ns_) / len(ns_)
+                nd_ = pol[2]
+                B_ = 128 * nbits_ // 8
+                nqc_ = min(nq_full, 32)
+                bytes_ = {"s0_centroid_scores": 4 * 128 * K_ / queries_per_step + 2 * 2 * 128 * nqc_,
+                          "s1_filter": 4 * P_m * codes_pp + 128 * ns_m + 8 * P_m,                      # the candidates' (distinct) codes, the surviving rows, the keys
+                          "s2_filter_sort": 4 * nd_ * codes_pp + 16 * nd_,
+                          "s3_maxsim": (4 + B_) * (nd_ // 4) * mean_len_ + 2 * 2 * 128 * nq_full}
+                flops_ = {"s0_centroid_scores": 2.0 * 1.02 * K_ * 128 * nqc_,
+                          "s2_filter_sort": 2.0 * 1.1 * nd_ * codes_pp * 128 * nqc_,
+                          "s3_maxsim": (5.0 if nq_full <= 32 else 3.0) * 2 * (nd_ // 4) * mean_len_ * 128 * nq_full}
+                r = {"kernel": stage, "launch_ms": st_[stage], "candidates_per_query": P_m, "surviving_centroids_per_query": ns_m,
+                     "codes_per_passage": codes_pp}
+                if bytes_.get(stage):
+                    r["hbm_GBs"] = bytes_[stage] * queries_per_step / t_s / 1e9
+                    r["hbm_frac"] = r["hbm_GBs"] / HBM_PEAK_GBS
+                if stage in flops_:
+                    r["TFLOPs"] = flops_[stage] * queries_per_step / t_s / 1e12
+                    r["mfma_frac"] = r["TFLOPs"] / F16_MFMA_PEAK_TFLOPS
+                mf, hf = r.get("mfma_frac", 0.0), r.get("hbm_frac", 0.0)
+                r.update({"bound": "mfma" if mf > hf else "hbm", "frac": max(mf, hf)})
+                if stage == "s1_filter":
+                    r["note"] = ("compulsory bytes (the candidates' distinct codes + the surviving rows) against HBM; the dense stage-1 kernels are VALU-issue-bound, "
+                                 "not bandwidth-bound (profiles/r06/sub/pmc_*_summary.csv: SQ_INSTS_VALU x 4 clocks over 1024 SIMDs = 70 % of the launch)")
+                return r
+            except Exception as e:  # noqa: BLE001
+                return {"failed": repr(e)}
+
+        def sub(name, sc, batches, targets, kk, note, pol=None, nbits_=None):
             try:
                 pol = pol or k_policy(kk)
                 dt_, _, rec, _ = timed(sc, batches, targets, kk, pol, 6, 2, collect_stages=False)
@@ -648,7 +690,8 @@ def main():
                 if not use_dist:   # the stage split of this shape, from a separate instrumented pass
                     _, st_, _, _ = timed(sc, batches, targets, kk, pol, 2, 0, collect_stages=True)
                 subs.append({"name": name, "value": args.batch * 6 / dt_, "unit": "queries/sec", "ms_per_step": dt_ / 6 * 1e3,
-                             "recall_at_5": rec, "stage_ms_per_step": {n_: round(v_, 3) for n_, v_ in st_.items()}, "note": note})
+                             "recall_at_5": rec, "stage_ms_per_step": {n_: round(v_, 3) for n_, v_ in st_.items()},
+                             "roofline": sub_roofline(sc, st_, pol, int(batches[0].size(1)), nbits_ or args.nbits, args.batch), "note": note})
             except Exception as e:
                 subs.append({"name": name, "value": None, "note": f"failed: {e!r}"})
 
@@ -846,7 +889,7 @@ def main():
                                  "parity": sr.get("parity"),
                                  "ms_per_step": sr["ms_per_step"], "recall_at_5": sr["recall_at_5"], "stage_ms_per_step": sr["stage_ms"],
                                  "surviving_centroids_per_query": sr["surviving_centroids"], "candidates_per_query": sr["candidates"],
-                                 "stage1_forms_of_256": sr.get("stage1_forms_of_256"), "index_info": sr.get("index_info"), "index_build": rec,
+                                 "stage1_forms_of_256": sr.get("stage1_forms_of_256"), "index_info": sr.get("index_info"), "roofline": sr.get("roofline"), "index_build": rec,
                                  "note": f"1 M passages x 128 raw token embeddings ({topics} topics; a token = a topic direction + a finer direction + "
                                          "noise, three topics per passage) indexed end to end on the device by indexing.build_index (k-means with "
                                          "the HIP argmax as its assignment step, compression, IVF by flmr_build_ivf), then searched with planted queries"})

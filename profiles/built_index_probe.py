@@ -111,6 +111,26 @@ def run(P=1_000_000, L=128, nbits=2, NT=256, policies=((2, 0.45, 1024, 100), (2,
                                                            "small_dense": forms.count(3), "slot_after_small_dense": forms.count(4),
                                                            "dense_image": forms.count(5), "dense_exact": forms.count(6), "recompute": forms.count(7)},
                                    "index_info": scorer.device_index.info()}
+        # the dominant stage against its roof (the same per-stage models as bench.py's headline: compulsory bytes / executed fp16 products)
+        info = scorer.device_index.info()
+        dup = info.get("duplicate_permille", 0) / 1000.0
+        codes_pp = L * (1.0 - dup) if dup >= 0.1 else float(L)
+        dom = max(st, key=st.get)
+        P_m, ns_m = sum(ncand) / len(ncand), sum(surv) / len(surv)
+        model_bytes = {"s1_filter": 4 * P_m * codes_pp + 128 * ns_m + 8 * P_m, "s2_filter_sort": 4 * ndocs * codes_pp + 16 * ndocs,
+                       "s3_maxsim": (4 + 128 * nbits // 8) * (ndocs // 4) * L, "s0_centroid_scores": 4 * 128 * K / nqr}
+        model_flops = {"s0_centroid_scores": 2.0 * 1.02 * K * 128 * 32, "s2_filter_sort": 2.0 * 1.1 * ndocs * codes_pp * 128 * 32,
+                       "s3_maxsim": 5.0 * 2 * (ndocs // 4) * L * 128 * 32}
+        roof = {"kernel": dom, "launch_ms": st[dom], "codes_per_passage": codes_pp}
+        if dom in model_bytes:
+            roof["hbm_GBs"] = model_bytes[dom] * nqr / (st[dom] * 1e-3) / 1e9
+            roof["hbm_frac"] = roof["hbm_GBs"] / 8000.0
+        if dom in model_flops:
+            roof["TFLOPs"] = model_flops[dom] * nqr / (st[dom] * 1e-3) / 1e12
+            roof["mfma_frac"] = roof["TFLOPs"] / 2500.0
+        roof["bound"] = "mfma" if roof.get("mfma_frac", 0.0) > roof.get("hbm_frac", 0.0) else "hbm"
+        roof["frac"] = max(roof.get("mfma_frac", 0.0), roof.get("hbm_frac", 0.0))
+        out[f"search_thr{thr}"]["roofline"] = roof
         if parity_queries:
             out[f"search_thr{thr}"]["parity"] = parity_vs_reference(arrays, scorer, Qs[0][:parity_queries], ncells, thr, ndocs)
     del scorer, arrays
