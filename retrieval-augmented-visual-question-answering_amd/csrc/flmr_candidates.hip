@@ -69,11 +69,12 @@ __global__ __launch_bounds__(1024) void qualifying_kernel(const uint32_t* idx_bi
                                                           int32_t* key_count, int ratio, uint32_t* idx_prefix,
                                                           float* rows_out, const _Float16* __restrict__ cen16,
                                                           const _Float16* __restrict__ q_hi, const _Float16* __restrict__ q_lo,
-                                                          int32_t* row_ovf, int32_t* fast_state) {
+                                                          int32_t* row_ovf, int32_t* fast_state, int32_t* any_zero) {
     __shared__ int scan_lds[17];
     __shared__ unsigned long long tot_q, tot_c;
     const int b = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) { tot_q = 0ull; tot_c = 0ull; }
+    if (b == 0 && tid == 0 && any_zero) { any_zero[0] = 0; any_zero[1] = 0; }   // (cand_plan_kernel, a later launch, ORs into them)
     __syncthreads();
     int base = 0;
     unsigned long long mylen = 0;
@@ -221,6 +222,18 @@ __global__ __launch_bounds__(64 * PLAN_WAVES) void cand_plan_kernel(flmr_cand_ar
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nl = a.ncell[b], nq = a.nqual[b];
     int32_t* const plan = a.fast_state + FLMR_FAST_HDR + b;
+    if (a.s1d_mode && tid == 0) {   // which dense form takes the query, if any (= s1_dense_modes_kernel: one launch less per batch)
+        int m = 0 /* FLMR_S1D_SKIP */, sk = 1;
+        if (!a.hit_valid[b] && !(a.row_ovf && a.row_ovf[b])) {
+            if (nq <= a.s1d_img_rows) m = 1 /* FLMR_S1D_IMAGE */;
+            else if (a.s1d_exact_too) m = 2 /* FLMR_S1D_EXACT */;
+            else sk = 0;   // the scan takes the query
+        }
+        a.s1d_mode[b] = m;
+        a.s1d_scan_skip[b] = sk;
+        if (m == 1) atomicOr(a.s1d_any + 0, 1);
+        if (m != 0) atomicOr(a.s1d_any + 1, 1);
+    }
     if (!a.hit_valid[b] || nl > 512 || nq > 512) {   // (block-uniform) not a list-scatter query / more lists than the fast forms index
         if (tid == 0) *plan = 1;
         return;
@@ -1620,7 +1633,7 @@ __global__ __launch_bounds__(1024) void cand_emit_kernel(const uint32_t* cand_bi
 int flmr_launch_qualifying(const flmr_cand_args& a, hipStream_t st) {
     hipLaunchKernelGGL(qualifying_kernel, dim3(a.nqueries), dim3(1024), 0, st, a.idx_bits, a.idx_words, a.ivf_offsets, a.cells,
                        a.ncell, a.max_cells, a.qual, a.nqual, a.qmax, 1 << S1S_IDBITS, a.hit_valid, nullptr, 2, a.idx_prefix, a.rows_out,
-                       a.cen16, a.q_hi, a.q_lo, a.row_ovf, nullptr);
+                       a.cen16, a.q_hi, a.q_lo, a.row_ovf, nullptr, nullptr);
     FLMR_LAUNCH_CHECK();
     return FLMR_OK;
 }
@@ -1628,7 +1641,8 @@ int flmr_launch_qualifying(const flmr_cand_args& a, hipStream_t st) {
 int flmr_launch_candidates_chunked(const flmr_cand_args& a, hipStream_t st) {
     hipLaunchKernelGGL(qualifying_kernel, dim3(a.nqueries), dim3(1024), 0, st, a.idx_bits, a.idx_words, a.ivf_offsets, a.cells,
                        a.ncell, a.max_cells, a.qual, a.nqual, a.qmax, 1 << S1S_IDBITS, a.hit_valid, a.scatter ? a.key_count : nullptr,
-                       a.scatter ? 8 : 2, a.idx_prefix, a.rows_out, a.cen16, a.q_hi, a.q_lo, a.row_ovf, a.scatter ? a.fast_state : nullptr);
+                       a.scatter ? 8 : 2, a.idx_prefix, a.rows_out, a.cen16, a.q_hi, a.q_lo, a.row_ovf, a.scatter ? a.fast_state : nullptr,
+                       (a.scatter && a.fast_state && a.s1d_mode) ? a.s1d_any : nullptr);
     if (a.scatter) {
         const size_t lds = (size_t)CAND_CHUNK_WORDS * (2 * sizeof(uint32_t) + 2 * sizeof(uint16_t)) +
                            ((size_t)S1S_SLOTS * S1S_STRIDE + 96 + 1024 + S1S_QCAP) * sizeof(int) + S1S_QCAP * sizeof(uint16_t);   // + scratch words of slot-less lanes, list constants, queue (+ its passages)

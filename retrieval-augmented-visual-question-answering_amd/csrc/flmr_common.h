@@ -238,6 +238,9 @@ struct flmr_cand_args {
     // form after the queue / small-dense form ran into a limit, 3 = done by the small-dense form), and [B + b] the fast forms' own key
     // counter.  Nothing in it outlives the batch.  NULL: slot kernel only (FLMR_S1_IMPL=slots)
     int32_t* fast_state;
+    // which queries the dense stage-1 forms take (flmr_launch_s1_dense_modes' outputs), written by cand_plan_kernel when it runs -- one
+    // launch less per batch; s1d_mode == NULL: not fused
+    int32_t* s1d_mode; int32_t* s1d_scan_skip; int32_t* s1d_any; int32_t s1d_img_rows, s1d_exact_too;
     int32_t* row_ovf;   // [nqueries] out: 1 = the query has more surviving centroids than compact score rows (qmax): its stage 1 is
                         // recomputed from the fp16 centroids (flmr_launch_filter_stage1_recompute); NULL on the full-table path
 };

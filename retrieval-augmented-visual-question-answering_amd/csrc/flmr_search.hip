@@ -524,6 +524,11 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
     const bool use_hits = !s->opt.has(FLMR_OPT_S1_NO_HITMAP);
     bool scatter = false;
     s->last_scatter = false;
+    // the dense stage-1 forms (flmr_stage1_dense.hip) need the sparse path, one column tile and the CPU-path numerics
+    const bool dense = s->s1d_img_rows > 0 && chunked && c.sparse && c.ncol == 32 && !c.f.f16_round && !s->opt.is(FLMR_OPT_S1_IMPL, "scan");
+    s->last_dense = dense;
+    const int32_t* sel_counts = s->cand_count;
+    bool modes_fused = false;
     flmr_cand_args ca{};
     {
         ca.nqueries = c.nqueries; ca.idx_words = s->idx_words; ca.max_cells = s->max_cells; ca.qmax = s->qmax;
@@ -537,6 +542,7 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
         // FLMR_S1_IMPL=scan keeps the code-scanning kernel for every query (A/B runs, cross-check tests)
         scatter = chunked && use_hits && c.ncol == 32 && !s->opt.is(FLMR_OPT_S1_IMPL, "scan");
         ca.scatter = scatter ? 1 : 0;
+        modes_fused = scatter && !s->opt.is(FLMR_OPT_S1_IMPL, "slots");   // (cand_plan_kernel runs)
         ca.cs = c.f.cs; ca.cs_query_stride = c.f.cs_query_stride; ca.nq_cand = c.nqc; ca.q_lens = c.q_lens;
         ca.cs_compact = c.f.cs_compact; ca.idx_prefix = s->idx_prefix;
         ca.rows_out = c.sparse ? s->rows : nullptr; ca.cen16 = ix->centroids_f16; ca.q_hi = s->q_hi; ca.q_lo = s->q_lo;
@@ -544,6 +550,13 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
         ca.f16_round = c.f.f16_round;
         ca.fast_state = s->opt.is(FLMR_OPT_S1_IMPL, "slots") ? nullptr : s->cand_fast;
         ca.row_ovf = s->row_ovf;
+        // who takes which query afterwards: the list-scatter forms (hit_valid), the dense forms, the recompute form (row_ovf), the scan
+        // (the rest); decided per query by cand_plan_kernel when it runs, else by flmr_launch_s1_dense_modes below
+        if (modes_fused) {
+            ca.s1d_mode = s->s1d_mode; ca.s1d_scan_skip = s->s1d_scan_skip; ca.s1d_any = s->s1d_any;
+            ca.s1d_img_rows = dense ? s->s1d_img_rows : 0;
+            ca.s1d_exact_too = (dense && !s->opt.is(FLMR_OPT_S1_IMPL, "image")) ? 1 : 0;
+        }
     }
     if (chunked) {
         RUN(flmr_launch_candidates_chunked(ca, st));
@@ -566,13 +579,10 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
     // the dense forms of flmr_stage1_dense.hip -- fp16 images of the query's score rows in LDS, upper-bound keys for every
     // candidate, the band around the cut rescored exactly -- where the rows fit (<= ~2 k survivors), the same kernel's exact form
     // beyond; the round-5 scan keeps the cases those do not cover (several column tiles, the fp16 numerics mode, no sorted copy).
-    const bool dense = s->s1d_img_rows > 0 && chunked && c.sparse && c.ncol == 32 && !c.f.f16_round && !s->opt.is(FLMR_OPT_S1_IMPL, "scan");
-    const int32_t* sel_counts = s->cand_count;
-    s->last_dense = dense;
-    // who takes which query: the list-scatter forms (hit_valid), the dense forms, the recompute form (row_ovf), the scan (the rest)
     const bool exact_too = dense && !s->opt.is(FLMR_OPT_S1_IMPL, "image");   // (development: "image" leaves the queries beyond the images to the scan)
-    RUN(flmr_launch_s1_dense_modes(scatter ? s->hit_valid : nullptr, s->nqual, s->row_ovf, c.nqueries, dense ? s->s1d_img_rows : 0,
-                                   exact_too ? 1 : 0, s->s1d_mode, s->s1d_scan_skip, s->s1d_any, st));
+    if (!modes_fused)
+        RUN(flmr_launch_s1_dense_modes(scatter ? s->hit_valid : nullptr, s->nqual, s->row_ovf, c.nqueries, dense ? s->s1d_img_rows : 0,
+                                       exact_too ? 1 : 0, s->s1d_mode, s->s1d_scan_skip, s->s1d_any, st));
     const int32_t* scan_skip = s->s1d_scan_skip;
     if (dense) {
         flmr_s1d_args d{};
@@ -589,12 +599,13 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
         RUN(flmr_launch_s1_exact(d, ix->mean_ulen, st));
         sel_counts = s->s1d_in_count;
     }
-    if (c.sparse)   // (a query over the score-row capacity; leaves at once when there is none)
+    if (c.sparse && s->row_cap < ix->K)   // (a query over the score-row capacity; leaves at once when there is none)
         RUN(flmr_launch_filter_stage1_recompute(c.f, s->idx_bits, s->idx_words, s->cand, s->cand_cap, s->cand_count, s->row_ovf, s->keys1,
                                                 ix->centroids_f16, s->q_hi, s->q_lo, st));
-    RUN(flmr_launch_filter_stage1(c.f, s->idx_bits, s->idx_words, s->cand, s->cand_cap, s->cand_count, s->keys1,
-                                  (use_hits && !chunked) ? s->hit_bits : nullptr, s->bitmap_words, use_hits ? s->hit_valid : nullptr,
-                                  (use_hits && chunked) ? s->cand_hit : nullptr, st, scan_skip));
+    if (!(dense && exact_too))   // (with both dense forms on, every query the list scatter leaves is theirs or the recompute form's: nothing to scan)
+        RUN(flmr_launch_filter_stage1(c.f, s->idx_bits, s->idx_words, s->cand, s->cand_cap, s->cand_count, s->keys1,
+                                      (use_hits && !chunked) ? s->hit_bits : nullptr, s->bitmap_words, use_hits ? s->hit_valid : nullptr,
+                                      (use_hits && chunked) ? s->cand_hit : nullptr, st, scan_skip));
     RUN(mark(c));
     RUN(flmr_launch_select_topn(s->keys1, s->cand_cap, sel_counts, c.nqueries, c.p.ndocs, s->s1_pids, s->maxp.ndocs,
                                 s->s1_count, st, out_keys, (uint64_t)ix->pid_base));
