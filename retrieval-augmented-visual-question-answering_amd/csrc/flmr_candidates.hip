@@ -74,7 +74,8 @@ __global__ __launch_bounds__(1024) void qualifying_kernel(const uint32_t* idx_bi
     __shared__ unsigned long long tot_q, tot_c;
     const int b = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) { tot_q = 0ull; tot_c = 0ull; }
-    if (b == 0 && tid == 0 && any_zero) { any_zero[0] = 0; any_zero[1] = 0; }   // (cand_plan_kernel, a later launch, ORs into them)
+    // (cand_plan_kernel, a later launch, ORs into [0] and [1]; [2 .. 9] are the exact pass's item counters, one per XCD)
+    if (b == 0 && tid < 16 && any_zero) any_zero[tid] = 0;
     __syncthreads();
     int base = 0;
     unsigned long long mylen = 0;

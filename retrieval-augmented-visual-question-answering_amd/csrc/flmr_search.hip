@@ -172,7 +172,7 @@ extern "C" int flmr_searcher_create(const flmr_index_t* ix, int32_t max_queries,
     WS(cand_hit, B * (size_t)s->cand_cap);
     // dense stage 1: needs the sorted code copy (whole 16-byte pieces are read: its padding) and 32-bit token offsets
     s->s1d_img_rows = (ix->codes_sorted && s->ncol_max == 32 && !s->opt.is(FLMR_OPT_S1_IMPL, "scan")) ? flmr_s1_dense_image_rows(max_queries, s->idx_words, ix->mean_ulen) : 0;
-    WS(s1d_any, 2); WS(s1d_mode, B); WS(s1d_band_count, B); WS(s1d_err, B); WS(s1d_in_count, B); WS(s1d_scan_skip, B); WS(row_ovf, B);
+    WS(s1d_any, 16); WS(s1d_mode, B); WS(s1d_band_count, B); WS(s1d_err, B); WS(s1d_in_count, B); WS(s1d_scan_skip, B); WS(row_ovf, B);
     if (s->s1d_img_rows > 0) WS(s1d_band, B * (size_t)s->cand_cap);
     WS(q3_hi, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
     WS(q3_lo, B * (size_t)flmr_round_up(max_nq, 32) * FLMR_DIM);
@@ -595,7 +595,9 @@ static int stage_cand_s1(run_ctx& c, uint64_t* out_keys) {
         RUN(flmr_launch_s1_image(d, ix->mean_ulen, st));
         RUN(flmr_launch_s1_band(s->keys1, s->cand_cap, s->cand_count, s->s1d_mode, s->s1d_err, c.nqueries, c.p.ndocs, s->s1d_band,
                                 s->s1d_band_count, s->s1d_in_count, st));
-        d.parts = 4; d.group = 0;   // (groups of 16 candidates for a band, 32 for a whole list: the kernel's choice per query)
+        // (16 parts a query: 2 queries' rows per XCD at a time stay in its L2 -- profiles/r06/s1_dense_probe_v5.txt; groups of 16
+        // candidates for a band, 32 for a whole list: the kernel's choice per query)
+        d.parts = 16; d.group = 0;
         RUN(flmr_launch_s1_exact(d, ix->mean_ulen, st));
         sel_counts = s->s1d_in_count;
     }

@@ -87,6 +87,27 @@ __device__ __forceinline__ uint32_t d1_row_addr(uint32_t q, int hi, uint32_t bas
     return r;
 }
 
+// byte offset of fp32 row `id` (the low / high half of q) from the query's rows: 128 * id + base
+__device__ __forceinline__ uint32_t d1x_row_off(uint32_t q, int hi, uint32_t base) {
+    uint32_t r;
+    const uint32_t rb = 128u;   // (no literal operand in a VOP3 of this family)
+    if (hi) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(q), "s"(rb), "v"(base));
+    else asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(q), "s"(rb), "v"(base));
+    return r;
+}
+// (written as the instructions: the builtin maximum first canonicalises operands it cannot prove canonical -- a v_max x, x each)
+__device__ __forceinline__ float d1_fmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float d1_fmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// the hit bits of a lane's codes, one per step: bit 0 of x enters at the top of hm (after CPL steps: hm >> (32 - CPL))
+__device__ __forceinline__ uint32_t d1_push_bit(uint32_t hm, uint32_t x) { return __builtin_amdgcn_alignbit(x, hm, 1); }
 
 // ---- the image form -----------------------------------------------------------------------------------------------------
 // LPC lanes per candidate x CPL codes per lane (16 x 4, 16 x 8 or 32 x 8 by the index's usual number of distinct codes per passage).
@@ -258,12 +279,12 @@ __global__ __launch_bounds__(D1_THREADS) void s1_image_kernel(flmr_s1d_args a) {
                     nv = nv < 0 ? 0 : (nv > CPL ? CPL : nv);
                     uint32_t wd[CPL], wi[CPL], hm = 0u;
 #pragma unroll
-                    for (int e = 0; e < CPL; e++) {
-                        wi[e] = min((uint32_t)c_[e] >> 5, (uint32_t)(a.idx_words - 1));
+                    for (int e = 0; e < CPL; e++) {   // (every word read is a code of the index: see the header)
+                        wi[e] = (uint32_t)c_[e] >> 5;
                         wd[e] = lbits[wi[e]];
-                        hm |= ((wd[e] >> (c_[e] & 31)) & 1u) << e;
+                        hm = d1_push_bit(hm, wd[e] >> (c_[e] & 31));
                     }
-                    hm &= (1u << nv) - 1u;
+                    hm = (hm >> (32 - CPL)) & ((1u << nv) - 1u);
                     const int cnt = __popc(hm);
                     int incl = cnt;
                     incl += D1_DPP(incl, D1_ROW_SHR(1));
@@ -423,7 +444,6 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
     constexpr int NV = CPL / 4;            // 16-byte requests per lane and round
     constexpr int LPR = 8;                 // lanes per fp32 row (16 bytes each)
     constexpr int HPI = LPC / LPR;         // hits folded per iteration and candidate
-    constexpr int NIT = LISTCAP / HPI;     // list entries of one hit group
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int scan_lds[17];
     __shared__ int s_nscan;
@@ -431,16 +451,22 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = lane / LPC, l = lane % LPC;
     const int hg = l / LPR, pr = l % LPR;
-    // LDS: [scan list][bits u32][prefix u16][lists: per wave R * LISTCAP u16][tr: per wave D1X_GROUP x D1X_TRS f32]
+    // LDS: [scan list][bits u32][prefix u16][lists: per wave R * LISTCAP u16][tr: per wave a.group x D1X_TRS f32][stash: per wave CPL x 64 i32]
     int* scan_list = reinterpret_cast<int*>(smem);
     uint32_t* lbits = reinterpret_cast<uint32_t*>(scan_list + ((a.nqueries + 3) & ~3));
     uint16_t* lpre = reinterpret_cast<uint16_t*>(lbits + a.idx_words);
     uint16_t* lists = lpre + ((a.idx_words + 7) & ~7);
     uint16_t* my_list = lists + (size_t)wave * (R * LISTCAP);
-    float* tr = reinterpret_cast<float*>(lists + (size_t)D1_WAVES * (R * LISTCAP)) + (size_t)wave * D1X_GROUP * D1X_TRS;
+    float* tr = reinterpret_cast<float*>(lists + (size_t)D1_WAVES * (R * LISTCAP)) + (size_t)wave * a.group * D1X_TRS;
+    // a lane's codes of the round, [code][lane]: the hit walk reads code e of its lane with one LDS load (a register array
+    // indexed by a lane's own e is a chain of CPL compare-and-selects)
+    int* stash = reinterpret_cast<int*>(reinterpret_cast<float*>(lists + (size_t)D1_WAVES * (R * LISTCAP)) + (size_t)D1_WAVES * a.group * D1X_TRS) +
+                 (size_t)wave * (CPL * 64) + lane;
 
     if (a.any && a.any[1] == 0) return;   // (uniform: no query of the batch takes this pass)
     if (tid == 0) s_nscan = 0;
+    // (list entries past a candidate's hits are read as row ids before they are known to be unused: never beyond row_cap)
+    for (int i = tid; i < D1_WAVES * R * LISTCAP / 2; i += D1_THREADS) reinterpret_cast<uint32_t*>(lists)[i] = 0u;
     __syncthreads();
     {
         int base = 0;
@@ -461,14 +487,33 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
     const int G = a.parts;
     const int nitems = nscan8 * G;
 
-    for (int t = blockIdx.x; t < nitems; t += gridDim.x) {
-        const int sidx = ((t >> 3) / G) * D1_XCDS + (t & 7), part = (t >> 3) % G;
+    // Items are taken from a counter per XCD (workgroup L runs on XCD L % 8 as far as the dispatcher keeps its round robin: affinity
+    // for speed only): a band (ndocs + a few per cent) fills a few of a query's G parts, a whole list all of them, and a static
+    // deal -- workgroup L sees the same part number in every one of its items when 256 / 8 is a multiple of G -- left 10 of 16
+    // workgroups without work on a batch of bands.  Consecutive items of a counter are the parts of one query: they run side by
+    // side on the XCD whose L2 holds the query's rows.
+    __shared__ int s_item;
+    const int xcd = blockIdx.x & (D1_XCDS - 1);
+    const int per_xcd = (nscan8 / D1_XCDS) * G;
+    for (int t = blockIdx.x;; t += gridDim.x) {
+        int it;
+        if (a.any) {
+            __syncthreads();   // (the previous item's readers of s_item and of the LDS tables are done)
+            if (tid == 0) s_item = atomicAdd(const_cast<int32_t*>(a.any) + 2 + xcd, 1);
+            __syncthreads();
+            it = s_item;
+            if (it >= per_xcd) break;
+        } else {   // (a caller without counters -- the stand-alone probe: the static deal)
+            if (t >= nitems) break;
+            it = t >> 3;
+        }
+        const int sidx = (it / G) * D1_XCDS + (a.any ? xcd : (t & 7)), part = it % G;
         if (sidx >= nscan) continue;   // (block-uniform)
-        const int b = scan_list[sidx];
+        const int b = __builtin_amdgcn_readfirstlane(scan_list[sidx]);
         const bool from_band = a.mode[b] == FLMR_S1D_IMAGE;
         const int P = from_band ? a.band_count[b] : a.cand_count[b];
         // a band is short (ndocs + a few per cent): groups of 16 so that every wave of the item has some; whole lists: 32
-        const int gsz = (from_band || a.group == 16) ? 16 : D1X_GROUP;
+        const int gsz = from_band ? 16 : a.group;
         const int32_t* const src = (from_band ? a.band : a.cand) + (size_t)b * a.cand_stride;
         uint64_t* const keys_b = a.keys + (size_t)b * a.cand_stride;
         const int qlen = a.q_lens ? a.q_lens[b] : a.nq_cand;
@@ -477,7 +522,9 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
         const int n = a.nqual[b] < a.row_cap ? a.nqual[b] : a.row_cap;
         const float* const rows_b = a.rows + (size_t)b * a.row_cap * 32;
         const int ngroups = (P + gsz - 1) / gsz;
-        if (part * ((ngroups + G - 1) / G) >= ngroups) continue;   // (block-uniform: this part of a short list is empty -- no table load)
+        // a part takes at least one group per wave: a band (ndocs + a few per cent) is a few parts' work, a whole list all G parts'
+        const int per = max((ngroups + G - 1) / G, D1_WAVES);
+        if (part * per >= ngroups) continue;   // (block-uniform: this part of a short list is empty -- no table load)
         __syncthreads();   // (the previous item's readers of the LDS tables are done)
         {
             const uint32_t* gb = a.idx_bits + (size_t)b * a.idx_words;
@@ -489,7 +536,6 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
             }
         }
         __syncthreads();
-        const int per = (ngroups + G - 1) / G;
         const int gbeg = part * per, gend = (gbeg + per) < ngroups ? (gbeg + per) : ngroups;
         auto meta = [&](int g, int& pid, uint32_t& off, int& len) {
             pid = 0; off = 0; len = 0;
@@ -521,6 +567,10 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
             int lenA = 0, lenB = 0;
             request_codes(cdA, 0, lenA);
             request_codes(cdB, 1, lenB);
+            const uint32_t prb = (uint32_t)pr * 16u;
+            const char* const rbytes = reinterpret_cast<const char*>(rows_b);
+            uint16_t* const lst = my_list + sub * LISTCAP;
+            const d1u4* const lp = reinterpret_cast<const d1u4*>(lst) + hg;   // block blk of this lane's hit group: lp[blk * HPI]
             auto round = [&](d1i4u (&cd)[NV], int& jlen, int r) {
                 const int my_len = jlen;
                 d1f4 facc;
@@ -530,16 +580,17 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
 #pragma unroll
                 for (int v = 0; v < NV; v++) { c_[4 * v] = cd[v].x; c_[4 * v + 1] = cd[v].y; c_[4 * v + 2] = cd[v].z; c_[4 * v + 3] = cd[v].w; }
                 for (int t0 = 0;; t0 += LISTCAP) {
-                    // ---- the hit mask of this lane's CPL codes ----
+                    // ---- the hit mask of this lane's CPL codes (what a lane reads past its passage -- the next passage's codes, the
+                    // copy's padding -- is a code of the index: a word of the mask; its bit is dropped with `nv`) ----
                     int nv = my_len - (t0 + CPL * l);
                     nv = nv < 0 ? 0 : (nv > CPL ? CPL : nv);
                     uint32_t hm = 0u;
 #pragma unroll
                     for (int e = 0; e < CPL; e++) {
-                        const uint32_t wi = min((uint32_t)c_[e] >> 5, (uint32_t)(a.idx_words - 1));
-                        hm |= ((lbits[wi] >> (c_[e] & 31)) & 1u) << e;
+                        hm = d1_push_bit(hm, lbits[(uint32_t)c_[e] >> 5] >> (c_[e] & 31));
+                        stash[e * 64] = c_[e];
                     }
-                    hm &= (1u << nv) - 1u;
+                    hm = (hm >> (32 - CPL)) & ((1u << nv) - 1u);
                     const int cnt = __popc(hm);
                     int incl = cnt;
                     incl += D1_DPP(incl, D1_ROW_SHR(1));
@@ -559,65 +610,71 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
                         nmax = max(n0, n1);
                     }
                     nh_total += nh_own;
-                    // ---- a lane walks its hits: row id = rank of the centroid among the survivors; entry o of a candidate's list
-                    // sits at [o % HPI][o / HPI] ----
+                    // ---- a lane walks its hits (7 % of the codes on the regime this form is for: listing every code costs more
+                    // instructions than the walk's ~2.7 iterations): entry o of a candidate's list = the row id (rank of the centroid
+                    // among the survivors) of its o-th hit ----
                     {
-                        uint32_t o = (uint32_t)(incl - cnt);
+                        uint16_t* at = lst + (incl - cnt);
                         uint32_t left = hm;
                         while (left) {
                             const int e = __ffs(left) - 1;
                             left &= left - 1u;
-                            int c = c_[0];
-#pragma unroll
-                            for (int x = 1; x < CPL; x++) c = e == x ? c_[x] : c;
+                            const int c = stash[e * 64];
                             const uint32_t wi = (uint32_t)c >> 5;
                             int rid = (int)lpre[wi] + __popc(lbits[wi] & ((1u << (c & 31)) - 1u));
                             rid = rid < n ? rid : n - 1;
-                            my_list[sub * LISTCAP + (o & (HPI - 1)) * NIT + (o / HPI)] = (uint16_t)rid;
-                            o++;
+                            *at++ = (uint16_t)rid;
                         }
                     }
                     const bool more_chunks = __ballot(my_len > t0 + LISTCAP) != 0ull;   // wave-uniform
-                    // ---- fold the listed rows: blocks of four entries per lane.  The codes of round r + 2 are requested behind the LAST
-                    // block's row loads (in-order returns: a request issued before them would be waited for with them), and at ONE place
-                    // in the program: the last block is peeled off the loop, so that every path through the fold has issued the same
-                    // loads in the same order and the compiler's counted wait for the last rows leaves the codes in flight ----
+                    // ---- fold the listed rows: blocks of EIGHT entries (16 bytes of the list) per lane, LPC slots per candidate, hit
+                    // group hg takes entries [blk * LPC + 8 hg, + 8); the rows of a block are requested together (a block is one L2
+                    // round trip whatever it holds).  No entry is tested: the slots of a candidate's blocks past its hits are filled
+                    // with its FIRST hit (a maximum is idempotent), and a candidate without a hit in the chunk drops what its lanes
+                    // folded (`has`).  The codes of round r + 2 are requested behind the LAST block's row loads (in-order returns: a
+                    // request issued before them would be waited for with them), at ONE place in the program ----
                     if (nmax > 0) {
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
-                        // EIGHT entries (16 bytes of the list) per lane and block, their rows requested together: a block is one L2 round
-                        // trip (~1 us under this load) whatever it holds, and the rounds of this regime are a chain of such trips
-                        const d1u4* lp = reinterpret_cast<const d1u4*>(my_list + sub * LISTCAP + hg * NIT);
-                        const float* rb = rows_b + pr * 4;
-                        const int nblocks = (nmax + 8 * HPI - 1) / (8 * HPI);   // (wave-uniform, >= 1)
-                        auto rows_of = [&](int blk, d1f4 (&v)[8], bool (&ok)[8]) {
-                            const d1u4 e4 = lp[blk];
-                            const uint32_t rid[8] = {e4.x & 0xffffu, e4.x >> 16, e4.y & 0xffffu, e4.y >> 16, e4.z & 0xffffu, e4.z >> 16, e4.w & 0xffffu, e4.w >> 16};
+                        const int nblocks = (nmax + LPC - 1) / LPC;   // (wave-uniform, >= 1)
+                        {
+                            const uint16_t first = lst[0];
+                            for (int slot = nh_own + l; slot < nblocks * LPC; slot += LPC) lst[slot] = first;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        d1f4 fch;
+                        fch.x = fch.y = fch.z = fch.w = -9999.0f;
+                        auto rows_of = [&](int blk, d1f4 (&v)[8]) {
+                            const d1u4 e4 = lp[blk * HPI];
+                            const uint32_t w[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
-                            for (int u = 0; u < 8; u++) {
-                                ok[u] = (8 * blk + u) * HPI + hg < nh_own;
-                                // (always issued: a load under a lane test makes the compiler's count unknown)
-                                v[u] = *reinterpret_cast<const d1f4*>(rb + (size_t)(ok[u] ? rid[u] : 0u) * 32);
-                            }
+                            for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const d1f4*>(rbytes + d1x_row_off(w[u >> 1], u & 1, prb));
                         };
-                        auto take = [&](const d1f4 (&v)[8], const bool (&ok)[8]) {
+                        auto take = [&](const d1f4 (&v)[8]) {
 #pragma unroll
-                            for (int u = 0; u < 8; u++) {
-                                facc.x = fmaxf(facc.x, ok[u] ? v[u].x : -9999.0f); facc.y = fmaxf(facc.y, ok[u] ? v[u].y : -9999.0f);
-                                facc.z = fmaxf(facc.z, ok[u] ? v[u].z : -9999.0f); facc.w = fmaxf(facc.w, ok[u] ? v[u].w : -9999.0f);
+                            for (int u = 0; u < 8; u += 2) {
+                                fch.x = d1_fmax3(fch.x, v[u].x, v[u + 1].x); fch.y = d1_fmax3(fch.y, v[u].y, v[u + 1].y);
+                                fch.z = d1_fmax3(fch.z, v[u].z, v[u + 1].z); fch.w = d1_fmax3(fch.w, v[u].w, v[u + 1].w);
                             }
                         };
 #pragma unroll 1
                         for (int blk = 0; blk + 1 < nblocks; blk++) {
-                            d1f4 v[8]; bool ok[8];
-                            rows_of(blk, v, ok);
-                            take(v, ok);
+                            d1f4 v[8];
+                            rows_of(blk, v);
+                            take(v);
                         }
                         {
-                            d1f4 v[8]; bool ok[8];
-                            rows_of(nblocks - 1, v, ok);
-                            request_codes(cd, r + 2, jlen);   // (in a later chunk of long passages: the same request again -- unconditional, see above)
-                            take(v, ok);
+                            d1f4 v[8];
+                            rows_of(nblocks - 1, v);
+                            asm volatile("" ::: "memory");   // (the order of the requests is the point)
+                            request_codes(cd, r + 2, jlen);   // (in a later chunk of long passages: the same request again -- unconditional)
+                            take(v);
+                        }
+                        {   // (a select, not a branch: under a lane test the compiler sinks the row loads into it)
+                            const bool has = nh_own > 0;
+                            facc.x = d1_fmax(facc.x, has ? fch.x : -9999.0f); facc.y = d1_fmax(facc.y, has ? fch.y : -9999.0f);
+                            facc.z = d1_fmax(facc.z, has ? fch.z : -9999.0f); facc.w = d1_fmax(facc.w, has ? fch.w : -9999.0f);
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();   // (the list is rewritten by the next chunk / round)
@@ -631,18 +688,21 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
                         const d1i4u* at = reinterpret_cast<const d1i4u*>(a.codes + ((uint64_t)o + (uint32_t)(t0 + LISTCAP + CPL * l)));
 #pragma unroll
                         for (int v = 0; v < NV; v++) { const d1i4u x = D1_LOAD(at + v); c_[4 * v] = x.x; c_[4 * v + 1] = x.y; c_[4 * v + 2] = x.z; c_[4 * v + 3] = x.w; }
+                        // (a use HERE: pending at the loop's header, these loads would turn the header's wait into a vmcnt(0))
+#pragma unroll
+                        for (int e = 0; e < CPL; e++) asm volatile("" : "+v"(c_[e]));
                     }
                 }
                 // ---- this round's candidates: combine the hit groups; the 8 lanes of a candidate park their 4 columns in the table ----
                 if (HPI >= 2) {
-                    facc.x = fmaxf(facc.x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.x), D1_ROW_ROR(8), 0xF, 0xF, false)));
-                    facc.y = fmaxf(facc.y, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.y), D1_ROW_ROR(8), 0xF, 0xF, false)));
-                    facc.z = fmaxf(facc.z, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.z), D1_ROW_ROR(8), 0xF, 0xF, false)));
-                    facc.w = fmaxf(facc.w, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.w), D1_ROW_ROR(8), 0xF, 0xF, false)));
+                    facc.x = d1_fmax(facc.x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.x), D1_ROW_ROR(8), 0xF, 0xF, false)));
+                    facc.y = d1_fmax(facc.y, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.y), D1_ROW_ROR(8), 0xF, 0xF, false)));
+                    facc.z = d1_fmax(facc.z, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.z), D1_ROW_ROR(8), 0xF, 0xF, false)));
+                    facc.w = d1_fmax(facc.w, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.w), D1_ROW_ROR(8), 0xF, 0xF, false)));
                 }
                 if (HPI >= 4) {
-                    facc.x = fmaxf(facc.x, __shfl_xor(facc.x, 16, 64)); facc.y = fmaxf(facc.y, __shfl_xor(facc.y, 16, 64));
-                    facc.z = fmaxf(facc.z, __shfl_xor(facc.z, 16, 64)); facc.w = fmaxf(facc.w, __shfl_xor(facc.w, 16, 64));
+                    facc.x = d1_fmax(facc.x, __shfl_xor(facc.x, 16, 64)); facc.y = d1_fmax(facc.y, __shfl_xor(facc.y, 16, 64));
+                    facc.z = d1_fmax(facc.z, __shfl_xor(facc.z, 16, 64)); facc.w = d1_fmax(facc.w, __shfl_xor(facc.w, 16, 64));
                 }
                 const int j = r * R + sub;
                 if (l < 8 && j < gsz) {
@@ -684,9 +744,9 @@ static void d1_shape(double mean_codes, int* lpc, int* cpl) {
     *lpc = mean_codes > 144.0 ? 32 : 16;
     *cpl = mean_codes > 72.0 ? 8 : 4;
 }
-static size_t d1x_lds(int nqueries, int idx_words, int lpc, int cpl) {
+static size_t d1x_lds(int nqueries, int idx_words, int lpc, int cpl, int group) {
     return (size_t)((nqueries + 3) & ~3) * 4 + (size_t)idx_words * 4 + (size_t)((idx_words + 7) & ~7) * 2 +
-           (size_t)D1_WAVES * (64 / lpc) * (lpc * cpl) * 2 + (size_t)D1_WAVES * D1X_GROUP * D1X_TRS * 4;
+           (size_t)D1_WAVES * (64 / lpc) * (lpc * cpl) * 2 + (size_t)D1_WAVES * group * D1X_TRS * 4 + (size_t)D1_WAVES * cpl * 64 * 4;
 }
 
 // the exact pass: (lanes per candidate, codes per lane) by the index's usual number of distinct codes per passage
@@ -694,7 +754,9 @@ int flmr_launch_s1_exact(const flmr_s1d_args& a_in, double mean_codes, hipStream
     flmr_s1d_args a = a_in;
     int lpc, cpl;
     d1_shape(mean_codes, &lpc, &cpl);
-    const size_t lds = d1x_lds(a.nqueries, a.idx_words, lpc, cpl);
+    // candidates per wave and group: 32 where the table fits (and the caller does not ask for 16), else 16
+    a.group = (a.group == 16 || d1x_lds(a.nqueries, a.idx_words, lpc, cpl, D1X_GROUP) > (size_t)160 * 1024 - 1024) ? 16 : D1X_GROUP;
+    const size_t lds = d1x_lds(a.nqueries, a.idx_words, lpc, cpl, a.group);
     if (lds > (size_t)160 * 1024 - 1024) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "dense stage 1: K = %d does not fit the LDS form", a.idx_words * 32);
     if (a.codes_len > 0xffffffffLL) FLMR_FAIL(FLMR_ERR_UNSUPPORTED, "dense stage 1: token offsets beyond 32 bits");
     if (a.parts < 1) a.parts = 8;
@@ -723,7 +785,7 @@ int flmr_s1_dense_image_rows(int nqueries, int idx_words, double mean_codes) {
     d1_shape(mean_codes, &lpc, &cpl);
     const size_t budget = (size_t)160 * 1024 - 1024;   // static __shared__ of the kernel and alignment
     const size_t fixed = d1_fixed_lds(nqueries, idx_words, lpc, cpl);
-    if (fixed + 64 * 65 > budget || d1x_lds(nqueries, idx_words, lpc, cpl) > budget) return 0;
+    if (fixed + 64 * 65 > budget || d1x_lds(nqueries, idx_words, lpc, cpl, 16) > budget) return 0;
     const size_t rows = (budget - fixed) / 64 - 1;   // (+ the padding row)
     return (int)(rows > 65000 ? 65000 : rows);
 }
@@ -772,6 +834,7 @@ __global__ __launch_bounds__(1024) void s1_dense_modes_kernel(const int32_t* ski
     any_img = __syncthreads_or(any_img);
     any_exact = __syncthreads_or(any_exact);
     if (threadIdx.x == 0) { any[0] = any_img; any[1] = any_exact; }
+    if (threadIdx.x >= 2 && threadIdx.x < 16) any[threadIdx.x] = 0;   // (the exact pass's item counters)
 }
 
 int flmr_launch_s1_dense_modes(const int32_t* skip, const int32_t* nqual, const int32_t* row_ovf, int32_t nqueries, int32_t img_rows,
