@@ -585,10 +585,19 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
                     int nv = my_len - (t0 + CPL * l);
                     nv = nv < 0 ? 0 : (nv > CPL ? CPL : nv);
                     uint32_t hm = 0u;
+                    {
+                        uint32_t wd[CPL];   // (all CPL words requested before the first is used: one LDS round trip, not CPL / 2)
 #pragma unroll
-                    for (int e = 0; e < CPL; e++) {
-                        hm = d1_push_bit(hm, lbits[(uint32_t)c_[e] >> 5] >> (c_[e] & 31));
-                        stash[e * 64] = c_[e];
+#ifdef D1X_ABL_NOMASK   // development switch: no mask reads (a hash of the code instead), no stash
+                        for (int e = 0; e < CPL; e++) wd[e] = ((uint32_t)c_[e] * 2654435761u) >> 28 == 0u ? ~0u : 0u;
+#else
+                        for (int e = 0; e < CPL; e++) wd[e] = lbits[(uint32_t)c_[e] >> 5];
+#pragma unroll
+                        for (int e = 0; e < CPL; e++) stash[e * 64] = c_[e];
+#endif
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int e = 0; e < CPL; e++) hm = d1_push_bit(hm, wd[e] >> (c_[e] & 31));
                     }
                     hm = (hm >> (32 - CPL)) & ((1u << nv) - 1u);
                     const int cnt = __popc(hm);
@@ -616,6 +625,9 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
                     {
                         uint16_t* at = lst + (incl - cnt);
                         uint32_t left = hm;
+#ifdef D1X_ABL_NOWALK   // development switch: one list entry per lane with a hit, no rank
+                        if (left) { *at = (uint16_t)(c_[0] & 1023); left = 0u; }
+#endif
                         while (left) {
                             const int e = __ffs(left) - 1;
                             left &= left - 1u;
@@ -649,7 +661,17 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
                             const d1u4 e4 = lp[blk * HPI];
                             const uint32_t w[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
+#ifdef D1X_ABL_NOROWS   // development switch (profiles/r06/s1_exact_ablation.txt): no row loads
+                            for (int u = 0; u < 8; u++) { v[u].x = v[u].y = v[u].z = v[u].w = __int_as_float((int)d1x_row_off(w[u >> 1], u & 1, prb)); }
+#elif defined(D1X_ABL_HALFROWS)   // development switch: half of the row loads
+                            for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const d1f4*>(rbytes + d1x_row_off(w[u >> 1], u & 1, prb));
+                            for (int u = 4; u < 8; u++) { v[u].x = v[u].y = v[u].z = v[u].w = __int_as_float((int)d1x_row_off(w[u >> 1], u & 1, prb)); }
+#elif defined(D1X_ABL_SAMEROWS)   // development switch: entries 4 .. 7 read ONE line (row 0) in every lane
+                            for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const d1f4*>(rbytes + d1x_row_off(w[u >> 1], u & 1, prb));
+                            for (int u = 4; u < 8; u++) v[u] = *reinterpret_cast<const d1f4*>(rbytes + (d1x_row_off(w[u >> 1], u & 1, prb) & 127u));
+#else
                             for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const d1f4*>(rbytes + d1x_row_off(w[u >> 1], u & 1, prb));
+#endif
                         };
                         auto take = [&](const d1f4 (&v)[8]) {
 #pragma unroll
