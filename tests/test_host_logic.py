@@ -444,6 +444,7 @@ def test_score_reduce_interactions_and_l2_on_the_host():
     ref_fn = None
     ref_root = os.path.join(os.environ.get("FLMR_REFERENCE_ROOT", "/root/reference"), "third_party", "ColBERT")
     if os.path.isdir(ref_root):
+        before = set(sys.modules)
         try:   # the reference's own function (imports its package: build container only; any failure leaves the restated expression)
             sys.path.insert(0, os.path.join(ROOT, "tests", "golden", "_shims"))
             sys.path.insert(0, ref_root)
@@ -455,6 +456,11 @@ def test_score_reduce_interactions_and_l2_on_the_host():
             ref_fn = None
         finally:
             sys.path[:] = [p for p in sys.path if p not in (ref_root, os.path.join(ROOT, "tests", "golden", "_shims"))]
+            # (the reference's `colbert` package and whatever the shims stood in for must not stay importable for the tests
+            # after this one: test_dropin installs over a stand-in package of the same name)
+            for name in set(sys.modules) - before:
+                if name.split(".")[0] in ("colbert", "faiss", "ujson", "git", "bitarray", "ninja"):
+                    del sys.modules[name]
     for nq in (80, 64, 70):
         for cfg in (SimpleNamespace(interaction="flipr", query_maxlen=64), SimpleNamespace(interaction="colbert", query_maxlen=64)):
             got = scoring.colbert_score_reduce(scores[:, :, :nq].clone(), mask.unsqueeze(-1), cfg)
