@@ -12,7 +12,7 @@ for w in ${SUBS:-k500 thr0.25 nq320 nq832 built4096 built256}; do
   # the path's own kernels only (the corpus generator's torch kernels are not part of the step), top 14 by total time
   if [ -n "$f" ]; then (head -1 "$f"; grep -E 's0_|filter_stage|s2_|maxsim|s3_|select_topn|sort_topn|s1_|cand_|qualifying' "$f" | head -14) > "$OUT/${w}_kernel_stats.csv"; fi
 done
-KREGEX='s1_dense|s1_exact|select_topn|filter_stage2_xcd|maxsim'
+KREGEX='s1_image|s1_exact|select_topn|filter_stage2_xcd|maxsim'
 for w in ${PMCS-thr0.25 built256}; do
   timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --kernel-include-regex "$KREGEX" --output-format csv -d "$OUT/pmc_$w/sq" -o p -- python $R/profiles/sub_result_probe.py $w > "$OUT/pmc_$w.sq.log" 2>&1
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-include-regex "$KREGEX" --output-format csv -d "$OUT/pmc_$w/fetch" -o p -- python $R/profiles/sub_result_probe.py $w > "$OUT/pmc_$w.fetch.log" 2>&1

@@ -51,6 +51,7 @@
 #define D1_XCDS 8
 
 typedef uint32_t d1u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t d1u2 __attribute__((ext_vector_type(2)));
 typedef int d1i4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef _Float16 d1h2 __attribute__((ext_vector_type(2)));
 typedef float d1f4 __attribute__((ext_vector_type(4)));
@@ -104,6 +105,12 @@ __device__ __forceinline__ float d1_fmax(float a, float b) {
 __device__ __forceinline__ float d1_fmax3(float a, float b, float c) {
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// LDS address of entry `wi` of the {mask word, rank} table (written as the instruction: the compiler forms it as shift, and, add)
+__device__ __forceinline__ uint32_t d1_tab_addr(uint32_t wi, uint32_t base) {
+    uint32_t r;
+    asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(r) : "v"(wi), "s"(base));
     return r;
 }
 // the hit bits of a lane's codes, one per step: bit 0 of x enters at the top of hm (after CPL steps: hm >> (32 - CPL))
@@ -445,23 +452,29 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
     constexpr int LPR = 8;                 // lanes per fp32 row (16 bytes each)
     constexpr int HPI = LPC / LPR;         // hits folded per iteration and candidate
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int scan_lds[17];
-    __shared__ int s_nscan;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = lane / LPC, l = lane % LPC;
     const int hg = l / LPR, pr = l % LPR;
-    // LDS: [scan list][bits u32][prefix u16][lists: per wave R * LISTCAP u16][tr: per wave a.group x D1X_TRS f32][stash: per wave CPL x 64 i32]
-    int* scan_list = reinterpret_cast<int*>(smem);
-    uint32_t* lbits = reinterpret_cast<uint32_t*>(scan_list + ((a.nqueries + 3) & ~3));
-    uint16_t* lpre = reinterpret_cast<uint16_t*>(lbits + a.idx_words);
-    uint16_t* lists = lpre + ((a.idx_words + 7) & ~7);
+    // LDS: [mask + ranks: idx_words x {u32, u32}][scan list][lists: per wave R * LISTCAP u16][tr: per wave a.group x D1X_TRS f32][stash: per wave CPL x 64 i32]
+    // (the mask first: its address is then a compile-time offset of the probes; a word and the rank of its first bit side by side:
+    // one 8-byte read per hit in the walk)
+    uint2* ltab = reinterpret_cast<uint2*>(smem);
+    const uint32_t ltab_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    int* scan_list = reinterpret_cast<int*>(ltab + a.idx_words);
+    uint16_t* lists = reinterpret_cast<uint16_t*>(scan_list + ((a.nqueries + 3) & ~3));
     uint16_t* my_list = lists + (size_t)wave * (R * LISTCAP);
     float* tr = reinterpret_cast<float*>(lists + (size_t)D1_WAVES * (R * LISTCAP)) + (size_t)wave * a.group * D1X_TRS;
     // a lane's codes of the round, [code][lane]: the hit walk reads code e of its lane with one LDS load (a register array
     // indexed by a lane's own e is a chain of CPL compare-and-selects)
     int* stash = reinterpret_cast<int*>(reinterpret_cast<float*>(lists + (size_t)D1_WAVES * (R * LISTCAP)) + (size_t)D1_WAVES * a.group * D1X_TRS) +
                  (size_t)wave * (CPL * 64) + lane;
+    // (no static __shared__ in this kernel: the dynamic block -- the mask -- then starts at LDS address 0 and a probe's address is
+    // the shifted code itself; the block scan's scratch and two scalars sit behind the stash)
+    int* const scan_lds = reinterpret_cast<int*>(reinterpret_cast<float*>(lists + (size_t)D1_WAVES * (R * LISTCAP)) + (size_t)D1_WAVES * a.group * D1X_TRS) +
+                          (size_t)D1_WAVES * (CPL * 64);
+    int& s_nscan = scan_lds[17];
+    int& s_item = scan_lds[18];
 
     if (a.any && a.any[1] == 0) return;   // (uniform: no query of the batch takes this pass)
     if (tid == 0) s_nscan = 0;
@@ -492,7 +505,6 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
     // deal -- workgroup L sees the same part number in every one of its items when 256 / 8 is a multiple of G -- left 10 of 16
     // workgroups without work on a batch of bands.  Consecutive items of a counter are the parts of one query: they run side by
     // side on the XCD whose L2 holds the query's rows.
-    __shared__ int s_item;
     const int xcd = blockIdx.x & (D1_XCDS - 1);
     const int per_xcd = (nscan8 / D1_XCDS) * G;
     for (int t = blockIdx.x;; t += gridDim.x) {
@@ -530,9 +542,7 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
             const uint32_t* gb = a.idx_bits + (size_t)b * a.idx_words;
             const uint32_t* gp = a.idx_prefix + (size_t)b * a.idx_words;
             for (int w = tid; w < a.idx_words; w += D1_THREADS) {
-                lbits[w] = gb[w];
-                const uint32_t p = gp[w];
-                lpre[w] = (uint16_t)(p < 65535u ? p : 65535u);
+                ltab[w] = make_uint2(gb[w], gp[w]);
             }
         }
         __syncthreads();
@@ -591,7 +601,7 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
 #ifdef D1X_ABL_NOMASK   // development switch: no mask reads (a hash of the code instead), no stash
                         for (int e = 0; e < CPL; e++) wd[e] = ((uint32_t)c_[e] * 2654435761u) >> 28 == 0u ? ~0u : 0u;
 #else
-                        for (int e = 0; e < CPL; e++) wd[e] = lbits[(uint32_t)c_[e] >> 5];
+                        for (int e = 0; e < CPL; e++) wd[e] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>((uintptr_t)d1_tab_addr((uint32_t)c_[e] >> 5, ltab_lds));
 #pragma unroll
                         for (int e = 0; e < CPL; e++) stash[e * 64] = c_[e];
 #endif
@@ -607,15 +617,15 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
                     incl += D1_DPP(incl, D1_ROW_SHR(4));
                     incl += D1_DPP(incl, D1_ROW_SHR(8));
                     if (LPC == 32) incl += __builtin_amdgcn_update_dpp(0, incl, 0x142 /* row_bcast15 */, 0xA, 0xF, false);
-                    int nh_own, nmax;
+                    // (the candidate's count: the scan's value in the last lane of its lanes)
+                    const int nh_own = __builtin_amdgcn_ds_bpermute((lane | (LPC - 1)) << 2, incl);
+                    int nmax;
                     if (LPC == 16) {
                         const int n0 = __builtin_amdgcn_readlane(incl, 15), n1 = __builtin_amdgcn_readlane(incl, 31);
                         const int n2 = __builtin_amdgcn_readlane(incl, 47), n3 = __builtin_amdgcn_readlane(incl, 63);
-                        nh_own = sub == 0 ? n0 : sub == 1 ? n1 : sub == 2 ? n2 : n3;
                         nmax = max(max(n0, n1), max(n2, n3));
                     } else {
                         const int n0 = __builtin_amdgcn_readlane(incl, 31), n1 = __builtin_amdgcn_readlane(incl, 63);
-                        nh_own = sub == 0 ? n0 : n1;
                         nmax = max(n0, n1);
                     }
                     nh_total += nh_own;
@@ -633,7 +643,8 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
                             left &= left - 1u;
                             const int c = stash[e * 64];
                             const uint32_t wi = (uint32_t)c >> 5;
-                            int rid = (int)lpre[wi] + __popc(lbits[wi] & ((1u << (c & 31)) - 1u));
+                            const d1u2 wp = *reinterpret_cast<const __attribute__((address_space(3))) d1u2*>((uintptr_t)d1_tab_addr(wi, ltab_lds));
+                            int rid = (int)wp.y + __popc(wp.x & ((1u << (c & 31)) - 1u));
                             rid = rid < n ? rid : n - 1;
                             *at++ = (uint16_t)rid;
                         }
@@ -767,8 +778,8 @@ static void d1_shape(double mean_codes, int* lpc, int* cpl) {
     *cpl = mean_codes > 72.0 ? 8 : 4;
 }
 static size_t d1x_lds(int nqueries, int idx_words, int lpc, int cpl, int group) {
-    return (size_t)((nqueries + 3) & ~3) * 4 + (size_t)idx_words * 4 + (size_t)((idx_words + 7) & ~7) * 2 +
-           (size_t)D1_WAVES * (64 / lpc) * (lpc * cpl) * 2 + (size_t)D1_WAVES * group * D1X_TRS * 4 + (size_t)D1_WAVES * cpl * 64 * 4;
+    return (size_t)((nqueries + 3) & ~3) * 4 + (size_t)idx_words * 8 +
+           (size_t)D1_WAVES * (64 / lpc) * (lpc * cpl) * 2 + (size_t)D1_WAVES * group * D1X_TRS * 4 + (size_t)D1_WAVES * cpl * 64 * 4 + 32 * 4;
 }
 
 // the exact pass: (lanes per candidate, codes per lane) by the index's usual number of distinct codes per passage
