@@ -600,10 +600,16 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
 #pragma unroll
 #ifdef D1X_ABL_NOMASK   // development switch: no mask reads (a hash of the code instead), no stash
                         for (int e = 0; e < CPL; e++) wd[e] = ((uint32_t)c_[e] * 2654435761u) >> 28 == 0u ? ~0u : 0u;
-#else
-                        for (int e = 0; e < CPL; e++) wd[e] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>((uintptr_t)d1_tab_addr((uint32_t)c_[e] >> 5, ltab_lds));
+#elif defined(D1X_ABL_LINMASK)   // development switch: the probes read conflict-free addresses (wrong words: timing only)
+                        for (int e = 0; e < CPL; e++) wd[e] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>((uintptr_t)d1_tab_addr((uint32_t)(lane + 64 * e) + ((uint32_t)c_[e] >> 31), ltab_lds));
 #pragma unroll
                         for (int e = 0; e < CPL; e++) stash[e * 64] = c_[e];
+#else
+                        for (int e = 0; e < CPL; e++) wd[e] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>((uintptr_t)d1_tab_addr((uint32_t)c_[e] >> 5, ltab_lds));
+#ifndef D1X_ABL_NOSTASH   // development switch: no stash writes (the walk reads stale codes: timing only)
+#pragma unroll
+                        for (int e = 0; e < CPL; e++) stash[e * 64] = c_[e];
+#endif
 #endif
                         asm volatile("" ::: "memory");
 #pragma unroll
