@@ -197,6 +197,39 @@ __device__ __forceinline__ float flmr_xhalf_max(float v) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));  // (fmaxf would first canonicalise both asm outputs: two more VALU ops)
     return r;
 }
+// max(a, b) as the instruction (no canonicalisation of the operands)
+__device__ __forceinline__ float flmr_fmax_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// The "keep one, send one" exchange across lane bit 4 of a transpose-reduce: a lane with bit 4 clear keeps x0 and needs its
+// partner's (lane ^ 16) x0, a lane with bit 4 set keeps x1 and needs its partner's x1.  v_permlane16_swap_b32 a, b swaps lanes
+// 16..31 of `a` with lanes 0..15 of `b` in each half-wave: afterwards `a` holds {own x0, partner's x1} in {low, high} rows and
+// `b` {partner's x0, own x1} -- the maximum of the two is what both kinds of lane want.  One VALU instruction instead of two
+// selects, an LDS-crossbar round trip and its wait.
+__device__ __forceinline__ float flmr_x16_max(float x0, float x1) {
+    float a = x0, b = x1;
+    asm volatile("s_nop 3\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
+    return flmr_fmax_raw(a, b);
+}
+// the value of lane ^ 4 by two DPP moves: row_shl:4 (lane i reads lane i + 4) into the lanes with bit 2 clear -- banks 0 and 2 of a
+// row of 16 -- and row_shr:4 into the others
+__device__ __forceinline__ float flmr_dpp_xor4(float v) {
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104 /* row_shl:4 */, 0xF, 0x5, false);
+    t = __builtin_amdgcn_update_dpp(t, __float_as_int(v), 0x114 /* row_shr:4 */, 0xF, 0xA, false);
+    return __int_as_float(t);
+}
+// (eight pairs at once: the wait states around the swaps are paid once)
+__device__ __forceinline__ void flmr_x16_max8(float (&a)[8], float (&b)[8], float (&out)[8]) {
+    asm volatile("s_nop 3\n\tv_permlane16_swap_b32 %0, %8\n\tv_permlane16_swap_b32 %1, %9\n\tv_permlane16_swap_b32 %2, %10\n\t"
+                 "v_permlane16_swap_b32 %3, %11\n\tv_permlane16_swap_b32 %4, %12\n\tv_permlane16_swap_b32 %5, %13\n\t"
+                 "v_permlane16_swap_b32 %6, %14\n\tv_permlane16_swap_b32 %7, %15\n\ts_nop 3"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+#pragma unroll
+    for (int r = 0; r < 8; r++) out[r] = flmr_fmax_raw(a[r], b[r]);
+}
 __device__ __forceinline__ float flmr_xhalf_sum(float v) { float a, b; flmr_both_halves(v, a, b); return a + b; }  // = v + other half's v
 
 // ---- the reference's CUDA-path numerics (FLMR_NUMERICS_GPU_FP16; index_storage.py:113-149, colbert.py:235-263) ------------

@@ -800,23 +800,29 @@ __global__ __launch_bounds__(64 * S0Q2_WAVES, 1) void s0_centroid_scores_qs2(flm
                 nflag++;
                 continue;
 #endif
+                // (the exchanges as VALU operations where the instruction set has one -- v_permlane16_swap across lane bit 4, DPP
+                // row_ror:8 across bit 3, row_shl:4 / row_shr:4 by bank across bit 2, quad_perm across bits 1 and 0: the same lanes, the same
+                // values as the __shfl_xor forms (profiles/microbench/xor_exchange_check.hip).  MOST tiles come through here
+                // once thousands of centroids pass the threshold, and 16 crossbar round trips per tile were half of this kernel's time there)
                 float v8[8];
-                const bool up = (i & 16) != 0;
+                {
+                    float x0[8], x1[8];   // lanes with bit 4 clear keep registers 0..7, the others 8..15
 #pragma unroll
-                for (int r = 0; r < 8; r++) {   // lanes with bit 4 clear keep registers 0..7, the others 8..15
-                    float x0 = acc[q][r], x1 = acc[q][r + 8];
-                    if (!full_cols[q]) { x0 = i < nqc[q] ? x0 : FLMR_NEG_INF; x1 = i < nqc[q] ? x1 : FLMR_NEG_INF; }
-                    const float keep = up ? x1 : x0, send = up ? x0 : x1;
-                    v8[r] = fmaxf(keep, __shfl_xor(send, 16, 64));
+                    for (int r = 0; r < 8; r++) {
+                        x0[r] = acc[q][r]; x1[r] = acc[q][r + 8];
+                        if (!full_cols[q]) { x0[r] = i < nqc[q] ? x0[r] : FLMR_NEG_INF; x1[r] = i < nqc[q] ? x1[r] : FLMR_NEG_INF; }
+                    }
+                    flmr_x16_max8(x0, x1, v8);
                 }
                 float v4[4], v2[2];
                 const bool up3 = (i & 8) != 0, up2 = (i & 4) != 0, up1 = (i & 2) != 0;
 #pragma unroll
-                for (int r = 0; r < 4; r++) v4[r] = fmaxf(up3 ? v8[r + 4] : v8[r], __shfl_xor(up3 ? v8[r] : v8[r + 4], 8, 64));
+                for (int r = 0; r < 4; r++)
+                    v4[r] = flmr_fmax_raw(up3 ? v8[r + 4] : v8[r], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(up3 ? v8[r] : v8[r + 4]), 0x128 /* row_ror:8 */, 0xF, 0xF, false)));
 #pragma unroll
-                for (int r = 0; r < 2; r++) v2[r] = fmaxf(up2 ? v4[r + 2] : v4[r], __shfl_xor(up2 ? v4[r] : v4[r + 2], 4, 64));
-                float rm = fmaxf(up1 ? v2[1] : v2[0], __shfl_xor(up1 ? v2[0] : v2[1], 2, 64));
-                rm = fmaxf(rm, __shfl_xor(rm, 1, 64));   // lane (i, h): the maximum of row r = i >> 1 (of this half's 16) over all columns
+                for (int r = 0; r < 2; r++) v2[r] = flmr_fmax_raw(up2 ? v4[r + 2] : v4[r], flmr_dpp_xor4(up2 ? v4[r] : v4[r + 2]));
+                float rm = flmr_fmax_raw(up1 ? v2[1] : v2[0], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(up1 ? v2[0] : v2[1]), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false)));
+                rm = flmr_fmax_raw(rm, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(rm), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false)));   // lane (i, h): the maximum of row r = i >> 1 (of this half's 16) over all columns
                 const unsigned long long amb = HI_ONLY ? 0ull : __ballot(rm + qemax[q] >= a.thr && rm - qemax[q] < a.thr);
                 if (amb != 0ull) {
                     if (lane == 0) flist[nflag] = (uint16_t)(t * S0Q_QT + q);
