@@ -308,16 +308,15 @@ __global__ __launch_bounds__(D1_THREADS) void s1_image_kernel(flmr_s1d_args a) {
                         const int n0 = __builtin_amdgcn_readlane(incl, 31), n1 = __builtin_amdgcn_readlane(incl, 63);
                         nmax = max(n0, n1);
                     }
-                    {   // entry o of a candidate's list sits at [o % HPI][o / HPI]: a lane's hit group reads its entries contiguously
-                        const int base = incl - cnt;
+                    {   // entry o of a candidate's list = its o-th hit; block b of the fold = entries [4 HPI b, 4 HPI (b + 1)), four per hit group
+                        uint16_t* const lst = my_list + sub * LISTCAP + (incl - cnt);
 #pragma unroll
                         for (int e = 0; e < CPL; e++) {
                             const int c = c_[e];
-                            int rid = (int)lpre[wi[e]] + __popc(wd[e] & ((1u << (c & 31)) - 1u));
-                            rid = rid < n ? rid : n;
-                            const uint32_t o = (uint32_t)base + __popc(hm & ((1u << e) - 1u));
-                            const uint32_t pos = sub * LISTCAP + (o & (HPI - 1)) * NIT + (o / HPI);
-                            my_list[((hm >> e) & 1u) ? pos : R * LISTCAP + lane] = (uint16_t)rid;   // (a miss: the lane's own scratch entry)
+                            // (a hit's rank is below n by construction; a miss goes to the lane's own scratch entry)
+                            const int rid = (int)lpre[wi[e]] + __popc(wd[e] & ((1u << (c & 31)) - 1u));
+                            uint16_t* const at = lst + __popc(hm & ((1u << e) - 1u));
+                            *(((hm >> e) & 1u) ? at : my_list + R * LISTCAP + lane) = (uint16_t)rid;
                         }
                     }
                     // the codes are dead: request the chunk-0 codes of round r + 2 into the same registers
@@ -327,27 +326,25 @@ __global__ __launch_bounds__(D1_THREADS) void s1_image_kernel(flmr_s1d_args a) {
                     if (nmax > 0) {
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
-                        // a lane's hit group reads its list entries 16 at a time (32 bytes), then the rows they name: blocks of four
-                        // entries, every index static, the four rows of a block requested together (an entry beyond a candidate's hits
-                        // names the padding row)
-                        const d1u4* lp = reinterpret_cast<const d1u4*>(my_list + sub * LISTCAP + hg * NIT);
+                        // blocks of four entries per lane (a candidate's hits are dealt to its hit groups four at a time: every group has
+                        // work while there are hits), the list entries of four blocks read together, every index static, the four rows
+                        // of a block requested together (an entry beyond a candidate's hits names the padding row)
+                        const uint2* lp = reinterpret_cast<const uint2*>(my_list + sub * LISTCAP) + hg;   // block b: lp[b * HPI]
                         const uint32_t pb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)img + pr * 16;
 #pragma unroll 1
-                        for (int hb = 0; hb < NIT; hb += 16) {
-                            if (hb * HPI >= nmax) break;   // (wave-uniform)
-                            uint32_t q[8];
-                            {
-                                const d1u4 t0v = lp[hb / 8], t1v = lp[hb / 8 + 1];
-                                q[0] = t0v.x; q[1] = t0v.y; q[2] = t0v.z; q[3] = t0v.w;
-                                q[4] = t1v.x; q[5] = t1v.y; q[6] = t1v.z; q[7] = t1v.w;
-                            }
+                        for (int b0 = 0; b0 < NIT / 4; b0 += 4) {
+                            if (b0 * 4 * HPI >= nmax) break;   // (wave-uniform)
+                            uint2 q[4];
 #pragma unroll
-                            for (int it = 0; it < 16; it += 4) {
-                                if ((hb + it) * HPI < nmax) {   // (wave-uniform)
+                            for (int u = 0; u < 4; u++) q[u] = lp[(b0 + u) * HPI];
+#pragma unroll
+                            for (int bb = 0; bb < 4; bb++) {
+                                if ((b0 + bb) * 4 * HPI < nmax) {   // (wave-uniform)
                                     d1u4 v[4];
+                                    const uint32_t w2[2] = {q[bb].x, q[bb].y};
 #pragma unroll
                                     for (int u = 0; u < 4; u++) {
-                                        const uint32_t at = d1_row_addr(q[(it + u) >> 1], (it + u) & 1, pb);
+                                        const uint32_t at = d1_row_addr(w2[u >> 1], u & 1, pb);
                                         v[u] = *reinterpret_cast<const __attribute__((address_space(3))) d1u4*>((uintptr_t)at);
                                     }
 #pragma unroll
