@@ -818,11 +818,11 @@ __global__ __launch_bounds__(64 * S0Q2_WAVES, 1) void s0_centroid_scores_qs2(flm
                 const bool up3 = (i & 8) != 0, up2 = (i & 4) != 0, up1 = (i & 2) != 0;
 #pragma unroll
                 for (int r = 0; r < 4; r++)
-                    v4[r] = flmr_fmax_raw(up3 ? v8[r + 4] : v8[r], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(up3 ? v8[r] : v8[r + 4]), 0x128 /* row_ror:8 */, 0xF, 0xF, false)));
+                    v4[r] = flmr_fmax_raw(up3 ? v8[r + 4] : v8[r], __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(up3 ? v8[r] : v8[r + 4]), 0x128 /* row_ror:8 */, 0xF, 0xF, false)));
 #pragma unroll
                 for (int r = 0; r < 2; r++) v2[r] = flmr_fmax_raw(up2 ? v4[r + 2] : v4[r], flmr_dpp_xor4(up2 ? v4[r] : v4[r + 2]));
-                float rm = flmr_fmax_raw(up1 ? v2[1] : v2[0], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(up1 ? v2[0] : v2[1]), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false)));
-                rm = flmr_fmax_raw(rm, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(rm), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false)));   // lane (i, h): the maximum of row r = i >> 1 (of this half's 16) over all columns
+                float rm = flmr_fmax_raw(up1 ? v2[1] : v2[0], __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(up1 ? v2[0] : v2[1]), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false)));
+                rm = flmr_fmax_raw(rm, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(rm), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false)));   // lane (i, h): the maximum of row r = i >> 1 (of this half's 16) over all columns
                 const unsigned long long amb = HI_ONLY ? 0ull : __ballot(rm + qemax[q] >= a.thr && rm - qemax[q] < a.thr);
                 if (amb != 0ull) {
                     if (lane == 0) flist[nflag] = (uint16_t)(t * S0Q_QT + q);

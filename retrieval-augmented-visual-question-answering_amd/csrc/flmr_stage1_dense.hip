@@ -180,6 +180,12 @@ __global__ __launch_bounds__(D1_THREADS) void s1_image_kernel(flmr_s1d_args a) {
         const float miss = flmr_miss_score(nqc, 0);
         const int n = a.nqual[b] < a.row_cap ? a.nqual[b] : a.row_cap;
         const float* const rows_b = a.rows + (size_t)b * a.row_cap * 32;
+        d1h2 colw[4];   // 1 for the columns of this lane's 16 bytes of a row that count (< nqc), else 0
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            colw[e].x = (_Float16)(pr * 8 + 2 * e < nqc ? 1.0f : 0.0f);
+            colw[e].y = (_Float16)(pr * 8 + 2 * e + 1 < nqc ? 1.0f : 0.0f);
+        }
         __syncthreads();   // (the previous item's readers of the LDS tables are done)
         // ---- the query's mask and ranks ----
         {
@@ -309,14 +315,16 @@ __global__ __launch_bounds__(D1_THREADS) void s1_image_kernel(flmr_s1d_args a) {
                         nmax = max(n0, n1);
                     }
                     {   // entry o of a candidate's list = its o-th hit; block b of the fold = entries [4 HPI b, 4 HPI (b + 1)), four per hit group
-                        uint16_t* const lst = my_list + sub * LISTCAP + (incl - cnt);
+                        uint16_t* at = my_list + sub * LISTCAP + (incl - cnt);
+                        uint16_t* const scratch = my_list + R * LISTCAP + lane;
 #pragma unroll
                         for (int e = 0; e < CPL; e++) {
-                            const int c = c_[e];
-                            // (a hit's rank is below n by construction; a miss goes to the lane's own scratch entry)
-                            const int rid = (int)lpre[wi[e]] + __popc(wd[e] & ((1u << (c & 31)) - 1u));
-                            uint16_t* const at = lst + __popc(hm & ((1u << e) - 1u));
-                            *(((hm >> e) & 1u) ? at : my_list + R * LISTCAP + lane) = (uint16_t)rid;
+                            // (a hit's rank is below n by construction; a miss goes to the lane's own scratch entry; the bit-field
+                            // extract takes its width from the low five bits of the code)
+                            const int rid = (int)lpre[wi[e]] + __popc(__builtin_amdgcn_ubfe(wd[e], 0u, (uint32_t)c_[e]));
+                            const uint32_t bit = __builtin_amdgcn_ubfe(hm, (uint32_t)e, 1u);
+                            *(bit ? at : scratch) = (uint16_t)rid;
+                            at += bit;
                         }
                     }
                     // the codes are dead: request the chunk-0 codes of round r + 2 into the same registers
@@ -365,41 +373,34 @@ __global__ __launch_bounds__(D1_THREADS) void s1_image_kernel(flmr_s1d_args a) {
                         request_codes(cx, r, t0 + LISTCAP, dl);
 #pragma unroll
                         for (int v = 0; v < NV; v++) { c_[4 * v] = cx[v].x; c_[4 * v + 1] = cx[v].y; c_[4 * v + 2] = cx[v].z; c_[4 * v + 3] = cx[v].w; }
+                        // (a use HERE: pending where the paths of the chunk loop meet, these loads turn the wait of the round's end -- on
+                        // the common path none at all: the codes of round r + 2 stay in flight -- into a vmcnt(0))
+#pragma unroll
+                        for (int e = 0; e < CPL; e++) asm volatile("" : "+v"(c_[e]));
                     }
                 }
                 // ---- this round's candidates: combine the hit groups, sum the columns, keep the score for lane j ----
                 if (HPI >= 2) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) acc[e] = d1_pk_max(acc[e], (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc[e], D1_ROW_ROR(4), 0xF, 0xF, false));
+                    for (int e = 0; e < 4; e++) acc[e] = d1_pk_max(acc[e], (uint32_t)__builtin_amdgcn_mov_dpp((int)acc[e], D1_ROW_ROR(4), 0xF, 0xF, false));
                 }
                 if (HPI >= 4) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) acc[e] = d1_pk_max(acc[e], (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc[e], D1_ROW_ROR(8), 0xF, 0xF, false));
+                    for (int e = 0; e < 4; e++) acc[e] = d1_pk_max(acc[e], (uint32_t)__builtin_amdgcn_mov_dpp((int)acc[e], D1_ROW_ROR(8), 0xF, 0xF, false));
                 }
                 if (HPI >= 8) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) acc[e] = d1_pk_max(acc[e], (uint32_t)__shfl_xor((int)acc[e], 16, 64));
                 }
                 const bool nohit = (acc[0] & 0xffffu) == 0xFC00u;   // a real row is finite: -inf = only padding rows were folded
+                // this lane's eight column maxima summed in fp32 by dot products with ones (zeros for the columns >= nqc): one
+                // instruction per pair instead of two conversions and two additions; the products are exact, the additions fp32
+                // (their order inside the instruction is the hardware's: E's roundoff term, 8 x the bound of any order, covers it)
                 float s = 0.0f;
-                if (nqc == 32) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const d1h2 h = __builtin_bit_cast(d1h2, acc[e]);
-                        s += (float)h.x;
-                        s += (float)h.y;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const d1h2 h = __builtin_bit_cast(d1h2, acc[e]);
-                        const int k0 = pr * 8 + 2 * e;
-                        s += k0 < nqc ? (float)h.x : 0.0f;
-                        s += k0 + 1 < nqc ? (float)h.y : 0.0f;
-                    }
-                }
-                s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false));
-                s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false));
+                for (int e = 0; e < 4; e++) s = __builtin_amdgcn_fdot2(__builtin_bit_cast(d1h2, acc[e]), colw[e], s, false);
+                s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false));
+                s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false));
                 const float sc = nohit ? miss : s;
                 // the finished score sits in lane 0 of each candidate's lanes: hand it to lane j of the group
 #pragma unroll
@@ -731,10 +732,10 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
                 }
                 // ---- this round's candidates: combine the hit groups; the 8 lanes of a candidate park their 4 columns in the table ----
                 if (HPI >= 2) {
-                    facc.x = d1_fmax(facc.x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.x), D1_ROW_ROR(8), 0xF, 0xF, false)));
-                    facc.y = d1_fmax(facc.y, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.y), D1_ROW_ROR(8), 0xF, 0xF, false)));
-                    facc.z = d1_fmax(facc.z, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.z), D1_ROW_ROR(8), 0xF, 0xF, false)));
-                    facc.w = d1_fmax(facc.w, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(facc.w), D1_ROW_ROR(8), 0xF, 0xF, false)));
+                    facc.x = d1_fmax(facc.x, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(facc.x), D1_ROW_ROR(8), 0xF, 0xF, false)));
+                    facc.y = d1_fmax(facc.y, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(facc.y), D1_ROW_ROR(8), 0xF, 0xF, false)));
+                    facc.z = d1_fmax(facc.z, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(facc.z), D1_ROW_ROR(8), 0xF, 0xF, false)));
+                    facc.w = d1_fmax(facc.w, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(facc.w), D1_ROW_ROR(8), 0xF, 0xF, false)));
                 }
                 if (HPI >= 4) {
                     facc.x = d1_fmax(facc.x, __shfl_xor(facc.x, 16, 64)); facc.y = d1_fmax(facc.y, __shfl_xor(facc.y, 16, 64));
