@@ -25,6 +25,7 @@ static float up16_host(float x) {
         if (b == 0x8000u) b = 1; else if (b & 0x8000u) b--; else b++;
         memcpy(&h, &b, 2);
     }
+    { uint16_t b; memcpy(&b, &h, 2); if ((b & 0x7C00u) == 0u) { b = x > 0.0f ? 0x0400u : 0x8000u; memcpy(&h, &b, 2); } }   // (no subnormal images: d1_up16)
     return (float)h;
 }
 

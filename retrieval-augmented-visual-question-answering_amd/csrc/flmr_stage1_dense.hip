@@ -71,6 +71,10 @@ __device__ __forceinline__ _Float16 d1_up16(float x) {
         else b++;                                  // positive: larger magnitude
         h = __builtin_bit_cast(_Float16, b);
     }
+    // no subnormal images: the image sums are v_dot2_f32_f16 instructions, which may flush them -- a positive one becomes the
+    // smallest normal number (still >= x; the step enters the query's E like any other), a negative one -0 (>= x)
+    const uint16_t hb = __builtin_bit_cast(uint16_t, h);
+    if ((hb & 0x7C00u) == 0u) h = __builtin_bit_cast(_Float16, (uint16_t)(x > 0.0f ? 0x0400u : 0x8000u));
     return h;
 }
 
