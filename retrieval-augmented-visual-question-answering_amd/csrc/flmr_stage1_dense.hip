@@ -685,6 +685,9 @@ __global__ __launch_bounds__(D1_THREADS) void s1_exact_kernel(flmr_s1d_args a) {
 #elif defined(D1X_ABL_HALFROWS)   // development switch: half of the row loads
                             for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const d1f4*>(rbytes + d1x_row_off(w[u >> 1], u & 1, prb));
                             for (int u = 4; u < 8; u++) { v[u].x = v[u].y = v[u].z = v[u].w = __int_as_float((int)d1x_row_off(w[u >> 1], u & 1, prb)); }
+#elif defined(D1X_ABL_ROWS64)   // development switch: what a pass over 64-byte (fp16) rows would move -- four loads a lane, rows 64 bytes apart
+                            for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const d1f4*>(rbytes + (d1x_row_off(w[u >> 1], u & 1, 0u) >> 1) + (prb & 48u));
+                            for (int u = 4; u < 8; u++) { v[u].x = v[u].y = v[u].z = v[u].w = __int_as_float((int)d1x_row_off(w[u >> 1], u & 1, prb)); }
 #elif defined(D1X_ABL_SAMEROWS)   // development switch: entries 4 .. 7 read ONE line (row 0) in every lane
                             for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const d1f4*>(rbytes + d1x_row_off(w[u >> 1], u & 1, prb));
                             for (int u = 4; u < 8; u++) v[u] = *reinterpret_cast<const d1f4*>(rbytes + (d1x_row_off(w[u >> 1], u & 1, prb) & 127u));
